@@ -1,0 +1,265 @@
+#!/opt/conda/bin/python3.9
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  Golden-vector generator.
+
+Run in the BUILD container only (never on the GPU box — /root/reference and the conda
+interpreter with scikit-image 0.18.3 / numpy 1.26.4 / scipy 1.7.1 exist only here):
+
+    PYTHONDONTWRITEBYTECODE=1 /opt/conda/bin/python3.9 oracle/gen_golden.py
+
+It imports the reference's own functions from /root/reference/batch_spalign_kmeans.py
+(with stub modules for chainer / cupy / chainercv / cv2, which are not installed) and
+scikit-image's private SLIC cores, runs them on seeded synthetic inputs and writes small
+input/expected-output fixtures to tests/golden/.  Only data is written — no reference
+source travels.  numpy 1.26 (legacy value-based casting, like the 2018 stack) matters
+for the float32 blend of superpixel_align, so fixtures must be made with this interpreter.
+"""
+import hashlib
+import os
+import random as pyrandom_mod
+import sys
+import types
+import warnings
+
+sys.dont_write_bytecode = True
+warnings.filterwarnings('ignore')
+
+import numpy as np  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+REF = '/root/reference'
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, 'superpixel-align_amd'))
+
+import oracle as orc  # noqa: E402
+import synth  # noqa: E402
+
+
+# ------------------------------------------------------------------ reference import
+class _NpProxy(object):
+    """numpy with a canonical (stable) argsort and a recording random.shuffle."""
+
+    def __init__(self):
+        self.shuffled = []
+        outer = self
+
+        class _R(object):
+            def shuffle(self, a):
+                np.random.shuffle(a)
+                outer.shuffled.append(np.array(a))
+
+            def seed(self, s):
+                np.random.seed(s)
+        self.random = _R()
+
+    def argsort(self, a, *args, **kw):
+        return np.argsort(a, kind='stable')
+
+    def __getattr__(self, name):
+        return getattr(np, name)
+
+
+XP = _NpProxy()
+
+
+def import_reference():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class Variable(object):
+        def __init__(self, a):
+            self.array = a
+
+    cuda = mod('chainer.cuda', get_array_module=lambda *a: XP, to_cpu=lambda a: a,
+               to_gpu=lambda a, *r: a, cupy=types.SimpleNamespace(ndarray=()))
+    ch = mod('chainer', cuda=cuda, Variable=Variable, config=types.SimpleNamespace(train=False))
+    ch.datasets = mod('chainer.datasets')
+    ch.serializers = mod('chainer.serializers')
+    ch.dataset = mod('chainer.dataset', concat_examples=None)
+    ch.functions = mod('chainer.functions')
+    cv = mod('chainercv')
+    cv.evaluations = mod('chainercv.evaluations')
+    mod('cupy', random=types.SimpleNamespace(seed=lambda s: None))
+    mod('cv2')
+    mod('drn')
+    mod('resize_image_dataset', ResizeImageDataset=None)
+    mod('zipped_cityscapes_road_dataset', ZippedCityscapesRoadDataset=None)
+    np.float = float          # alias removed from numpy, used at :233
+    sys.path.insert(0, REF)
+    cwd = os.getcwd()
+    import batch_spalign_kmeans as ref
+    os.chdir(cwd)
+    return ref
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def save(name, **arrays):
+    path = os.path.join(GOLD, name + '.npz')
+    np.savez_compressed(path, **arrays)
+    print('%-28s %8.1f KB' % (name, os.path.getsize(path) / 1024.0))
+
+
+def args_ns(**kw):
+    d = dict(superpixel_method='slic', n_slic_segments=100, n_anchors=10, n_neighbors=4,
+             without_pos=False, y_rel_pos=0.75, x_rel_pos=0.5, y_rel_sigma=0.1, x_rel_sigma=0.1,
+             gpu=-1, n_clusters=2, use_feature_maps=[7])
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+# ------------------------------------------------------------------ generators
+def gen_slic(ref):
+    from skimage.segmentation._slic import _slic_cython, _enforce_label_connectivity_cython
+    from skimage.segmentation.slic_superpixels import _get_grid_centroids
+    from skimage.segmentation import slic
+    from skimage.color import rgb2lab
+    from skimage.util import regular_grid
+
+    # regular_grid known answers
+    rows = []
+    for (H, W, n) in [(64, 128, 20), (128, 256, 100), (256, 512, 100), (96, 96, 30), (224, 224, 100),
+                      (512, 1024, 200), (1024, 2048, 200), (1024, 2048, 400), (1024, 2048, 100),
+                      (100, 37, 50), (37, 100, 7), (16, 16, 300), (33, 65, 5), (1024, 2048, 800)]:
+        sl = regular_grid((1, H, W), n)
+        rows.append([H, W, n] + [s.start or 0 for s in sl] + [s.step if s.step is not None else -1 for s in sl])
+    save('regular_grid', cases=np.array(rows, np.int64))
+
+    cases = [(0, 64, 128, 20), (1, 128, 256, 100), (2, 256, 512, 100), (3, 96, 96, 30),
+             (4, 224, 224, 100), (5, 100, 37, 12), (0, 512, 1024, 200), (0, 1024, 2048, 200)]
+    for (seed, H, W, n) in cases:
+        img = synth.synth_image(seed, H, W)                      # CHW f32 0..255
+        lab = orc.rgb2lab_scaled(img)                             # deterministic Lab * 0.1
+        image = np.ascontiguousarray(lab[None], dtype=np.float32)
+        cent, steps = _get_grid_centroids(image, n)
+        nC = cent.shape[0]
+        segs = np.ascontiguousarray(np.concatenate([cent, np.zeros((nC, 3))], axis=-1), dtype=np.float32)
+        pre = _slic_cython(image, None, segs, max(steps), 10, np.ones(3, np.float32), False,
+                           ignore_color=False, start_label=0)
+        mn, mx = orc.connectivity_sizes(H, W, nC)
+        post = _enforce_label_connectivity_cython(pre, mn, mx, start_label=0)
+        # end-to-end call exactly as batch_spalign_kmeans.py:311 makes it
+        e2e = ref.batch_superpixel(args_ns(n_slic_segments=n), img[None])[0]
+        extra = {}
+        if H * W <= 64 * 128:
+            hwc = np.ascontiguousarray(img.transpose(1, 2, 0))
+            extra['skimage_lab_scaled'] = np.ascontiguousarray(rgb2lab(hwc) * 0.1, dtype=np.float32)
+        save('slic_s%d_%dx%d_n%d' % (seed, H, W, n),
+             meta=np.array([seed, H, W, n, nC, mn, mx], np.int64),
+             lab_sha256=np.array(sha(lab)), pre=pre[0].astype(np.int16), post=post[0].astype(np.int16),
+             centres=segs, e2e_skimage=e2e.astype(np.int16), **extra)
+
+    # connectivity stress: random blobs with many small fragments and an oversize component
+    rs = np.random.RandomState(7)
+    H, W = 96, 160
+    base = (np.arange(H)[:, None] // 24) * 5 + (np.arange(W)[None, :] // 32)
+    noise = rs.randint(0, 20, size=(H, W))
+    seg = np.where(rs.uniform(size=(H, W)) < 0.25, noise, base).astype(np.int64)
+    for (mn, mx) in [(30, 200), (8, 5000), (100, 400), (1, 50)]:
+        post = _enforce_label_connectivity_cython(seg[None].copy(), mn, mx, start_label=0)
+        save('connectivity_stress_%d_%d' % (mn, mx), seg=seg.astype(np.int16),
+             meta=np.array([mn, mx], np.int64), post=post[0].astype(np.int32))
+
+
+def gen_pipeline(ref):
+    """prior / anchor pool / k-means / paint on two small cases, from the reference functions."""
+    for tag, (seed, H, W, n, C) in {'small': (0, 64, 128, 20, 16), 'config1': (0, 256, 512, 100, 64)}.items():
+        B = 2 if tag == 'small' else 1
+        imgs = synth.synth_batch([seed + b for b in range(B)], H, W)
+        args = args_ns(n_slic_segments=n)
+        sps = ref.batch_superpixel(args, imgs)                     # skimage slic from RGB
+        fmaps = synth.synth_feature_map(seed + 1, C, H // 8, W // 8, batch=B)
+
+        # --- prior (launcher parameters and the function default x sigma)
+        prior = ref.batch_create_prior(args, sps)
+        prior_dflt = ref.create_prior(sps[0])
+
+        # --- anchor pooling with recorded anchors and canonical tie-break
+        picked = []
+        real_shuffle = pyrandom_mod.shuffle
+
+        def rec_shuffle(lst):
+            real_shuffle(lst)
+            picked.append(list(lst[:args.n_anchors]))
+        ref.random.seed(1111)
+        ref.random.shuffle = rec_shuffle
+        model = types.SimpleNamespace(xp=XP)
+        feats, n_per = ref.batch_superpixel_align(args, model, imgs, sps, fmaps)
+        ref.random.shuffle = real_shuffle
+        A = args.n_anchors
+        anchors = np.zeros((len(picked), A, 2), np.int32)
+        n_valid = np.zeros(len(picked), np.int32)
+        for i, p in enumerate(picked):
+            n_valid[i] = len(p)
+            anchors[i, :len(p)] = np.array(p, np.int32).reshape(-1, 2)
+        args_np = args_ns(n_slic_segments=n, without_pos=True)
+        ref.random.seed(1111)
+        feats_nopos, _ = ref.batch_superpixel_align(args_np, model, imgs, sps, fmaps)
+
+        # --- k-means k=2 (deterministic) and k=4 (numpy global RNG seeded 1111)
+        k2 = ref.kmeans(2, feats, prior)
+        np.random.seed(1111)
+        XP.shuffled.clear()
+        k4 = ref.kmeans(4, feats, prior)
+        k4_idx = XP.shuffled[-1].copy()
+        # --- paint
+        cl, road = ref.weighted_kmeans(sps, feats, prior, 2, n_per)
+
+        save('pipeline_' + tag,
+             meta=np.array([seed, H, W, n, C, B], np.int64), superpixels=sps.astype(np.int16),
+             n_per=np.array(n_per, np.int64), prior=prior, prior_default_img0=prior_dflt,
+             anchors=anchors, n_valid=n_valid, feats=feats, feats_nopos=feats_nopos,
+             feats_dtype=np.array(str(feats.dtype)), feats_nopos_dtype=np.array(str(feats_nopos.dtype)),
+             k2_assign=np.asarray(k2).astype(np.int32), k4_assign=np.asarray(k4).astype(np.int32),
+             k4_shuffled_idx=k4_idx.astype(np.int64),
+             clustering=cl.astype(np.uint8), road=road.astype(np.uint8))
+
+    # engineered k-means cases: empty cluster exit, loop never changing, NaN centre
+    rs = np.random.RandomState(3)
+    X = np.concatenate([rs.normal(0, 1, (40, 6)), rs.normal(8, 1, (40, 6))])
+    w = np.concatenate([rs.uniform(0.6, 1.0, 40), rs.uniform(0.0, 0.4, 40)])
+    a = ref.kmeans(2, X, w)
+    Xe = np.concatenate([rs.normal(0, 0.1, (30, 4)), rs.normal(0.5, 0.1, (3, 4))])
+    we = np.concatenate([rs.uniform(0.0, 0.2, 30), rs.uniform(0.8, 1.0, 3)])
+    np.random.seed(5)
+    XP.shuffled.clear()
+    ae = ref.kmeans(5, Xe, we)
+    save('kmeans_engineered', X=X, w=w, assign=np.asarray(a).astype(np.int32),
+         Xe=Xe, we=we, assign_e=np.asarray(ae).astype(np.int32), idx_e=XP.shuffled[-1].astype(np.int64))
+
+
+def gen_rng():
+    out = {}
+    for n in (5, 1000, 70000):
+        pyrandom_mod.seed(1111)
+        lst = list(range(n))
+        pyrandom_mod.shuffle(lst)
+        out['py_%d' % n] = np.array(lst[:32], np.int64)
+        lst2 = list(range(n // 2 + 1))
+        pyrandom_mod.shuffle(lst2)                    # state carries over
+        out['py_%d_second' % n] = np.array(lst2[:32], np.int64)
+        np.random.seed(1111)
+        a = np.arange(n)
+        np.random.shuffle(a)
+        out['np_%d' % n] = a[:32].astype(np.int64)
+    save('rng', **out)
+
+
+if __name__ == '__main__':
+    os.makedirs(GOLD, exist_ok=True)
+    ref = import_reference()
+    gen_rng()
+    gen_slic(ref)
+    gen_pipeline(ref)
+    import skimage, scipy
+    with open(os.path.join(GOLD, 'PROVENANCE.txt'), 'w') as fp:
+        fp.write('generated by oracle/gen_golden.py\n'
+                 'python %s\nnumpy %s\nscipy %s\nscikit-image %s\n'
+                 'reference: /root/reference/batch_spalign_kmeans.py (imported with stub modules)\n'
+                 % (sys.version.split()[0], np.__version__, scipy.__version__, skimage.__version__))
