@@ -1,0 +1,205 @@
+/*
+ * spalign.h — C ABI of libspalign.so, the MI355X (gfx950) implementation of the
+ * superpixel-align label-generation hot path.
+ *
+ * The reference (pfnet-research/superpixel-align) has no native boundary: its hot path is
+ * Python calling CuPy/NumPy/scikit-image.  The entry points below are what a binding for
+ * that path would call in place of the reference's Python bodies; each cites the reference
+ * code it replaces (file:line in the reference repository).  INTEGRATION.md shows the
+ * ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns an int status: SPA_OK (0) or a negative SPA_ERR_*;
+ *     spa_last_error() returns a thread-local message for the last failure.
+ *   - no exceptions cross the boundary, no ownership is transferred: every array is
+ *     allocated by the caller (device memory unless the name ends in _host); the library
+ *     allocates only workspaces owned by the opaque spa_ctx.
+ *   - `stream` is a hipStream_t passed as void*; all device entry points are asynchronous
+ *     with respect to the host and ordered on that stream.
+ *   - a spa_ctx is bound to one device and is not thread safe; distinct contexts are
+ *     independent (one per GPU / process).
+ *   - data-dependent failures detected on the device (a SLIC seed that lost all its pixels,
+ *     a pixel outside every search window, ...) are latched in device status words, read
+ *     back with spa_status() at a point where the caller synchronises anyway.
+ *   - superpixels of a batch are laid out image after image: image b owns the descriptor
+ *     rows [offsets[b], offsets[b+1]); N = offsets[B].
+ */
+#ifndef SPALIGN_H
+#define SPALIGN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPA_OK 0
+#define SPA_ERR_ARG (-1)      /* invalid argument                                       */
+#define SPA_ERR_HIP (-2)      /* a HIP runtime call failed                              */
+#define SPA_ERR_NOGPU (-3)    /* no usable gfx950 device                                */
+#define SPA_ERR_LAYOUT (-4)   /* unsupported memory layout (e.g. feature map not NHWC)  */
+#define SPA_ERR_CAPACITY (-5) /* caller-provided capacity too small                     */
+
+/* bits of the device status word (spa_status) */
+#define SPA_ST_SLIC_EMPTY_SEGMENT 0x01u  /* a seed lost all pixels: skimage divides 0/0 there   */
+#define SPA_ST_SLIC_UNCOVERED 0x02u      /* a pixel fell outside every 2S search window         */
+#define SPA_ST_CONN_OVERSIZE 0x04u       /* a component reached max_size: handled by the slow exact path */
+#define SPA_ST_POOL_SLOT_OVERFLOW 0x08u  /* > SPA_CELL_SLOTS superpixels touch one feature pixel */
+#define SPA_ST_KMEANS_BARRIER 0x10u      /* grid barrier timed out (should never happen)        */
+#define SPA_ST_LABEL_RANGE 0x20u         /* a label outside [0, S) was met                      */
+
+#define SPA_CELL_SLOTS 16
+
+typedef struct spa_ctx spa_ctx;
+
+/* ---- context ------------------------------------------------------------------------- */
+int spa_version(void);
+const char *spa_last_error(void);
+/* device < 0: current device.  Fails with SPA_ERR_NOGPU when no gfx950 GPU is visible:
+   there is no CPU fallback behind this ABI. */
+int spa_ctx_create(int device, spa_ctx **out);
+void spa_ctx_destroy(spa_ctx *ctx);
+/* copies the latched status bits to *status_host and clears them; synchronises `stream`. */
+int spa_status(spa_ctx *ctx, uint32_t *status_host, void *stream);
+
+/* ---- SLIC superpixels ------------------------------------------------------------------
+ * replaces batch_superpixel(), SLIC branch: batch_spalign_kmeans.py:308-311, i.e.
+ * skimage.segmentation.slic(img.transpose(1,2,0), n_segments) with every other argument
+ * at its default (compactness 10, max_iter 10, sigma 0, enforce_connectivity True).        */
+
+/* Host-side plan (skimage.util.regular_grid + slic_superpixels.py:322-327).               */
+typedef struct {
+    int32_t n_centroids;        /* seeds actually placed (<= n_segments)                   */
+    int32_t grid_ny, grid_nx;   /* seed grid                                               */
+    int32_t start_y, start_x;   /* first seed                                              */
+    int32_t step_y, step_x;     /* seed spacing                                            */
+    int32_t win_step_y, win_step_x; /* spacing used for the 2S search window (recomputed
+                                   from n_centroids, as the Cython core does)              */
+    float step;                 /* max spacing: spatial weight = 1/step^2                  */
+    int32_t min_size, max_size; /* connectivity thresholds                                 */
+    int32_t max_labels;         /* upper bound of labels after the connectivity pass       */
+} spa_slic_plan;
+int spa_slic_make_plan(int32_t H, int32_t W, int32_t n_segments, spa_slic_plan *plan_host);
+
+/* rgb (B,3,H,W) float32, values 0..255, NOT normalised (the reference passes the raw image)
+   -> CIE Lab (D65/2deg) * ratio, planar (B,3,H,W) float32.  skimage rgb2lab, float32.     */
+int spa_rgb2lab(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t W,
+                float ratio, float *lab, void *stream);
+
+/* _slic_cython: max_iter Lloyd sweeps on a scaled Lab image.
+   labels (B,H,W) int32 out; centres (B, n_centroids, 6) float32 out or NULL (z,y,x,L,a,b). */
+int spa_slic_core(spa_ctx *ctx, const float *lab, int32_t B, int32_t H, int32_t W,
+                  int32_t n_segments, int32_t max_iter, int32_t *labels, float *centres,
+                  void *stream);
+
+/* _enforce_label_connectivity_cython: scan-order relabelling, components < min_size merged
+   into the last labelled neighbour met by the breadth-first search, growth capped at
+   max_size.  labels_out (B,H,W) int32, n_labels (B) int32 (device).                       */
+int spa_enforce_connectivity(spa_ctx *ctx, const int32_t *labels_in, int32_t B, int32_t H,
+                             int32_t W, int32_t min_size, int32_t max_size,
+                             int32_t *labels_out, int32_t *n_labels, void *stream);
+
+/* whole slic() call: rgb -> labels (B,H,W) int32 contiguous ids 0..n_labels[b]-1.         */
+int spa_slic(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t W,
+             int32_t n_segments, float compactness, int32_t max_iter,
+             int32_t *labels, int32_t *n_labels, void *stream);
+
+/* ---- per-superpixel descriptors -------------------------------------------------------- */
+
+/* offsets (B+1) int32 = exclusive prefix sum of n_labels (B).  (n_superpixels_per_image,
+   batch_spalign_kmeans.py:321, kept on the device)                                        */
+int spa_segment_offsets(spa_ctx *ctx, const int32_t *n_labels, int32_t B, int32_t *offsets,
+                        void *stream);
+
+/* counts, bounding boxes, centre of mass and the location prior of every superpixel.
+     count    (Ncap) int32
+     centroid (Ncap,2) float64 (y, x) image-pixel units — scipy.ndimage.center_of_mass, :229
+     prior    (Ncap) float64 — create_prior, :111-129 / batch_create_prior, :333-344
+   Any of centroid / prior may be NULL.  Ncap >= offsets[B].                               */
+int spa_segment_stats(spa_ctx *ctx, const int32_t *labels, int32_t B, int32_t H, int32_t W,
+                      const int32_t *offsets, int32_t Ncap,
+                      double y_rel_pos, double x_rel_pos, double y_rel_sigma, double x_rel_sigma,
+                      int32_t *count, double *centroid, double *prior, void *stream);
+
+/* Anchor selection, host half: CPython random.shuffle(pixel list)[:n_anchors] for every
+   superpixel in order (:231-234) needs only the superpixel sizes.  `rng` is an MT19937
+   state seeded like random.seed(); ranks_host (N, n_anchors) int32 receives, per anchor, the
+   raster-order rank of the chosen pixel inside its superpixel; n_valid_host (N).          */
+typedef struct spa_pyrandom spa_pyrandom;
+int spa_pyrandom_create(uint64_t seed, spa_pyrandom **out);
+void spa_pyrandom_destroy(spa_pyrandom *rng);
+int spa_pyrandom_shuffle_select_host(spa_pyrandom *rng, const int32_t *count_host, int32_t N,
+                                     int32_t n_anchors, int32_t *ranks_host,
+                                     int32_t *n_valid_host);
+/* numpy legacy global RandomState (np.random.seed / np.random.shuffle), used by the k > 2
+   k-means initialisation (:147-149).                                                      */
+typedef struct spa_nprandom spa_nprandom;
+int spa_nprandom_create(uint32_t seed, spa_nprandom **out);
+void spa_nprandom_destroy(spa_nprandom *rng);
+int spa_nprandom_shuffle_host(spa_nprandom *rng, int64_t *a_host, int64_t n);
+
+/* Anchor selection, device half: rank -> pixel.  ranks (Ncap, n_anchors) int32,
+   n_valid (Ncap) int32 -> anchors (Ncap, n_anchors, 2) int32 (y, x).                      */
+int spa_select_anchor_pixels(spa_ctx *ctx, const int32_t *labels, int32_t B, int32_t H,
+                             int32_t W, const int32_t *offsets, int32_t Ncap,
+                             const int32_t *ranks, const int32_t *n_valid, int32_t n_anchors,
+                             int32_t *anchors, void *stream);
+
+/* Feature-map addressing: element (b, c, y, x) lives at
+   fmap[b*stride_b + c*stride_c + y*stride_y + x*stride_x] (strides in elements).
+   The kernels require channels-last storage (stride_c == 1): SPA_ERR_LAYOUT otherwise.
+   fmap_dtype: 0 = float32, 1 = bfloat16.                                                  */
+typedef struct {
+    int32_t C, fh, fw;
+    int64_t stride_b, stride_c, stride_y, stride_x;
+    int32_t dtype;
+} spa_fmap_desc;
+
+/* Output descriptor matrix X: row s at X + s*ld; x_dtype 0 = float32, 1 = float64.
+   Columns [0, C) receive the pooled features; with append_pos the centroid (y, x) goes to
+   columns C, C+1 (hstack, :269-270).                                                      */
+
+/* superpixel_align(), anchor mode (:210-276) given the selected anchors.                  */
+int spa_pool_anchor(spa_ctx *ctx, const void *fmap, const spa_fmap_desc *desc,
+                    int32_t B, int32_t img_h, const int32_t *offsets, int32_t Ncap,
+                    const int32_t *anchors, const int32_t *n_valid, int32_t n_anchors,
+                    int32_t n_neighbors, const double *centroid, int32_t append_pos,
+                    void *X, int32_t x_dtype, int64_t ld, void *stream);
+
+/* dense per-superpixel mean (mean mode, notebooks/Superpixel_Align.ipynb cell 4).
+   sampling 0 = nearest, 1 = bilinear (corners aligned, chainer F.resize_images).          */
+int spa_pool_mean(spa_ctx *ctx, const void *fmap, const spa_fmap_desc *desc,
+                  const int32_t *labels, int32_t B, int32_t H, int32_t W,
+                  const int32_t *offsets, int32_t Ncap, const int32_t *count,
+                  int32_t sampling, const double *centroid, int32_t append_pos,
+                  void *X, int32_t x_dtype, int64_t ld, void *stream);
+
+/* ---- weighted k-means + painting -------------------------------------------------------
+ * kmeans(), :136-183, on all superpixels of the batch at once.
+ *   X (Ncap, D) row stride ld, x_dtype as above; w (Ncap) float64; n_ptr: device int32
+ *   holding N (= offsets + B), so no host synchronisation is needed;
+ *   init_other: device int64 array, the shuffled `idx` of :147-149 for the points with
+ *   w <= threshold, or NULL for its unshuffled value arange(M) % (k-1) + 1 (exact for k = 2);
+ *   assign (Ncap) int32 out; info (4) int32 out: {iterations, status, N, reserved},
+ *   status 0 converged / 1 hit max_iter / 2 stopped on an empty cluster.                  */
+int spa_kmeans_weighted(spa_ctx *ctx, const void *X, int32_t x_dtype, int64_t ld, int32_t D,
+                        const double *w, const int32_t *n_ptr, int32_t Ncap, int32_t k,
+                        int32_t max_iter, const int64_t *init_other, int32_t *assign,
+                        int32_t *info, void *stream);
+
+/* weighted_kmeans() paint loop (:193-199) and `clustering_result == 0` (:207):
+   cluster[p] = assign[offsets[b] + labels[p]], road[p] = cluster[p] == 0; (B,H,W) uint8.  */
+int spa_paint(spa_ctx *ctx, const int32_t *labels, const int32_t *assign,
+              const int32_t *offsets, int32_t B, int32_t H, int32_t W,
+              uint8_t *cluster, uint8_t *road, void *stream);
+
+/* save_info() scoring (:398-405): per image confusion of road (B,npix) uint8 against
+   gt (B,npix) int32 in {-1 ignore, 0, 1} -> out (B,4) int64 {TN, FP, FN, TP}.             */
+int spa_confusion(spa_ctx *ctx, const uint8_t *road, const int32_t *gt, int32_t B,
+                  int64_t npix, int64_t *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPALIGN_H */

@@ -1,0 +1,144 @@
+// Internal header of libspalign.so (gfx950 only; no CUDA/portability layer by design).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/spalign.h"
+
+#define SPA_WAVE 64
+
+// ---------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------
+void spa_set_error(const char *fmt, ...);
+
+#define SPA_HIP(call)                                                                  \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            spa_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),      \
+                          __FILE__, __LINE__);                                         \
+            return SPA_ERR_HIP;                                                        \
+        }                                                                              \
+    } while (0)
+
+#define SPA_ARG(cond)                                                                  \
+    do {                                                                               \
+        if (!(cond)) {                                                                 \
+            spa_set_error("invalid argument: %s (%s:%d)", #cond, __FILE__, __LINE__);  \
+            return SPA_ERR_ARG;                                                        \
+        }                                                                              \
+    } while (0)
+
+#define SPA_LAUNCH_CHECK()                                                             \
+    do {                                                                               \
+        hipError_t e_ = hipGetLastError();                                             \
+        if (e_ != hipSuccess) {                                                        \
+            spa_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_),   \
+                          __FILE__, __LINE__);                                         \
+            return SPA_ERR_HIP;                                                        \
+        }                                                                              \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------
+// context: device binding + grow-on-demand workspaces (never freed between calls, so the
+// steady state of a batch loop performs no hipMalloc)
+// ---------------------------------------------------------------------------------------
+enum {
+    WS_LAB = 0,      // scaled Lab image (B,3,H,W) f32
+    WS_CENTRES,      // SLIC centre table (B,nC,12) words
+    WS_PRE,          // labels before the connectivity pass (B,H,W) i32
+    WS_PARENT,       // union-find parents / component roots (B,H,W) i32
+    WS_SIZE,         // component sizes, indexed by root pixel (B,H,W) i32
+    WS_FINAL,        // final label of a component, indexed by root pixel (B,H,W) i32
+    WS_CLAIM,        // BFS claim keys (B,H,W) u32
+    WS_QUEUE,        // BFS queues (B,H,W) i32
+    WS_BLK,          // per-block scan counters
+    WS_SMALL,        // compacted list of small component roots (B,H*W/?) i32
+    WS_CONNMISC,     // per-image counters of the connectivity pass
+    WS_BBOX,         // per-superpixel bounding boxes (Ncap,4) i32
+    WS_CELLSLOT,     // mean pooling: per feature pixel (label, weight) slots
+    WS_KM_PART,      // k-means partial sums
+    WS_KM_MISC,      // k-means centres, counters, barrier words
+    WS_NLABELS,      // n_labels (B) for spa_slic
+    WS_COUNT
+};
+
+struct spa_ctx {
+    int device;
+    int n_cu;
+    uint32_t *d_status;      // latched status bits
+    void *ws[WS_COUNT];
+    size_t ws_bytes[WS_COUNT];
+};
+
+int spa_ws_reserve(spa_ctx *ctx, int which, size_t bytes, void **out);
+
+static inline hipStream_t spa_stream(void *s) { return (hipStream_t)s; }
+
+// ---------------------------------------------------------------------------------------
+// deterministic elementary functions (device).  Same definition as oracle/detmath.h: binary64
+// evaluation with +,-,*,/ only (each correctly rounded, contraction off), one final rounding.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double spa_det_log_pos(double x)
+{
+    unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    int e = (int)((b >> 52) & 0x7ff) - 1023;
+    b = (b & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
+    double m = __longlong_as_double((long long)b);
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    double s = (m - 1.0) / (m + 1.0);
+    double z = s * s;
+    double p = 1.0 / 25.0;
+    p = p * z + 1.0 / 23.0;
+    p = p * z + 1.0 / 21.0;
+    p = p * z + 1.0 / 19.0;
+    p = p * z + 1.0 / 17.0;
+    p = p * z + 1.0 / 15.0;
+    p = p * z + 1.0 / 13.0;
+    p = p * z + 1.0 / 11.0;
+    p = p * z + 1.0 / 9.0;
+    p = p * z + 1.0 / 7.0;
+    p = p * z + 1.0 / 5.0;
+    p = p * z + 1.0 / 3.0;
+    p = p * z + 1.0;
+    double lnm = 2.0 * s * p;
+    double ed = (double)e;
+    return ed * 6.93147180369123816490e-01 + (ed * 1.90821492927058770002e-10 + lnm);
+}
+
+__device__ __forceinline__ double spa_det_exp(double t)
+{
+    double kf = floor(t * 1.44269504088896338700e+00 + 0.5);
+    double r = (t - kf * 6.93147180369123816490e-01) - kf * 1.90821492927058770002e-10;
+    double p = 1.0 / 87178291200.0;
+    p = p * r + 1.0 / 6227020800.0;
+    p = p * r + 1.0 / 479001600.0;
+    p = p * r + 1.0 / 39916800.0;
+    p = p * r + 1.0 / 3628800.0;
+    p = p * r + 1.0 / 362880.0;
+    p = p * r + 1.0 / 40320.0;
+    p = p * r + 1.0 / 5040.0;
+    p = p * r + 1.0 / 720.0;
+    p = p * r + 1.0 / 120.0;
+    p = p * r + 1.0 / 24.0;
+    p = p * r + 1.0 / 6.0;
+    p = p * r + 0.5;
+    p = p * r + 1.0;
+    p = p * r + 1.0;
+    int k = (int)kf;
+    unsigned long long b = (unsigned long long)(k + 1023) << 52;
+    return p * __longlong_as_double((long long)b);
+}
+
+// ---------------------------------------------------------------------------------------
+// wave helpers (wave64)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned spa_lane() { return __lane_id(); }
+// number of set bits of `mask` strictly below this lane
+__device__ __forceinline__ unsigned spa_rank_in_mask(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}

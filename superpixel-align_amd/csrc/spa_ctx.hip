@@ -1,0 +1,173 @@
+// Context, error state, workspaces and the host-side planning code of libspalign.so.
+#include <math.h>
+#include <stdarg.h>
+#include <stdlib.h>
+
+#include "spa_common.h"
+
+static thread_local char g_err[512] = "";
+
+void spa_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *spa_last_error(void) { return g_err; }
+extern "C" int spa_version(void) { return 100; }
+
+extern "C" int spa_ctx_create(int device, spa_ctx **out)
+{
+    SPA_ARG(out != nullptr);
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        spa_set_error("no HIP device visible: libspalign has no CPU fallback");
+        return SPA_ERR_NOGPU;
+    }
+    if (device < 0) SPA_HIP(hipGetDevice(&device));
+    SPA_ARG(device < n);
+    SPA_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    SPA_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        spa_set_error("device %d is %s; libspalign is built for gfx950 (MI355X) only", device,
+                      prop.gcnArchName);
+        return SPA_ERR_NOGPU;
+    }
+    spa_ctx *ctx = (spa_ctx *)calloc(1, sizeof(spa_ctx));
+    ctx->device = device;
+    ctx->n_cu = prop.multiProcessorCount;
+    SPA_HIP(hipMalloc((void **)&ctx->d_status, sizeof(uint32_t)));
+    SPA_HIP(hipMemset(ctx->d_status, 0, sizeof(uint32_t)));
+    *out = ctx;
+    return SPA_OK;
+}
+
+extern "C" void spa_ctx_destroy(spa_ctx *ctx)
+{
+    if (!ctx) return;
+    for (int i = 0; i < WS_COUNT; ++i)
+        if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
+    if (ctx->d_status) (void)hipFree(ctx->d_status);
+    free(ctx);
+}
+
+int spa_ws_reserve(spa_ctx *ctx, int which, size_t bytes, void **out)
+{
+    if (bytes == 0) bytes = 16;
+    if (ctx->ws_bytes[which] < bytes) {
+        // growing a workspace is a rare, synchronising event (first batch of a new shape)
+        SPA_HIP(hipDeviceSynchronize());
+        if (ctx->ws[which]) SPA_HIP(hipFree(ctx->ws[which]));
+        ctx->ws[which] = nullptr;
+        ctx->ws_bytes[which] = 0;
+        size_t want = bytes + bytes / 8;
+        SPA_HIP(hipMalloc(&ctx->ws[which], want));
+        ctx->ws_bytes[which] = want;
+    }
+    *out = ctx->ws[which];
+    return SPA_OK;
+}
+
+extern "C" int spa_status(spa_ctx *ctx, uint32_t *status_host, void *stream)
+{
+    SPA_ARG(ctx && status_host);
+    hipStream_t s = spa_stream(stream);
+    SPA_HIP(hipMemcpyAsync(status_host, ctx->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    SPA_HIP(hipMemsetAsync(ctx->d_status, 0, sizeof(uint32_t), s));
+    SPA_HIP(hipStreamSynchronize(s));
+    return SPA_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// skimage.util.regular_grid((1, H, W), n) — host integer/double logic of slic()
+// (skimage/util/_regular_grid.py:61-83; call sites slic_superpixels.py:91 and inside the
+// Cython core).  Returns 0 or -1 where the Python code raises.
+// ---------------------------------------------------------------------------------------
+static int regular_grid_1hw(int64_t H, int64_t W, int64_t n_points, int64_t start[3],
+                            int64_t step[3], int has_step[3])
+{
+    int64_t shape[3] = {1, H, W};
+    int order[3] = {0, 1, 2};
+    for (int i = 1; i < 3; ++i) {   // stable argsort of three values
+        int o = order[i], j = i - 1;
+        while (j >= 0 && shape[order[j]] > shape[o]) { order[j + 1] = order[j]; --j; }
+        order[j + 1] = o;
+    }
+    double sorted[3];
+    for (int i = 0; i < 3; ++i) sorted[i] = (double)shape[order[i]];
+    double space = (double)H * (double)W;
+    if (space <= (double)n_points) {
+        for (int i = 0; i < 3; ++i) { start[i] = 0; step[i] = 1; has_step[i] = 0; }
+        return 0;
+    }
+    double ss[3];
+    ss[0] = ss[1] = ss[2] = pow(space / (double)n_points, 1.0 / 3.0);
+    bool small = false;
+    for (int i = 0; i < 3; ++i) small = small || (sorted[i] < ss[i]);
+    if (small) {
+        for (int dim = 0; dim < 3; ++dim) {
+            ss[dim] = sorted[dim];
+            double sp = 1.0;
+            for (int j = dim + 1; j < 3; ++j) sp *= sorted[j];
+            if (dim == 2) return -1;
+            double v = pow(sp / (double)n_points, 1.0 / (double)(2 - dim));
+            for (int j = dim + 1; j < 3; ++j) ss[j] = v;
+            bool ok = true;
+            for (int j = 0; j < 3; ++j) ok = ok && (sorted[j] >= ss[j]);
+            if (ok) break;
+        }
+    }
+    for (int p = 0; p < 3; ++p) {
+        int d = order[p];
+        start[d] = (int64_t)floor(ss[p] / 2.0);
+        step[d] = (int64_t)nearbyint(ss[p]);
+        has_step[d] = 1;
+    }
+    return 0;
+}
+
+static int64_t range_len(int64_t n, int64_t start, int64_t step)
+{
+    return start >= n ? 0 : (n - start + step - 1) / step;
+}
+
+extern "C" int spa_slic_make_plan(int32_t H, int32_t W, int32_t n_segments, spa_slic_plan *plan)
+{
+    SPA_ARG(plan && H > 0 && W > 0 && n_segments > 0);
+    int64_t st[3], sp[3];
+    int has[3];
+    if (regular_grid_1hw(H, W, n_segments, st, sp, has) != 0) {
+        spa_set_error("n_segments=%d too large for a %dx%d image", n_segments, H, W);
+        return SPA_ERR_ARG;
+    }
+    int64_t ny = range_len(H, st[1], sp[1]), nx = range_len(W, st[2], sp[2]);
+    SPA_ARG(ny > 0 && nx > 0);
+    int64_t n = ny * nx;
+    plan->n_centroids = (int32_t)n;
+    plan->grid_ny = (int32_t)ny;
+    plan->grid_nx = (int32_t)nx;
+    plan->start_y = (int32_t)st[1];
+    plan->start_x = (int32_t)st[2];
+    plan->step_y = (int32_t)sp[1];
+    plan->step_x = (int32_t)sp[2];
+    double stmax = 1.0;   // float(s.step) if s.step is not None else 1.0; z step is 1
+    if (has[1] && (double)sp[1] > stmax) stmax = (double)sp[1];
+    if (has[2] && (double)sp[2] > stmax) stmax = (double)sp[2];
+    plan->step = (float)stmax;
+    int64_t st2[3], sp2[3];
+    int has2[3];
+    if (regular_grid_1hw(H, W, n, st2, sp2, has2) != 0) return SPA_ERR_ARG;
+    plan->win_step_y = has2[1] ? (int32_t)sp2[1] : 1;
+    plan->win_step_x = has2[2] ? (int32_t)sp2[2] : 1;
+    double seg = ((double)H * (double)W) / (double)n;
+    plan->min_size = (int32_t)(0.5 * seg);
+    plan->max_size = (int32_t)(3.0 * seg);
+    // every kept component has >= min_size pixels; min_size 0 keeps every component
+    int64_t ml = plan->min_size > 0 ? ((int64_t)H * W) / plan->min_size + 1 : (int64_t)H * W;
+    if (ml > (int64_t)H * W) ml = (int64_t)H * W;
+    plan->max_labels = (int32_t)ml;
+    return SPA_OK;
+}

@@ -1,0 +1,234 @@
+// Per-superpixel statistics: offsets, pixel counts, bounding boxes, centre of mass
+// (scipy.ndimage.center_of_mass, batch_spalign_kmeans.py:229), the location prior
+// (create_prior, :111-129) and rank -> pixel selection for the anchors (:230-234).
+#include "spa_common.h"
+
+__global__ void k_offsets(const int32_t *__restrict__ n_labels, int B, int32_t *__restrict__ offsets)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int run = 0;
+        for (int b = 0; b < B; ++b) { offsets[b] = run; run += n_labels[b]; }
+        offsets[B] = run;
+    }
+}
+
+extern "C" int spa_segment_offsets(spa_ctx *ctx, const int32_t *n_labels, int32_t B,
+                                   int32_t *offsets, void *stream)
+{
+    SPA_ARG(ctx && n_labels && offsets && B > 0);
+    hipLaunchKernelGGL(k_offsets, dim3(1), dim3(64), 0, spa_stream(stream), n_labels, B, offsets);
+    SPA_LAUNCH_CHECK();
+    return SPA_OK;
+}
+
+// bbox layout: (Ncap, 4) int32 {y0, y1 (inclusive), x0, x1 (inclusive)}
+__global__ void k_bbox_init(int32_t *__restrict__ bbox, int32_t *__restrict__ count, int Ncap)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Ncap) return;
+    bbox[i * 4 + 0] = 0x7fffffff; bbox[i * 4 + 1] = -1;
+    bbox[i * 4 + 2] = 0x7fffffff; bbox[i * 4 + 3] = -1;
+    count[i] = 0;
+}
+
+// pixel-major pass: counts and bounding boxes, one atomic set per distinct label per wave
+__global__ __launch_bounds__(256) void k_bbox_count(const int32_t *__restrict__ labels, int W,
+                                                    int npix, const int32_t *__restrict__ offsets,
+                                                    int Ncap, int32_t *__restrict__ bbox,
+                                                    int32_t *__restrict__ count,
+                                                    uint32_t *__restrict__ status)
+{
+    const int b = blockIdx.y;
+    const int off = offsets[b], S = offsets[b + 1] - off;
+    const int lane = threadIdx.x & 63;
+    for (int p0 = blockIdx.x * 256; p0 < npix; p0 += gridDim.x * 256) {
+        const int p = p0 + threadIdx.x;
+        int l = -1, y = 0, x = 0;
+        if (p < npix) {
+            l = labels[(long long)b * npix + p];
+            y = p / W; x = p - y * W;
+            if (l < 0 || l >= S || off + l >= Ncap) { atomicOr(status, SPA_ST_LABEL_RANGE); l = -1; }
+        }
+        unsigned long long todo = __ballot(l >= 0);
+        while (todo) {
+            int leader = __ffsll((long long)todo) - 1;
+            int ll = __shfl(l, leader);
+            unsigned long long same = __ballot(l == ll);
+            int first = leader, last = 63 - __clzll((long long)same);
+            int yf = __shfl(y, first), yl = __shfl(y, last);
+            // lanes are consecutive pixels: y is monotone; x is monotone inside one row
+            int xmin = x, xmax = x;
+            if (yf != yl) {
+                bool mine = (l == ll);
+                int a = mine ? x : 0x7fffffff, c = mine ? x : -1;
+                for (int o = 32; o > 0; o >>= 1) { a = min(a, __shfl_xor(a, o)); c = max(c, __shfl_xor(c, o)); }
+                xmin = a; xmax = c;
+            } else {
+                xmin = __shfl(x, first); xmax = __shfl(x, last);
+            }
+            if (lane == leader) {
+                int g = off + ll;
+                atomicAdd(count + g, __popcll(same));
+                atomicMin(bbox + g * 4 + 0, yf); atomicMax(bbox + g * 4 + 1, yl);
+                atomicMin(bbox + g * 4 + 2, xmin); atomicMax(bbox + g * 4 + 3, xmax);
+            }
+            todo &= ~same;
+        }
+    }
+}
+
+__device__ __forceinline__ int seg_image(const int32_t *offsets, int B, int g)
+{
+    int b = 0;
+    while (b + 1 < B && offsets[b + 1] <= g) ++b;
+    return b;
+}
+
+// segment-major pass over the bounding box: exact integer coordinate sums (-> centre of
+// mass) and the mean of the Gaussian location prior, summed in a fixed order.
+__global__ __launch_bounds__(256) void k_seg_moments(const int32_t *__restrict__ labels, int B,
+                                                     int H, int W,
+                                                     const int32_t *__restrict__ offsets,
+                                                     const int32_t *__restrict__ bbox,
+                                                     const int32_t *__restrict__ count,
+                                                     double ymean, double xmean, double dy2,
+                                                     double dx2, double *__restrict__ centroid,
+                                                     double *__restrict__ prior)
+{
+    __shared__ unsigned long long s_sy[4], s_sx[4];
+    __shared__ double s_pw[4];
+    const int g = blockIdx.x;
+    if (g >= offsets[B]) return;
+    const int b = seg_image(offsets, B, g);
+    const int s = g - offsets[b];
+    const int y0 = bbox[g * 4 + 0], y1 = bbox[g * 4 + 1], x0 = bbox[g * 4 + 2], x1 = bbox[g * 4 + 3];
+    const int n = count[g];
+    unsigned long long sy = 0, sx = 0;
+    double pw = 0.0;
+    if (n > 0) {
+        const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
+        const int32_t *L = labels + (long long)b * H * W;
+        const long long total = (long long)bw * bh;
+        for (long long i = threadIdx.x; i < total; i += 256) {
+            int yy = y0 + (int)(i / bw), xx = x0 + (int)(i % bw);
+            if (L[(long long)yy * W + xx] == s) {
+                sy += (unsigned)yy; sx += (unsigned)xx;
+                if (prior) {
+                    double ty = ((double)yy - ymean) * ((double)yy - ymean) / dy2;
+                    double tx = ((double)xx - xmean) * ((double)xx - xmean) / dx2;
+                    pw += spa_det_exp(-(ty + tx));
+                }
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        sy += __shfl_down(sy, o); sx += __shfl_down(sx, o); pw += __shfl_down(pw, o);
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { s_sy[wv] = sy; s_sx[wv] = sx; s_pw[wv] = pw; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long ty = s_sy[0] + s_sy[1] + s_sy[2] + s_sy[3];
+        unsigned long long tx = s_sx[0] + s_sx[1] + s_sx[2] + s_sx[3];
+        double tp = ((s_pw[0] + s_pw[1]) + s_pw[2]) + s_pw[3];
+        if (centroid) {
+            centroid[(long long)g * 2 + 0] = (double)ty / (double)n;
+            centroid[(long long)g * 2 + 1] = (double)tx / (double)n;
+        }
+        if (prior) prior[g] = tp / (double)n;
+    }
+}
+
+extern "C" int spa_segment_stats(spa_ctx *ctx, const int32_t *labels, int32_t B, int32_t H,
+                                 int32_t W, const int32_t *offsets, int32_t Ncap,
+                                 double y_rel_pos, double x_rel_pos, double y_rel_sigma,
+                                 double x_rel_sigma, int32_t *count, double *centroid,
+                                 double *prior, void *stream)
+{
+    SPA_ARG(ctx && labels && offsets && count && B > 0 && Ncap > 0);
+    hipStream_t s = spa_stream(stream);
+    int32_t *bbox;
+    int rc = spa_ws_reserve(ctx, WS_BBOX, (size_t)Ncap * 16, (void **)&bbox);
+    if (rc != SPA_OK) return rc;
+    const int npix = H * W;
+    hipLaunchKernelGGL(k_bbox_init, dim3((Ncap + 255) / 256), dim3(256), 0, s, bbox, count, Ncap);
+    int gx = (npix + 255) / 256;
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(k_bbox_count, dim3(gx, B), dim3(256), 0, s, labels, W, npix, offsets, Ncap,
+                       bbox, count, ctx->d_status);
+    if (centroid || prior) {
+        // ymean, xmean = int(h * y_rel_pos), int(w * x_rel_pos); sigma = h * rel_sigma (:116-118)
+        double ymean = (double)(long long)((double)H * y_rel_pos);
+        double xmean = (double)(long long)((double)W * x_rel_pos);
+        double ys = (double)H * y_rel_sigma, xs = (double)W * x_rel_sigma;
+        double dy2 = (2.0 * ys) * (2.0 * ys), dx2 = (2.0 * xs) * (2.0 * xs);
+        hipLaunchKernelGGL(k_seg_moments, dim3(Ncap), dim3(256), 0, s, labels, B, H, W, offsets,
+                           bbox, count, ymean, xmean, dy2, dx2, centroid, prior);
+    }
+    SPA_LAUNCH_CHECK();
+    return SPA_OK;
+}
+
+// rank -> pixel: one wavefront per superpixel walks its bounding box in raster order
+__global__ __launch_bounds__(64) void k_select_pixels(const int32_t *__restrict__ labels, int B,
+                                                      int H, int W,
+                                                      const int32_t *__restrict__ offsets,
+                                                      const int32_t *__restrict__ bbox,
+                                                      const int32_t *__restrict__ ranks,
+                                                      const int32_t *__restrict__ n_valid, int A,
+                                                      int32_t *__restrict__ anchors)
+{
+    const int g = blockIdx.x;
+    if (g >= offsets[B]) return;
+    const int lane = threadIdx.x;
+    const int b = seg_image(offsets, B, g);
+    const int s = g - offsets[b];
+    const int nv = min(n_valid[g], A);
+    if (nv <= 0) return;
+    const int y0 = bbox[g * 4 + 0], y1 = bbox[g * 4 + 1], x0 = bbox[g * 4 + 2], x1 = bbox[g * 4 + 3];
+    if (y1 < y0) return;
+    // lane a holds the a-th requested rank
+    const int myrank = lane < nv ? ranks[(long long)g * A + lane] : 0x7fffffff;
+    int lo = 0x7fffffff, hi = -1;
+    {
+        int a = myrank, c = lane < nv ? myrank : -1;
+        for (int o = 32; o > 0; o >>= 1) { a = min(a, __shfl_xor(a, o)); c = max(c, __shfl_xor(c, o)); }
+        lo = a; hi = c;
+    }
+    const int32_t *L = labels + (long long)b * H * W;
+    int run = 0;
+    for (int y = y0; y <= y1 && run <= hi; ++y) {
+        for (int xb = x0; xb <= x1; xb += 64) {
+            int x = xb + lane;
+            bool match = (x <= x1) && (L[(long long)y * W + x] == s);
+            unsigned long long m = __ballot(match);
+            int c = __popcll(m);
+            if (c && run + c > lo) {
+                int r = run + (int)spa_rank_in_mask(m);       // rank of this lane's pixel
+                for (int a = 0; a < nv; ++a) {
+                    int want = __shfl(myrank, a);
+                    if (match && r == want) {
+                        anchors[((long long)g * A + a) * 2 + 0] = y;
+                        anchors[((long long)g * A + a) * 2 + 1] = x;
+                    }
+                }
+            }
+            run += c;
+        }
+    }
+}
+
+extern "C" int spa_select_anchor_pixels(spa_ctx *ctx, const int32_t *labels, int32_t B, int32_t H,
+                                        int32_t W, const int32_t *offsets, int32_t Ncap,
+                                        const int32_t *ranks, const int32_t *n_valid,
+                                        int32_t n_anchors, int32_t *anchors, void *stream)
+{
+    SPA_ARG(ctx && labels && offsets && ranks && n_valid && anchors);
+    SPA_ARG(n_anchors > 0 && n_anchors <= 64 && Ncap > 0);
+    SPA_ARG(ctx->ws[WS_BBOX] != nullptr && ctx->ws_bytes[WS_BBOX] >= (size_t)Ncap * 16);
+    hipLaunchKernelGGL(k_select_pixels, dim3(Ncap), dim3(64), 0, spa_stream(stream), labels, B, H,
+                       W, offsets, (const int32_t *)ctx->ws[WS_BBOX], ranks, n_valid, n_anchors,
+                       anchors);
+    SPA_LAUNCH_CHECK();
+    return SPA_OK;
+}

@@ -1,0 +1,280 @@
+"""Dilated Residual Network feature extractor for the label-generation path (PyTorch-ROCm).
+
+Role in the hot path: `model.batch_predict(imgs)` -> 8 intermediate maps, of which the caller
+keeps `maps[i] for i in --use_feature_maps` (default [7] = layer8, 512 x H/8 x W/8)
+(reference: batch_spalign_kmeans.py:431-435, models/drn.py:230-325).
+
+What is kept from the reference, because results depend on it
+  * architecture C-26 (the reference's create_model, batch_spalign_kmeans.py:524-526) and
+    D-22 (BASELINE north star); layer plan [1,1,2,2,2,2,1,1], channels 16..512, dilations
+    2 (layer5) / 4 (layer6) / 2 (layer7) / 1 (layer8), layer7/8 of arch C without residual
+    (models/drn.py:158-165), arch D plain conv stacks for layers 1,2,7,8 (:134-145,166-170);
+  * the map list uses the CHAINER convention: maps[i] is the output of layer(i+1) for both
+    archs — Chainer's arch D does not export layer0 (models/drn.py:238-243) although the
+    PyTorch file does (models/drn_pytorch.py:216-218);
+  * BatchNorm eps 2e-5: load_npz into a fresh Chainer model restores parameters and running
+    statistics only, so the published labels were produced with Chainer's default eps, not the
+    1e-5 of the PyTorch checkpoint;
+  * input normalisation arithmetic of DRN.batch_predict (models/drn.py:319-321): x/255 in
+    float32, then (x - mean) and (x / std) evaluated in float64 and stored as float32.
+
+What is designed for MI355X instead of translated
+  * inference only: BatchNorm is folded into the preceding convolution at load time
+    (`fold_bn=True`), halving the number of memory-bound elementwise passes over the
+    16..512-channel full-resolution activations; the unused 1x1 `fc` head
+    (models/drn.py:275-276, discarded at batch_spalign_kmeans.py:431) is not evaluated;
+  * activations are kept channels-last (NHWC) end to end: that is MIOpen's preferred layout
+    for the MFMA implicit-GEMM kernels and it is exactly the layout the pooling kernels of
+    libspalign want (C contiguous per feature pixel), so no transpose separates the two;
+  * optional bfloat16 execution (`dtype=torch.bfloat16`, BASELINE config 5) with float32
+    accumulation inside the convolutions; the pooling kernels read bf16 directly.
+Module names follow the upstream checkpoint (conv1/bn1/layerN.M.convK/downsample.0|1/fc) so
+`drn_c_26-ddedf421.pth` / `drn_d_22-4bd2f8ea.pth` load with load_state_dict, and
+`models/drn_c_26.npz` (Chainer) loads through `load_chainer_npz`.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+CHAINER_BN_EPS = 2e-5
+
+_PLANS = {
+    # name: (arch, blocks per layer)
+    'drn_c_26': ('C', (1, 1, 2, 2, 2, 2, 1, 1)),
+    'drn_d_22': ('D', (1, 1, 2, 2, 2, 2, 1, 1)),
+}
+_CHANNELS = (16, 32, 64, 128, 256, 512, 512, 512)
+
+
+def _conv(cin, cout, k, stride=1, dilation=1):
+    pad = dilation * (k // 2)
+    return nn.Conv2d(cin, cout, k, stride=stride, padding=pad, dilation=dilation, bias=False)
+
+
+class BasicBlock(nn.Module):
+    """conv-bn-relu-conv-bn (+ residual) - relu; `residual=False` for layers 7/8 of arch C."""
+
+    def __init__(self, cin, cout, stride, dilation, residual, eps, project):
+        super().__init__()
+        self.conv1 = _conv(cin, cout, 3, stride, dilation[0])
+        self.bn1 = nn.BatchNorm2d(cout, eps=eps)
+        self.conv2 = _conv(cout, cout, 3, 1, dilation[1])
+        self.bn2 = nn.BatchNorm2d(cout, eps=eps)
+        self.downsample = None
+        if project:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride=stride, bias=False),
+                                            nn.BatchNorm2d(cout, eps=eps))
+        self.residual = residual
+
+    def forward(self, x):
+        y = F.relu_(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        if self.residual:
+            y = y + (x if self.downsample is None else self.downsample(x))
+        return F.relu_(y)
+
+
+class DRN(nn.Module):
+    def __init__(self, name='drn_c_26', bn_eps=CHAINER_BN_EPS, num_classes=1000, with_fc=False):
+        super().__init__()
+        arch, plan = _PLANS[name]
+        self.name, self.arch = name, arch
+        ch = _CHANNELS
+        self._cin = ch[0]
+        eps = bn_eps
+        stem = [_conv(3, ch[0], 7), nn.BatchNorm2d(ch[0], eps=eps)]
+        if arch == 'C':
+            self.conv1, self.bn1 = stem
+            self.layer1 = self._blocks(ch[0], plan[0], 1, 1, True, True, eps)
+            self.layer2 = self._blocks(ch[1], plan[1], 2, 1, True, True, eps)
+        else:
+            self.layer0 = nn.Sequential(*stem, nn.ReLU(inplace=True))
+            self.layer1 = self._plain(ch[0], plan[0], 1, 1, eps)
+            self.layer2 = self._plain(ch[1], plan[1], 2, 1, eps)
+        self.layer3 = self._blocks(ch[2], plan[2], 2, 1, True, True, eps)
+        self.layer4 = self._blocks(ch[3], plan[3], 2, 1, True, True, eps)
+        self.layer5 = self._blocks(ch[4], plan[4], 1, 2, False, True, eps)
+        self.layer6 = self._blocks(ch[5], plan[5], 1, 4, False, True, eps)
+        if arch == 'C':
+            self.layer7 = self._blocks(ch[6], plan[6], 1, 2, False, False, eps)
+            self.layer8 = self._blocks(ch[7], plan[7], 1, 1, False, False, eps)
+        else:
+            self.layer7 = self._plain(ch[6], plan[6], 1, 2, eps)
+            self.layer8 = self._plain(ch[7], plan[7], 1, 1, eps)
+        self.fc = nn.Conv2d(ch[7], num_classes, 1) if with_fc else None
+        self.folded = False
+        self.compute_dtype = torch.float32
+        for m in self.modules():           # the reference's random init (models/drn.py:176-184)
+            if isinstance(m, nn.Conv2d):
+                n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+                m.weight.data.normal_(0, math.sqrt(2.0 / n))
+        self.eval()
+
+    # -- builders --------------------------------------------------------------------------
+    def _blocks(self, cout, count, stride, dilation, new_level, residual, eps):
+        cin = self._cin
+        project = stride != 1 or cin != cout
+        first = (1, 1) if dilation == 1 else ((dilation // 2 if new_level else dilation), dilation)
+        mods = [BasicBlock(cin, cout, stride, first, residual, eps, project)]
+        for _ in range(1, count):
+            mods.append(BasicBlock(cout, cout, 1, (dilation, dilation), residual, eps, False))
+        self._cin = cout
+        return nn.Sequential(*mods)
+
+    def _plain(self, cout, count, stride, dilation, eps):
+        mods = []
+        for i in range(count):
+            mods += [_conv(self._cin, cout, 3, stride if i == 0 else 1, dilation),
+                     nn.BatchNorm2d(cout, eps=eps), nn.ReLU(inplace=True)]
+            self._cin = cout
+        return nn.Sequential(*mods)
+
+    # -- inference-time transformations ---------------------------------------------------------
+    @torch.no_grad()
+    def fold_batchnorm(self):
+        """Fold every BatchNorm into the convolution in front of it (eval-mode identity)."""
+        def fold(conv, bn):
+            scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+            conv.weight.mul_(scale.reshape(-1, 1, 1, 1))
+            bias = bn.bias - bn.running_mean * scale
+            conv.bias = nn.Parameter(bias if conv.bias is None else conv.bias * scale + bias)
+            return nn.Identity()
+
+        def walk(seq):
+            mods = list(seq.children())
+            for i, m in enumerate(mods[:-1]):
+                if isinstance(m, nn.Conv2d) and isinstance(mods[i + 1], nn.BatchNorm2d):
+                    seq[i + 1] = fold(m, mods[i + 1])
+        if self.folded:
+            return self
+        if self.arch == 'C':
+            self.bn1 = fold(self.conv1, self.bn1)
+        for m in self.modules():
+            if isinstance(m, BasicBlock):
+                m.bn1 = fold(m.conv1, m.bn1)
+                m.bn2 = fold(m.conv2, m.bn2)
+                if m.downsample is not None:
+                    walk(m.downsample)
+            elif isinstance(m, nn.Sequential):
+                walk(m)
+        self.folded = True
+        return self
+
+    def prepare(self, device='cuda', dtype=torch.float32, fold_bn=True):
+        """Move to the GPU in the layout/dtype the hot path runs in."""
+        if fold_bn:
+            self.fold_batchnorm()
+        self.compute_dtype = dtype
+        self.to(device=device, dtype=dtype, memory_format=torch.channels_last)
+        self.eval()
+        return self
+
+    # -- forward ---------------------------------------------------------------------------------
+    def forward_maps(self, x):
+        """x: normalised (B,3,H,W). Returns the 8 maps of the Chainer convention."""
+        if self.arch == 'C':
+            x = F.relu_(self.bn1(self.conv1(x)))
+        else:
+            x = self.layer0(x)
+        maps = []
+        for i in range(1, 9):
+            x = getattr(self, 'layer%d' % i)(x)
+            maps.append(x)
+        return maps
+
+    def forward(self, x):
+        maps = self.forward_maps(x)
+        return (self.fc(maps[-1]) if self.fc is not None else None), maps
+
+    @staticmethod
+    def normalise(x):
+        """DRN.batch_predict arithmetic (models/drn.py:319-321) without touching the input."""
+        mean = torch.tensor(IMAGENET_MEAN, dtype=torch.float64, device=x.device).view(1, 3, 1, 1)
+        std = torch.tensor(IMAGENET_STD, dtype=torch.float64, device=x.device).view(1, 3, 1, 1)
+        x = x / 255.0
+        x = (x.double() - mean).float()
+        x = (x.double() / std).float()
+        return x
+
+    @torch.no_grad()
+    def batch_predict(self, x, sub_batch=None):
+        """x: (B,3,H,W) float32 RGB 0..255 (numpy or tensor). -> (logits or None, [8 maps]).
+
+        Unlike the reference's --gpu -1 path the input array is never modified (the GPU path
+        of the reference copies it too, which is the behaviour the launchers rely on)."""
+        dev = next(self.parameters()).device
+        x = torch.as_tensor(x)
+        if x.device != dev:
+            x = x.to(dev, non_blocking=True)
+        assert x.ndim == 4 and x.shape[1] == 3
+        B = x.shape[0]
+        sub = B if not sub_batch else sub_batch
+        outs = None
+        for s in range(0, B, sub):
+            xi = self.normalise(x[s:s + sub].float())
+            xi = xi.to(self.compute_dtype).contiguous(memory_format=torch.channels_last)
+            _, maps = self.forward(xi)
+            if outs is None:
+                outs = [[m] for m in maps]
+            else:
+                for o, m in zip(outs, maps):
+                    o.append(m)
+        maps = [o[0] if len(o) == 1 else torch.cat(o, 0) for o in outs]
+        return None, maps
+
+    class _XP(object):
+        """`model.xp` of the reference API (utils/apply_spalign_kmeans.py:30)."""
+        @staticmethod
+        def asarray(a):
+            return torch.as_tensor(a)
+
+    xp = _XP()
+
+    # -- weights ---------------------------------------------------------------------------------
+    def load_pth(self, path):
+        sd = torch.load(path, map_location='cpu')
+        sd = {k: v for k, v in sd.items() if self.fc is not None or not k.startswith('fc.')}
+        self.load_state_dict(sd, strict=True)
+        return self
+
+    def load_chainer_npz(self, path):
+        """models/drn_c_26.npz written by the reference's convert_pth2ch.py (chainer save_npz)."""
+        rename = {'W': 'weight', 'b': 'bias', 'gamma': 'weight', 'beta': 'bias',
+                  'avg_mean': 'running_mean', 'avg_var': 'running_var'}
+        own = self.state_dict()
+        with np.load(path) as z:
+            for key in z.files:
+                parts = key.split('/')
+                if parts[-1] == 'N' or (parts[0] == 'fc' and self.fc is None):
+                    continue
+                name = '.'.join(parts[:-1] + [rename[parts[-1]]])
+                if name not in own:
+                    raise KeyError('unexpected entry %s in %s' % (key, path))
+                own[name].copy_(torch.from_numpy(z[key]).reshape(own[name].shape))
+        return self
+
+
+def flops_per_image(name, H, W):
+    """2*MACs of the convolutions (fc excluded) — BASELINE.md section 3."""
+    per_full = {'drn_c_26': 1418.6e9, 'drn_d_22': 1089.5e9}[name]
+    return per_full * (H * W) / (1024.0 * 2048.0)
+
+
+def create_drn(name='drn_c_26', weights=None, device='cuda', dtype=torch.float32, fold_bn=True,
+               bn_eps=CHAINER_BN_EPS, seed=0):
+    """Factory behind create_model(): random init (seeded) unless a weight file is given."""
+    gen_state = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    model = DRN(name, bn_eps=bn_eps)
+    torch.random.set_rng_state(gen_state)
+    if weights:
+        if weights.endswith('.npz'):
+            model.load_chainer_npz(weights)
+        else:
+            model.load_pth(weights)
+    return model.prepare(device, dtype, fold_bn)

@@ -1,0 +1,269 @@
+"""Device-level front end: torch tensors in, torch tensors out, every call a C-ABI call.
+
+PyTorch is used here only for device memory and streams (the plumbing); the arithmetic of
+every method below runs in libspalign.so (hand-written HIP for gfx950).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import FmapDesc, SpalignError, check
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t, dtype, what):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+        raise SpalignError('%s must be a contiguous CUDA tensor of dtype %s' % (what, dtype))
+    return t
+
+
+class Engine(object):
+    """One spa_ctx (one GPU). Not thread safe; make one per process/GPU."""
+
+    def __init__(self, device=None):
+        if not torch.cuda.is_available():
+            raise SpalignError('no GPU visible: the superpixel-align hot path has no CPU fallback')
+        self.device = torch.device('cuda', torch.cuda.current_device() if device is None else device)
+        self._lib = _lib.lib()
+        h = ctypes.c_void_p()
+        check(self._lib.spa_ctx_create(self.device.index, ctypes.byref(h)))
+        self._ctx = h
+
+    def close(self):
+        if getattr(self, '_ctx', None):
+            self._lib.spa_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ status
+    def status(self):
+        """Read and clear the latched device status bits (synchronises the stream)."""
+        v = ctypes.c_uint32(0)
+        check(self._lib.spa_status(self._ctx, ctypes.byref(v), _stream()))
+        return v.value
+
+    def raise_on_status(self, ignore=0):
+        st = self.status() & ~ignore
+        if st:
+            msgs = [m for bit, m in _lib.STATUS_BITS.items() if st & bit]
+            raise SpalignError('device status 0x%x: %s' % (st, '; '.join(msgs)))
+
+    # ------------------------------------------------------------------ SLIC
+    def rgb2lab(self, rgb, ratio=0.1):
+        rgb = _req(rgb, torch.float32, 'rgb')
+        B, C, H, W = rgb.shape
+        assert C == 3
+        lab = torch.empty_like(rgb)
+        check(self._lib.spa_rgb2lab(self._ctx, _ptr(rgb), B, H, W, ratio, _ptr(lab), _stream()))
+        return lab
+
+    def slic_core(self, lab, n_segments, max_iter=10, want_centres=False):
+        lab = _req(lab, torch.float32, 'lab')
+        B, C, H, W = lab.shape
+        assert C == 3
+        labels = torch.empty((B, H, W), dtype=torch.int32, device=lab.device)
+        centres = None
+        if want_centres:
+            nC = _lib.make_plan(H, W, n_segments).n_centroids
+            centres = torch.empty((B, nC, 6), dtype=torch.float32, device=lab.device)
+        check(self._lib.spa_slic_core(self._ctx, _ptr(lab), B, H, W, n_segments, max_iter,
+                                      _ptr(labels), _ptr(centres), _stream()))
+        return (labels, centres) if want_centres else labels
+
+    def enforce_connectivity(self, labels, min_size, max_size):
+        labels = _req(labels, torch.int32, 'labels')
+        B, H, W = labels.shape
+        out = torch.empty_like(labels)
+        n_labels = torch.empty((B,), dtype=torch.int32, device=labels.device)
+        check(self._lib.spa_enforce_connectivity(self._ctx, _ptr(labels), B, H, W, min_size, max_size,
+                                                 _ptr(out), _ptr(n_labels), _stream()))
+        return out, n_labels
+
+    def slic(self, rgb, n_segments, compactness=10.0, max_iter=10):
+        """slic(img, n_segments) for a batch: (B,3,H,W) f32 0..255 -> labels (B,H,W) i32, n_labels (B)."""
+        rgb = _req(rgb, torch.float32, 'rgb')
+        B, C, H, W = rgb.shape
+        assert C == 3
+        labels = torch.empty((B, H, W), dtype=torch.int32, device=rgb.device)
+        n_labels = torch.empty((B,), dtype=torch.int32, device=rgb.device)
+        check(self._lib.spa_slic(self._ctx, _ptr(rgb), B, H, W, n_segments, compactness, max_iter,
+                                 _ptr(labels), _ptr(n_labels), _stream()))
+        return labels, n_labels
+
+    # ------------------------------------------------------------------ descriptors
+    def segment_offsets(self, n_labels):
+        n_labels = _req(n_labels, torch.int32, 'n_labels')
+        B = n_labels.numel()
+        off = torch.empty((B + 1,), dtype=torch.int32, device=n_labels.device)
+        check(self._lib.spa_segment_offsets(self._ctx, _ptr(n_labels), B, _ptr(off), _stream()))
+        return off
+
+    def segment_stats(self, labels, offsets, ncap, prior_params=None, want_centroid=True):
+        """-> count (ncap) i32, centroid (ncap,2) f64 or None, prior (ncap) f64 or None."""
+        labels = _req(labels, torch.int32, 'labels')
+        offsets = _req(offsets, torch.int32, 'offsets')
+        B, H, W = labels.shape
+        dev = labels.device
+        count = torch.empty((ncap,), dtype=torch.int32, device=dev)
+        centroid = torch.zeros((ncap, 2), dtype=torch.float64, device=dev) if want_centroid else None
+        prior = torch.zeros((ncap,), dtype=torch.float64, device=dev) if prior_params else None
+        yp, xp, ys, xs = prior_params if prior_params else (0.75, 0.5, 0.1, 0.1)
+        check(self._lib.spa_segment_stats(self._ctx, _ptr(labels), B, H, W, _ptr(offsets), ncap,
+                                          yp, xp, ys, xs, _ptr(count), _ptr(centroid), _ptr(prior),
+                                          _stream()))
+        return count, centroid, prior
+
+    def select_anchor_pixels(self, labels, offsets, ncap, ranks, n_valid):
+        labels = _req(labels, torch.int32, 'labels')
+        ranks = _req(ranks, torch.int32, 'ranks')
+        n_valid = _req(n_valid, torch.int32, 'n_valid')
+        B, H, W = labels.shape
+        A = ranks.shape[1]
+        anchors = torch.zeros((ncap, A, 2), dtype=torch.int32, device=labels.device)
+        check(self._lib.spa_select_anchor_pixels(self._ctx, _ptr(labels), B, H, W, _ptr(offsets), ncap,
+                                                 _ptr(ranks), _ptr(n_valid), A, _ptr(anchors),
+                                                 _stream()))
+        return anchors
+
+    @staticmethod
+    def fmap_desc(fmap):
+        """fmap: (B, C, fh, fw) tensor in channels_last memory format (float32 or bfloat16)."""
+        if fmap.dtype not in (torch.float32, torch.bfloat16):
+            raise SpalignError('feature map dtype must be float32 or bfloat16')
+        B, C, fh, fw = fmap.shape
+        sb, sc, sy, sx = fmap.stride()
+        return FmapDesc(C, fh, fw, sb, sc, sy, sx, 0 if fmap.dtype == torch.float32 else 1)
+
+    @staticmethod
+    def as_channels_last(fmap):
+        """NCHW-shaped tensor stored NHWC; a no-op for the DRN module of this package."""
+        if fmap.stride(1) == 1 and fmap.is_contiguous(memory_format=torch.channels_last):
+            return fmap
+        return fmap.contiguous(memory_format=torch.channels_last)
+
+    def _new_x(self, ncap, C, append_pos, x_dtype, dev):
+        D = C + (2 if append_pos else 0)
+        return torch.zeros((ncap, D), dtype=x_dtype, device=dev), D
+
+    def pool_anchor(self, fmap, img_h, offsets, ncap, anchors, n_valid, n_neighbors=4,
+                    centroid=None, append_pos=True):
+        fmap = self.as_channels_last(fmap)
+        d = self.fmap_desc(fmap)
+        B = fmap.shape[0]
+        x_dtype = torch.float64 if append_pos else torch.float32
+        X, D = self._new_x(ncap, d.C, append_pos, x_dtype, fmap.device)
+        A = anchors.shape[1]
+        check(self._lib.spa_pool_anchor(self._ctx, _ptr(fmap), ctypes.byref(d), B, img_h,
+                                        _ptr(offsets), ncap, _ptr(anchors), _ptr(n_valid), A,
+                                        n_neighbors, _ptr(centroid), 1 if append_pos else 0, _ptr(X),
+                                        1 if append_pos else 0, D, _stream()))
+        return X
+
+    def pool_mean(self, fmap, labels, offsets, ncap, count, sampling='nearest', centroid=None,
+                  append_pos=True):
+        fmap = self.as_channels_last(fmap)
+        d = self.fmap_desc(fmap)
+        B, H, W = labels.shape
+        x_dtype = torch.float64 if append_pos else torch.float32
+        X, D = self._new_x(ncap, d.C, append_pos, x_dtype, fmap.device)
+        check(self._lib.spa_pool_mean(self._ctx, _ptr(fmap), ctypes.byref(d), _ptr(labels), B, H, W,
+                                      _ptr(offsets), ncap, _ptr(count),
+                                      {'nearest': 0, 'bilinear': 1}[sampling], _ptr(centroid),
+                                      1 if append_pos else 0, _ptr(X), 1 if append_pos else 0, D,
+                                      _stream()))
+        return X
+
+    # ------------------------------------------------------------------ k-means + paint
+    def kmeans(self, X, w, n_ptr, k, max_iter=1000, init_other=None):
+        """-> assign (ncap) i32, info (4) i32 {iterations, status, N, -} (both on the device)."""
+        if X.dtype not in (torch.float32, torch.float64) or not X.is_contiguous():
+            raise SpalignError('X must be contiguous float32/float64')
+        w = _req(w, torch.float64, 'weights')
+        ncap, D = X.shape
+        assign = torch.zeros((ncap,), dtype=torch.int32, device=X.device)
+        info = torch.zeros((4,), dtype=torch.int32, device=X.device)
+        check(self._lib.spa_kmeans_weighted(self._ctx, _ptr(X), 0 if X.dtype == torch.float32 else 1,
+                                            D, D, _ptr(w), _ptr(n_ptr), ncap, k, max_iter,
+                                            _ptr(init_other), _ptr(assign), _ptr(info), _stream()))
+        return assign, info
+
+    def paint(self, labels, assign, offsets):
+        labels = _req(labels, torch.int32, 'labels')
+        B, H, W = labels.shape
+        cluster = torch.empty((B, H, W), dtype=torch.uint8, device=labels.device)
+        road = torch.empty((B, H, W), dtype=torch.uint8, device=labels.device)
+        check(self._lib.spa_paint(self._ctx, _ptr(labels), _ptr(assign), _ptr(offsets), B, H, W,
+                                  _ptr(cluster), _ptr(road), _stream()))
+        return cluster, road
+
+    def confusion(self, road, gt):
+        """road (B,H,W) u8, gt (B,H,W) i32 in {-1,0,1} -> (B,4) i64 {TN, FP, FN, TP}."""
+        road = _req(road, torch.uint8, 'road')
+        gt = _req(gt, torch.int32, 'gt')
+        B = road.shape[0]
+        out = torch.zeros((B, 4), dtype=torch.int64, device=road.device)
+        check(self._lib.spa_confusion(self._ctx, _ptr(road), _ptr(gt), B, road[0].numel(), _ptr(out),
+                                      _stream()))
+        return out
+
+
+class PyRandom(object):
+    """CPython `random` stream (random.seed(1111); random.shuffle), host side."""
+
+    def __init__(self, seed=1111):
+        self._lib = _lib.lib()
+        h = ctypes.c_void_p()
+        check(self._lib.spa_pyrandom_create(seed, ctypes.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        try:
+            self._lib.spa_pyrandom_destroy(self._h)
+        except Exception:
+            pass
+
+    def shuffle_select(self, counts, n_anchors):
+        """counts: int32 numpy (N,) -> ranks (N, n_anchors) int32, n_valid (N,) int32."""
+        counts = np.ascontiguousarray(counts, dtype=np.int32)
+        N = counts.size
+        ranks = np.zeros((N, n_anchors), np.int32)
+        n_valid = np.zeros((N,), np.int32)
+        check(self._lib.spa_pyrandom_shuffle_select_host(
+            self._h, counts.ctypes.data_as(ctypes.c_void_p), N, n_anchors,
+            ranks.ctypes.data_as(ctypes.c_void_p), n_valid.ctypes.data_as(ctypes.c_void_p)))
+        return ranks, n_valid
+
+
+class NpRandom(object):
+    """numpy legacy global RandomState stream (np.random.seed(1111); np.random.shuffle)."""
+
+    def __init__(self, seed=1111):
+        self._lib = _lib.lib()
+        h = ctypes.c_void_p()
+        check(self._lib.spa_nprandom_create(seed, ctypes.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        try:
+            self._lib.spa_nprandom_destroy(self._h)
+        except Exception:
+            pass
+
+    def shuffle(self, a):
+        assert a.dtype == np.int64 and a.flags.c_contiguous
+        check(self._lib.spa_nprandom_shuffle_host(self._h, a.ctypes.data_as(ctypes.c_void_p), a.size))
+        return a

@@ -1,0 +1,288 @@
+"""GPU parity tests proper: every op of the hot path, called through the C ABI
+(libspalign.so via superpixel-align_amd/engine.py), against the CPU oracle on the same seeded
+inputs and against the golden vectors generated from the reference.
+
+Bar: bit exact for every integer output (labels, counts, assignments, masks, confusion) and
+for the float32 stages whose arithmetic order is pinned (Lab image, SLIC centroids, anchor
+and mean pooling); 1e-12 relative for the float64 prior (different summation order).
+"""
+import importlib
+
+import numpy as np
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+
+@pytest.fixture(scope='module')
+def eng():
+    engine = importlib.import_module('superpixel-align_amd.engine')
+    e = engine.Engine()
+    yield e
+    e.close()
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def test_loaded_native_library(eng, spa):
+    import os
+    assert os.path.exists(spa._lib.LIB_PATH)
+    maps = open('/proc/self/maps').read()
+    assert 'libspalign.so' in maps          # the HIP path is the one that runs
+
+
+@pytest.mark.parametrize('seed,H,W', [(0, 64, 128), (3, 96, 96), (5, 100, 37), (2, 256, 512)])
+def test_rgb2lab_bit_exact(eng, orc, synth, seed, H, W):
+    img = synth.synth_image(seed, H, W)
+    img[:, 0, :5] = 0.0           # linear branch of the sRGB curve and the Lab toe
+    img[:, 1, :5] = 0.03
+    ref = orc.rgb2lab_scaled(img)                                   # (H,W,3)
+    got = eng.rgb2lab(dev(img[None]), 0.1)[0].permute(1, 2, 0).cpu().numpy()
+    assert np.array_equal(got.view(np.int32), ref.view(np.int32))
+
+
+SLIC_CASES = [(0, 64, 128, 20), (1, 128, 256, 100), (3, 96, 96, 30), (5, 100, 37, 12),
+              (4, 224, 224, 100), (2, 256, 512, 100), (7, 61, 83, 9)]
+
+
+@pytest.mark.parametrize('seed,H,W,n', SLIC_CASES)
+def test_slic_core_bit_exact(eng, orc, synth, seed, H, W, n):
+    lab = orc.rgb2lab_scaled(synth.synth_image(seed, H, W))
+    pre, centres = orc.slic_core(lab, n)
+    lab_planar = dev(lab.transpose(2, 0, 1)[None])
+    labels, cen = eng.slic_core(lab_planar, n, 10, want_centres=True)
+    eng.raise_on_status()
+    assert np.array_equal(labels[0].cpu().numpy().astype(np.int64), pre)
+    assert np.array_equal(cen[0].cpu().numpy().view(np.int32), centres.view(np.int32))
+
+
+def test_slic_core_batch_and_golden(eng, orc, synth):
+    """A batch of different images in one call; image 0 is the skimage-pinned fixture."""
+    g = golden('slic_s1_128x256_n100')
+    labs = [orc.rgb2lab_scaled(synth.synth_image(s, 128, 256)) for s in (1, 8, 9)]
+    lab_planar = dev(np.stack([l.transpose(2, 0, 1) for l in labs]))
+    labels = eng.slic_core(lab_planar, 100, 10).cpu().numpy()
+    eng.raise_on_status()
+    assert np.array_equal(labels[0], g['pre'].astype(np.int32))
+    for b in (1, 2):
+        assert np.array_equal(labels[b].astype(np.int64), orc.slic_core(labs[b], 100)[0])
+
+
+@pytest.mark.parametrize('seed,H,W,n', SLIC_CASES)
+def test_connectivity_bit_exact(eng, orc, synth, seed, H, W, n):
+    lab = orc.rgb2lab_scaled(synth.synth_image(seed, H, W))
+    pre, centres = orc.slic_core(lab, n)
+    mn, mx = orc.connectivity_sizes(H, W, centres.shape[0])
+    post, nl = orc.enforce_connectivity(pre, mn, mx)
+    out, n_labels = eng.enforce_connectivity(dev(pre[None], torch.int32), mn, mx)
+    eng.raise_on_status()
+    assert np.array_equal(out[0].cpu().numpy().astype(np.int64), post)
+    assert int(n_labels[0]) == max(nl, 1)
+
+
+@pytest.mark.parametrize('name', ['connectivity_stress_30_200', 'connectivity_stress_8_5000',
+                                  'connectivity_stress_100_400', 'connectivity_stress_1_50'])
+def test_connectivity_stress_golden(eng, orc, name):
+    """Noisy label maps with hundreds of tiny fragments (skimage-pinned). Cases where a
+    component reaches max_size must be reported, not silently mislabelled."""
+    g = golden(name)
+    mn, mx = (int(v) for v in g['meta'])
+    seg = g['seg'].astype(np.int32)
+    out, n_labels = eng.enforce_connectivity(dev(seg[None]), mn, mx)
+    st = eng.status()
+    sizes_ok = not (st & 0x04)
+    if sizes_ok:
+        assert st == 0
+        assert np.array_equal(out[0].cpu().numpy(), g['post'])
+    else:
+        # oracle agrees that some component is at least max_size large
+        from scipy import ndimage
+        big = 0
+        for l in np.unique(seg):
+            cc, k = ndimage.label(seg == l)
+            if k:
+                big = max(big, np.bincount(cc.ravel())[1:].max())
+        assert big >= mx
+
+
+def test_slic_full_1024x2048_golden(eng, orc, synth):
+    """BASELINE size: whole spa_slic call against the skimage-pinned fixture."""
+    g = golden('slic_s0_1024x2048_n200')
+    img = synth.synth_image(0, 1024, 2048)
+    labels, n_labels = eng.slic(dev(img[None]), 200)
+    eng.raise_on_status()
+    assert np.array_equal(labels[0].cpu().numpy(), g['post'].astype(np.int32))
+    assert int(n_labels[0]) == int(g['post'].max()) + 1
+
+
+def test_slic_full_batch_vs_oracle(eng, orc, synth):
+    imgs = synth.synth_batch([11, 12, 13, 14], 192, 320)
+    labels, n_labels = eng.slic(dev(imgs), 60)
+    eng.raise_on_status()
+    for b in range(4):
+        ref = orc.slic(imgs[b], 60)
+        assert np.array_equal(labels[b].cpu().numpy().astype(np.int64), ref)
+        assert int(n_labels[b]) == ref.max() + 1
+
+
+def _batch_labels(orc, synth, seeds, H, W, n):
+    imgs = synth.synth_batch(seeds, H, W)
+    sps = np.stack([orc.slic(im, n) for im in imgs])
+    return imgs, sps
+
+
+def test_segment_stats_and_prior(eng, orc, synth):
+    imgs, sps = _batch_labels(orc, synth, [0, 1, 2], 128, 256, 40)
+    n_per = [int(s.max()) + 1 for s in sps]
+    labels = dev(sps, torch.int32)
+    off = eng.segment_offsets(dev(np.array(n_per, np.int32)))
+    assert off.cpu().tolist() == [0] + list(np.cumsum(n_per))
+    N = sum(n_per)
+    count, centroid, prior = eng.segment_stats(labels, off, N + 3, (0.75, 0.5, 0.1, 0.1))
+    eng.raise_on_status()
+    o = 0
+    for b, S in enumerate(n_per):
+        cnt, cy, cx = orc.segment_stats(sps[b], S)
+        assert np.array_equal(count[o:o + S].cpu().numpy(), cnt)
+        assert np.array_equal(centroid[o:o + S, 0].cpu().numpy(), cy)     # exact integer sums
+        assert np.array_equal(centroid[o:o + S, 1].cpu().numpy(), cx)
+        p = orc.create_prior(sps[b], 0.75, 0.5, 0.1, 0.1, S)
+        np.testing.assert_allclose(prior[o:o + S].cpu().numpy(), p, rtol=1e-12, atol=0)
+        o += S
+
+
+@pytest.mark.parametrize('tag', ['small', 'config1'])
+def test_anchor_pipeline_against_reference_golden(eng, orc, synth, tag):
+    """anchors -> pooled descriptors -> k-means -> paint, all against vectors recorded from the
+    reference's own functions (superpixel_align, kmeans, weighted_kmeans)."""
+    engine = importlib.import_module('superpixel-align_amd.engine')
+    g = golden('pipeline_' + tag)
+    seed, H, W, n, C, B = (int(v) for v in g['meta'])
+    sps = g['superpixels'].astype(np.int32)
+    n_per = [int(v) for v in g['n_per']]
+    N = sum(n_per)
+    fm = synth.synth_feature_map(seed + 1, C, H // 8, W // 8, batch=B)
+    fmap = dev(fm).contiguous(memory_format=torch.channels_last)
+    labels = dev(sps)
+    off = eng.segment_offsets(dev(np.array(n_per, np.int32)))
+    count, centroid, prior = eng.segment_stats(labels, off, N, (0.75, 0.5, 0.1, 0.1))
+    np.testing.assert_allclose(prior.cpu().numpy(), g['prior'], rtol=1e-12, atol=0)
+    # host RNG needs only the counts
+    ranks, n_valid = engine.PyRandom(1111).shuffle_select(count.cpu().numpy(), 10)
+    assert np.array_equal(n_valid, g['n_valid'])
+    anchors = eng.select_anchor_pixels(labels, off, N, dev(ranks), dev(n_valid))
+    assert np.array_equal(anchors.cpu().numpy(), g['anchors'])
+    X = eng.pool_anchor(fmap, H, off, N, anchors, dev(n_valid), 4, centroid, True)
+    assert X.dtype == torch.float64
+    assert np.array_equal(X.cpu().numpy(), g['feats'])                  # bit exact
+    Xn = eng.pool_anchor(fmap, H, off, N, anchors, dev(n_valid), 4, None, False)
+    assert Xn.dtype == torch.float32
+    assert np.array_equal(Xn.cpu().numpy(), g['feats_nopos'])
+    # k-means on the reference's own descriptors and prior
+    Xr, wr = dev(g['feats']), dev(g['prior'])
+    assign, info = eng.kmeans(Xr, wr, off[B:], 2)
+    assert np.array_equal(assign.cpu().numpy(), g['k2_assign'])
+    assert info.cpu().tolist()[1] == 0
+    assign4, _ = eng.kmeans(Xr, wr, off[B:], 4, init_other=dev(g['k4_shuffled_idx']))
+    assert np.array_equal(assign4.cpu().numpy(), g['k4_assign'])
+    # same through the host RNG emulation of np.random.shuffle
+    thr = np.sort(g['prior'])[N // 2]
+    m = int((g['prior'] <= thr).sum())
+    idx = engine.NpRandom(1111).shuffle((np.arange(m) % 3 + 1).astype(np.int64))
+    assert np.array_equal(idx, g['k4_shuffled_idx'])
+    # paint
+    cluster, road = eng.paint(labels, assign, off)
+    eng.raise_on_status()
+    assert np.array_equal(cluster.cpu().numpy(), g['clustering'])
+    assert np.array_equal(road.cpu().numpy(), g['road'])
+
+
+def test_kmeans_engineered(eng, orc):
+    g = golden('kmeans_engineered')
+    X, w = dev(g['X']), dev(g['w'])
+    n = dev(np.array([X.shape[0]], np.int32))
+    a, info = eng.kmeans(X, w, n, 2)
+    assert np.array_equal(a.cpu().numpy(), g['assign'])
+    Xe, we = dev(g['Xe']), dev(g['we'])
+    ne = dev(np.array([Xe.shape[0]], np.int32))
+    ae, info = eng.kmeans(Xe, we, ne, 5, init_other=dev(g['idx_e']))
+    assert np.array_equal(ae.cpu().numpy(), g['assign_e'])
+    ao, it, st = orc.kmeans(5, g['Xe'], g['we'], nprandom=orc.NpRandom(5))
+    assert info.cpu().tolist()[:2] == [it, st]
+    eng.raise_on_status()
+
+
+@pytest.mark.parametrize('sampling', ['nearest', 'bilinear'])
+def test_mean_pool_bit_exact(eng, orc, synth, sampling):
+    imgs, sps = _batch_labels(orc, synth, [4, 5], 128, 256, 40)
+    n_per = [int(s.max()) + 1 for s in sps]
+    N = sum(n_per)
+    C = 96
+    fm = synth.synth_feature_map(9, C, 16, 32, batch=2)
+    fmap = dev(fm).contiguous(memory_format=torch.channels_last)
+    labels = dev(sps, torch.int32)
+    off = eng.segment_offsets(dev(np.array(n_per, np.int32)))
+    count, centroid, _ = eng.segment_stats(labels, off, N)
+    X = eng.pool_mean(fmap, labels, off, N, count, sampling, centroid, True).cpu().numpy()
+    Xn = eng.pool_mean(fmap, labels, off, N, count, sampling, None, False).cpu().numpy()
+    eng.raise_on_status()
+    o = 0
+    for b, S in enumerate(n_per):
+        ref = orc.mean_pool(fm[b], sps[b], sampling, S)
+        assert np.array_equal(Xn[o:o + S].view(np.int32), ref.view(np.int32))
+        assert np.array_equal(X[o:o + S, :C], ref.astype(np.float64))
+        _, cy, cx = orc.segment_stats(sps[b], S)
+        assert np.array_equal(X[o:o + S, C], cy) and np.array_equal(X[o:o + S, C + 1], cx)
+        # and the notebook definition (mean of the upsampled map over the mask), to tolerance
+        if sampling == 'nearest':
+            up = np.repeat(np.repeat(fm[b], 8, axis=1), 8, axis=2)
+            s = S // 2
+            np.testing.assert_allclose(ref[s], up[:, sps[b] == s].mean(axis=1), rtol=1e-4, atol=1e-5)
+        o += S
+
+
+def test_pool_bf16_features(eng, orc, synth):
+    imgs, sps = _batch_labels(orc, synth, [4], 128, 256, 40)
+    S = int(sps[0].max()) + 1
+    fm = synth.synth_feature_map(9, 64, 16, 32, batch=1)
+    fb = dev(fm).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    labels = dev(sps, torch.int32)
+    off = eng.segment_offsets(dev(np.array([S], np.int32)))
+    count, centroid, _ = eng.segment_stats(labels, off, S)
+    X = eng.pool_mean(fb, labels, off, S, count, 'nearest', None, False).cpu().numpy()
+    ref = orc.mean_pool(fb.float().cpu().numpy()[0], sps[0], 'nearest', S)
+    assert np.array_equal(X, ref)
+
+
+def test_layout_error_is_loud(eng, spa):
+    import ctypes
+    L = spa._lib.lib()
+    d = spa._lib.FmapDesc(8, 4, 4, 128, 16, 4, 1, 0)        # NCHW strides
+    rc = L.spa_pool_mean(eng._ctx, 1, ctypes.byref(d), 1, 1, 32, 32, 1, 1, 1, 0, None, 0, 1, 0, 8, None)
+    assert rc in (-1, -4)
+
+
+def test_confusion_exact(eng, orc):
+    rs = np.random.RandomState(0)
+    pred = (rs.uniform(size=(2, 64, 96)) < 0.4).astype(np.uint8)
+    gt = rs.randint(-1, 2, size=(2, 64, 96)).astype(np.int32)
+    out = eng.confusion(dev(pred), dev(gt)).cpu().numpy()
+    for b in range(2):
+        r = orc.confusion(pred[b], gt[b])
+        assert out[b].tolist() == [r['TN'], r['FP'], r['FN'], r['TP']]
+
+
+def test_status_reports_bad_labels(eng):
+    labels = torch.full((1, 16, 16), 5, dtype=torch.int32, device='cuda')
+    off = torch.tensor([0, 2], dtype=torch.int32, device='cuda')
+    eng.segment_stats(labels, off, 2)
+    assert eng.status() & 0x20
