@@ -1,0 +1,259 @@
+#!/usr/bin/env python
+"""bench.py — images/sec of end-to-end superpixel-align labelling on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic 1024x2048 RGB images that is
+already resident in HBM: DRN features (PyTorch-ROCm/MIOpen) -> HIP SLIC -> per-superpixel pooling
+-> location prior -> weighted k-means -> painted road masks -> per-image confusion counts
+(BASELINE.json configs[1]: DRN-D-22 fp32, SLIC 200 superpixels, k = 2).  With N > 1 every rank
+labels its own batches (images shard with no data-path collective; weak scaling) and the
+per-image score records are exchanged by one RCCL all_gather at the end of the timed region,
+the native replacement of the reference's shared result.json append.
+
+Prints ONE JSON line on rank 0 (see README/DESIGN for the fields).  `roofline` prices the
+dominant hand-written HIP kernel of libspalign (HIP events on its launch stream, recorded during
+the timed region) against the HBM roof; `drn` reports the MFMA side of the step (the DRN forward
+is PyTorch-ROCm by design); `cpu_baseline` times the CPU oracle (+ the same DRN on the host
+cores through PyTorch) on a bounded sample of the same workload, rank 0 at N = 1 only.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+FP32_MATRIX_PEAK_TF = 157.3    # fp32 MFMA peak; bf16 dense 2500
+BF16_MATRIX_PEAK_TF = 2500.0
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=6)
+    p.add_argument('--warmup', type=int, default=2)
+    p.add_argument('--batch', type=int, default=30, help='images per step per GPU (reference batchsize)')
+    p.add_argument('--height', type=int, default=1024)
+    p.add_argument('--width', type=int, default=2048)
+    p.add_argument('--arch', default='drn_d_22', choices=['drn_d_22', 'drn_c_26'])
+    p.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'])
+    p.add_argument('--n_slic_segments', type=int, default=200)
+    p.add_argument('--n_clusters', type=int, default=2)
+    p.add_argument('--pool_mode', default='mean', choices=['mean', 'anchor'])
+    p.add_argument('--drn_sub_batch', type=int, default=10)
+    p.add_argument('--no_cpu_baseline', action='store_true')
+    p.add_argument('--cpu_sample', type=int, default=1, help='images of the CPU baseline sample')
+    p.add_argument('--no_prof', action='store_true', help='do not record per-kernel events')
+    return p.parse_args()
+
+
+def algorithmic_bytes(kernel, B, H, W, C, fh, fw, n_seg, feat_bytes):
+    """Algorithmic HBM bytes per launch (DESIGN.md 'Kernels'), B images/launch."""
+    px = H * W
+    per_image = {
+        'k_rgb2lab': px * (12 + 12),                      # f32 RGB in, f32 Lab out
+        'k_slic_assign': px * (12 + 4),                   # Lab in, i32 label out (centres on chip)
+        'k_slic_update': px * (4 + 12),                   # labels + Lab of every pixel once
+        'connectivity(all)': px * (4 + 4),
+        'segment_stats(all)': px * 4,
+        'k_cell_weights': px * 4,
+        'k_pool_mean': C * fh * fw * feat_bytes + n_seg * C * 4,
+        'k_pool_anchor': n_seg * 10 * 4 * C * feat_bytes + n_seg * C * 8,
+        'k_paint': px * (4 + 1 + 1),
+        'k_kmeans': 0,
+    }
+    return per_image.get(kernel, 0) * B
+
+
+def make_batch(synth, B, H, W):
+    """B synthetic images from 4 generated ones (rolled copies are new images for SLIC/DRN)."""
+    base = [synth.synth_image(s, H, W) for s in range(min(4, B))]
+    imgs = np.empty((B, 3, H, W), np.float32)
+    gts = np.empty((B, H, W), np.int32)
+    gt0 = [synth.synth_gt_labels(s, H, W) for s in range(min(4, B))]
+    for b in range(B):
+        shift = 37 * (b // 4)
+        imgs[b] = np.roll(base[b % 4], shift, axis=2)
+        g = np.roll(gt0[b % 4], shift, axis=1).astype(np.int32)
+        gts[b] = np.where(g <= 6, -1, np.where(g == 7, 1, 0))     # create_label_mask (:279-296)
+    return imgs, gts
+
+
+def cpu_baseline(a, synth, n_img):
+    """The oracle (kind "port") + the same DRN on the host through PyTorch, on n_img images."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import oracle as orc
+    drn = importlib.import_module('superpixel-align_amd.drn')
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    H, W = a.height, a.width
+    imgs = np.stack([synth.synth_image(100 + i, H, W) for i in range(n_img)])
+    args = types.SimpleNamespace(superpixel_method='slic', n_slic_segments=a.n_slic_segments,
+                                 n_anchors=10, n_neighbors=4, without_pos=False, y_rel_pos=0.75,
+                                 x_rel_pos=0.5, y_rel_sigma=0.1, x_rel_sigma=0.1, n_clusters=a.n_clusters)
+    model = drn.create_drn(a.arch, device='cpu', dtype=torch.float32)
+    orc.lib()
+    t0 = time.time()
+    with torch.no_grad():
+        fm = [model.batch_predict(imgs[i:i + 1])[1][7].float().numpy() for i in range(n_img)]
+    fmaps = np.concatenate(fm, 0)
+    t1 = time.time()
+    sps = orc.batch_superpixel(args, imgs)
+    feats, n_per = orc.batch_superpixel_align(args, imgs, sps, fmaps, orc.PyRandom(1111),
+                                              a.pool_mode, 'nearest')
+    prior = orc.batch_create_prior(args, sps)
+    orc.batch_weighted_kmeans(args, sps, feats, prior, n_per)
+    t2 = time.time()
+    return {'value': n_img / (t2 - t0), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': '%d synthetic %dx%d image(s): PyTorch-CPU %s fp32 forward on %d threads (%.1f s) '
+                      '+ single-threaded C oracle SLIC/pool(%s)/prior/k-means/paint (%.1f s)'
+                      % (n_img, H, W, a.arch, cores, t1 - t0, a.pool_mode, t2 - t1)}
+
+
+def main():
+    a = parse()
+    import torch
+    spa = importlib.import_module('superpixel-align_amd')
+    dist = importlib.import_module('superpixel-align_amd.dist')
+    pipeline = importlib.import_module('superpixel-align_amd.pipeline')
+    drn = importlib.import_module('superpixel-align_amd.drn')
+
+    rank, ws, local = dist.init()
+    if ws != a.gpus:
+        if rank == 0:
+            print('warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE' % (a.gpus, ws), file=sys.stderr)
+    torch.cuda.set_device(local)
+    torch.backends.cudnn.benchmark = True
+    dtype = {'fp32': torch.float32, 'bf16': torch.bfloat16}[a.dtype]
+
+    args = types.SimpleNamespace(
+        superpixel_method='slic', n_slic_segments=a.n_slic_segments, n_anchors=10, n_neighbors=4,
+        without_pos=False, y_rel_pos=0.75, x_rel_pos=0.5, y_rel_sigma=0.1, x_rel_sigma=0.1,
+        gpu=local, n_clusters=a.n_clusters, use_feature_maps=[7], pool_mode=a.pool_mode,
+        mean_sampling='nearest', drn_sub_batch=a.drn_sub_batch)
+    model = drn.create_drn(a.arch, device='cuda:%d' % local, dtype=dtype)
+    pipe = pipeline.LabelPipeline(args, model)
+    eng = pipe.eng
+
+    B, H, W = a.batch, a.height, a.width
+    imgs_h, gts_h = make_batch(spa.synth, B, H, W)
+    imgs = torch.from_numpy(imgs_h).cuda()
+    gts = torch.from_numpy(gts_h).cuda()
+    conf_total = torch.zeros((B, 4), dtype=torch.int64, device='cuda')
+
+    def step():
+        res = pipe.run(imgs, check_status=False)
+        conf_total.add_(eng.confusion(res.road, gts))
+        return res
+
+    for _ in range(a.warmup):
+        res = step()
+    eng.raise_on_status()
+    torch.cuda.synchronize()
+    conf_total.zero_()
+    if not a.no_prof:
+        eng.prof_enable(True)
+    stage = {'time_feature_maps': 0.0, 'time_superpixel': 0.0, 'time_roialign': 0.0, 'time_kmeans': 0.0}
+
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    evs = []
+    for _ in range(a.steps):
+        res = step()
+        evs.append(dict(pipe._ev))
+    # the result.json reduction: one all_gather of per-image records
+    info = res.info.cpu().numpy()
+    conf = conf_total.cpu().numpy()
+    n_sp = res.n_labels.cpu().numpy()
+    rec = np.zeros((B, dist.RECORD_WIDTH), np.int64)
+    rec[:, 0] = rank * B + np.arange(B)
+    rec[:, 1:5] = conf
+    rec[:, 5] = n_sp
+    rec[:, 6], rec[:, 7] = info[0], info[1]
+    allrec = dist.gather_records(rec)
+    dist.barrier()
+    torch.cuda.synchronize()
+    dt = dist.max_over_ranks(time.perf_counter() - t0)
+    eng.raise_on_status()
+
+    for e in evs:
+        stage['time_feature_maps'] += e['start'].elapsed_time(e['features'])
+        stage['time_superpixel'] += e['features'].elapsed_time(e['superpixel'])
+        stage['time_roialign'] += e['superpixel'].elapsed_time(e['describe'])
+        stage['time_kmeans'] += e['describe'].elapsed_time(e['kmeans'])
+    prof = eng.prof_read() if not a.no_prof else {}
+    eng.prof_enable(False)
+
+    if rank != 0:
+        return
+    total_images = ws * B * a.steps
+    C = res.fmap.shape[1]
+    fh, fw = res.fmap.shape[2], res.fmap.shape[3]
+    n_seg = float(n_sp.mean())
+    feat_bytes = 4 if a.dtype == 'fp32' else 2
+    kernels = {}
+    for name, (ms, n) in prof.items():
+        avg = ms / n
+        ab = algorithmic_bytes(name, B, H, W, C, fh, fw, n_seg, feat_bytes)
+        kernels[name] = {'launches_per_step': n / a.steps, 'avg_ms': round(avg, 4),
+                         'ms_per_step': round(ms / a.steps, 3),
+                         'achieved_GBs': round(ab / (avg * 1e-3) / 1e9, 1) if ab else None}
+    roof = None
+    single = [k for k in kernels if not k.endswith('(all)') and kernels[k]['achieved_GBs']]
+    if single:
+        dom = max(single, key=lambda k: kernels[k]['ms_per_step'])
+        ach = kernels[dom]['achieved_GBs']
+        roof = {'kernel': dom, 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
+                'avg_launch_ms': kernels[dom]['avg_ms'],
+                'algorithmic_bytes_per_launch': algorithmic_bytes(dom, B, H, W, C, fh, fw, n_seg, feat_bytes)}
+    drn_ms = stage['time_feature_maps'] / a.steps
+    flops = drn.flops_per_image(a.arch, H, W) * B
+    peak_tf = FP32_MATRIX_PEAK_TF if a.dtype == 'fp32' else BF16_MATRIX_PEAK_TF
+    drn_tf = flops / (drn_ms * 1e-3) / 1e12
+    tp = allrec[:, 4].sum(); fp = allrec[:, 2].sum(); fn = allrec[:, 3].sum()
+    out = {
+        'metric': 'images/sec superpixel-align labelling (1024x2048)' if (H, W) == (1024, 2048)
+                  else 'images/sec superpixel-align labelling (%dx%d)' % (H, W),
+        'value': round(total_images / dt, 3), 'unit': 'images/sec', 'n_gpus': ws, 'steps': a.steps,
+        'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if a.dtype == 'fp32' else 'bf16',
+        'data': 'synthetic',
+        'config': {'workload': 'BASELINE configs[1] x batch: %s %s features + HIP SLIC(%d)/%s-pool/'
+                               'prior/k-means(k=%d)/paint, %dx%d, %d images per step per GPU, '
+                               'random-init weights' % (a.arch, a.dtype, a.n_slic_segments, a.pool_mode,
+                                                        a.n_clusters, H, W, B),
+                   'images_per_step_per_gpu': B, 'sharding': 'images (no data-path collective), '
+                   'one all_gather of score records'},
+        'roofline': roof,
+        'drn': {'bound': 'mfma', 'achieved': round(drn_tf, 2), 'peak': peak_tf, 'unit': 'TFLOP/s',
+                'frac': round(drn_tf / peak_tf, 4), 'ms_per_step': round(drn_ms, 3),
+                'note': 'DRN forward is PyTorch-ROCm (MIOpen) by design; not a libspalign kernel'},
+        'stage_ms_per_step': {k: round(v / a.steps, 3) for k, v in stage.items()},
+        'kernels': kernels,
+        'quality': {'superpixels_per_image': round(n_seg, 1), 'kmeans_iterations': int(info[0]),
+                    'synthetic_road_iou': round(float(tp) / max(1.0, float(tp + fp + fn)), 4),
+                    'records_gathered': int(allrec.shape[0])},
+    }
+    if ws == 1 and not a.no_cpu_baseline:
+        try:
+            out['cpu_baseline'] = cpu_baseline(a, spa.synth, a.cpu_sample)
+        except Exception as exc:                      # the baseline must never hide the GPU number
+            out['cpu_baseline'] = {'error': repr(exc)}
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

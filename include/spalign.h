@@ -63,6 +63,14 @@ void spa_ctx_destroy(spa_ctx *ctx);
 /* copies the latched status bits to *status_host and clears them; synchronises `stream`. */
 int spa_status(spa_ctx *ctx, uint32_t *status_host, void *stream);
 
+/* Per-kernel timing for the roofline report (bench.py): when enabled, HIP events are recorded on
+   the launch stream around each kernel family; spa_prof_read synchronises the device and
+   returns the summed duration and the number of launches of one slot since spa_prof_enable. */
+int spa_prof_enable(spa_ctx *ctx, int on);
+int spa_prof_slots(void);
+const char *spa_prof_name(int slot);
+int spa_prof_read(spa_ctx *ctx, int slot, double *total_ms_host, int *launches_host);
+
 /* ---- SLIC superpixels ------------------------------------------------------------------
  * replaces batch_superpixel(), SLIC branch: batch_spalign_kmeans.py:308-311, i.e.
  * skimage.segmentation.slic(img.transpose(1,2,0), n_segments) with every other argument

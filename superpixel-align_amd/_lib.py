@@ -48,7 +48,12 @@ PROTOTYPES = {
     'spa_ctx_create': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(c_p)]),
     'spa_ctx_destroy': (None, [c_p]),
     'spa_status': (ctypes.c_int, [c_p, ctypes.POINTER(ctypes.c_uint32), c_p]),
-    'spa_slic_make_plan': (ctypes.c_int, [c_i32, c_i32, c_i32, ctypes.POINTER(SlicPlan)]),
+    'spa_prof_enable': (ctypes.c_int, [c_p, ctypes.c_int]),
+    'spa_prof_slots': (ctypes.c_int, []),
+    'spa_prof_name': (ctypes.c_char_p, [ctypes.c_int]),
+    'spa_prof_read': (ctypes.c_int, [c_p, ctypes.c_int, ctypes.POINTER(c_f64),
+                                     ctypes.POINTER(ctypes.c_int)]),
+    'spa_slic_make_plan':(ctypes.c_int, [c_i32, c_i32, c_i32, ctypes.POINTER(SlicPlan)]),
     'spa_rgb2lab': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_f32, c_p, c_p]),
     'spa_slic_core': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_p]),
     'spa_enforce_connectivity': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p,
@@ -95,6 +100,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise SpalignError('%s is missing: run `python -c "import __graft_entry__ as g; '
                                'g.build()"` (there is no CPU fallback)' % LIB_PATH)
+        # PyTorch-ROCm wheels bundle their own libamdhip64; libspalign receives torch's device
+        # pointers and streams, so both must live in ONE HIP runtime: import torch first, then
+        # libspalign's NEEDED libamdhip64.so.7 resolves to the runtime torch already loaded.
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(L, name)

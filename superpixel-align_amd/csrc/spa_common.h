@@ -66,12 +66,29 @@ enum {
     WS_COUNT
 };
 
+// optional per-kernel timing (spa_prof_*): HIP events recorded on the launch stream around the
+// kernels bench.py prices against the roofline
+enum {
+    PROF_RGB2LAB = 0, PROF_SLIC_ASSIGN, PROF_SLIC_UPDATE, PROF_CONNECT, PROF_STATS,
+    PROF_CELL_WEIGHTS, PROF_POOL_MEAN, PROF_POOL_ANCHOR, PROF_KMEANS, PROF_PAINT, PROF_SLOTS
+};
+
 struct spa_ctx {
     int device;
     int n_cu;
     uint32_t *d_status;      // latched status bits
     void *ws[WS_COUNT];
     size_t ws_bytes[WS_COUNT];
+    int prof_on;
+    hipEvent_t *prof_ev[PROF_SLOTS];   // pairs (start, stop)
+    int prof_cap[PROF_SLOTS], prof_used[PROF_SLOTS];
+};
+
+void spa_prof_mark(spa_ctx *ctx, int slot, int end, hipStream_t s);
+struct SpaProfScope {
+    spa_ctx *c; int slot; hipStream_t s;
+    SpaProfScope(spa_ctx *c_, int slot_, hipStream_t s_) : c(c_), slot(slot_), s(s_) { if (c->prof_on) spa_prof_mark(c, slot, 0, s); }
+    ~SpaProfScope() { if (c->prof_on) spa_prof_mark(c, slot, 1, s); }
 };
 
 int spa_ws_reserve(spa_ctx *ctx, int which, size_t bytes, void **out);

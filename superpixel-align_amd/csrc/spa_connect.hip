@@ -377,6 +377,7 @@ extern "C" int spa_enforce_connectivity(spa_ctx *ctx, const int32_t *labels_in, 
     if ((rc = spa_ws_reserve(ctx, WS_BLK, (size_t)B * nblk * 4, (void **)&blk)) != SPA_OK) return rc;
     if ((rc = spa_ws_reserve(ctx, WS_CONNMISC, (size_t)B * sizeof(ConnMisc), (void **)&misc)) != SPA_OK) return rc;
 
+    SpaProfScope prof_(ctx, PROF_CONNECT, s);
     SPA_HIP(hipMemsetAsync(size, 0, img, s));
     SPA_HIP(hipMemsetAsync(claim, 0xFF, img, s));
     hipLaunchKernelGGL(k_conn_init_misc, dim3((B + 63) / 64), dim3(64), 0, s, misc, B, npix);

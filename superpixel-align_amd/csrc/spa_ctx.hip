@@ -48,6 +48,10 @@ extern "C" int spa_ctx_create(int device, spa_ctx **out)
 extern "C" void spa_ctx_destroy(spa_ctx *ctx)
 {
     if (!ctx) return;
+    for (int i = 0; i < PROF_SLOTS; ++i) {
+        for (int j = 0; j < ctx->prof_cap[i]; ++j) (void)hipEventDestroy(ctx->prof_ev[i][j]);
+        free(ctx->prof_ev[i]);
+    }
     for (int i = 0; i < WS_COUNT; ++i)
         if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
@@ -169,5 +173,55 @@ extern "C" int spa_slic_make_plan(int32_t H, int32_t W, int32_t n_segments, spa_
     int64_t ml = plan->min_size > 0 ? ((int64_t)H * W) / plan->min_size + 1 : (int64_t)H * W;
     if (ml > (int64_t)H * W) ml = (int64_t)H * W;
     plan->max_labels = (int32_t)ml;
+    return SPA_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// per-kernel timing with HIP events on the launch stream
+// ---------------------------------------------------------------------------------------
+void spa_prof_mark(spa_ctx *ctx, int slot, int end, hipStream_t s)
+{
+    int idx = ctx->prof_used[slot] * 2 + end;
+    if (idx >= ctx->prof_cap[slot]) {
+        int ncap = ctx->prof_cap[slot] ? ctx->prof_cap[slot] * 2 : 256;
+        ctx->prof_ev[slot] = (hipEvent_t *)realloc(ctx->prof_ev[slot], (size_t)ncap * sizeof(hipEvent_t));
+        for (int j = ctx->prof_cap[slot]; j < ncap; ++j) (void)hipEventCreate(&ctx->prof_ev[slot][j]);
+        ctx->prof_cap[slot] = ncap;
+    }
+    (void)hipEventRecord(ctx->prof_ev[slot][idx], s);
+    if (end) ctx->prof_used[slot] += 1;
+}
+
+extern "C" int spa_prof_enable(spa_ctx *ctx, int on)
+{
+    SPA_ARG(ctx);
+    ctx->prof_on = on ? 1 : 0;
+    for (int i = 0; i < PROF_SLOTS; ++i) ctx->prof_used[i] = 0;
+    return SPA_OK;
+}
+
+extern "C" int spa_prof_slots(void) { return PROF_SLOTS; }
+
+extern "C" const char *spa_prof_name(int slot)
+{
+    static const char *names[PROF_SLOTS] = {"k_rgb2lab", "k_slic_assign", "k_slic_update",
+        "connectivity(all)", "segment_stats(all)", "k_cell_weights", "k_pool_mean", "k_pool_anchor",
+        "k_kmeans", "k_paint"};
+    return (slot >= 0 && slot < PROF_SLOTS) ? names[slot] : "";
+}
+
+// total_ms / launches of one slot since spa_prof_enable; synchronises the device
+extern "C" int spa_prof_read(spa_ctx *ctx, int slot, double *total_ms, int *launches)
+{
+    SPA_ARG(ctx && total_ms && launches && slot >= 0 && slot < PROF_SLOTS);
+    SPA_HIP(hipDeviceSynchronize());
+    double t = 0.0;
+    for (int j = 0; j < ctx->prof_used[slot]; ++j) {
+        float ms = 0.0f;
+        SPA_HIP(hipEventElapsedTime(&ms, ctx->prof_ev[slot][2 * j], ctx->prof_ev[slot][2 * j + 1]));
+        t += ms;
+    }
+    *total_ms = t;
+    *launches = ctx->prof_used[slot];
     return SPA_OK;
 }

@@ -246,6 +246,7 @@ extern "C" int spa_kmeans_weighted(spa_ctx *ctx, const void *X, int32_t x_dtype,
     size_t total = o_na + (size_t)Ncap * 4;
     if ((rc = spa_ws_reserve(ctx, WS_KM_MISC, total, (void **)&misc)) != SPA_OK) return rc;
     SPA_HIP(hipMemsetAsync(misc + o_sh, 0, o_na - o_sh, s));   // barrier, thr, part_n, changed
+    SpaProfScope prof_(ctx, PROF_KMEANS, s);
     static bool attr_done[2] = {false, false};
     if (x_dtype == 1) {
         if (!attr_done[1]) {

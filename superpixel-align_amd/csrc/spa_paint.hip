@@ -53,6 +53,7 @@ extern "C" int spa_paint(spa_ctx *ctx, const int32_t *labels, const int32_t *ass
     int gx = (npix / 4 + 255) / 256;
     if (gx > 1024) gx = 1024;
     if (gx < 1) gx = 1;
+    SpaProfScope prof_(ctx, PROF_PAINT, spa_stream(stream));
     hipLaunchKernelGGL(k_paint, dim3(gx, B), dim3(256), 0, spa_stream(stream), labels, assign,
                        offsets, npix, cluster, road, ctx->d_status);
     SPA_LAUNCH_CHECK();

@@ -141,6 +141,7 @@ extern "C" int spa_pool_anchor(spa_ctx *ctx, const void *fmap, const spa_fmap_de
                       (long long)d->stride_c);
         return SPA_ERR_LAYOUT;
     }
+    SpaProfScope prof_(ctx, PROF_POOL_ANCHOR, spa_stream(stream));
     hipLaunchKernelGGL(k_pool_anchor, dim3(Ncap), dim3(256), 0, spa_stream(stream), fmap, d->dtype,
                        d->C, d->fh, d->fw, (long long)d->stride_b, (long long)d->stride_y,
                        (long long)d->stride_x, B, img_h, offsets, anchors, n_valid, n_anchors,
@@ -314,8 +315,10 @@ extern "C" int spa_pool_mean(spa_ctx *ctx, const void *fmap, const spa_fmap_desc
     const int ncell = d->fh * d->fw;
     int rc = spa_ws_reserve(ctx, WS_CELLSLOT, (size_t)B * ncell * sizeof(CellSlots), (void **)&cells);
     if (rc != SPA_OK) return rc;
+    { SpaProfScope prof_(ctx, PROF_CELL_WEIGHTS, s);
     hipLaunchKernelGGL(k_cell_weights, dim3((ncell + 255) / 256, B), dim3(256), 0, s, labels, H, W,
-                       d->fh, d->fw, sampling, offsets, cells, ctx->d_status);
+                       d->fh, d->fw, sampling, offsets, cells, ctx->d_status); }
+    SpaProfScope prof_(ctx, PROF_POOL_MEAN, s);
     hipLaunchKernelGGL(k_pool_mean, dim3(Ncap), dim3(256), 0, s, fmap, d->dtype, d->C, d->fh, d->fw,
                        (long long)d->stride_b, (long long)d->stride_y, (long long)d->stride_x, B, H,
                        W, sampling, offsets, (const int32_t *)ctx->ws[WS_BBOX], count, cells, centroid,

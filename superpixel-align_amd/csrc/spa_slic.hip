@@ -102,8 +102,9 @@ extern "C" int spa_rgb2lab(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H,
     long long work = vec4 ? npix / 4 : npix;
     int gx = (int)((work + 255) / 256);
     if (gx > 2048) gx = 2048;
+    { SpaProfScope prof_(ctx, PROF_RGB2LAB, spa_stream(stream));
     hipLaunchKernelGGL(k_rgb2lab, dim3(gx, B), dim3(256), 0, spa_stream(stream), rgb, lab, npix,
-                       ratio, vec4);
+                       ratio, vec4); }
     SPA_LAUNCH_CHECK();
     return SPA_OK;
 }
@@ -395,11 +396,13 @@ extern "C" int spa_slic_core(spa_ctx *ctx, const float *lab, int32_t B, int32_t 
     const float sw = (float)(1.0 / (double)(pl.step * pl.step));
     dim3 ga((W + TILE - 1) / TILE, (H + TILE - 1) / TILE, B);
     for (int it = 0; it < max_iter; ++it) {
+        { SpaProfScope prof_(ctx, PROF_SLIC_ASSIGN, s);
         hipLaunchKernelGGL(k_slic_assign, ga, dim3(256), 0, s, lab, cen, nC, H, W, sw, labels,
-                           ctx->d_status);
+                           ctx->d_status); }
         SPA_LAUNCH_CHECK();
         // the centroids computed after the last sweep never influence the labels
         if (it + 1 < max_iter || centres) {
+            SpaProfScope prof_(ctx, PROF_SLIC_UPDATE, s);
             hipLaunchKernelGGL(k_slic_update, dim3(nC, B), dim3(64), 0, s, lab, labels, cen, nC,
                                H, W, s2y, s2x, ctx->d_status);
             SPA_LAUNCH_CHECK();

@@ -151,6 +151,7 @@ extern "C" int spa_segment_stats(spa_ctx *ctx, const int32_t *labels, int32_t B,
     int rc = spa_ws_reserve(ctx, WS_BBOX, (size_t)Ncap * 16, (void **)&bbox);
     if (rc != SPA_OK) return rc;
     const int npix = H * W;
+    SpaProfScope prof_(ctx, PROF_STATS, s);
     hipLaunchKernelGGL(k_bbox_init, dim3((Ncap + 255) / 256), dim3(256), 0, s, bbox, count, Ncap);
     int gx = (npix + 255) / 256;
     if (gx > 1024) gx = 1024;

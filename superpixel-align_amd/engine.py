@@ -62,6 +62,20 @@ class Engine(object):
             msgs = [m for bit, m in _lib.STATUS_BITS.items() if st & bit]
             raise SpalignError('device status 0x%x: %s' % (st, '; '.join(msgs)))
 
+    # ------------------------------------------------------------------ per-kernel timing
+    def prof_enable(self, on=True):
+        check(self._lib.spa_prof_enable(self._ctx, 1 if on else 0))
+
+    def prof_read(self):
+        """{kernel name: (total ms, launches)} since prof_enable (synchronises)."""
+        out = {}
+        for slot in range(self._lib.spa_prof_slots()):
+            ms, n = ctypes.c_double(0), ctypes.c_int(0)
+            check(self._lib.spa_prof_read(self._ctx, slot, ctypes.byref(ms), ctypes.byref(n)))
+            if n.value:
+                out[self._lib.spa_prof_name(slot).decode()] = (ms.value, n.value)
+        return out
+
     # ------------------------------------------------------------------ SLIC
     def rgb2lab(self, rgb, ratio=0.1):
         rgb = _req(rgb, torch.float32, 'rgb')

@@ -1,0 +1,168 @@
+"""The drop-in boundary: the five names utils/apply_spalign_kmeans.py:17-21 imports from
+batch_spalign_kmeans, with the reference's positional signatures, argument meaning and return
+types, backed by libspalign.so on the GPU.
+
+    batch_superpixel(args, imgs)                                   (:299-313)
+    batch_superpixel_align(args, model, imgs, superpixels, feature_maps)   (:316-330)
+    batch_create_prior(args, superpixels)                          (:333-344)
+    batch_weighted_kmeans(args, superpixels, superpixel_features,
+                          superpixel_weights, n_superpixels_per_image)     (:347-358)
+    create_model(args)                                             (:524-530)
+
+Host arrays go in and out exactly as in the reference (numpy int64 label maps, float64
+descriptors, bool masks), so both reference drivers run unchanged apart from their import line.
+Inputs that came out of a previous op are recognised (by identity) and their device copies are
+reused, so chaining the five ops uploads nothing twice.  The fused, download-once path is
+pipeline.LabelPipeline.
+"""
+import weakref
+
+import numpy as np
+import torch
+
+from . import _lib
+from .drn import create_drn
+from .engine import Engine, NpRandom, PyRandom
+
+_ENGINE = None
+_PYRANDOM = None
+_NPRANDOM = None
+_DEVCACHE = {}          # id(host array) -> (weakref to it, dict of device tensors)
+
+
+def engine():
+    global _ENGINE
+    if _ENGINE is None:
+        _ENGINE = Engine()
+    return _ENGINE
+
+
+def seed(value=1111):
+    """random.seed / np.random.seed of the reference module scope (:33-34)."""
+    global _PYRANDOM, _NPRANDOM
+    _PYRANDOM, _NPRANDOM = PyRandom(value), NpRandom(value)
+
+
+def _rng():
+    if _PYRANDOM is None:
+        seed(1111)
+    return _PYRANDOM, _NPRANDOM
+
+
+def _remember(host, **dev):
+    key = id(host)
+    _DEVCACHE[key] = (weakref.ref(host, lambda _r, k=key: _DEVCACHE.pop(k, None)), dev)
+    return host
+
+
+def _recall(host):
+    hit = _DEVCACHE.get(id(host))
+    if hit is not None and hit[0]() is host:
+        return hit[1]
+    return None
+
+
+def _dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a) if isinstance(a, np.ndarray) else a)
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    return t.to(engine().device).contiguous()
+
+
+def _labels_on_device(superpixels):
+    """-> labels (B,H,W) i32, n_labels (B) i32 — n = len(np.unique(sp)) for contiguous ids (:321)."""
+    hit = _recall(superpixels)
+    if hit is not None and 'labels' in hit:
+        return hit['labels'], hit['n_labels']
+    labels = _dev(np.asarray(superpixels), torch.int32)
+    n_labels = (labels.flatten(1).max(dim=1).values + 1).to(torch.int32)
+    return labels, n_labels
+
+
+def create_model(args):
+    """DRN feature extractor. The reference hard-codes drn_c_26 + models/drn_c_26.npz; here the
+    architecture (--arch), precision (--dtype) and weight file (--drn_weights, .npz or .pth)
+    are flags and the default weights are random (no checkpoint ships with the repository)."""
+    if args.gpu is not None and args.gpu >= 0 and torch.cuda.is_available():
+        torch.cuda.set_device(args.gpu)
+    dtype = {'fp32': torch.float32, 'bf16': torch.bfloat16}[getattr(args, 'dtype', 'fp32')]
+    return create_drn(getattr(args, 'arch', 'drn_c_26'), getattr(args, 'drn_weights', None),
+                      device=engine().device, dtype=dtype)
+
+
+def batch_superpixel(args, imgs):
+    if args.superpixel_method != 'slic':
+        raise NotImplementedError(
+            "superpixel_method=%r: only 'slic' runs on the MI355X path so far" % args.superpixel_method)
+    eng = engine()
+    labels, n_labels = eng.slic(_dev(imgs, torch.float32), args.n_slic_segments)
+    eng.raise_on_status()
+    out = labels.cpu().numpy().astype(np.int64)          # np.asarray(list of int64 maps) (:312)
+    return _remember(out, labels=labels, n_labels=n_labels)
+
+
+def batch_superpixel_align(args, model, imgs, superpixels, feature_maps):
+    eng = engine()
+    labels, n_labels = _labels_on_device(superpixels)
+    B, H, W = labels.shape
+    fmap = getattr(feature_maps, 'array', feature_maps)
+    fmap = _dev(fmap) if not (isinstance(fmap, torch.Tensor) and fmap.is_cuda) else fmap
+    off = eng.segment_offsets(n_labels)
+    n_per = [int(v) for v in n_labels.cpu()]
+    N = sum(n_per)
+    append_pos = not args.without_pos
+    count, centroid, _ = eng.segment_stats(labels, off, N, None, want_centroid=True)
+    mode = getattr(args, 'pool_mode', 'anchor')
+    if mode == 'anchor':
+        ranks_h, nvalid_h = _rng()[0].shuffle_select(count.cpu().numpy(), args.n_anchors)
+        ranks, nvalid = _dev(ranks_h), _dev(nvalid_h)
+        anchors = eng.select_anchor_pixels(labels, off, N, ranks, nvalid)
+        X = eng.pool_anchor(fmap.float() if fmap.dtype not in (torch.float32, torch.bfloat16) else fmap,
+                            imgs.shape[2], off, N, anchors, nvalid, args.n_neighbors,
+                            centroid if append_pos else None, append_pos)
+    else:
+        X = eng.pool_mean(fmap, labels, off, N, count, getattr(args, 'mean_sampling', 'nearest'),
+                          centroid if append_pos else None, append_pos)
+    eng.raise_on_status()
+    feats = X.cpu().numpy()
+    return _remember(feats, X=X), n_per
+
+
+def batch_create_prior(args, superpixels):
+    eng = engine()
+    labels, n_labels = _labels_on_device(superpixels)
+    off = eng.segment_offsets(n_labels)
+    N = int(off[-1])
+    _, _, prior = eng.segment_stats(labels, off, N, (args.y_rel_pos, args.x_rel_pos,
+                                                     args.y_rel_sigma, args.x_rel_sigma),
+                                    want_centroid=False)
+    eng.raise_on_status()
+    w = prior.cpu().numpy()
+    return _remember(w, prior=prior)
+
+
+def batch_weighted_kmeans(args, superpixels, superpixel_features, superpixel_weights,
+                          n_superpixels_per_image):
+    eng = engine()
+    labels, _ = _labels_on_device(superpixels)
+    B = labels.shape[0]
+    hx, hw = _recall(superpixel_features), _recall(superpixel_weights)
+    X = hx['X'] if hx and 'X' in hx else _dev(superpixel_features)
+    w = hw['prior'] if hw and 'prior' in hw else _dev(superpixel_weights, torch.float64)
+    off = _dev(np.concatenate([[0], np.cumsum(n_superpixels_per_image)]).astype(np.int32))
+    k = args.n_clusters
+    init_other = None
+    if k > 2:
+        wh = np.asarray(superpixel_weights, dtype=np.float64)
+        thr = np.sort(wh)[len(wh) // 2]
+        idx = (np.arange(int((wh <= thr).sum())) % (k - 1) + 1).astype(np.int64)
+        _rng()[1].shuffle(idx)
+        init_other = _dev(idx)
+    assign, info = eng.kmeans(X, w, off[B:], k, 1000, init_other)
+    cluster, road = eng.paint(labels, assign, off)
+    eng.raise_on_status()
+    cl = cluster.cpu().numpy()
+    if (cl.reshape(B, -1) == 0).sum(axis=1).min() == 0:
+        # the reference prints this and re-runs k-means with the result discarded (:201-205)
+        print('\nSomehow KMeans seems failed. Try again\n')
+    return cl.astype(np.int64), cl == 0
