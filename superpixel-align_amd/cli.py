@@ -1,0 +1,315 @@
+"""The two command-line drivers of the label-generation path, on the MI355X pipeline.
+
+  labelled   : batch_spalign_kmeans.py        (reference :38-108 flags, :427-548 loop/outputs)
+  label-free : utils/apply_spalign_kmeans.py  (reference :75-145)
+
+Flags, defaults (including the two dead flags), the "keep the batch size" loop, the NPY /
+result.json / PNG naming and contents are the reference's; additions are optional flags
+(--arch, --dtype, --drn_weights, --pool_mode, --mean_sampling, --no_figure, --balanced).
+Under `python -m torch.distributed.run --nproc-per-node N` the labelled driver shards the image
+range like utils/create_*_labels.sh does and rank 0 writes result.json after one all_gather.
+"""
+import argparse
+import glob
+import json
+import os
+import time
+import zipfile
+
+import numpy as np
+import torch
+
+from . import dist as spdist
+from . import ops
+from .pipeline import LabelPipeline
+
+# (flag, kwargs) shared by both drivers, in the reference's order
+_COMMON_FLAGS = [
+    ('--superpixel_method', dict(type=str, default='felzenszwalb', choices=['felzenszwalb', 'slic'])),
+    ('--n_clusters', dict(type=int, default=4)),
+    ('--y_rel_pos', dict(type=float, default=0.75)),
+    ('--x_rel_pos', dict(type=float, default=0.5)),
+    ('--y_rel_sigma', dict(type=float, default=0.1)),
+    ('--x_rel_sigma', dict(type=float, default=0.1)),
+    ('--n_anchors', dict(type=int, default=10)),
+    ('--n_neighbors', dict(type=int, default=4)),
+    ('--without_pos', dict(action='store_true', default=False)),
+    ('--horizontal_line_filtering', dict(action='store_true', default=False)),   # dead in the reference too
+    ('--resize_shape', dict(type=int, nargs=2, default=[224, 224])),
+    ('--batchsize', dict(type=int, default=30)),
+    ('--felzenszwalb_scale', dict(type=float, default=300.0)),
+    ('--felzenszwalb_sigma', dict(type=float, default=0.8)),
+    ('--felzenszwalb_min_size', dict(type=int, default=20)),
+    ('--n_slic_segments', dict(type=int, default=100)),
+    ('--use_feature_maps', dict(type=int, nargs='*', default=[7])),
+    ('--start_index', dict(type=int)),
+    ('--end_index', dict(type=int)),
+    # --- additions of this implementation
+    ('--arch', dict(type=str, default='drn_c_26', choices=['drn_c_26', 'drn_d_22'])),
+    ('--dtype', dict(type=str, default='fp32', choices=['fp32', 'bf16'])),
+    ('--drn_weights', dict(type=str, default=None)),
+    ('--pool_mode', dict(type=str, default='anchor', choices=['anchor', 'mean'])),
+    ('--mean_sampling', dict(type=str, default='nearest', choices=['nearest', 'bilinear'])),
+    ('--no_figure', dict(action='store_true', default=False)),
+    ('--balanced', dict(action='store_true', default=False)),
+]
+
+
+def _parser(extra):
+    p = argparse.ArgumentParser()
+    for flag, kw in extra + _COMMON_FLAGS:
+        p.add_argument(flag, **kw)
+    return p
+
+
+def get_args(argv=None):
+    """batch_spalign_kmeans.py:38-108"""
+    extra = [('--gpu', dict(type=int, default=0)),
+             ('--out_dir', dict(type=str, default='data/test_images')),
+             ('--img_file_list', dict(type=str, default=None)),
+             ('--label_file_list', dict(type=str, default=None)),
+             ('--cityscapes_img_dir', dict(type=str, default=None)),
+             ('--cityscapes_label_dir', dict(type=str, default=None)),
+             ('--cityscapes_img_zip', dict(type=str, default=None)),
+             ('--cityscapes_label_zip', dict(type=str, default=None)),
+             ('--camera_param_dir', dict(type=str, default='data/camera'))]
+    args = _parser(extra).parse_args(argv)
+    args.resize_shape = tuple(args.resize_shape)
+    os.makedirs(args.out_dir, exist_ok=True)
+    return args
+
+
+def get_args_labelfree(argv=None):
+    """utils/apply_spalign_kmeans.py:75-122"""
+    extra = [('--img_list_fn', dict(type=str, default='data/demoVideo_fns.txt')),
+             ('--label_shape', dict(type=int, nargs=2, default=[1024, 2048])),
+             ('--gpu', dict(type=int, default=-1)),
+             ('--out_dir', dict(type=str))]
+    return _parser(extra).parse_args(argv)
+
+
+# ------------------------------------------------------------------------------- data
+def _decode(fp_or_path):
+    from PIL import Image
+    with Image.open(fp_or_path) as f:
+        return np.asarray(f, dtype=np.uint8)
+
+
+def resize_bicubic_chw(img_chw, shape):
+    """datasets/resize_image_dataset.py:31-34 (chainercv.transforms.resize(img, size, 3)).
+    PIL bicubic here; OpenCV INTER_CUBIC bit-parity is a later row."""
+    from PIL import Image
+    h, w = shape
+    out = [np.asarray(Image.fromarray(c).resize((w, h), Image.BICUBIC)) for c in img_chw]
+    return np.stack(out)
+
+
+class ImageList(object):
+    """ResizeImageDataset (datasets/resize_image_dataset.py:8-36): path -> CHW array."""
+
+    def __init__(self, paths, resize_shape=None, dtype=np.float32, opener=None):
+        self._paths, self._shape, self._dtype, self._open = list(paths), resize_shape, dtype, opener
+
+    def __len__(self):
+        return len(self._paths)
+
+    def get(self, i):
+        src = self._open(self._paths[i]) if self._open else self._paths[i]
+        img = _decode(src)
+        if img.ndim == 2:
+            img = img[:, :, None]
+        img = img[:, :, :3].transpose(2, 0, 1)
+        if self._shape is not None and tuple(img.shape[1:]) != tuple(self._shape):
+            img = resize_bicubic_chw(img, self._shape)
+        return img.astype(self._dtype)
+
+    def batch(self, lo, hi):
+        return np.stack([self.get(i) for i in range(len(self))[lo:hi]])
+
+
+def create_dataset(args):
+    """batch_spalign_kmeans.py:486-521 -> (images, labels) ImageLists with ._paths."""
+    if args.cityscapes_img_zip and args.cityscapes_label_zip:
+        zi, zl = zipfile.ZipFile(args.cityscapes_img_zip), zipfile.ZipFile(args.cityscapes_label_zip)
+        key = lambda fn: '_'.join(os.path.basename(fn).split('_')[:3])
+        li = {key(f): f for f in zi.namelist() if f.endswith('.png')}
+        ll = {key(f): f for f in zl.namelist() if f.endswith('labelIds.png')}
+        keys = sorted(ll)
+        return (ImageList([li[k] for k in keys], args.resize_shape, np.float32, zi.open),
+                ImageList([ll[k] for k in keys], None, np.uint8, zl.open))
+    if args.img_file_list and args.label_file_list:
+        il = [l.strip() for l in open(args.img_file_list) if l.strip()]
+        ll = [l.strip() for l in open(args.label_file_list) if l.strip()]
+    else:
+        key = lambda fn: '_'.join(os.path.basename(fn).split('_')[:3])
+        vi = {key(f): f for f in glob.glob(os.path.join(args.cityscapes_img_dir, '*', '*.png'))}
+        vl = {key(f): f for f in glob.glob(os.path.join(args.cityscapes_label_dir, '*', '*labelIds.png'))}
+        il, ll = [vi[k] for k in vl], [vl[k] for k in vl]
+    return ImageList(il, args.resize_shape, np.float32), ImageList(ll, None, np.uint8)
+
+
+def create_label_mask(label):
+    """:279-296 — void ids 0..6 -> -1, road id 7 -> 1, rest 0."""
+    out = np.zeros(label.shape, np.int32)
+    out[label <= 6] = -1
+    out[label == 7] = 1
+    return out
+
+
+def resize_nearest(a, shape):
+    """cv.resize(..., interpolation=cv.INTER_NEAREST): src = min(floor(dst * src/dst), src-1)."""
+    h, w = shape
+    ys = np.minimum((np.arange(h) * (a.shape[0] / h)).astype(np.int64), a.shape[0] - 1)
+    xs = np.minimum((np.arange(w) * (a.shape[1] / w)).astype(np.int64), a.shape[1] - 1)
+    return a[ys][:, xs]
+
+
+# ------------------------------------------------------------------------------- outputs
+def score(road_mask, gt):
+    """:398-405 — chainercv confusion/IoU on the host copy (integer counts: exact)."""
+    m = gt >= 0
+    conf = np.bincount(2 * gt[m].astype(np.int64) + road_mask[m].astype(np.int64), minlength=4).reshape(2, 2)
+    TP, FP, FN = int(conf[1, 1]), int(conf[0, 1]), int(conf[1, 0])
+    with np.errstate(divide='ignore', invalid='ignore'):
+        iou = np.diag(conf) / (conf.sum(1) + conf.sum(0) - np.diag(conf))
+    return dict(road_iou=float(iou[1]), non_road_iou=float(iou[0]),
+                precision=float(TP / (TP + FP)) if TP + FP > 0 else None,
+                recall=float(TP / (TP + FN)) if TP + FN > 0 else None, TP=TP, FP=FP, FN=FN)
+
+
+def save_npy(args, img_fn, road_mask, clustering_result):
+    """:392-396 — <basename>.npy (uint8, 1 = road) and <basename>_all_cluster.npy."""
+    out_fn = os.path.splitext(os.path.basename(img_fn))[0]
+    np.save(os.path.join(args.out_dir, out_fn), road_mask.astype(np.uint8))
+    np.save(os.path.join(args.out_dir, out_fn + '_all_cluster'), clustering_result.astype(np.uint8))
+
+
+def save_figure(args, img, road_mask, label, clustering_result, img_fn):
+    """:361-386 — 2x2 overview figure at 300 dpi (about a second per image: --no_figure)."""
+    import matplotlib
+    matplotlib.use('Agg')
+    import matplotlib.pyplot as plt
+    fig, axes = plt.subplots(2, 2)
+    fig.set_dpi(300)
+    for ax in axes.ravel():
+        ax.axis('off')
+    axes[0, 0].imshow(img / 255.)
+    axes[0, 0].imshow(road_mask, alpha=0.4, cmap=plt.cm.Set1_r)
+    axes[0, 0].set_title('Estimated road mask (input image overlayed)', fontsize=8)
+    axes[0, 1].imshow(label == 1)
+    axes[0, 1].set_title('Ground truth road mask', fontsize=8)
+    axes[1, 0].imshow(clustering_result)
+    axes[1, 0].set_title('All clusters', fontsize=8)
+    axes[1, 1].imshow(clustering_result == 0)
+    axes[1, 1].set_title('Estimated road mask', fontsize=8)
+    plt.savefig(os.path.join(args.out_dir, os.path.basename(img_fn)), bbox_inches='tight')
+    plt.close(fig)
+
+
+def result_line(args, img_fn, label_fn, sc, elapsed_times, st_all):
+    """:408-421 — one JSON object per image: scores + every CLI arg + timers."""
+    info = dict(img_fn=img_fn, label_fn=label_fn, road_iou=sc['road_iou'],
+                non_road_iou=sc['non_road_iou'], precision=sc['precision'], recall=sc['recall'],
+                TP=sc['TP'], FP=sc['FP'], FN=sc['FN'])
+    info.update(vars(args))
+    info.update(elapsed_times)
+    info['elapsed_time'] = time.time() - st_all
+    return info
+
+
+# ------------------------------------------------------------------------------- drivers
+def _effective_range(args, n_data):
+    start = 0 if args.start_index is None else args.start_index
+    end = n_data if args.end_index is None else args.end_index
+    return start, end
+
+
+def main_labelled(argv=None):
+    args = get_args(argv)
+    rank, ws, local = spdist.init()
+    if ws > 1:
+        args.gpu = local
+    imgs_ds, labels_ds = create_dataset(args)
+    model = ops.create_model(args)
+    pipe = LabelPipeline(args, model, ops.engine())
+    start, end = _effective_range(args, len(imgs_ds))
+    if ws > 1:
+        s, e = spdist.shard_range(end - start, ws, rank, args.balanced)
+        start, end = start + s, start + e
+    lines, records = [], []
+    for lo, hi in (spdist.batch_ranges(start, end, args.batchsize) if end > start else []):
+        st_all = time.time()
+        imgs = imgs_ds.batch(lo, hi)
+        res = pipe.run(imgs)
+        times = pipe.elapsed_times()
+        cluster, road = res.masks_to_host()
+        info = res.info.cpu().numpy()
+        idx = list(range(len(imgs_ds)))[lo:hi]
+        for j, i in enumerate(idx):
+            img_fn, label_fn = imgs_ds._paths[i], labels_ds._paths[i]
+            gt = create_label_mask(labels_ds.get(i)[0])
+            rm, cl = road[j], cluster[j]
+            if rm.shape != gt.shape:                                   # :470-477
+                rm, cl = resize_nearest(rm, gt.shape), resize_nearest(cl, gt.shape)
+            save_npy(args, img_fn, rm, cl)
+            if not args.no_figure:
+                full = _decode(imgs_ds._open(img_fn) if imgs_ds._open else img_fn)   # :464 reloads the PNG
+                save_figure(args, full, rm, gt, cl, img_fn)
+            sc = score(rm, gt)
+            line = result_line(args, img_fn, label_fn, sc, times, st_all)
+            lines.append((i, line))
+            tn = int(((gt == 0) & (rm == 0)).sum())
+            records.append([i, tn, sc['FP'], sc['FN'], sc['TP'], int(res.n_labels[j]), int(info[0]), int(info[1])])
+            print('Road IoU:', line['road_iou'], os.path.basename(img_fn))
+    path = os.path.join(args.out_dir, 'result.json')
+    if ws == 1:
+        with open(path, 'a') as fp:                                    # reference: append
+            for _, line in lines:
+                print(json.dumps(line), file=fp)
+    else:
+        # one collective: fixed-size records; rank 0 rewrites the lines it did not produce from
+        # the gathered scores (file names come from the shared lists)
+        allrec = spdist.gather_records(np.array(records, np.int64).reshape(-1, spdist.RECORD_WIDTH))
+        own = dict(lines)
+        if rank == 0:
+            with open(path, 'a') as fp:
+                for r in allrec:                                        # rank order == index order
+                    i = int(r[0])
+                    if i in own:
+                        line = own[i]
+                    else:
+                        TP, FP, FN, TN = int(r[4]), int(r[2]), int(r[3]), int(r[1])
+                        conf = np.array([[TN, FP], [FN, TP]], np.float64)
+                        with np.errstate(divide='ignore', invalid='ignore'):
+                            iou = np.diag(conf) / (conf.sum(1) + conf.sum(0) - np.diag(conf))
+                        sc = dict(road_iou=float(iou[1]), non_road_iou=float(iou[0]),
+                                  precision=float(TP / (TP + FP)) if TP + FP else None,
+                                  recall=float(TP / (TP + FN)) if TP + FN else None, TP=TP, FP=FP, FN=FN)
+                        line = result_line(args, imgs_ds._paths[i], labels_ds._paths[i], sc, {}, time.time())
+                    print(json.dumps(line), file=fp)
+        spdist.barrier()
+    return 0
+
+
+def main_labelfree(argv=None):
+    args = get_args_labelfree(argv)
+    args.resize_shape = tuple(args.resize_shape)
+    model = ops.create_model(args)
+    pipe = LabelPipeline(args, model, ops.engine())
+    img_fns = sorted(fn.strip() for fn in open(args.img_list_fn) if fn.strip())
+    print('img_fns:', len(img_fns))
+    ds = ImageList(img_fns, args.resize_shape, np.float32)
+    os.makedirs(args.out_dir, exist_ok=True)
+    start, end = _effective_range(args, len(ds))
+    from PIL import Image
+    for lo, hi in spdist.batch_ranges(start, end, args.batchsize):
+        res = pipe.run(ds.batch(lo, hi))
+        _, road = res.masks_to_host()
+        for j, i in enumerate(list(range(len(ds)))[lo:hi]):
+            rm = road[j]
+            if rm.shape != tuple(args.label_shape):                    # :62-67
+                rm = resize_nearest(rm, tuple(args.label_shape))
+            save_fn = os.path.join(args.out_dir, os.path.basename(img_fns[i]))
+            Image.fromarray(rm.astype(np.uint8)).save(save_fn)          # cv.imwrite(save_fn, mask)
+            print(save_fn)
+    return 0

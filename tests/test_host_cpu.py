@@ -1,0 +1,185 @@
+"""CPU suite, part 3: host logic of the path — DRN module structure and numerics against the
+reference's PyTorch definition (golden maps), the reference batch loop / sharding rules, the
+N > 1 record exchange over gloo (world_size 2), output helpers and the result.json summary."""
+import importlib
+import json
+import os
+import subprocess
+import sys
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden
+
+drn = importlib.import_module('superpixel-align_amd.drn')
+dist = importlib.import_module('superpixel-align_amd.dist')
+cli = importlib.import_module('superpixel-align_amd.cli')
+
+
+def det_fill(model):
+    """Same name-keyed deterministic weights as oracle/gen_golden_drn.py."""
+    with torch.no_grad():
+        for name, t in list(model.named_parameters()) + list(model.named_buffers()):
+            if name.endswith('num_batches_tracked'):
+                continue
+            g = torch.Generator().manual_seed(zlib.crc32(name.encode()) & 0x7fffffff)
+            if name.endswith('running_var'):
+                t.copy_(torch.rand(t.shape, generator=g) * 0.5 + 0.75)
+            elif name.endswith('running_mean'):
+                t.copy_(torch.randn(t.shape, generator=g) * 0.1)
+            elif t.ndim == 4:
+                fan = t.shape[1] * t.shape[2] * t.shape[3]
+                t.copy_(torch.randn(t.shape, generator=g) * (2.0 / fan) ** 0.5)
+            elif name.endswith('weight'):
+                t.copy_(torch.rand(t.shape, generator=g) * 0.5 + 0.75)
+            else:
+                t.copy_(torch.randn(t.shape, generator=g) * 0.1)
+
+
+@pytest.mark.parametrize('name', ['drn_c_26', 'drn_d_22'])
+def test_drn_matches_reference_definition(name):
+    g = golden('drn_maps')
+    m = drn.DRN(name)
+    assert sum(p.numel() for p in m.parameters()) == int(g[name + '_nparams'])
+    det_fill(m)
+    x = torch.from_numpy(g['x'])
+    keep = x.clone()
+    _, maps = m.batch_predict(x)                 # un-folded BatchNorm, CPU float32
+    assert torch.equal(x, keep)                  # the input batch is never modified
+    assert len(maps) == 8                        # Chainer map convention for both archs
+    assert [list(t.shape) for t in maps] == g[name + '_shapes'].tolist()
+    np.testing.assert_allclose([float(t.double().mean()) for t in maps], g[name + '_means'], rtol=1e-4, atol=1e-6)
+    scale = float(np.abs(g[name + '_map7']).max())
+    # 24 float32 convolutions deep: accumulation order differs between conv back ends
+    np.testing.assert_allclose(maps[7].numpy(), g[name + '_map7'], rtol=1e-4, atol=1e-4 * scale)
+    # folding BatchNorm into the convolutions is an identity in eval mode (to float32 rounding)
+    m.fold_batchnorm()
+    assert not any(isinstance(mod, torch.nn.BatchNorm2d) for mod in m.modules())
+    _, folded = m.batch_predict(x)
+    np.testing.assert_allclose(folded[7].numpy(), g[name + '_map7'], rtol=1e-4, atol=1e-4 * scale)
+    # sub-batching does not change results
+    _, sub = m.batch_predict(x, sub_batch=1)
+    np.testing.assert_allclose(sub[7].numpy(), folded[7].numpy(), rtol=1e-4, atol=1e-4 * scale)
+
+
+def test_drn_state_dict_names_match_upstream_checkpoint_layout():
+    keys = set(drn.DRN('drn_c_26').state_dict())
+    for k in ('conv1.weight', 'bn1.running_var', 'layer1.0.conv1.weight', 'layer2.0.downsample.0.weight',
+              'layer2.0.downsample.1.bias', 'layer6.1.bn2.weight', 'layer8.0.conv2.weight'):
+        assert k in keys
+    keys = set(drn.DRN('drn_d_22').state_dict())
+    for k in ('layer0.0.weight', 'layer0.1.running_mean', 'layer1.0.weight', 'layer2.1.bias',
+              'layer3.0.downsample.0.weight', 'layer8.0.weight'):
+        assert k in keys
+
+
+def test_chainer_npz_loader(tmp_path):
+    src = drn.DRN('drn_c_26')
+    det_fill(src)
+    rename = {'weight': ('W', 'gamma'), 'bias': ('b', 'beta'), 'running_mean': ('avg_mean',) * 2,
+              'running_var': ('avg_var',) * 2}
+    arrays = {}
+    for k, v in src.state_dict().items():
+        if k.endswith('num_batches_tracked'):
+            arrays[k.rsplit('.', 1)[0].replace('.', '/') + '/N'] = np.array(0)
+            continue
+        parts = k.split('.')
+        is_bn = v.ndim == 1
+        arrays['/'.join(parts[:-1] + [rename[parts[-1]][1 if is_bn else 0]])] = v.numpy()
+    path = str(tmp_path / 'drn_c_26.npz')
+    np.savez(path, **arrays)
+    dst = drn.DRN('drn_c_26').load_chainer_npz(path)
+    for k, v in src.state_dict().items():
+        if not k.endswith('num_batches_tracked'):
+            assert torch.equal(v, dst.state_dict()[k]), k
+
+
+def test_batch_loop_and_sharding_rules():
+    # batch_spalign_kmeans.py:538-544 — the last batch is shifted back to keep its size
+    assert dist.batch_ranges(0, 100, 30) == [(0, 30), (30, 60), (60, 90), (70, 100)]
+    assert dist.batch_ranges(0, 90, 30) == [(0, 30), (30, 60), (60, 90)]
+    assert dist.batch_ranges(38, 76, 30) == [(38, 68), (46, 76)]
+    assert dist.batch_ranges(0, 10, 30) == [(-20, 10)]              # reference quirk kept
+    # utils/create_random300_labels.sh:37-51 — step = 300/8+1 = 38
+    got = [dist.shard_range(300, 8, r) for r in range(8)]
+    assert got == [(0, 38), (38, 76), (76, 114), (114, 152), (152, 190), (190, 228), (228, 266), (266, 300)]
+    assert [dist.shard_range(10, 4, r) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
+    bal = [dist.shard_range(10, 4, r, balanced=True) for r in range(4)]
+    assert bal == [(0, 3), (3, 6), (6, 8), (8, 10)]
+
+
+_WORKER = r'''
+import importlib, os, sys, numpy as np
+sys.path.insert(0, %r)
+dist = importlib.import_module('superpixel-align_amd.dist')
+rank, ws, local = dist.init('gloo')
+lo, hi = dist.shard_range(11, ws, rank)
+rec = np.zeros((hi - lo, dist.RECORD_WIDTH), np.int64)
+rec[:, 0] = np.arange(lo, hi); rec[:, 4] = 100 * rank + np.arange(hi - lo)
+allrec = dist.gather_records(rec)
+mx = dist.max_over_ranks(1.5 + rank)
+if rank == 0:
+    np.save(os.environ['OUT'], allrec)
+    open(os.environ['OUT'] + '.max', 'w').write(str(mx))
+dist.barrier()
+'''
+
+
+def test_two_rank_gloo_gather(tmp_path):
+    """N > 1 path on CPU: 2 processes, gloo, uneven shard sizes, one all_gather of records."""
+    script = tmp_path / 'worker.py'
+    script.write_text(_WORKER % ROOT)
+    out = str(tmp_path / 'rec.npy')
+    env = dict(os.environ, OUT=out, MASTER_ADDR='127.0.0.1', MASTER_PORT='29577')
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=e))
+    for p in procs:
+        assert p.wait(timeout=120) == 0
+    rec = np.load(out)
+    assert rec[:, 0].tolist() == list(range(11))                      # rank order == index order
+    assert rec[:6, 4].tolist() == list(range(6)) and rec[6:, 4].tolist() == [100 + i for i in range(5)]
+    assert float(open(out + '.max').read()) == 2.5
+
+
+def test_output_helpers_and_summary(tmp_path, orc):
+    rs = np.random.RandomState(1)
+    a = rs.randint(0, 4, size=(7, 9)).astype(np.uint8)
+    up = cli.resize_nearest(a, (14, 27))
+    assert np.array_equal(up[::2, ::3], a) and np.array_equal(up[1::2, 2::3], a)
+    gt = orc.create_label_mask(rs.randint(0, 12, size=(40, 50)).astype(np.uint8))
+    assert np.array_equal(cli.create_label_mask(rs.randint(0, 2, size=(2, 2))), [[-1, -1], [-1, -1]])
+    pred = (rs.uniform(size=(40, 50)) < 0.5).astype(np.uint8)
+    sc, ref = cli.score(pred, gt), orc.confusion(pred, gt)
+    for k in ('TP', 'FP', 'FN', 'road_iou', 'non_road_iou', 'precision', 'recall'):
+        assert sc[k] == ref[k]
+    # result.json round trip through utils/mean_result.py
+    import types
+    args = types.SimpleNamespace(out_dir=str(tmp_path), n_clusters=2)
+    cli.save_npy(args, 'x/aachen_000000_000019_leftImg8bit.png', pred, pred * 3)
+    assert np.load(tmp_path / 'aachen_000000_000019_leftImg8bit.npy').dtype == np.uint8
+    assert np.load(tmp_path / 'aachen_000000_000019_leftImg8bit_all_cluster.npy').max() == 3
+    with open(tmp_path / 'result.json', 'w') as fp:
+        for i in range(3):
+            line = cli.result_line(args, 'img%d.png' % (i % 2), 'lab.png', sc, {'time_kmeans': 0.1}, 0.0)
+            print(json.dumps(line), file=fp)
+    sys.path.insert(0, os.path.join(ROOT, 'utils'))
+    mean_result = importlib.import_module('mean_result')
+    s, text = mean_result.summarise(str(tmp_path / 'result.json'))
+    assert abs(s['Road mean IoU'] - sc['road_iou']) < 1e-12 and 'N\t:2' in text      # de-duplicated
+    s2, text2 = mean_result.summarise(str(tmp_path / 'result.json'), count_duplicated=True)
+    assert 'N\t:3' in text2
+
+
+def test_cli_flags_match_reference_defaults():
+    a = cli.get_args(['--out_dir', '/tmp/spa_cli_test'])
+    assert (a.gpu, a.superpixel_method, a.n_clusters, a.n_anchors, a.n_neighbors) == (0, 'felzenszwalb', 4, 10, 4)
+    assert (a.resize_shape, a.batchsize, a.n_slic_segments, a.use_feature_maps) == ((224, 224), 30, 100, [7])
+    assert (a.y_rel_pos, a.x_rel_pos, a.y_rel_sigma, a.x_rel_sigma) == (0.75, 0.5, 0.1, 0.1)
+    assert a.camera_param_dir == 'data/camera' and a.horizontal_line_filtering is False
+    b = cli.get_args_labelfree([])
+    assert (b.gpu, b.label_shape, b.img_list_fn) == (-1, [1024, 2048], 'data/demoVideo_fns.txt')
