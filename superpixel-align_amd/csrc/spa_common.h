@@ -63,6 +63,9 @@ enum {
     WS_KM_PART,      // k-means partial sums
     WS_KM_MISC,      // k-means centres, counters, barrier words
     WS_NLABELS,      // n_labels (B) for spa_slic
+    WS_SBOX,         // bounding boxes of small components
+    WS_TODO,         // BFS tier hand-over lists
+    WS_ROWMASK,      // SLIC per (centre, row) occupancy bits
     WS_COUNT
 };
 

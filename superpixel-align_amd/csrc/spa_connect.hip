@@ -22,10 +22,14 @@
 #define INF_KEY 0xFFFFFFFFu
 
 struct ConnMisc {
-    int n_small;       // number of small component roots
+    int n_small;       // number of tiny (<= LANE_MAX pixels) small component roots
     int first_kept;    // smallest kept root (npix if none)
     int qalloc;        // BFS queue allocation cursor
     int n_kept;        // number of kept components
+    int n_todo1;       // small components that did not fit the 40 KB LDS tier
+    int n_todo2;       // ... nor the 156 KB tier (handled in global memory)
+    int n_big;         // small components with more than LANE_MAX pixels
+    int pad;
 };
 
 __device__ __forceinline__ int ld_i32(const int *p)
@@ -119,110 +123,417 @@ __global__ __launch_bounds__(256) void k_ccl_flatten(int *__restrict__ parent,
     }
 }
 
-// pass 1 of the raster-order prefix sum over kept roots (+ small-root list, status bits)
+// ---------------------------------------------------------------------------------------
+// Raster-order numbering.  Roots fall in three classes:
+//   kept  (size >= min_size)            : label = number of kept roots before it (prefix sum)
+//   tiny  (size <= LANE_MAX)            : listed in raster order (prefix sum), one LANE each
+//   big-small (LANE_MAX < size < min)   : few; appended to `big_list` with an atomic counter
+// A noisy image has ~10^5 tiny components (single boundary pixels), so nothing on their path
+// may cost one atomic on a shared word per component.
+// ---------------------------------------------------------------------------------------
 #define SCAN_PX 1024
+#define SBOX_CAP 65536      // big-small components with an index below this get a bounding box
+#define LANE_MAX 32
+
+__device__ __forceinline__ void load4_roots(const int *P, int base, int npix, bool aligned, int pv[4])
+{
+    if (base + 3 < npix && aligned) {
+        int4 t = *(const int4 *)(P + base);
+        pv[0] = t.x; pv[1] = t.y; pv[2] = t.z; pv[3] = t.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pv[i] = (base + i < npix) ? P[base + i] : -1;
+    }
+}
+
+// pass 1: per-block counts of kept and tiny roots
 __global__ __launch_bounds__(256) void k_conn_count(const int *__restrict__ parent,
                                                     const int *__restrict__ size, int npix,
                                                     int min_size, int max_size,
                                                     int *__restrict__ blk, int nblk,
-                                                    int *__restrict__ small_list,
                                                     ConnMisc *__restrict__ misc,
                                                     uint32_t *__restrict__ status)
 {
-    __shared__ int wsum[4];
+    __shared__ int wk[4], wt[4], wf[4];
     const int b = blockIdx.y;
     const int *P = parent + (long long)b * npix;
     const int *S = size + (long long)b * npix;
     const int base = blockIdx.x * SCAN_PX + threadIdx.x * 4;
-    int c = 0;
+    int pv[4];
+    load4_roots(P, base, npix, (((long long)b * npix) & 3) == 0, pv);
+    int ck = 0, ct = 0, fk = 0x7fffffff;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        int p = base + i;
-        if (p < npix && P[p] == p) {
-            int sz = S[p];
-            if (sz >= min_size) {
-                ++c;
-                atomicMin(&misc[b].first_kept, p);
-                if (sz >= max_size) atomicOr(status, SPA_ST_CONN_OVERSIZE);
-            } else {
-                int slot = atomicAdd(&misc[b].n_small, 1);
-                small_list[(long long)b * npix + slot] = p;
-            }
+        if (pv[i] != base + i) continue;
+        const int sz = S[base + i];
+        if (sz >= min_size) {
+            ++ck;
+            fk = min(fk, base + i);
+            if (sz >= max_size) atomicOr(status, SPA_ST_CONN_OVERSIZE);
+        } else if (sz <= LANE_MAX) {
+            ++ct;
         }
     }
-    // block sum
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    for (int o = 32; o > 0; o >>= 1) {
+        ck += __shfl_down(ck, o); ct += __shfl_down(ct, o); fk = min(fk, __shfl_down(fk, o));
+    }
+    if ((threadIdx.x & 63) == 0) { wk[threadIdx.x >> 6] = ck; wt[threadIdx.x >> 6] = ct; wf[threadIdx.x >> 6] = fk; }
     __syncthreads();
-    if (threadIdx.x == 0) blk[(long long)b * nblk + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (threadIdx.x == 0) {
+        blk[((long long)b * 2 + 0) * nblk + blockIdx.x] = wk[0] + wk[1] + wk[2] + wk[3];
+        blk[((long long)b * 2 + 1) * nblk + blockIdx.x] = wt[0] + wt[1] + wt[2] + wt[3];
+        int f = min(min(wf[0], wf[1]), min(wf[2], wf[3]));
+        if (f != 0x7fffffff) atomicMin(&misc[b].first_kept, f);
+    }
 }
 
-// pass 2: exclusive scan of the block counts of one image (single workgroup)
+// pass 2: exclusive scans of the two block-count arrays of one image (single workgroup)
 __global__ __launch_bounds__(256) void k_conn_scan(int *__restrict__ blk, int nblk,
                                                    ConnMisc *__restrict__ misc,
                                                    int32_t *__restrict__ n_labels)
 {
     __shared__ int part[256];
     const int b = blockIdx.x;
-    int *B_ = blk + (long long)b * nblk;
     const int per = (nblk + 255) / 256;
     const int lo = threadIdx.x * per, hi = min(nblk, lo + per);
-    int s = 0;
-    for (int i = lo; i < hi; ++i) s += B_[i];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int run = 0;
-        for (int i = 0; i < 256; ++i) { int t = part[i]; part[i] = run; run += t; }
-        misc[b].n_kept = run;
-        n_labels[b] = run > 0 ? run : 1;
+    for (int which = 0; which < 2; ++which) {
+        int *B_ = blk + ((long long)b * 2 + which) * nblk;
+        int s = 0;
+        for (int i = lo; i < hi; ++i) s += B_[i];
+        part[threadIdx.x] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int run = 0;
+            for (int i = 0; i < 256; ++i) { int t = part[i]; part[i] = run; run += t; }
+            if (which == 0) { misc[b].n_kept = run; n_labels[b] = run > 0 ? run : 1; }
+            else misc[b].n_small = run;
+        }
+        __syncthreads();
+        int run = part[threadIdx.x];
+        for (int i = lo; i < hi; ++i) { int t = B_[i]; B_[i] = run; run += t; }
+        __syncthreads();
     }
-    __syncthreads();
-    int run = part[threadIdx.x];
-    for (int i = lo; i < hi; ++i) { int t = B_[i]; B_[i] = run; run += t; }
 }
 
-// pass 3: label of every kept root = number of kept roots before it in raster order
+// pass 3: kept roots get their label, tiny roots their list position (both by prefix sums, so
+// in raster order); big-small roots are appended to big_list and their bounding box is seeded
 __global__ __launch_bounds__(256) void k_conn_number(const int *__restrict__ parent,
-                                                     const int *__restrict__ size, int npix,
+                                                     const int *__restrict__ size, int npix, int W,
                                                      int min_size, const int *__restrict__ blk,
-                                                     int nblk, int *__restrict__ final_)
+                                                     int nblk, int *__restrict__ final_,
+                                                     int *__restrict__ tiny_list,
+                                                     int *__restrict__ big_list,
+                                                     int *__restrict__ sbox,
+                                                     ConnMisc *__restrict__ misc)
 {
-    __shared__ int wsum[4];
+    __shared__ int wsk[4], wst[4];
     const int b = blockIdx.y;
     const int *P = parent + (long long)b * npix;
     const int *S = size + (long long)b * npix;
     int *F = final_ + (long long)b * npix;
     const int base = blockIdx.x * SCAN_PX + threadIdx.x * 4;
-    bool k[4];
-    int c = 0;
+    int pv[4];
+    load4_roots(P, base, npix, (((long long)b * npix) & 3) == 0, pv);
+    int cls[4];            // 0 none, 1 kept, 2 tiny, 3 big-small
+    int ck = 0, ct = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        int p = base + i;
-        k[i] = (p < npix) && (P[p] == p) && (S[p] >= min_size);
-        c += k[i] ? 1 : 0;
+        cls[i] = 0;
+        if (pv[i] == base + i) {
+            const int sz = S[base + i];
+            cls[i] = sz >= min_size ? 1 : (sz <= LANE_MAX ? 2 : 3);
+        }
+        ck += cls[i] == 1; ct += cls[i] == 2;
     }
-    // exclusive prefix of c over the workgroup (thread order == raster order)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int inc = c;
+    int ik = ck, it = ct;
     for (int o = 1; o < 64; o <<= 1) {
-        int t = __shfl_up(inc, o);
-        if (lane >= o) inc += t;
+        int a = __shfl_up(ik, o), c = __shfl_up(it, o);
+        if (lane >= o) { ik += a; it += c; }
     }
-    if (lane == 63) wsum[wv] = inc;
+    if (lane == 63) { wsk[wv] = ik; wst[wv] = it; }
     __syncthreads();
-    int off = blk[(long long)b * nblk + blockIdx.x];
-    for (int i = 0; i < wv; ++i) off += wsum[i];
-    int rank = off + inc - c;
+    int offk = blk[((long long)b * 2 + 0) * nblk + blockIdx.x];
+    int offt = blk[((long long)b * 2 + 1) * nblk + blockIdx.x];
+    for (int i = 0; i < wv; ++i) { offk += wsk[i]; offt += wst[i]; }
+    int rk = offk + ik - ck, rt = offt + it - ct;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        if (k[i]) F[base + i] = rank++;
+    for (int i = 0; i < 4; ++i) {
+        const int p = base + i;
+        if (cls[i] == 1) F[p] = rk++;
+        else if (cls[i] == 2) tiny_list[(long long)b * npix + rt++] = p;
+        else if (cls[i] == 3) {
+            const int slot = atomicAdd(&misc[b].n_big, 1);
+            big_list[(long long)b * npix + slot] = p;
+            F[p] = slot;
+            if (slot < SBOX_CAP) {
+                int *bb = sbox + ((long long)b * SBOX_CAP + slot) * 4;
+                const int y = p / W, x = p - y * W;
+                bb[0] = y; bb[1] = y; bb[2] = x; bb[3] = x;
+            }
+        }
+    }
+}
+
+// bounding boxes of the big-small components (only their pixels issue atomics, one set per
+// distinct root per wave)
+__global__ __launch_bounds__(256) void k_small_bbox(const int *__restrict__ parent,
+                                                    const int *__restrict__ size,
+                                                    const int *__restrict__ final_, int W, int npix,
+                                                    int min_size, int *__restrict__ sbox)
+{
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int *P = parent + (long long)b * npix;
+    const int *S = size + (long long)b * npix;
+    const int *F = final_ + (long long)b * npix;
+    for (int p0 = blockIdx.x * 256; p0 < npix; p0 += gridDim.x * 256) {
+        const int p = p0 + threadIdx.x;
+        int r = -1, y = 0, x = 0;
+        if (p < npix) {
+            r = P[p];
+            const int sz = S[r];
+            if (sz >= min_size || sz <= LANE_MAX) r = -1;
+            y = p / W; x = p - y * W;
+        }
+        unsigned long long todo = __ballot(r >= 0);
+        while (todo) {
+            int leader = __ffsll((long long)todo) - 1;
+            int rr = __shfl(r, leader);
+            unsigned long long same = __ballot(r == rr);
+            bool mine = (r == rr);
+            int ya = mine ? y : 0x7fffffff, yb = mine ? y : -1, xa = mine ? x : 0x7fffffff, xb = mine ? x : -1;
+            for (int o = 32; o > 0; o >>= 1) {
+                ya = min(ya, __shfl_xor(ya, o)); yb = max(yb, __shfl_xor(yb, o));
+                xa = min(xa, __shfl_xor(xa, o)); xb = max(xb, __shfl_xor(xb, o));
+            }
+            if (lane == leader) {
+                int slot = F[rr];
+                if (slot < SBOX_CAP) {
+                    int *bb = sbox + ((long long)b * SBOX_CAP + slot) * 4;
+                    atomicMin(bb + 0, ya); atomicMax(bb + 1, yb);
+                    atomicMin(bb + 2, xa); atomicMax(bb + 3, xb);
+                }
+            }
+            todo &= ~same;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// BFS replay, lane tier: one THREAD per tiny component (<= LANE_MAX pixels) runs the sequential
+// BFS literally — queue in LDS, "already queued" by searching its own queue — and keeps the
+// last outside neighbour that belongs to a component with a smaller seed.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_conn_bfs_lane(const int *__restrict__ parent,
+                                                       const int *__restrict__ size,
+                                                       const int *__restrict__ tiny_list,
+                                                       const ConnMisc *__restrict__ misc,
+                                                       int *__restrict__ final_, int H, int W)
+{
+    __shared__ int q[LANE_MAX * 256];
+    const int b = blockIdx.y;
+    const int npix = H * W;
+    const int tid = threadIdx.x;
+    const int *P = parent + (long long)b * npix;
+    const int *S = size + (long long)b * npix;
+    int *F = final_ + (long long)b * npix;
+    const int n = misc[b].n_small;
+    const int first_kept = misc[b].first_kept;
+    for (int i = blockIdx.x * 256 + tid; i < n; i += gridDim.x * 256) {
+        const int r = tiny_list[(long long)b * npix + i];
+        if (r < first_kept) { F[r] = -1; continue; }      // before the first kept component: label 0
+        const int sz = S[r];
+        int best = -1;
+        int head = 0, tail = 1;
+        q[tid] = r;
+        while (head < tail) {
+            const int u = q[head * 256 + tid];
+            const int uy = u / W, ux = u - uy * W;
+            // neighbour order of the reference: +x, -x, +y, -y
+            const int vx[4] = {ux + 1, ux - 1, ux, ux};
+            const int vy[4] = {uy, uy, uy + 1, uy - 1};
+            int rv[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const bool inb = vx[d] >= 0 && vx[d] < W && vy[d] >= 0 && vy[d] < H;
+                rv[d] = inb ? P[vy[d] * W + vx[d]] : 0x7fffffff;
+            }
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                if (rv[d] == r) {
+                    if (sz > 1) {
+                        const int v = vy[d] * W + vx[d];
+                        bool seen = false;
+                        for (int j = 0; j < tail; ++j) seen = seen || (q[j * 256 + tid] == v);
+                        if (!seen) { q[tail * 256 + tid] = v; ++tail; }
+                    }
+                } else if (rv[d] < r) {
+                    best = rv[d];
+                }
+            }
+            ++head;
+        }
+        F[r] = best < 0 ? -1 : -2 - best;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// BFS replay of one small component, LDS tier: the component's bounding box (+1 pixel margin)
+// is staged in LDS as one code word per pixel
+//     INF_KEY      pixel of this component, not yet discovered
+//     CODE_EARLIER pixel of a component with a smaller seed (a candidate for `adjacent`)
+//     CODE_OTHER   anything else
+//     key < CODE_OTHER: pixel of this component, discovered with that (queue index*4+dir) key
+// and the queue holds 16-bit box-local indices, so every step of the replay is a handful of LDS
+// round trips (~100 cycles) instead of L2/HBM round trips (~1-2 us).  Components that do not fit
+// `lds_bytes` are appended to `todo` for the next tier.
+// ---------------------------------------------------------------------------------------
+#define CODE_EARLIER 0xFFFFFFFEu
+#define CODE_OTHER 0xFFFFFFFDu
+
+__global__ __launch_bounds__(64) void k_conn_bfs_lds(const int *__restrict__ parent,
+                                                     const int *__restrict__ size,
+                                                     const int *__restrict__ big_list,
+                                                     const int *__restrict__ sbox,
+                                                     const int *__restrict__ list,     // slots, or NULL = all
+                                                     int *__restrict__ todo,           // slots that do not fit
+                                                     ConnMisc *__restrict__ misc, int tier,
+                                                     int *__restrict__ final_, int H, int W,
+                                                     int lds_bytes)
+{
+    extern __shared__ uint32_t lds_u32[];
+    const int b = blockIdx.y;
+    const int npix = H * W;
+    const int lane = threadIdx.x;
+    const int *P = parent + (long long)b * npix;
+    const int *S = size + (long long)b * npix;
+    const int *BL = big_list + (long long)b * npix;
+    int *F = final_ + (long long)b * npix;
+    const int n_items = tier == 0 ? misc[b].n_big : misc[b].n_todo1;
+    int *todo_count = tier == 0 ? &misc[b].n_todo1 : &misc[b].n_todo2;
+    const int first_kept = misc[b].first_kept;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int ddx[4] = {1, -1, 0, 0};
+    const int ddy[4] = {0, 0, 1, -1};
+
+    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const int slot = list ? list[(long long)b * npix + it] : it;
+        const int r = BL[slot];
+        if (r < first_kept) {           // before the first kept component everything is label 0
+            if (lane == 0) F[r] = -1;
+            continue;
+        }
+        const int sz = S[r];
+        bool fits = slot < SBOX_CAP;
+        int y0 = 0, y1 = 0, x0 = 0, x1 = 0, bw = 0, bh = 0, area = 0;
+        if (fits) {
+            const int *bb = sbox + ((long long)b * SBOX_CAP + slot) * 4;
+            y0 = max(bb[0] - 1, 0); y1 = min(bb[1] + 1, H - 1);
+            x0 = max(bb[2] - 1, 0); x1 = min(bb[3] + 1, W - 1);
+            bw = x1 - x0 + 1; bh = y1 - y0 + 1;
+            area = bw * bh;
+            fits = area <= 65535 && (long long)area * 4 + (long long)((sz + 1) & ~1) * 2 <= lds_bytes;
+        }
+        if (!fits) {
+            if (lane == 0) {
+                int k = atomicAdd(todo_count, 1);
+                todo[(long long)b * npix + k] = slot;
+            }
+            continue;
+        }
+        uint32_t *code = lds_u32;
+        unsigned short *Q = (unsigned short *)(lds_u32 + area);
+        __syncthreads();
+        // stage the box: coalesced row reads of the component roots, 4 in flight per lane
+        for (int i0 = 0; i0 < area; i0 += 256) {
+            int rv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int idx = i0 + u * 64 + lane;
+                int yy = y0 + idx / bw, xx = x0 + idx % bw;
+                rv[u] = idx < area ? P[yy * W + xx] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int idx = i0 + u * 64 + lane;
+                if (idx < area) code[idx] = rv[u] == r ? INF_KEY : (rv[u] < r ? CODE_EARLIER : CODE_OTHER);
+            }
+        }
+        const int ry = r / W, rx = r - ry * W;
+        const int rloc = (ry - y0) * bw + (rx - x0);
+        if (lane == 0) { Q[0] = (unsigned short)rloc; code[rloc] = 0u; }
+        __syncthreads();
+        int head = 0, tail = 1;
+        long long best = -1;            // (key << 32) | box-local index of the outside neighbour
+        while (head < tail) {
+            const int cnt = min(64, tail - head);
+            const bool act = lane < cnt;
+            const int uidx = head + lane;
+            const int u = act ? (int)Q[uidx] : 0;
+            const int uy = u / bw, ux = u - uy * bw;
+            int v[4];
+            bool cand[4];
+            uint32_t keyd[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                int xx = ux + ddx[d], yy = uy + ddy[d];
+                bool inb = act && xx >= 0 && xx < bw && yy >= 0 && yy < bh;
+                v[d] = yy * bw + xx;
+                keyd[d] = (uint32_t)(uidx * 4 + d);
+                cand[d] = false;
+                if (inb) {
+                    uint32_t c = code[v[d]];
+                    if (c == INF_KEY) cand[d] = true;
+                    else if (c == CODE_EARLIER) {
+                        long long key = ((long long)keyd[d] << 32) | (unsigned)v[d];
+                        if (key > best) best = key;
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                if (cand[d]) atomicMin(code + v[d], keyd[d]);
+            __syncthreads();
+            int mywins = 0, before = 0, total = 0;
+            bool win[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                win[d] = cand[d] && code[v[d]] == keyd[d];
+                unsigned long long m = __ballot(win[d]);
+                before += __popcll(m & below);
+                total += __popcll(m);
+            }
+            int pos = tail + before;
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                if (win[d]) { Q[pos + mywins] = (unsigned short)v[d]; ++mywins; }
+            __syncthreads();
+            head += cnt;
+            tail += total;
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            long long t = __shfl_xor(best, o);
+            if (t > best) best = t;
+        }
+        if (lane == 0) {
+            int f = -1;
+            if (best >= 0) {
+                int loc = (int)(best & 0xFFFFFFFFll);
+                int gy = y0 + loc / bw, gx = x0 + loc % bw;
+                f = -2 - P[gy * W + gx];
+            }
+            F[r] = f;
+        }
+    }
 }
 
 // one wavefront per small component: replay the BFS in queue order, find `adjacent`
 __global__ __launch_bounds__(64) void k_conn_bfs(const int *__restrict__ parent,
                                                  const int *__restrict__ size,
-                                                 const int *__restrict__ small_list,
+                                                 const int *__restrict__ big_list,
+                                                 const int *__restrict__ list,
                                                  ConnMisc *__restrict__ misc,
                                                  uint32_t *__restrict__ claim,
                                                  int *__restrict__ queue,
@@ -233,17 +544,17 @@ __global__ __launch_bounds__(64) void k_conn_bfs(const int *__restrict__ parent,
     const int lane = threadIdx.x;
     const int *P = parent + (long long)b * npix;
     const int *S = size + (long long)b * npix;
-    const int *SL = small_list + (long long)b * npix;
+    const int *BL = big_list + (long long)b * npix;
     uint32_t *CL = claim + (long long)b * npix;
     int *F = final_ + (long long)b * npix;
-    const int n_small = misc[b].n_small;
+    const int n_small = misc[b].n_todo2;
     const int first_kept = misc[b].first_kept;
     const unsigned long long below = (1ull << lane) - 1ull;
     const int ddx[4] = {1, -1, 0, 0};
     const int ddy[4] = {0, 0, 1, -1};
 
     for (int i = blockIdx.x; i < n_small; i += gridDim.x) {
-        const int r = SL[i];
+        const int r = BL[list[(long long)b * npix + i]];
         if (r < first_kept) {           // before the first kept component everything is label 0
             if (lane == 0) F[r] = -1;
             continue;
@@ -322,18 +633,19 @@ __global__ __launch_bounds__(64) void k_conn_bfs(const int *__restrict__ parent,
 }
 
 // final label of small components: follow the `adjacent` pointers to a kept component
-__global__ __launch_bounds__(256) void k_conn_resolve(const int *__restrict__ small_list,
+__global__ __launch_bounds__(256) void k_conn_resolve(const int *__restrict__ list, int which,
                                                       const ConnMisc *__restrict__ misc,
                                                       int *__restrict__ final_, int npix)
 {
     const int b = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= misc[b].n_small) return;
+    const int n = which == 0 ? misc[b].n_small : misc[b].n_big;
     int *F = final_ + (long long)b * npix;
-    const int r = small_list[(long long)b * npix + i];
-    int f = ld_i32(F + r);
-    while (f < -1) f = ld_i32(F + (-2 - f));   // pointer to a component with a smaller seed
-    st_i32(F + r, f == -1 ? 0 : f);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int r = list[(long long)b * npix + i];
+        int f = ld_i32(F + r);
+        while (f < -1) f = ld_i32(F + (-2 - f));   // pointer to a component with a smaller seed
+        st_i32(F + r, f == -1 ? 0 : f);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_conn_relabel(const int *__restrict__ parent,
@@ -351,7 +663,10 @@ __global__ __launch_bounds__(256) void k_conn_relabel(const int *__restrict__ pa
 __global__ void k_conn_init_misc(ConnMisc *misc, int B, int npix)
 {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < B) { misc[b].n_small = 0; misc[b].first_kept = npix; misc[b].qalloc = 0; misc[b].n_kept = 0; }
+    if (b < B) {
+        misc[b].n_small = 0; misc[b].first_kept = npix; misc[b].qalloc = 0; misc[b].n_kept = 0;
+        misc[b].n_todo1 = 0; misc[b].n_todo2 = 0; misc[b].n_big = 0; misc[b].pad = 0;
+    }
 }
 
 extern "C" int spa_enforce_connectivity(spa_ctx *ctx, const int32_t *labels_in, int32_t B,
@@ -363,7 +678,7 @@ extern "C" int spa_enforce_connectivity(spa_ctx *ctx, const int32_t *labels_in, 
     hipStream_t s = spa_stream(stream);
     const int npix = H * W;
     const size_t img = (size_t)B * npix * 4;
-    int *parent, *size, *final_, *queue, *blk, *small;
+    int *parent, *size, *final_, *queue, *blk, *tiny, *big, *sbox, *todo1, *todo2;
     uint32_t *claim;
     ConnMisc *misc;
     int rc;
@@ -373,29 +688,50 @@ extern "C" int spa_enforce_connectivity(spa_ctx *ctx, const int32_t *labels_in, 
     if ((rc = spa_ws_reserve(ctx, WS_FINAL, img, (void **)&final_)) != SPA_OK) return rc;
     if ((rc = spa_ws_reserve(ctx, WS_CLAIM, img, (void **)&claim)) != SPA_OK) return rc;
     if ((rc = spa_ws_reserve(ctx, WS_QUEUE, img, (void **)&queue)) != SPA_OK) return rc;
-    if ((rc = spa_ws_reserve(ctx, WS_SMALL, img, (void **)&small)) != SPA_OK) return rc;
-    if ((rc = spa_ws_reserve(ctx, WS_BLK, (size_t)B * nblk * 4, (void **)&blk)) != SPA_OK) return rc;
+    if ((rc = spa_ws_reserve(ctx, WS_SMALL, 2 * img, (void **)&tiny)) != SPA_OK) return rc;
+    big = tiny + (size_t)B * npix;
+    if ((rc = spa_ws_reserve(ctx, WS_BLK, (size_t)B * 2 * nblk * 4, (void **)&blk)) != SPA_OK) return rc;
+    if ((rc = spa_ws_reserve(ctx, WS_SBOX, (size_t)B * SBOX_CAP * 16, (void **)&sbox)) != SPA_OK) return rc;
+    if ((rc = spa_ws_reserve(ctx, WS_TODO, 2 * img, (void **)&todo1)) != SPA_OK) return rc;
+    todo2 = todo1 + (size_t)B * npix;
     if ((rc = spa_ws_reserve(ctx, WS_CONNMISC, (size_t)B * sizeof(ConnMisc), (void **)&misc)) != SPA_OK) return rc;
 
     SpaProfScope prof_(ctx, PROF_CONNECT, s);
     SPA_HIP(hipMemsetAsync(size, 0, img, s));
-    SPA_HIP(hipMemsetAsync(claim, 0xFF, img, s));
     hipLaunchKernelGGL(k_conn_init_misc, dim3((B + 63) / 64), dim3(64), 0, s, misc, B, npix);
     dim3 gp((npix + 255) / 256, B);
     hipLaunchKernelGGL(k_ccl_init, gp, dim3(256), 0, s, labels_in, parent, W, npix);
     hipLaunchKernelGGL(k_ccl_merge, gp, dim3(256), 0, s, labels_in, parent, W, npix);
     hipLaunchKernelGGL(k_ccl_flatten, gp, dim3(256), 0, s, parent, size, npix);
     hipLaunchKernelGGL(k_conn_count, dim3(nblk, B), dim3(256), 0, s, parent, size, npix, min_size,
-                       max_size, blk, nblk, small, misc, ctx->d_status);
+                       max_size, blk, nblk, misc, ctx->d_status);
     hipLaunchKernelGGL(k_conn_scan, dim3(B), dim3(256), 0, s, blk, nblk, misc, n_labels);
-    hipLaunchKernelGGL(k_conn_number, dim3(nblk, B), dim3(256), 0, s, parent, size, npix, min_size,
-                       blk, nblk, final_);
-    hipLaunchKernelGGL(k_conn_bfs, dim3(512, B), dim3(64), 0, s, parent, size, small, misc, claim,
-                       queue, final_, H, W);
-    // the number of small roots lives on the device: launch over the worst case (one root per
-    // pixel) and let surplus workgroups exit at once
-    hipLaunchKernelGGL(k_conn_resolve, dim3((npix + 255) / 256, B), dim3(256), 0, s, small, misc,
-                       final_, npix);
+    hipLaunchKernelGGL(k_conn_number, dim3(nblk, B), dim3(256), 0, s, parent, size, npix, W, min_size,
+                       blk, nblk, final_, tiny, big, sbox, misc);
+    int gb = (npix + 255) / 256;
+    if (gb > 1024) gb = 1024;
+    hipLaunchKernelGGL(k_small_bbox, dim3(gb, B), dim3(256), 0, s, parent, size, final_, W, npix,
+                       min_size, sbox);
+    // BFS replay of the small components: lane tier for the tiny ones, then 40 KB LDS, 156 KB LDS
+    // and global-memory wave tiers for the rest.  The lists live on the device; surplus
+    // workgroups exit at once.
+    hipLaunchKernelGGL(k_conn_bfs_lane, dim3(gb, B), dim3(256), 0, s, parent, size, tiny, misc,
+                       final_, H, W);
+    static bool attr_done = false;
+    if (!attr_done) {
+        SPA_HIP(hipFuncSetAttribute((const void *)k_conn_bfs_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k_conn_bfs_lds, dim3(1024, B), dim3(64), 40 * 1024, s, parent, size, big, sbox,
+                       (const int *)nullptr, todo1, misc, 0, final_, H, W, 40 * 1024);
+    hipLaunchKernelGGL(k_conn_bfs_lds, dim3(256, B), dim3(64), 156 * 1024, s, parent, size, big, sbox,
+                       (const int *)todo1, todo2, misc, 1, final_, H, W, 156 * 1024);
+    // the global tier is the only user of the claim array
+    SPA_HIP(hipMemsetAsync(claim, 0xFF, img, s));
+    hipLaunchKernelGGL(k_conn_bfs, dim3(256, B), dim3(64), 0, s, parent, size, big, (const int *)todo2,
+                       misc, claim, queue, final_, H, W);
+    hipLaunchKernelGGL(k_conn_resolve, dim3(gb, B), dim3(256), 0, s, tiny, 0, misc, final_, npix);
+    hipLaunchKernelGGL(k_conn_resolve, dim3(64, B), dim3(256), 0, s, big, 1, misc, final_, npix);
     int gr = (npix + 255) / 256;
     if (gr > 2048) gr = 2048;
     hipLaunchKernelGGL(k_conn_relabel, dim3(gr, B), dim3(256), 0, s, parent, final_, labels_out, npix);

@@ -227,9 +227,12 @@ __global__ __launch_bounds__(256) void k_cell_weights(const int32_t *__restrict_
     for (int j = 0; j < n; ++j) { o->lab[j] = s_lab[j * 256 + t]; o->w[j] = s_w[j * 256 + t]; }
 }
 
-// Step 2: one workgroup per superpixel; walk the feature pixels of its bounding box in raster
-// order; thread t owns channels t, t+256, ...: acc = acc + w * F (mul and add rounded apart).
+// Step 2: one workgroup per superpixel.  All 256 threads first search the feature pixels of the
+// segment's bounding box in parallel for the segment's weight and compact the hits, in raster
+// order, into an LDS list (cell offset, weight); then thread t, owner of channels t, t+256, ...,
+// walks the list: acc = acc + w * F (mul and add rounded apart), 4 independent row reads in flight.
 #define MAX_CPT 8
+#define POOL_LIST 1024
 __global__ __launch_bounds__(256) void k_pool_mean(const void *__restrict__ fmap, int dtype, int C,
                                                    int fh, int fw, long long sb, long long sy,
                                                    long long sx, int B, int H, int W, int sampling,
@@ -241,8 +244,12 @@ __global__ __launch_bounds__(256) void k_pool_mean(const void *__restrict__ fmap
                                                    int append_pos, void *__restrict__ X,
                                                    int x_dtype, long long ld)
 {
+    __shared__ long long l_off[POOL_LIST];
+    __shared__ float l_w[POOL_LIST];
+    __shared__ int wave_cnt[4];
     const int g = blockIdx.x;
     if (g >= offsets[B]) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int b = seg_image_p(offsets, B, g);
     const int s = g - offsets[b];
     const int n = count[g];
@@ -263,25 +270,65 @@ __global__ __launch_bounds__(256) void k_pool_mean(const void *__restrict__ fmap
         }
         const CellSlots *cb = cells + (long long)b * fh * fw;
         const long long fb = (long long)b * sb;
-        for (int u = u0; u <= u1; ++u)
-            for (int v = v0; v <= v1; ++v) {
-                const CellSlots *cs = cb + (long long)u * fw + v;
-                const int nn = cs->n;
+        const int bwc = v1 - v0 + 1;
+        const int ncell = (u1 - u0 + 1) * bwc;
+        int len = 0;                               // workgroup-uniform list length
+        for (int c0 = 0; c0 < ncell || len > 0; c0 += 256) {
+            if (c0 < ncell) {
+                const int ci = c0 + tid;
                 float w = 0.0f;
                 bool found = false;
-                for (int j = 0; j < nn; ++j)
-                    if (cs->lab[j] == s) { w = cs->w[j]; found = true; break; }
-                if (!found) continue;
-                const long long fo = fb + u * sy + v * sx;
+                long long fo = 0;
+                if (ci < ncell) {
+                    const int u = u0 + ci / bwc, v = v0 + ci % bwc;
+                    const CellSlots *cs = cb + (long long)u * fw + v;
+                    const int nn = cs->n;
+                    for (int j = 0; j < nn; ++j)
+                        if (cs->lab[j] == s) { w = cs->w[j]; found = true; break; }
+                    fo = fb + u * sy + v * sx;
+                }
+                const unsigned long long m = __ballot(found);
+                if (lane == 0) wave_cnt[wv] = __popcll(m);
+                __syncthreads();
+                int off = len, tot = 0;
 #pragma unroll
-                for (int i = 0; i < MAX_CPT; ++i) {
-                    int c = threadIdx.x + i * 256;
-                    if (c < C) {
-                        float prod = w * load_feat(fmap, fo + c, dtype);
-                        acc[i] = acc[i] + prod;
+                for (int i = 0; i < 4; ++i) { int c = wave_cnt[i]; if (i < wv) off += c; tot += c; }
+                if (found) { int pos = off + (int)spa_rank_in_mask(m); l_off[pos] = fo; l_w[pos] = w; }
+                len += tot;
+                __syncthreads();
+            }
+            // consume when the next chunk might not fit, or at the end
+            if (len + 256 > POOL_LIST || c0 + 256 >= ncell) {
+                int j = 0;
+                for (; j + 4 <= len; j += 4) {
+                    const long long o0 = l_off[j], o1 = l_off[j + 1], o2 = l_off[j + 2], o3 = l_off[j + 3];
+                    const float w0 = l_w[j], w1 = l_w[j + 1], w2 = l_w[j + 2], w3 = l_w[j + 3];
+#pragma unroll
+                    for (int i = 0; i < MAX_CPT; ++i) {
+                        const int c = tid + i * 256;
+                        if (c < C) {
+                            const float f0 = load_feat(fmap, o0 + c, dtype), f1 = load_feat(fmap, o1 + c, dtype);
+                            const float f2 = load_feat(fmap, o2 + c, dtype), f3 = load_feat(fmap, o3 + c, dtype);
+                            float pr = w0 * f0; acc[i] = acc[i] + pr;
+                            pr = w1 * f1; acc[i] = acc[i] + pr;
+                            pr = w2 * f2; acc[i] = acc[i] + pr;
+                            pr = w3 * f3; acc[i] = acc[i] + pr;
+                        }
                     }
                 }
+                for (; j < len; ++j) {
+                    const long long o0 = l_off[j];
+                    const float w0 = l_w[j];
+#pragma unroll
+                    for (int i = 0; i < MAX_CPT; ++i) {
+                        const int c = tid + i * 256;
+                        if (c < C) { float pr = w0 * load_feat(fmap, o0 + c, dtype); acc[i] = acc[i] + pr; }
+                    }
+                }
+                __syncthreads();
+                len = 0;
             }
+        }
     }
     const float tot = (float)n;
 #pragma unroll

@@ -112,10 +112,13 @@ extern "C" int spa_rgb2lab(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H,
 // ------------------------------------------------------------------------------------
 // centre table: 12 words per (image, centre)
 //   [0] cy [1] cx [2] cL [3] ca [4] cb [5] -  [6] y0 [7] y1 [8] x0 [9] x1 [10] count [11] -
+//   [12] by0 [13] by1 [14] bx0 [15] bx1 : bounding box (inclusive) of the pixels the last
+//   assignment sweep gave to this centre, accumulated by k_slic_assign with atomics and
+//   consumed + reset by k_slic_update
 // [y0,y1) x [x0,x1) is skimage's search window of the centre:
 //   y_min = <Py_ssize_t>max(cy - 2*step_y, 0); y_max = <Py_ssize_t>min(cy + 2*step_y + 1, H)
 // ------------------------------------------------------------------------------------
-#define CEN_WORDS 12
+#define CEN_WORDS 16
 
 __device__ __forceinline__ void slic_window(float cy, float cx, int s2y, int s2x, int H, int W,
                                             int &y0, int &y1, int &x0, int &x1)
@@ -146,6 +149,7 @@ __global__ void k_slic_init(uint32_t *__restrict__ cen, int nC, int grid_nx, int
     c[2] = 0u; c[3] = 0u; c[4] = 0u; c[5] = 0u;
     c[6] = (uint32_t)y0; c[7] = (uint32_t)y1; c[8] = (uint32_t)x0; c[9] = (uint32_t)x1;
     c[10] = 0u; c[11] = 0u;
+    c[12] = 0x7fffffffu; c[13] = 0u; c[14] = 0x7fffffffu; c[15] = 0u;
 }
 
 // ------------------------------------------------------------------------------------
@@ -157,9 +161,10 @@ __global__ void k_slic_init(uint32_t *__restrict__ cen, int nC, int grid_nx, int
 #define TILE 32
 
 __global__ __launch_bounds__(256) void k_slic_assign(const float *__restrict__ lab,
-                                                     const uint32_t *__restrict__ cen, int nC,
+                                                     uint32_t *__restrict__ cen, int nC,
                                                      int H, int W, float sw,
                                                      int32_t *__restrict__ labels,
+                                                     unsigned long long *__restrict__ rowmask, int HG,
                                                      uint32_t *__restrict__ status)
 {
     __shared__ uint4 cand[256 * 3];
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(256) void k_slic_assign(const float *__restrict__ l
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const long long npix = (long long)H * W;
     const float *pl = lab + (long long)b * 3 * npix;
-    const uint32_t *cb = cen + (long long)b * nC * CEN_WORDS;
+    uint32_t *cb = cen + (long long)b * nC * CEN_WORDS;
 
     const int y = ty0 + (tid >> 3);
     const int xb = tx0 + (tid & 7) * 4;
@@ -261,6 +266,35 @@ __global__ __launch_bounds__(256) void k_slic_assign(const float *__restrict__ l
 #pragma unroll
     for (int i = 0; i < 4; ++i) uncovered = uncovered || (ok[i] && bl[i] < 0);
     if (uncovered) atomicOr(status, SPA_ST_SLIC_UNCOVERED);
+    // occupancy masks of the new segments for the centroid update: the distinct labels of a wave
+    // (8 rows x 32 columns, lane = row*8 + column group) are enumerated with ballots and each
+    // sets one bit — scattered atomics run at a fixed chip-wide rate, so they are kept to one per
+    // (wave, label)
+    {
+        // runs of equal label inside the thread's 4 pixels (static indexing only: a runtime
+        // index into bl[]/ok[] would push the arrays to scratch memory)
+        bool val[4], st[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) val[i] = ok[i] && bl[i] >= 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) st[i] = val[i] && (i == 0 || !val[i - 1] || bl[i] != bl[i - 1]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rl = st[i] ? bl[i] : -1;
+            unsigned long long todo = __ballot(rl >= 0);
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const int ll = __shfl(rl, leader);
+                const bool mine = (rl == ll);
+                const unsigned long long same = __ballot(mine);
+                // occupancy: one bit per (8-row group, 64-pixel piece) of the centre; a wave covers
+                // exactly one such cell (rows ty0 + 8*wv .. +7, 32 columns inside one piece)
+                if (lane == leader)
+                    atomicOr(rowmask + ((long long)b * nC + ll) * HG + ((ty0 >> 3) + wv), 1ull << (tx0 >> 6));
+                todo &= ~same;
+            }
+        }
+    }
     int32_t *out = labels + (long long)b * npix;
     if (ok[3] && ((base & 3) == 0)) {
         *(int4 *)(out + base) = make_int4(bl[0], bl[1], bl[2], bl[3]);
@@ -273,23 +307,33 @@ __global__ __launch_bounds__(256) void k_slic_assign(const float *__restrict__ l
 
 // ------------------------------------------------------------------------------------
 // centroid update: one wavefront per (image, centre).  Raster-order float32 running sums.
+// The wave walks the bounding box of its segment (left by the assignment sweep) as a list of
+// 64-pixel row pieces, 8 pieces per step: their labels AND Lab values are requested together
+// (32 independent loads in flight per lane) so that a step costs one memory round trip; the
+// matching pixels are compacted in raster order (ballot + mbcnt) into an LDS ring, which five
+// lanes then drain serially — the float32 chains of y, x, L, a, b.
 // ------------------------------------------------------------------------------------
 #define RING 512   // entries of 5 floats
+#define UPD_PIECES 8
+#define UPD_GROUPS 16    // 8-row groups per piece-list batch (16 * 8 rows * <= 32 pieces)
 
 __global__ __launch_bounds__(64) void k_slic_update(const float *__restrict__ lab,
                                                     const int32_t *__restrict__ labels,
                                                     uint32_t *__restrict__ cen, int nC, int H,
                                                     int W, int s2y, int s2x,
+                                                    unsigned long long *__restrict__ rowmask, int HG,
                                                     uint32_t *__restrict__ status)
 {
     __shared__ float ring[RING * 5];
+    __shared__ unsigned plist[UPD_GROUPS * 8 * 32];
     const int k = blockIdx.x, b = blockIdx.y;
     const int lane = threadIdx.x;
     const long long npix = (long long)H * W;
     const float *pl = lab + (long long)b * 3 * npix;
     const int32_t *lb = labels + (long long)b * npix;
     uint32_t *c = cen + ((long long)b * nC + k) * CEN_WORDS;
-    const int y0 = (int)c[6], y1 = (int)c[7], x0 = (int)c[8], x1 = (int)c[9];
+    const int wy0 = (int)c[6], wy1 = (int)c[7];   // the search window [wy0, wy1) bounds the segment
+    unsigned long long *rm = rowmask + ((long long)b * nC + k) * HG;
 
     float acc = 0.0f;          // lanes 0..4: running sums of y, x, L, a, b
     int fill = 0;              // wave-uniform
@@ -313,36 +357,66 @@ __global__ __launch_bounds__(64) void k_slic_update(const float *__restrict__ la
         fill = 0;
     };
 
-    const int nch = (x1 - x0 + 63) >> 6;
-    for (int y = y0; y < y1; ++y) {
-        const int32_t *row = lb + (long long)y * W;
-        for (int c0 = 0; c0 < nch; c0 += 8) {
-            int lv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                int x = x0 + ((c0 + u) << 6) + lane;
-                lv[u] = (c0 + u < nch && x < x1) ? row[x] : -1;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                bool match = (lv[u] == k);
-                unsigned long long m = __ballot(match);
-                if (m == 0ull) continue;
-                int cntm = __popcll(m);
-                if (fill + cntm > RING) drain();
-                if (match) {
-                    int x = x0 + ((c0 + u) << 6) + lane;
-                    long long p = (long long)y * W + x;
-                    int pos = (fill + (int)spa_rank_in_mask(m)) * 5;
-                    ring[pos + 0] = (float)y;
-                    ring[pos + 1] = (float)x;
-                    ring[pos + 2] = pl[p];
-                    ring[pos + 3] = pl[npix + p];
-                    ring[pos + 4] = pl[2 * npix + p];
+    {
+        // piece list of this segment in raster order: for every 8-row group of the search window
+        // with occupancy bits, rows in order, set bits (64-pixel pieces) in order
+        const int g0 = wy0 >> 3, g1 = (wy1 - 1) >> 3;
+        for (int gb = g0; gb <= g1; gb += UPD_GROUPS) {
+            const int gg = gb + lane;
+            unsigned long long m = 0ull;
+            if (lane < UPD_GROUPS && gg <= g1) { m = rm[gg]; rm[gg] = 0ull; }   // consume + clear
+            const int rows = (lane < UPD_GROUPS && gg <= g1) ? min(8, H - (gg << 3)) : 0;
+            const int cntl = __popcll(m) * rows;
+            int inc = cntl;
+            for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+            const int npieces = __shfl(inc, 63);
+            int pos = inc - cntl;
+            for (int r = 0; r < rows; ++r) {
+                unsigned long long bits = m;
+                while (bits) {
+                    const int bit = __ffsll((long long)bits) - 1;
+                    plist[pos++] = (unsigned)(((gg << 3) + r) << 6) | (unsigned)bit;
+                    bits &= bits - 1ull;
                 }
-                fill += cntm;
-                n += (unsigned)cntm;
             }
+            __syncthreads();
+            for (int t0 = 0; t0 < npieces; t0 += UPD_PIECES) {
+                int lv[UPD_PIECES];
+                float vL[UPD_PIECES], vA[UPD_PIECES], vB[UPD_PIECES];
+                unsigned pe[UPD_PIECES];
+#pragma unroll
+                for (int u = 0; u < UPD_PIECES; ++u) {
+                    const int t = t0 + u;
+                    pe[u] = t < npieces ? plist[t] : 0u;
+                    const int yy = (int)(pe[u] >> 6), xx = (int)((pe[u] & 63u) << 6) + lane;
+                    const bool in = (t < npieces) && (xx < W);
+                    const long long p = (long long)yy * W + xx;
+                    lv[u] = in ? lb[p] : -1;
+                    vL[u] = in ? pl[p] : 0.0f;
+                    vA[u] = in ? pl[npix + p] : 0.0f;
+                    vB[u] = in ? pl[2 * npix + p] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < UPD_PIECES; ++u) {
+                    const bool match = (lv[u] == k);
+                    const unsigned long long mm = __ballot(match);
+                    if (mm == 0ull) continue;
+                    const int cntm = __popcll(mm);
+                    if (fill + cntm > RING) drain();
+                    if (match) {
+                        const int yy = (int)(pe[u] >> 6), xx = (int)((pe[u] & 63u) << 6) + lane;
+                        const int ps = (fill + (int)spa_rank_in_mask(mm)) * 5;
+                        ring[ps + 0] = (float)yy;
+                        ring[ps + 1] = (float)xx;
+                        ring[ps + 2] = vL[u];
+                        ring[ps + 3] = vA[u];
+                        ring[ps + 4] = vB[u];
+                    }
+                    fill += cntm;
+                    n += (unsigned)cntm;
+                }
+            }
+            __syncthreads();
         }
     }
     drain();
@@ -389,6 +463,12 @@ extern "C" int spa_slic_core(spa_ctx *ctx, const float *lab, int32_t B, int32_t 
     rc = spa_ws_reserve(ctx, WS_CENTRES, (size_t)B * nC * CEN_WORDS * 4, (void **)&cen);
     if (rc != SPA_OK) return rc;
     const int s2y = 2 * pl.win_step_y, s2x = 2 * pl.win_step_x;
+    SPA_ARG(W <= 2048);      // occupancy masks: <= 32 pieces of 64 pixels per row (piece-list LDS budget)
+    const int HG = (H + 7) / 8;
+    unsigned long long *rowmask;
+    rc = spa_ws_reserve(ctx, WS_ROWMASK, (size_t)B * nC * HG * 8, (void **)&rowmask);
+    if (rc != SPA_OK) return rc;
+    SPA_HIP(hipMemsetAsync(rowmask, 0, (size_t)B * nC * HG * 8, s));
     hipLaunchKernelGGL(k_slic_init, dim3((nC + 127) / 128, B), dim3(128), 0, s, cen, nC,
                        pl.grid_nx, pl.start_y, pl.start_x, pl.step_y, pl.step_x, s2y, s2x, H, W);
     SPA_LAUNCH_CHECK();
@@ -398,13 +478,13 @@ extern "C" int spa_slic_core(spa_ctx *ctx, const float *lab, int32_t B, int32_t 
     for (int it = 0; it < max_iter; ++it) {
         { SpaProfScope prof_(ctx, PROF_SLIC_ASSIGN, s);
         hipLaunchKernelGGL(k_slic_assign, ga, dim3(256), 0, s, lab, cen, nC, H, W, sw, labels,
-                           ctx->d_status); }
+                           rowmask, HG, ctx->d_status); }
         SPA_LAUNCH_CHECK();
         // the centroids computed after the last sweep never influence the labels
         if (it + 1 < max_iter || centres) {
             SpaProfScope prof_(ctx, PROF_SLIC_UPDATE, s);
             hipLaunchKernelGGL(k_slic_update, dim3(nC, B), dim3(64), 0, s, lab, labels, cen, nC,
-                               H, W, s2y, s2x, ctx->d_status);
+                               H, W, s2y, s2x, rowmask, HG, ctx->d_status);
             SPA_LAUNCH_CHECK();
         }
     }

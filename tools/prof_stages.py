@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Development aid: run the non-DRN stages of the hot path on a synthetic batch and print the
+per-kernel HIP-event times recorded by libspalign (spa_prof_*).  Fast to launch (no MIOpen
+tuning), so it is the loop used while optimising kernels:
+
+    python tools/prof_stages.py --batch 8 --reps 3
+    rocprofv3 --kernel-trace --stats ... -- python3 tools/prof_stages.py
+"""
+import argparse
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--batch', type=int, default=8)
+ap.add_argument('--height', type=int, default=1024)
+ap.add_argument('--width', type=int, default=2048)
+ap.add_argument('--n', type=int, default=200)
+ap.add_argument('--channels', type=int, default=512)
+ap.add_argument('--reps', type=int, default=3)
+ap.add_argument('--pool_mode', default='mean')
+a = ap.parse_args()
+
+spa = importlib.import_module('superpixel-align_amd')
+pipeline = importlib.import_module('superpixel-align_amd.pipeline')
+bench = importlib.import_module('bench')
+args = types.SimpleNamespace(superpixel_method='slic', n_slic_segments=a.n, n_anchors=10, n_neighbors=4,
+                             without_pos=False, y_rel_pos=0.75, x_rel_pos=0.5, y_rel_sigma=0.1,
+                             x_rel_sigma=0.1, gpu=0, n_clusters=2, use_feature_maps=[7],
+                             pool_mode=a.pool_mode, mean_sampling='nearest')
+pipe = pipeline.LabelPipeline(args, model=None)
+imgs_h, _ = bench.make_batch(spa.synth, a.batch, a.height, a.width)
+imgs = torch.from_numpy(imgs_h).cuda()
+fmap = torch.randn((a.batch, a.channels, a.height // 8, a.width // 8), device='cuda').contiguous(
+    memory_format=torch.channels_last)
+pipe.features = lambda x: fmap
+pipe.run(imgs)
+pipe.eng.prof_enable(True)
+for _ in range(a.reps):
+    pipe.run(imgs)
+torch.cuda.synchronize()
+t = pipe.elapsed_times()
+print('last run: superpixel %.3f ms  describe %.3f ms  kmeans+paint %.3f ms' %
+      (t['time_superpixel'] * 1e3, t['time_roialign'] * 1e3, t['time_kmeans'] * 1e3))
+for name, (ms, n) in pipe.eng.prof_read().items():
+    print('%-22s launches/run %5.1f  avg %9.1f us  per run %9.3f ms' % (name, n / a.reps, ms / n * 1e3, ms / a.reps))
