@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void k_slic_assign(const float *__restrict__ l
                                                      uint32_t *__restrict__ cen, int nC,
                                                      int H, int W, float sw,
                                                      int32_t *__restrict__ labels,
-                                                     unsigned long long *__restrict__ rowmask, int HG,
+                                                     unsigned long long *__restrict__ rowmask, int HG, int PW,
                                                      uint32_t *__restrict__ status)
 {
     __shared__ uint4 cand[256 * 3];
@@ -287,10 +287,16 @@ __global__ __launch_bounds__(256) void k_slic_assign(const float *__restrict__ l
                 const int ll = __shfl(rl, leader);
                 const bool mine = (rl == ll);
                 const unsigned long long same = __ballot(mine);
-                // occupancy: one bit per (8-row group, 64-pixel piece) of the centre; a wave covers
-                // exactly one such cell (rows ty0 + 8*wv .. +7, 32 columns inside one piece)
-                if (lane == leader)
-                    atomicOr(rowmask + ((long long)b * nC + ll) * HG + ((ty0 >> 3) + wv), 1ull << (tx0 >> 6));
+                // occupancy: one bit per (row, 64-pixel piece) of the centre.  A wave covers 8 rows of
+                // one piece, i.e. one byte of the mask word of its (8-row group, piece octet), so one
+                // atomicOr per (wave, label) records all of its rows.
+                const unsigned long long rb =
+                    __ballot(lane < 8 && ((same >> (lane * 8)) & 0xFFull) != 0ull) & 0xFFull;
+                if (lane == leader) {
+                    const int piece = tx0 >> 6;
+                    atomicOr(rowmask + (((long long)b * nC + ll) * HG + ((ty0 >> 3) + wv)) * PW + (piece >> 3),
+                             rb << ((piece & 7) * 8));
+                }
                 todo &= ~same;
             }
         }
@@ -306,120 +312,175 @@ __global__ __launch_bounds__(256) void k_slic_assign(const float *__restrict__ l
 }
 
 // ------------------------------------------------------------------------------------
-// centroid update: one wavefront per (image, centre).  Raster-order float32 running sums.
-// The wave walks the bounding box of its segment (left by the assignment sweep) as a list of
-// 64-pixel row pieces, 8 pieces per step: their labels AND Lab values are requested together
-// (32 independent loads in flight per lane) so that a step costs one memory round trip; the
-// matching pixels are compacted in raster order (ballot + mbcnt) into an LDS ring, which five
-// lanes then drain serially — the float32 chains of y, x, L, a, b.
+// centroid update: one 256-thread workgroup per (image, centre).  Raster-order float32 sums.
+//
+// skimage adds the pixels of a segment to float32 accumulators in raster order; float32
+// addition does not commute with regrouping, so the order is kept: lanes 0..4 of wave 0 carry
+// the five running sums (y, x, L, a, b) through the segment's pixels one by one.  Everything
+// around that serial chain is parallel and overlapped with it:
+//   * the assignment sweep left one occupancy bit per (8-row group, 64-pixel piece) of the
+//     segment; wave 1 expands the bits into a raster-ordered piece list in LDS;
+//   * waves 1..3 (gatherers) take 4 pieces each per round: the labels and Lab values of their
+//     pieces are requested together (16 independent loads in flight per lane), the matching
+//     pixels are compacted with ballot + mbcnt, in raster order, into that wave's sub-ring;
+//   * wave 0 (consumer) drains the three sub-rings of the PREVIOUS round in order while the
+//     gatherers fill the other buffer (double buffering, one barrier per round).
+// Thousands of these chains (B * n_centroids workgroups) run concurrently.
 // ------------------------------------------------------------------------------------
-#define RING 512   // entries of 5 floats
-#define UPD_PIECES 8
-#define UPD_GROUPS 16    // 8-row groups per piece-list batch (16 * 8 rows * <= 32 pieces)
+#define UPD_NG 3           // gather waves
+#define UPD_PPW 4          // pieces per gather wave per round
+#define UPD_SUB (UPD_PPW * 64)
+#define UPD_STRIDE (UPD_SUB + 16)   // floats per feature row of a sub-ring (+16: zero pad, read slack)
+#define UPD_PLIST 4096     // piece-list capacity (entries of 16 bits: row in window << 5 | piece)
 
-__global__ __launch_bounds__(64) void k_slic_update(const float *__restrict__ lab,
-                                                    const int32_t *__restrict__ labels,
-                                                    uint32_t *__restrict__ cen, int nC, int H,
-                                                    int W, int s2y, int s2x,
-                                                    unsigned long long *__restrict__ rowmask, int HG,
-                                                    uint32_t *__restrict__ status)
+struct UpdRegs { int lv[UPD_PPW]; float vL[UPD_PPW], vA[UPD_PPW], vB[UPD_PPW]; unsigned pe[UPD_PPW]; };
+
+__global__ __launch_bounds__(256) void k_slic_update(const float *__restrict__ lab,
+                                                     const int32_t *__restrict__ labels,
+                                                     uint32_t *__restrict__ cen, int nC, int H,
+                                                     int W, int s2y, int s2x,
+                                                     unsigned long long *__restrict__ rowmask, int HG, int PW,
+                                                     uint32_t *__restrict__ status)
 {
-    __shared__ float ring[RING * 5];
-    __shared__ unsigned plist[UPD_GROUPS * 8 * 32];
+    __shared__ __attribute__((aligned(16))) float ring[2][UPD_NG][UPD_STRIDE * 5];   // [feature][entry]
+    __shared__ int ring_cnt[2][UPD_NG];
+    __shared__ unsigned short plist[UPD_PLIST];
+    __shared__ int s_npieces, s_gtake;
     const int k = blockIdx.x, b = blockIdx.y;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const long long npix = (long long)H * W;
     const float *pl = lab + (long long)b * 3 * npix;
     const int32_t *lb = labels + (long long)b * npix;
     uint32_t *c = cen + ((long long)b * nC + k) * CEN_WORDS;
     const int wy0 = (int)c[6], wy1 = (int)c[7];   // the search window [wy0, wy1) bounds the segment
-    unsigned long long *rm = rowmask + ((long long)b * nC + k) * HG;
+    unsigned long long *rm = rowmask + ((long long)b * nC + k) * HG * PW;
 
-    float acc = 0.0f;          // lanes 0..4: running sums of y, x, L, a, b
-    int fill = 0;              // wave-uniform
-    unsigned n = 0;            // wave-uniform pixel count
+    float acc = 0.0f;          // wave 0, lanes 0..4: running sums of y, x, L, a, b
+    unsigned n = 0;            // wave 0: pixel count
 
-    auto drain = [&]() {
-        __syncthreads();
-        if (lane < 5) {
-            int j = 0;
-            for (; j + 8 <= fill; j += 8) {
-                float v0 = ring[(j + 0) * 5 + lane], v1 = ring[(j + 1) * 5 + lane];
-                float v2 = ring[(j + 2) * 5 + lane], v3 = ring[(j + 3) * 5 + lane];
-                float v4 = ring[(j + 4) * 5 + lane], v5 = ring[(j + 5) * 5 + lane];
-                float v6 = ring[(j + 6) * 5 + lane], v7 = ring[(j + 7) * 5 + lane];
-                acc = acc + v0; acc = acc + v1; acc = acc + v2; acc = acc + v3;
-                acc = acc + v4; acc = acc + v5; acc = acc + v6; acc = acc + v7;
-            }
-            for (; j < fill; ++j) acc = acc + ring[j * 5 + lane];
-        }
-        __syncthreads();
-        fill = 0;
-    };
-
-    {
-        // piece list of this segment in raster order: for every 8-row group of the search window
-        // with occupancy bits, rows in order, set bits (64-pixel pieces) in order
-        const int g0 = wy0 >> 3, g1 = (wy1 - 1) >> 3;
-        for (int gb = g0; gb <= g1; gb += UPD_GROUPS) {
+    const int g0 = wy0 >> 3, g1 = (wy1 - 1) >> 3;
+    const int ybase = g0 << 3;                    // plist rows are relative to this
+    int gb = g0;
+    while (gb <= g1) {
+        if (wv == 1) {
+            // piece list in raster order: groups in order, rows in order, pieces in order.
+            // lane g expands group gb+g: PW mask words, byte q of word i = rows of piece 8i+q.
+            // As many whole groups as fit the list are taken (and their masks cleared).
             const int gg = gb + lane;
-            unsigned long long m = 0ull;
-            if (lane < UPD_GROUPS && gg <= g1) { m = rm[gg]; rm[gg] = 0ull; }   // consume + clear
-            const int rows = (lane < UPD_GROUPS && gg <= g1) ? min(8, H - (gg << 3)) : 0;
-            const int cntl = __popcll(m) * rows;
+            const bool has = gg <= g1;
+            unsigned long long mw[4] = {0ull, 0ull, 0ull, 0ull};
+            int cntl = 0;
+            unsigned long long *w = rm + (long long)gg * PW;
+            if (has) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < PW) { mw[i] = w[i]; cntl += __popcll(mw[i]); }
+            }
             int inc = cntl;
             for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
-            const int npieces = __shfl(inc, 63);
-            int pos = inc - cntl;
-            for (int r = 0; r < rows; ++r) {
-                unsigned long long bits = m;
-                while (bits) {
-                    const int bit = __ffsll((long long)bits) - 1;
-                    plist[pos++] = (unsigned)(((gg << 3) + r) << 6) | (unsigned)bit;
-                    bits &= bits - 1ull;
+            const bool take = has && inc <= UPD_PLIST;
+            const unsigned long long tm = __ballot(take);
+            const int gtake = __popcll(tm);               // prefix property: lanes 0..gtake-1
+            const int total = gtake ? __shfl(inc, gtake - 1) : 0;
+            if (lane == 0) { s_npieces = total; s_gtake = gtake > 0 ? gtake : 1; }
+            if (take) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < PW) w[i] = 0ull;                                      // consumed
+                int pos = inc - cntl;
+                if (cntl) {
+                    const int yrel = (gg << 3) - ybase;
+                    for (int r = 0; r < 8; ++r) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            unsigned long long bits = (mw[i] >> r) & 0x0101010101010101ull;
+                            while (bits) {
+                                const int q = (__ffsll((long long)bits) - 1) >> 3;
+                                plist[pos++] = (unsigned short)(((yrel + r) << 5) | (i * 8 + q));
+                                bits &= bits - 1ull;
+                            }
+                        }
+                    }
                 }
             }
-            __syncthreads();
-            for (int t0 = 0; t0 < npieces; t0 += UPD_PIECES) {
-                int lv[UPD_PIECES];
-                float vL[UPD_PIECES], vA[UPD_PIECES], vB[UPD_PIECES];
-                unsigned pe[UPD_PIECES];
+        }
+        __syncthreads();
+        const int npieces = s_npieces;
+        gb += s_gtake;
+        const int rounds = (npieces + UPD_NG * UPD_PPW - 1) / (UPD_NG * UPD_PPW);
+        const int gw = wv - 1;
+        UpdRegs cur, nxt;
+        auto fetch = [&](UpdRegs &R, int rd) {
+            const int t0 = (rd * UPD_NG + gw) * UPD_PPW;
 #pragma unroll
-                for (int u = 0; u < UPD_PIECES; ++u) {
-                    const int t = t0 + u;
-                    pe[u] = t < npieces ? plist[t] : 0u;
-                    const int yy = (int)(pe[u] >> 6), xx = (int)((pe[u] & 63u) << 6) + lane;
-                    const bool in = (t < npieces) && (xx < W);
-                    const long long p = (long long)yy * W + xx;
-                    lv[u] = in ? lb[p] : -1;
-                    vL[u] = in ? pl[p] : 0.0f;
-                    vA[u] = in ? pl[npix + p] : 0.0f;
-                    vB[u] = in ? pl[2 * npix + p] : 0.0f;
-                }
+            for (int u = 0; u < UPD_PPW; ++u) {
+                const int t = t0 + u;
+                R.pe[u] = t < npieces ? (unsigned)plist[t] : 0u;
+                const int yy = ybase + (int)(R.pe[u] >> 5), xx = (int)((R.pe[u] & 31u) << 6) + lane;
+                const bool in = (t < npieces) && (xx < W) && (yy < H);
+                const long long p = (long long)yy * W + xx;
+                R.lv[u] = in ? lb[p] : -1;
+                R.vL[u] = in ? pl[p] : 0.0f;
+                R.vA[u] = in ? pl[npix + p] : 0.0f;
+                R.vB[u] = in ? pl[2 * npix + p] : 0.0f;
+            }
+        };
+        if (wv >= 1 && rounds > 0) fetch(cur, 0);
+        for (int rd = 0; rd <= rounds; ++rd) {
+            if (wv >= 1 && rd < rounds) {
+                // ---- gather: request the next round's pixels, then compact this round's
+                if (rd + 1 < rounds) fetch(nxt, rd + 1);
+                float *sub = ring[rd & 1][gw];
+                int fill = 0;
 #pragma unroll
-                for (int u = 0; u < UPD_PIECES; ++u) {
-                    const bool match = (lv[u] == k);
+                for (int u = 0; u < UPD_PPW; ++u) {
+                    const bool match = (cur.lv[u] == k);
                     const unsigned long long mm = __ballot(match);
-                    if (mm == 0ull) continue;
-                    const int cntm = __popcll(mm);
-                    if (fill + cntm > RING) drain();
                     if (match) {
-                        const int yy = (int)(pe[u] >> 6), xx = (int)((pe[u] & 63u) << 6) + lane;
-                        const int ps = (fill + (int)spa_rank_in_mask(mm)) * 5;
-                        ring[ps + 0] = (float)yy;
-                        ring[ps + 1] = (float)xx;
-                        ring[ps + 2] = vL[u];
-                        ring[ps + 3] = vA[u];
-                        ring[ps + 4] = vB[u];
+                        const int yy = ybase + (int)(cur.pe[u] >> 5), xx = (int)((cur.pe[u] & 31u) << 6) + lane;
+                        const int ps = fill + (int)spa_rank_in_mask(mm);
+                        sub[0 * UPD_STRIDE + ps] = (float)yy;
+                        sub[1 * UPD_STRIDE + ps] = (float)xx;
+                        sub[2 * UPD_STRIDE + ps] = cur.vL[u];
+                        sub[3 * UPD_STRIDE + ps] = cur.vA[u];
+                        sub[4 * UPD_STRIDE + ps] = cur.vB[u];
                     }
-                    fill += cntm;
-                    n += (unsigned)cntm;
+                    fill += __popcll(mm);
+                }
+                // pad to a multiple of 8 with +0.0f (x + 0.0f == x): the consumer needs no tail loop
+                if (lane < 8) {
+#pragma unroll
+                    for (int f = 0; f < 5; ++f) sub[f * UPD_STRIDE + fill + lane] = 0.0f;
+                }
+                if (lane == 0) ring_cnt[rd & 1][gw] = fill;
+                cur = nxt;
+            } else if (wv == 0 && rd > 0) {
+                // ---- chain: sub-rings of round rd-1, in order
+#pragma unroll
+                for (int g = 0; g < UPD_NG; ++g) {
+                    const float *sub = ring[(rd - 1) & 1][g];
+                    const int cnt = ring_cnt[(rd - 1) & 1][g];
+                    if (lane < 5) {
+                        // lane f walks feature row f: two 16-byte LDS reads per 8 pixels, issued one
+                        // step ahead of the dependent float32 adds
+                        const float *row = sub + lane * UPD_STRIDE;
+                        const float4 *r4 = (const float4 *)row;
+                        float4 a = r4[0], bq = r4[1];
+                        int j = 0;
+                        for (; j < cnt; j += 8) {
+                            const float4 na = r4[(j >> 2) + 2], nb = r4[(j >> 2) + 3];
+                            acc = acc + a.x; acc = acc + a.y; acc = acc + a.z; acc = acc + a.w;
+                            acc = acc + bq.x; acc = acc + bq.y; acc = acc + bq.z; acc = acc + bq.w;
+                            a = na; bq = nb;
+                        }
+                    }
+                    n += (unsigned)cnt;
                 }
             }
             __syncthreads();
         }
     }
-    drain();
+    if (wv != 0) return;
     if (n == 0u) {
         if (lane == 0) atomicOr(status, SPA_ST_SLIC_EMPTY_SEGMENT);
         return;
@@ -463,12 +524,14 @@ extern "C" int spa_slic_core(spa_ctx *ctx, const float *lab, int32_t B, int32_t 
     rc = spa_ws_reserve(ctx, WS_CENTRES, (size_t)B * nC * CEN_WORDS * 4, (void **)&cen);
     if (rc != SPA_OK) return rc;
     const int s2y = 2 * pl.win_step_y, s2x = 2 * pl.win_step_x;
-    SPA_ARG(W <= 2048);      // occupancy masks: <= 32 pieces of 64 pixels per row (piece-list LDS budget)
+    SPA_ARG(W <= 2048);      // occupancy masks: <= 32 pieces of 64 pixels per row (piece-list encoding)
+    SPA_ARG(4 * pl.win_step_y + 24 < 2048);   // piece-list rows are 11-bit offsets into the search window
     const int HG = (H + 7) / 8;
+    const int PW = (((W + 63) / 64) + 7) / 8;      // mask words per (centre, 8-row group)
     unsigned long long *rowmask;
-    rc = spa_ws_reserve(ctx, WS_ROWMASK, (size_t)B * nC * HG * 8, (void **)&rowmask);
+    rc = spa_ws_reserve(ctx, WS_ROWMASK, (size_t)B * nC * HG * PW * 8, (void **)&rowmask);
     if (rc != SPA_OK) return rc;
-    SPA_HIP(hipMemsetAsync(rowmask, 0, (size_t)B * nC * HG * 8, s));
+    SPA_HIP(hipMemsetAsync(rowmask, 0, (size_t)B * nC * HG * PW * 8, s));
     hipLaunchKernelGGL(k_slic_init, dim3((nC + 127) / 128, B), dim3(128), 0, s, cen, nC,
                        pl.grid_nx, pl.start_y, pl.start_x, pl.step_y, pl.step_x, s2y, s2x, H, W);
     SPA_LAUNCH_CHECK();
@@ -478,13 +541,13 @@ extern "C" int spa_slic_core(spa_ctx *ctx, const float *lab, int32_t B, int32_t 
     for (int it = 0; it < max_iter; ++it) {
         { SpaProfScope prof_(ctx, PROF_SLIC_ASSIGN, s);
         hipLaunchKernelGGL(k_slic_assign, ga, dim3(256), 0, s, lab, cen, nC, H, W, sw, labels,
-                           rowmask, HG, ctx->d_status); }
+                           rowmask, HG, PW, ctx->d_status); }
         SPA_LAUNCH_CHECK();
         // the centroids computed after the last sweep never influence the labels
         if (it + 1 < max_iter || centres) {
             SpaProfScope prof_(ctx, PROF_SLIC_UPDATE, s);
-            hipLaunchKernelGGL(k_slic_update, dim3(nC, B), dim3(64), 0, s, lab, labels, cen, nC,
-                               H, W, s2y, s2x, rowmask, HG, ctx->d_status);
+            hipLaunchKernelGGL(k_slic_update, dim3(nC, B), dim3(256), 0, s, lab, labels, cen, nC,
+                               H, W, s2y, s2x, rowmask, HG, PW, ctx->d_status);
             SPA_LAUNCH_CHECK();
         }
     }

@@ -77,6 +77,79 @@ __global__ __launch_bounds__(256) void k_bbox_count(const int32_t *__restrict__ 
     }
 }
 
+// same, aggregated per workgroup in LDS first (labels per image <= BBOX_LDS_MAX): a workgroup
+// walks a strip of rows, its waves merge their distinct labels into LDS tables with LDS
+// atomics, and only the touched entries go to global memory: ~100x fewer global atomics.
+#define BBOX_LDS_MAX 1024
+__global__ __launch_bounds__(256) void k_bbox_count_lds(const int32_t *__restrict__ labels, int W,
+                                                        int H, int rows_per_block,
+                                                        const int32_t *__restrict__ offsets,
+                                                        int Ncap, int32_t *__restrict__ bbox,
+                                                        int32_t *__restrict__ count,
+                                                        uint32_t *__restrict__ status)
+{
+    __shared__ int l_cnt[BBOX_LDS_MAX], l_y0[BBOX_LDS_MAX], l_y1[BBOX_LDS_MAX], l_x0[BBOX_LDS_MAX], l_x1[BBOX_LDS_MAX];
+    const int b = blockIdx.y;
+    const int off = offsets[b], S = offsets[b + 1] - off;
+    const int lane = threadIdx.x & 63;
+    const int SL = min(S, BBOX_LDS_MAX);          // labels beyond the LDS tables go straight to global
+    for (int l = threadIdx.x; l < SL; l += 256) {
+        l_cnt[l] = 0; l_y0[l] = 0x7fffffff; l_y1[l] = -1; l_x0[l] = 0x7fffffff; l_x1[l] = -1;
+    }
+    __syncthreads();
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(H, r0 + rows_per_block);
+    const int p_lo = r0 * W, p_hi = r1 * W;
+    const int32_t *L = labels + (long long)b * H * W;
+    for (int p0 = p_lo; p0 < p_hi; p0 += 256) {
+        const int p = p0 + threadIdx.x;
+        int l = -1, y = 0, x = 0;
+        if (p < p_hi) {
+            l = L[p];
+            y = p / W; x = p - y * W;
+            if (l < 0 || l >= S || off + l >= Ncap) { atomicOr(status, SPA_ST_LABEL_RANGE); l = -1; }
+        }
+        unsigned long long todo = __ballot(l >= 0);
+        while (todo) {
+            int leader = __ffsll((long long)todo) - 1;
+            int ll = __shfl(l, leader);
+            unsigned long long same = __ballot(l == ll);
+            int last = 63 - __clzll((long long)same);
+            int yf = __shfl(y, leader), yl = __shfl(y, last);
+            int xmin, xmax;
+            if (yf != yl) {
+                bool mine = (l == ll);
+                int a = mine ? x : 0x7fffffff, c = mine ? x : -1;
+                for (int o = 32; o > 0; o >>= 1) { a = min(a, __shfl_xor(a, o)); c = max(c, __shfl_xor(c, o)); }
+                xmin = a; xmax = c;
+            } else {
+                xmin = __shfl(x, leader); xmax = __shfl(x, last);
+            }
+            if (lane == leader) {
+                if (ll < BBOX_LDS_MAX) {
+                    atomicAdd(&l_cnt[ll], __popcll(same));
+                    atomicMin(&l_y0[ll], yf); atomicMax(&l_y1[ll], yl);
+                    atomicMin(&l_x0[ll], xmin); atomicMax(&l_x1[ll], xmax);
+                } else {
+                    const int g = off + ll;
+                    atomicAdd(count + g, __popcll(same));
+                    atomicMin(bbox + g * 4 + 0, yf); atomicMax(bbox + g * 4 + 1, yl);
+                    atomicMin(bbox + g * 4 + 2, xmin); atomicMax(bbox + g * 4 + 3, xmax);
+                }
+            }
+            todo &= ~same;
+        }
+    }
+    __syncthreads();
+    for (int l = threadIdx.x; l < SL; l += 256) {
+        if (l_cnt[l] > 0) {
+            const int g = off + l;
+            atomicAdd(count + g, l_cnt[l]);
+            atomicMin(bbox + g * 4 + 0, l_y0[l]); atomicMax(bbox + g * 4 + 1, l_y1[l]);
+            atomicMin(bbox + g * 4 + 2, l_x0[l]); atomicMax(bbox + g * 4 + 3, l_x1[l]);
+        }
+    }
+}
+
 __device__ __forceinline__ int seg_image(const int32_t *offsets, int B, int g)
 {
     int b = 0;
@@ -106,17 +179,17 @@ __global__ __launch_bounds__(256) void k_seg_moments(const int32_t *__restrict__
     unsigned long long sy = 0, sx = 0;
     double pw = 0.0;
     if (n > 0) {
-        const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
         const int32_t *L = labels + (long long)b * H * W;
-        const long long total = (long long)bw * bh;
-        for (long long i = threadIdx.x; i < total; i += 256) {
-            int yy = y0 + (int)(i / bw), xx = x0 + (int)(i % bw);
-            if (L[(long long)yy * W + xx] == s) {
-                sy += (unsigned)yy; sx += (unsigned)xx;
-                if (prior) {
-                    double ty = ((double)yy - ymean) * ((double)yy - ymean) / dy2;
-                    double tx = ((double)xx - xmean) * ((double)xx - xmean) / dx2;
-                    pw += spa_det_exp(-(ty + tx));
+        // wave w takes rows y0+w, y0+w+4, ...; lanes sweep the row in 64-pixel steps
+        for (int yy = y0 + (threadIdx.x >> 6); yy <= y1; yy += 4) {
+            const double ty = ((double)yy - ymean) * ((double)yy - ymean) / dy2;
+            for (int xx = x0 + (threadIdx.x & 63); xx <= x1; xx += 64) {
+                if (L[(long long)yy * W + xx] == s) {
+                    sy += (unsigned)yy; sx += (unsigned)xx;
+                    if (prior) {
+                        double tx = ((double)xx - xmean) * ((double)xx - xmean) / dx2;
+                        pw += spa_det_exp(-(ty + tx));
+                    }
                 }
             }
         }
@@ -153,10 +226,16 @@ extern "C" int spa_segment_stats(spa_ctx *ctx, const int32_t *labels, int32_t B,
     const int npix = H * W;
     SpaProfScope prof_(ctx, PROF_STATS, s);
     hipLaunchKernelGGL(k_bbox_init, dim3((Ncap + 255) / 256), dim3(256), 0, s, bbox, count, Ncap);
-    int gx = (npix + 255) / 256;
-    if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL(k_bbox_count, dim3(gx, B), dim3(256), 0, s, labels, W, npix, offsets, Ncap,
-                       bbox, count, ctx->d_status);
+    if (W >= 64) {
+        const int rows = 16;
+        hipLaunchKernelGGL(k_bbox_count_lds, dim3((H + rows - 1) / rows, B), dim3(256), 0, s, labels, W,
+                           H, rows, offsets, Ncap, bbox, count, ctx->d_status);
+    } else {
+        int gx = (npix + 255) / 256;
+        if (gx > 1024) gx = 1024;
+        hipLaunchKernelGGL(k_bbox_count, dim3(gx, B), dim3(256), 0, s, labels, W, npix, offsets, Ncap,
+                           bbox, count, ctx->d_status);
+    }
     if (centroid || prior) {
         // ymean, xmean = int(h * y_rel_pos), int(w * x_rel_pos); sigma = h * rel_sigma (:116-118)
         double ymean = (double)(long long)((double)H * y_rel_pos);
