@@ -232,31 +232,34 @@ __global__ __launch_bounds__(256) void k_slic_assign(const float *__restrict__ l
         }
         __syncthreads();
         if (row_ok) {
+            // straight-line body: the three 16-byte LDS reads of an entry are issued together and
+            // the window test is folded into the final comparison (no divergent branches), so the
+            // compiler can overlap the next entry's reads with this entry's arithmetic
+#pragma unroll 2
             for (int j = 0; j < total; ++j) {
-                uint4 e0 = cand[j * 3 + 0], e1 = cand[j * 3 + 1], e2 = cand[j * 3 + 2];
-                int y0 = (int)e1.z, y1 = (int)e1.w;
-                if (y < y0 || y >= y1) continue;
-                int x0 = (int)e2.x, x1 = (int)e2.y;
-                float cy = __uint_as_float(e0.x), cx = __uint_as_float(e0.y);
-                float cl = __uint_as_float(e0.z), ca = __uint_as_float(e0.w);
-                float cbb = __uint_as_float(e1.x);
-                int kk = (int)e1.y;
-                float ty = cy - fy;
-                float dy = ty * ty;
+                const uint4 e0 = cand[j * 3 + 0], e1 = cand[j * 3 + 1], e2 = cand[j * 3 + 2];
+                const int y0 = (int)e1.z, y1 = (int)e1.w, x0 = (int)e2.x, x1 = (int)e2.y;
+                const float cy = __uint_as_float(e0.x), cx = __uint_as_float(e0.y);
+                const float cl = __uint_as_float(e0.z), ca = __uint_as_float(e0.w);
+                const float cbb = __uint_as_float(e1.x);
+                const int kk = (int)e1.y;
+                const bool rowin = (y >= y0) && (y < y1);
+                const float ty = cy - fy;
+                const float dy = ty * ty;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    int x = xb + i;
-                    if (ok[i] && x >= x0 && x < x1) {
-                        float tx = cx - (float)x;
-                        float dx = tx * tx;
-                        float dc = (dy + dx) * sw;
-                        float t0 = pL[i] - cl, t1 = pA[i] - ca, t2 = pB[i] - cbb;
-                        float col = t0 * t0;
-                        col = col + t1 * t1;
-                        col = col + t2 * t2;
-                        dc = dc + col;
-                        if (best[i] > dc) { best[i] = dc; bl[i] = kk; }
-                    }
+                    const int x = xb + i;
+                    const float tx = cx - (float)x;
+                    const float dx = tx * tx;
+                    float dc = (dy + dx) * sw;
+                    const float t0 = pL[i] - cl, t1 = pA[i] - ca, t2 = pB[i] - cbb;
+                    float col = t0 * t0;
+                    col = col + t1 * t1;
+                    col = col + t2 * t2;
+                    dc = dc + col;
+                    const bool take = rowin && ok[i] && (x >= x0) && (x < x1) && (best[i] > dc);
+                    best[i] = take ? dc : best[i];
+                    bl[i] = take ? kk : bl[i];
                 }
             }
         }
