@@ -29,7 +29,7 @@ struct ConnMisc {
     int n_todo1;       // small components that did not fit the 40 KB LDS tier
     int n_todo2;       // ... nor the 156 KB tier (handled in global memory)
     int n_big;         // small components with more than LANE_MAX pixels
-    int pad;
+    int n_over;        // components larger than max_size (cut in BFS order by the reference)
 };
 
 __device__ __forceinline__ int ld_i32(const int *p)
@@ -124,6 +124,151 @@ __global__ __launch_bounds__(256) void k_ccl_flatten(int *__restrict__ parent,
 }
 
 // ---------------------------------------------------------------------------------------
+// Components larger than max_size.  The reference stops the breadth-first growth of a component
+// at max_size pixels; the pixels it did not reach are found again later by the raster scan and
+// start new components (again capped).  That decomposition depends only on the component itself,
+// so it is replayed here, one wavefront per oversize component, before anything else looks at
+// the roots: piece after piece (seed = first pixel of the component, in raster order, that no
+// earlier piece took; growth in exact queue order, truncated at max_size), then the parents of
+// the pixels are rewritten to their piece's seed and the sizes to the piece sizes.  Rare (a
+// component must exceed three times the mean superpixel area), so it runs from global memory.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_conn_find_oversize(const int *__restrict__ parent,
+                                                            const int *__restrict__ size, int npix,
+                                                            int max_size, int *__restrict__ over_list,
+                                                            ConnMisc *__restrict__ misc)
+{
+    const int b = blockIdx.y;
+    const int *P = parent + (long long)b * npix;
+    const int *S = size + (long long)b * npix;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < npix; p += gridDim.x * 256) {
+        if (P[p] == p && S[p] > max_size) {
+            int k = atomicAdd(&misc[b].n_over, 1);
+            over_list[(long long)b * npix + k] = p;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_conn_split(int *__restrict__ parent, int *__restrict__ size,
+                                                   const int *__restrict__ over_list,
+                                                   ConnMisc *__restrict__ misc,
+                                                   uint32_t *__restrict__ claim,
+                                                   int *__restrict__ queue, int H, int W, int max_size)
+{
+    const int b = blockIdx.y;
+    const int npix = H * W;
+    const int lane = threadIdx.x;
+    int *P = parent + (long long)b * npix;
+    int *S = size + (long long)b * npix;
+    uint32_t *CL = claim + (long long)b * npix;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int ddx[4] = {1, -1, 0, 0};
+    const int ddy[4] = {0, 0, 1, -1};
+    const int n_over = misc[b].n_over;
+    for (int it = blockIdx.x; it < n_over; it += gridDim.x) {
+        const int r0 = over_list[(long long)b * npix + it];
+        const int total = S[r0];
+        int qbase = 0;
+        if (lane == 0) qbase = atomicAdd(&misc[b].qalloc, total);
+        qbase = __shfl(qbase, 0);
+        int *Q0 = queue + (long long)b * npix + qbase;     // all pieces of this component, back to back
+        int done = 0;                                       // pixels assigned to pieces so far
+        int cursor = r0;
+        while (done < total) {
+            // seed: first pixel >= cursor that belongs to the component and to no piece yet
+            int seed = -1;
+            for (int p0 = cursor; p0 < npix && seed < 0; p0 += 64) {
+                const int p = p0 + lane;
+                bool hit = false;
+                if (p < npix && ld_i32(P + p) == r0)
+                    hit = __hip_atomic_load(CL + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == INF_KEY;
+                const unsigned long long m = __ballot(hit);
+                if (m) seed = p0 + __ffsll((long long)m) - 1;
+            }
+            if (seed < 0) break;                           // cannot happen: sizes are exact
+            int *Q = Q0 + done;
+            if (lane == 0) {
+                st_i32(Q, seed);
+                __hip_atomic_store(CL + seed, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_s_waitcnt(0);
+            int head = 0, tail = 1;
+            while (head < tail && tail < max_size) {
+                const int cnt = min(64, tail - head);
+                const bool act = lane < cnt;
+                const int uidx = head + lane;
+                const int u = act ? ld_i32(Q + uidx) : 0;
+                const int uy = u / W, ux = u - uy * W;
+                int v[4];
+                bool cand[4];
+                uint32_t keyd[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    int xx = ux + ddx[d], yy = uy + ddy[d];
+                    bool inb = act && xx >= 0 && xx < W && yy >= 0 && yy < H;
+                    v[d] = yy * W + xx;
+                    keyd[d] = (uint32_t)(uidx * 4 + d);
+                    cand[d] = inb && ld_i32(P + v[d]) == r0 &&
+                              __hip_atomic_load(CL + v[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == INF_KEY;
+                }
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+                    if (cand[d]) atomicMin(CL + v[d], keyd[d]);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_s_waitcnt(0);
+                int mywins = 0, before = 0, tot = 0;
+                bool win[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    win[d] = cand[d] && (__hip_atomic_load(CL + v[d], __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT) == keyd[d]);
+                    unsigned long long m = __ballot(win[d]);
+                    before += __popcll(m & below);
+                    tot += __popcll(m);
+                }
+                const int room = max_size - tail;          // the reference stops at max_size pixels
+                int pos = before;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    if (win[d]) {
+                        if (pos < room) st_i32(Q + tail + pos, v[d]);
+                        else __hip_atomic_store(CL + v[d], INF_KEY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ++pos; ++mywins;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_s_waitcnt(0);
+                head += cnt;
+                tail += min(tot, room);
+            }
+            // this piece: pixels Q[0..tail); they keep their claim (= taken) until the end
+            for (int i = lane; i < tail; i += 64) st_i32(P + ld_i32(Q + i), -2 - seed);   // provisional
+            if (lane == 0) st_i32(S + seed, tail);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_s_waitcnt(0);
+            done += tail;
+            cursor = seed + 1;
+        }
+        // finalise: parents -> piece seeds, claims released for the later global tier
+        for (int i = lane; i < done; i += 64) {
+            const int v = ld_i32(Q0 + i);
+            st_i32(P + v, -2 - ld_i32(P + v));
+            __hip_atomic_store(CL + v, INF_KEY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0);
+    }
+    // queue allocations are released for the BFS tiers that follow (they allocate again)
+}
+
+__global__ void k_conn_reset_qalloc(ConnMisc *misc, int B)
+{
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) misc[b].qalloc = 0;
+}
+
+// ---------------------------------------------------------------------------------------
 // Raster-order numbering.  Roots fall in three classes:
 //   kept  (size >= min_size)            : label = number of kept roots before it (prefix sum)
 //   tiny  (size <= LANE_MAX)            : listed in raster order (prefix sum), one LANE each
@@ -169,7 +314,6 @@ __global__ __launch_bounds__(256) void k_conn_count(const int *__restrict__ pare
         if (sz >= min_size) {
             ++ck;
             fk = min(fk, base + i);
-            if (sz >= max_size) atomicOr(status, SPA_ST_CONN_OVERSIZE);
         } else if (sz <= LANE_MAX) {
             ++ct;
         }
@@ -665,7 +809,7 @@ __global__ void k_conn_init_misc(ConnMisc *misc, int B, int npix)
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B) {
         misc[b].n_small = 0; misc[b].first_kept = npix; misc[b].qalloc = 0; misc[b].n_kept = 0;
-        misc[b].n_todo1 = 0; misc[b].n_todo2 = 0; misc[b].n_big = 0; misc[b].pad = 0;
+        misc[b].n_todo1 = 0; misc[b].n_todo2 = 0; misc[b].n_big = 0; misc[b].n_over = 0;
     }
 }
 
@@ -703,6 +847,17 @@ extern "C" int spa_enforce_connectivity(spa_ctx *ctx, const int32_t *labels_in, 
     hipLaunchKernelGGL(k_ccl_init, gp, dim3(256), 0, s, labels_in, parent, W, npix);
     hipLaunchKernelGGL(k_ccl_merge, gp, dim3(256), 0, s, labels_in, parent, W, npix);
     hipLaunchKernelGGL(k_ccl_flatten, gp, dim3(256), 0, s, parent, size, npix);
+    {
+        // components above max_size are cut the way the reference cuts them (no-op otherwise)
+        int gf = (npix + 255) / 256;
+        if (gf > 1024) gf = 1024;
+        SPA_HIP(hipMemsetAsync(claim, 0xFF, img, s));
+        hipLaunchKernelGGL(k_conn_find_oversize, dim3(gf, B), dim3(256), 0, s, parent, size, npix, max_size,
+                           todo1, misc);
+        hipLaunchKernelGGL(k_conn_split, dim3(64, B), dim3(64), 0, s, parent, size, (const int *)todo1, misc,
+                           claim, queue, H, W, max_size);
+        hipLaunchKernelGGL(k_conn_reset_qalloc, dim3((B + 63) / 64), dim3(64), 0, s, misc, B);
+    }
     hipLaunchKernelGGL(k_conn_count, dim3(nblk, B), dim3(256), 0, s, parent, size, npix, min_size,
                        max_size, blk, nblk, misc, ctx->d_status);
     hipLaunchKernelGGL(k_conn_scan, dim3(B), dim3(256), 0, s, blk, nblk, misc, n_labels);
@@ -726,8 +881,7 @@ extern "C" int spa_enforce_connectivity(spa_ctx *ctx, const int32_t *labels_in, 
                        (const int *)nullptr, todo1, misc, 0, final_, H, W, 40 * 1024);
     hipLaunchKernelGGL(k_conn_bfs_lds, dim3(256, B), dim3(64), 156 * 1024, s, parent, size, big, sbox,
                        (const int *)todo1, todo2, misc, 1, final_, H, W, 156 * 1024);
-    // the global tier is the only user of the claim array
-    SPA_HIP(hipMemsetAsync(claim, 0xFF, img, s));
+    // (the claim array is all-INF again: k_conn_split releases what it takes)
     hipLaunchKernelGGL(k_conn_bfs, dim3(256, B), dim3(64), 0, s, parent, size, big, (const int *)todo2,
                        misc, claim, queue, final_, H, W);
     hipLaunchKernelGGL(k_conn_resolve, dim3(gb, B), dim3(256), 0, s, tiny, 0, misc, final_, npix);

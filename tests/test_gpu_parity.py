@@ -92,26 +92,42 @@ def test_connectivity_bit_exact(eng, orc, synth, seed, H, W, n):
 @pytest.mark.parametrize('name', ['connectivity_stress_30_200', 'connectivity_stress_8_5000',
                                   'connectivity_stress_100_400', 'connectivity_stress_1_50'])
 def test_connectivity_stress_golden(eng, orc, name):
-    """Noisy label maps with hundreds of tiny fragments (skimage-pinned). Cases where a
-    component reaches max_size must be reported, not silently mislabelled."""
+    """Noisy label maps with hundreds of tiny fragments, several of them with max_size small
+    enough that components are cut in BFS order (skimage-pinned fixtures)."""
     g = golden(name)
     mn, mx = (int(v) for v in g['meta'])
     seg = g['seg'].astype(np.int32)
     out, n_labels = eng.enforce_connectivity(dev(seg[None]), mn, mx)
-    st = eng.status()
-    sizes_ok = not (st & 0x04)
-    if sizes_ok:
-        assert st == 0
-        assert np.array_equal(out[0].cpu().numpy(), g['post'])
-    else:
-        # oracle agrees that some component is at least max_size large
-        from scipy import ndimage
-        big = 0
-        for l in np.unique(seg):
-            cc, k = ndimage.label(seg == l)
-            if k:
-                big = max(big, np.bincount(cc.ravel())[1:].max())
-        assert big >= mx
+    eng.raise_on_status()
+    assert np.array_equal(out[0].cpu().numpy(), g['post'])
+    assert int(n_labels[0]) == int(g['post'].max()) + 1
+
+
+@pytest.mark.parametrize('seed,H,W,n', [(1, 40, 56, 6), (2, 33, 65, 5), (3, 17, 300, 9), (4, 300, 17, 9),
+                                        (5, 64, 64, 64), (6, 128, 128, 400), (7, 250, 250, 3),
+                                        (8, 480, 640, 100), (11, 512, 1024, 800), (10, 1024, 2048, 400)])
+def test_slic_edge_shapes(eng, orc, synth, seed, H, W, n):
+    """Odd widths (no float4 path), one-seed grids, more seeds than fit, n up to 800, full size."""
+    img = synth.synth_image(seed, H, W)
+    ref = orc.slic(img, n)
+    labels, n_labels = eng.slic(dev(img[None]), n)
+    eng.raise_on_status()
+    assert np.array_equal(labels[0].cpu().numpy().astype(np.int64), ref)
+    assert int(n_labels[0]) == ref.max() + 1
+
+
+def test_connectivity_random_cuts(eng, orc):
+    """Random label maps with max_size small enough that many components are cut in BFS order."""
+    rs = np.random.RandomState(11)
+    for trial in range(6):
+        H, W = 64 + 16 * trial, 96 + 8 * trial
+        base = (np.arange(H)[:, None] // 16) * 7 + (np.arange(W)[None, :] // 24)
+        seg = np.where(rs.uniform(size=(H, W)) < 0.15, rs.randint(0, 30, size=(H, W)), base).astype(np.int64)
+        mn, mx = int(rs.randint(1, 60)), int(rs.randint(60, 400))
+        ref, nl = orc.enforce_connectivity(seg, mn, mx)
+        out, n_labels = eng.enforce_connectivity(dev(seg[None], torch.int32), mn, mx)
+        eng.raise_on_status()
+        assert np.array_equal(out[0].cpu().numpy().astype(np.int64), ref), (trial, mn, mx)
 
 
 def test_slic_full_1024x2048_golden(eng, orc, synth):
