@@ -130,6 +130,8 @@ def main():
     drn = importlib.import_module('superpixel-align_amd.drn')
 
     rank, ws, local = dist.init()
+    if os.environ.get('SPA_BENCH_SAME_DEVICE') == '1':
+        local = 0               # test hook: several ranks on one GPU (with SPA_DIST_BACKEND=gloo)
     if ws != a.gpus:
         if rank == 0:
             print('warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE' % (a.gpus, ws), file=sys.stderr)

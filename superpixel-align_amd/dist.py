@@ -32,7 +32,10 @@ def init(backend=None):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            # SPA_DIST_BACKEND=gloo lets two ranks share ONE GPU (tests of the N > 1 code path on
+            # a single-GPU box); production uses nccl (= RCCL over xGMI)
+            backend = os.environ.get('SPA_DIST_BACKEND') or \
+                ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
             torch.cuda.set_device(local)
         dist.init_process_group(backend, rank=rank, world_size=ws)

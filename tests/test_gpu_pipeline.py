@@ -159,3 +159,22 @@ def test_cli_drivers_on_synthetic_pngs(mods, orc, synth, tmp_path):
     for fn in img_fns:
         m = np.asarray(Image.open(out2 / os.path.basename(fn)))
         assert m.shape == (2 * H, 2 * W) and set(np.unique(m)) <= {0, 1}
+
+
+def test_bench_two_ranks_on_one_gpu(tmp_path):
+    """bench.py's N > 1 path end to end (sharding, barrier, max-over-ranks timing, record
+    all_gather) with two ranks sharing this box's single GPU over gloo."""
+    import subprocess
+    env = dict(os.environ, SPA_DIST_BACKEND='gloo', SPA_BENCH_SAME_DEVICE='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', '29611', os.path.join(ROOT, 'bench.py'),
+           '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '2', '--height', '128', '--width', '256',
+           '--n_slic_segments', '40', '--drn_sub_batch', '2', '--no_cpu_baseline']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1                                   # rank 0 only
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['value'] > 0
+    assert d['quality']['records_gathered'] == 4             # 2 ranks x 2 images
+    assert d['roofline']['bound'] == 'hbm' and 'cpu_baseline' not in d
