@@ -54,6 +54,11 @@ def parse():
     p.add_argument('--no_cpu_baseline', action='store_true')
     p.add_argument('--cpu_sample', type=int, default=1, help='images of the CPU baseline sample')
     p.add_argument('--no_prof', action='store_true', help='do not record per-kernel events')
+    p.add_argument('--overlap', action='store_true',
+                   help='run the superpixel branch on a second stream under the DRN forward (+5%% '
+                        'images/s; per-kernel durations then include contention, so the roofline '
+                        'of the default run is measured without it). Anchor mode always overlaps: '
+                        'it hides the host-side random draws.')
     return p.parse_args()
 
 
@@ -145,7 +150,8 @@ def main():
         gpu=local, n_clusters=a.n_clusters, use_feature_maps=[7], pool_mode=a.pool_mode,
         mean_sampling='nearest', drn_sub_batch=a.drn_sub_batch)
     model = drn.create_drn(a.arch, device='cuda:%d' % local, dtype=dtype)
-    pipe = pipeline.LabelPipeline(args, model)
+    overlap = a.overlap or a.pool_mode == 'anchor'
+    pipe = pipeline.LabelPipeline(args, model, overlap=overlap)
     eng = pipe.eng
 
     B, H, W = a.batch, a.height, a.width
@@ -174,7 +180,7 @@ def main():
     evs = []
     for _ in range(a.steps):
         res = step()
-        evs.append(dict(pipe._ev))
+        evs.append(dict(pipe._ev))             # device events, read after the timed region
     # the result.json reduction: one all_gather of per-image records
     info = res.info.cpu().numpy()
     conf = conf_total.cpu().numpy()
@@ -191,10 +197,10 @@ def main():
     eng.raise_on_status()
 
     for e in evs:
-        stage['time_feature_maps'] += e['start'].elapsed_time(e['features'])
-        stage['time_superpixel'] += e['features'].elapsed_time(e['superpixel'])
-        stage['time_roialign'] += e['superpixel'].elapsed_time(e['describe'])
-        stage['time_kmeans'] += e['describe'].elapsed_time(e['kmeans'])
+        pipe._ev = e
+        for k2, v2 in pipe.stage_ms().items():
+            if k2 in stage:
+                stage[k2] += v2
     prof = eng.prof_read() if not a.no_prof else {}
     eng.prof_enable(False)
 
@@ -243,7 +249,9 @@ def main():
         'drn': {'bound': 'mfma', 'achieved': round(drn_tf, 2), 'peak': peak_tf, 'unit': 'TFLOP/s',
                 'frac': round(drn_tf / peak_tf, 4), 'ms_per_step': round(drn_ms, 3),
                 'note': 'DRN forward is PyTorch-ROCm (MIOpen) by design; not a libspalign kernel'},
-        'stage_ms_per_step': {k: round(v / a.steps, 3) for k, v in stage.items()},
+        'stage_ms_per_step': dict({k: round(v / a.steps, 3) for k, v in stage.items()},
+                                  streams='two: superpixel branch overlaps the DRN forward' if overlap
+                                  else 'one'),
         'kernels': kernels,
         'quality': {'superpixels_per_image': round(n_seg, 1), 'kmeans_iterations': int(info[0]),
                     'synthetic_road_iou': round(float(tp) / max(1.0, float(tp + fp + fn)), 4),

@@ -9,6 +9,7 @@
 // Both are MT19937; what differs is seeding and how bounded integers are drawn.
 #include <stdint.h>
 #include <stdlib.h>
+#include <thread>
 #include <vector>
 
 #include "../../include/spalign.h"
@@ -41,26 +42,41 @@ struct MT {
         mt[0] = 0x80000000u;
         idx = 624;
     }
+    uint32_t out[624];
+    void refill()
+    {
+        // the classic three-segment regeneration (no modulo in the loops), then tempering of
+        // the whole block: both loops vectorise
+        int k = 0;
+        for (; k < 624 - 397; ++k) {
+            uint32_t y = (mt[k] & 0x80000000u) | (mt[k + 1] & 0x7fffffffu);
+            mt[k] = mt[k + 397] ^ (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
+        }
+        for (; k < 623; ++k) {
+            uint32_t y = (mt[k] & 0x80000000u) | (mt[k + 1] & 0x7fffffffu);
+            mt[k] = mt[k + (397 - 624)] ^ (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
+        }
+        uint32_t y = (mt[623] & 0x80000000u) | (mt[0] & 0x7fffffffu);
+        mt[623] = mt[396] ^ (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
+        for (int i = 0; i < 624; ++i) {
+            uint32_t t = mt[i];
+            t ^= (t >> 11);
+            t ^= (t << 7) & 0x9d2c5680u;
+            t ^= (t << 15) & 0xefc60000u;
+            t ^= (t >> 18);
+            out[i] = t;
+        }
+        idx = 0;
+    }
     inline uint32_t next()
     {
-        if (idx >= 624) {
-            for (int k = 0; k < 624; ++k) {
-                uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
-                mt[k] = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-            }
-            idx = 0;
-        }
-        uint32_t y = mt[idx++];
-        y ^= (y >> 11);
-        y ^= (y << 7) & 0x9d2c5680u;
-        y ^= (y << 15) & 0xefc60000u;
-        y ^= (y >> 18);
-        return y;
+        if (idx >= 624) refill();
+        return out[idx++];
     }
 };
 }  // namespace
 
-struct spa_pyrandom { MT g; std::vector<int32_t> draws; };
+struct spa_pyrandom { MT g; };
 struct spa_nprandom { MT g; };
 
 extern "C" int spa_pyrandom_create(uint64_t seed, spa_pyrandom **out)
@@ -75,38 +91,87 @@ extern "C" int spa_pyrandom_create(uint64_t seed, spa_pyrandom **out)
 }
 extern "C" void spa_pyrandom_destroy(spa_pyrandom *r) { delete r; }
 
+// Two phases so that only the generator itself is sequential:
+//   phase 1 (this thread, in stream order): the accepted draws j of every swap of every
+//            superpixel — for i in reversed(range(1, n)): j = randbelow(i + 1), where randbelow
+//            takes the top bit_length(i+1) bits of a 32-bit output and redraws while >= i+1;
+//   phase 2 (worker threads, one superpixel each): replay the swaps on an identity array and
+//            read off its first n_anchors entries (which original ranks ended in front).
+// Superpixels are processed in groups of ~2 M draws; phase 2 of a group overlaps phase 1 of the
+// next one.
+static void replay_group(const int32_t *count, const int32_t *draws, const int64_t *doff, int32_t s0,
+                         int32_t s1, int32_t A, int32_t *ranks, const int32_t *n_valid, int tid, int nthreads)
+{
+    std::vector<int32_t> perm;
+    for (int32_t s = s0 + tid; s < s1; s += nthreads) {
+        const int32_t n = count[s];
+        if (n <= 0) continue;
+        perm.resize((size_t)n);
+        for (int32_t i = 0; i < n; ++i) perm[i] = i;
+        const int32_t *j_of = draws + doff[s - s0];       // j_of[i] for i = 1 .. n-1
+        for (int32_t i = n - 1; i >= 1; --i) {
+            const int32_t j = j_of[i];
+            const int32_t t = perm[i]; perm[i] = perm[j]; perm[j] = t;
+        }
+        for (int a = 0; a < n_valid[s]; ++a) ranks[(int64_t)s * A + a] = perm[a];
+    }
+}
+
 extern "C" int spa_pyrandom_shuffle_select_host(spa_pyrandom *r, const int32_t *count, int32_t N,
                                                 int32_t A, int32_t *ranks, int32_t *n_valid)
 {
     if (!r || !count || !ranks || !n_valid || A <= 0) return SPA_ERR_ARG;
-    for (int32_t s = 0; s < N; ++s) {
-        const int32_t n = count[s];
-        const int32_t nv = n < A ? (n < 0 ? 0 : n) : A;
-        n_valid[s] = nv;
-        for (int a = 0; a < A; ++a) ranks[(int64_t)s * A + a] = 0;
-        if (n <= 0) continue;
-        // for i in reversed(range(1, n)): j = randbelow(i + 1); x[i], x[j] = x[j], x[i]
-        // randbelow: k = (i+1).bit_length(); r = getrandbits(k); while r >= i+1: redraw
-        r->draws.resize((size_t)n);
-        int32_t *j_of = r->draws.data();
-        for (int32_t i = n - 1; i >= 1; --i) {
-            const uint32_t m = (uint32_t)i + 1u;
-            const int k = 32 - __builtin_clz(m);
-            uint32_t v = r->g.next() >> (32 - k);
-            while (v >= m) v = r->g.next() >> (32 - k);
-            j_of[i] = (int32_t)v;
+    unsigned hw = std::thread::hardware_concurrency();
+    const int nthreads = hw >= 16 ? 8 : (hw >= 4 ? (int)hw / 2 : 1);
+    const int64_t group_draws = 2 << 20;
+    std::vector<int32_t> buf[2];
+    std::vector<int64_t> doff[2];
+    std::vector<std::thread> workers;
+    int cur = 0;
+    int32_t s = 0;
+    while (s < N) {
+        // ---- phase 1 for the group [s, e)
+        std::vector<int32_t> &d = buf[cur];
+        std::vector<int64_t> &off = doff[cur];
+        off.clear();
+        int64_t total = 0;
+        int32_t e = s;
+        while (e < N && (e == s || total + (count[e] > 0 ? count[e] : 0) <= group_draws)) {
+            off.push_back(total);
+            total += count[e] > 0 ? count[e] : 0;
+            ++e;
         }
-        // which original element ends at position a < nv: undo the swaps, last swap first
-        for (int a = 0; a < nv; ++a) {
-            int32_t q = a;
-            for (int32_t i = 1; i < n; ++i) {
-                const int32_t j = j_of[i];
-                if (q == i) q = j;
-                else if (q == j) q = i;
+        d.resize((size_t)(total > 0 ? total : 1));
+        for (int32_t t = s; t < e; ++t) {
+            const int32_t n = count[t];
+            const int32_t nv = n < A ? (n < 0 ? 0 : n) : A;
+            n_valid[t] = nv;
+            for (int a = 0; a < A; ++a) ranks[(int64_t)t * A + a] = 0;
+            if (n <= 0) continue;
+            int32_t *j_of = d.data() + off[t - s];
+            for (int32_t i = n - 1; i >= 1; --i) {
+                const uint32_t m = (uint32_t)i + 1u;
+                const int sh = __builtin_clz(m);           // 32 - bit_length(m)
+                uint32_t v = r->g.next() >> sh;
+                while (v >= m) v = r->g.next() >> sh;
+                j_of[i] = (int32_t)v;
             }
-            ranks[(int64_t)s * A + a] = q;
         }
+        // ---- phase 2 of the previous group must be done before its buffers are reused next time
+        for (auto &w : workers) w.join();
+        workers.clear();
+        const int32_t *dp = d.data();
+        const int64_t *op = off.data();
+        if (nthreads <= 1) {
+            replay_group(count, dp, op, s, e, A, ranks, n_valid, 0, 1);
+        } else {
+            for (int t = 0; t < nthreads; ++t)
+                workers.emplace_back(replay_group, count, dp, op, s, e, A, ranks, n_valid, t, nthreads);
+        }
+        cur ^= 1;
+        s = e;
     }
+    for (auto &w : workers) w.join();
     return SPA_OK;
 }
 

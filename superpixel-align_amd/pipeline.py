@@ -2,11 +2,15 @@
 
 Mirrors estimate_road_mask() of the reference (batch_spalign_kmeans.py:427-458 and
 utils/apply_spalign_kmeans.py:26-57): DRN features -> superpixels -> superpixel align ->
-location prior -> weighted k-means -> painted masks, in that order, with the same timer keys.
+location prior -> weighted k-means -> painted masks, with the same timer keys.
 Where the reference crosses the host/device boundary five times per batch, this
 path uploads the images once and downloads the two uint8 masks once; in anchor mode the
 superpixel sizes additionally visit the host, because the anchors are drawn from the CPython
 `random` stream exactly as the reference draws them.
+
+Two HIP streams: the superpixel branch (SLIC, per-segment statistics, and in anchor mode the
+host-side random draws) does not depend on the DRN features, so it runs on an auxiliary stream
+while the DRN forward (MFMA-bound, MIOpen) occupies the main stream; they join before pooling.
 """
 import numpy as np
 import torch
@@ -27,7 +31,8 @@ class BatchResult(object):
 
 
 class LabelPipeline(object):
-    def __init__(self, args, model=None, engine=None, pool_mode=None, mean_sampling=None):
+    def __init__(self, args, model=None, engine=None, pool_mode=None, mean_sampling=None,
+                 overlap=True):
         self.args = args
         self.model = model
         self.eng = engine or Engine()
@@ -37,6 +42,7 @@ class LabelPipeline(object):
         # their state carries over from batch to batch
         self.pyrandom = PyRandom(getattr(args, 'seed', 1111))
         self.nprandom = NpRandom(getattr(args, 'seed', 1111))
+        self.aux = torch.cuda.Stream(device=self.eng.device) if overlap else None
         self._ev = {}
 
     # ---------------------------------------------------------------- stages
@@ -62,21 +68,19 @@ class LabelPipeline(object):
             return B * _lib.make_plan(H, W, self.args.n_slic_segments).max_labels
         return B * H * W
 
-    def describe(self, imgs_shape, labels, n_labels, fmap):
-        """batch_superpixel_align (:316-330) + batch_create_prior (:333-344) on the device.
-        -> offsets, count, X (Ncap, D), prior (Ncap)"""
+    def segments(self, imgs_shape, labels, n_labels):
+        """Everything of batch_superpixel_align (:316-330) + batch_create_prior (:333-344) that
+        needs only the label maps: offsets, sizes, centres of mass, prior, and in anchor mode the
+        anchor pixels (random.shuffle stream of the reference, :231-234)."""
         a, eng = self.args, self.eng
         B, _, H, W = imgs_shape
         ncap = self.capacity(B, H, W)
         off = eng.segment_offsets(n_labels)
-        append_pos = not a.without_pos
         count, centroid, prior = eng.segment_stats(
             labels, off, ncap, (a.y_rel_pos, a.x_rel_pos, a.y_rel_sigma, a.x_rel_sigma),
             want_centroid=True)
-        if self.pool_mode == 'mean':
-            X = eng.pool_mean(fmap, labels, off, ncap, count, self.mean_sampling,
-                              centroid if append_pos else None, append_pos)
-        elif self.pool_mode == 'anchor':
+        anchors = nvalid = None
+        if self.pool_mode == 'anchor':
             n = int(off[-1].item())                      # sizes visit the host for the RNG
             cnt_h = count[:n].cpu().numpy()
             ranks_h, nvalid_h = self.pyrandom.shuffle_select(cnt_h, a.n_anchors)
@@ -85,11 +89,21 @@ class LabelPipeline(object):
             ranks[:n] = torch.from_numpy(ranks_h).to(labels.device, non_blocking=True)
             nvalid[:n] = torch.from_numpy(nvalid_h).to(labels.device, non_blocking=True)
             anchors = eng.select_anchor_pixels(labels, off, ncap, ranks, nvalid)
-            X = eng.pool_anchor(fmap, H, off, ncap, anchors, nvalid, a.n_neighbors,
-                                centroid if append_pos else None, append_pos)
-        else:
+        elif self.pool_mode != 'mean':
             raise ValueError('pool_mode must be anchor or mean')
-        return off, count, X, prior
+        return dict(ncap=ncap, off=off, count=count, centroid=centroid, prior=prior,
+                    anchors=anchors, nvalid=nvalid)
+
+    def pool(self, imgs_shape, labels, seg, fmap):
+        """The part of batch_superpixel_align that reads the feature map -> X (Ncap, D)."""
+        a, eng = self.args, self.eng
+        append_pos = not a.without_pos
+        cen = seg['centroid'] if append_pos else None
+        if self.pool_mode == 'mean':
+            return eng.pool_mean(fmap, labels, seg['off'], seg['ncap'], seg['count'],
+                                 self.mean_sampling, cen, append_pos)
+        return eng.pool_anchor(fmap, imgs_shape[2], seg['off'], seg['ncap'], seg['anchors'],
+                               seg['nvalid'], a.n_neighbors, cen, append_pos)
 
     def cluster(self, labels, off, X, prior):
         """batch_weighted_kmeans (:347-358) -> assign, info, cluster map, road mask (device)."""
@@ -117,35 +131,63 @@ class LabelPipeline(object):
 
     def run(self, imgs, check_status=True):
         """imgs: (B,3,H,W) float32 RGB 0..255, numpy (pinned or not) or CUDA tensor."""
+        main = torch.cuda.current_stream()
         imgs_dev = torch.as_tensor(imgs)
         if not imgs_dev.is_cuda:
             imgs_dev = imgs_dev.to(self.eng.device, non_blocking=True)
         imgs_dev = imgs_dev.float().contiguous()
         self._tick('start')
-        fmap = self.features(imgs_dev)
-        self._tick('features')
-        labels, n_labels = self.superpixels(imgs_dev)
-        self._tick('superpixel')
-        off, count, X, prior = self.describe(imgs_dev.shape, labels, n_labels, fmap)
+        if self.aux is not None:
+            # superpixel branch on the auxiliary stream; it also waits for the previous batch's
+            # consumers of the shared workspaces, which ran on the main stream
+            self.aux.wait_stream(main)
+            with torch.cuda.stream(self.aux):
+                self._tick('sp_start')
+                labels, n_labels = self.superpixels(imgs_dev)
+                self._tick('superpixel')
+            # enqueue the DRN forward BEFORE anything on the aux branch can block the host
+            # (anchor mode synchronises the aux stream to draw the anchors on the host)
+            fmap = self.features(imgs_dev)
+            self._tick('features')
+            with torch.cuda.stream(self.aux):
+                seg = self.segments(imgs_dev.shape, labels, n_labels)
+                self._tick('segments')
+            main.wait_stream(self.aux)
+            for t in [labels, n_labels] + [v for v in seg.values() if isinstance(v, torch.Tensor)]:
+                t.record_stream(main)
+        else:
+            fmap = self.features(imgs_dev)
+            self._tick('features')
+            self._tick('sp_start')
+            labels, n_labels = self.superpixels(imgs_dev)
+            self._tick('superpixel')
+            seg = self.segments(imgs_dev.shape, labels, n_labels)
+            self._tick('segments')
+        self._tick('joined')
+        X = self.pool(imgs_dev.shape, labels, seg, fmap)
         self._tick('describe')
-        assign, info, cluster, road = self.cluster(labels, off, X, prior)
+        assign, info, cluster, road = self.cluster(labels, seg['off'], X, seg['prior'])
         self._tick('kmeans')
         if check_status:
             self.eng.raise_on_status()
-        return BatchResult(labels=labels, n_labels=n_labels, offsets=off, count=count, X=X,
-                           prior=prior, assign=assign, info=info, cluster=cluster, road=road,
-                           fmap=fmap)
+        return BatchResult(labels=labels, n_labels=n_labels, offsets=seg['off'], count=seg['count'],
+                           X=X, prior=seg['prior'], assign=assign, info=info, cluster=cluster,
+                           road=road, fmap=fmap)
+
+    def stage_ms(self):
+        """Device-event durations of the last run() in ms.  With two streams the superpixel
+        branch overlaps the DRN forward, so the stages do not add up to the step time."""
+        torch.cuda.synchronize()
+        e = self._ev
+        return {'time_feature_maps': e['start'].elapsed_time(e['features']),
+                'time_superpixel': e['sp_start'].elapsed_time(e['superpixel']),
+                'time_roialign': e['superpixel'].elapsed_time(e['segments']) + e['joined'].elapsed_time(e['describe']),
+                'time_prior': 0.0,
+                'time_kmeans': e['describe'].elapsed_time(e['kmeans'])}
 
     def elapsed_times(self):
         """Stage times of the last run() in seconds, under the reference's result.json keys
         (:428-458) plus time_feature_maps (the baselines' key, direct_clustering.py:292-294).
-        Measured with device events; prior is computed inside the descriptor pass, so its share
-        is reported under time_roialign and time_prior is 0."""
-        torch.cuda.synchronize()
-        e = self._ev
-        ms = lambda a, b: e[a].elapsed_time(e[b]) / 1000.0
-        return {'time_feature_maps': ms('start', 'features'),
-                'time_superpixel': ms('features', 'superpixel'),
-                'time_roialign': ms('superpixel', 'describe'),
-                'time_prior': 0.0,
-                'time_kmeans': ms('describe', 'kmeans')}
+        The prior is computed inside the segment-statistics pass: its share is reported under
+        time_roialign and time_prior is 0."""
+        return {k: v / 1000.0 for k, v in self.stage_ms().items()}

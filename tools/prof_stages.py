@@ -34,7 +34,7 @@ args = types.SimpleNamespace(superpixel_method='slic', n_slic_segments=a.n, n_an
                              without_pos=False, y_rel_pos=0.75, x_rel_pos=0.5, y_rel_sigma=0.1,
                              x_rel_sigma=0.1, gpu=0, n_clusters=2, use_feature_maps=[7],
                              pool_mode=a.pool_mode, mean_sampling='nearest')
-pipe = pipeline.LabelPipeline(args, model=None)
+pipe = pipeline.LabelPipeline(args, model=None, overlap=False)
 imgs_h, _ = bench.make_batch(spa.synth, a.batch, a.height, a.width)
 imgs = torch.from_numpy(imgs_h).cuda()
 fmap = torch.randn((a.batch, a.channels, a.height // 8, a.width // 8), device='cuda').contiguous(
