@@ -27,7 +27,7 @@ def build(force=False):
     """Compile liborc.so with gcc (a few seconds). Building the checker is not using it."""
     so = os.path.join(_HERE, 'liborc.so')
     srcs = [os.path.join(_HERE, f) for f in
-            ('slic_oracle.c', 'pool_oracle.c', 'kmeans_oracle.c', 'detmath.h', 'Makefile')]
+            ('slic_oracle.c', 'pool_oracle.c', 'kmeans_oracle.c', 'fz_oracle.c', 'detmath.h', 'Makefile')]
     if force or not os.path.exists(so) or \
             any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(['make', '-s', '-C', _HERE, 'liborc.so'])
@@ -351,3 +351,68 @@ def batch_weighted_kmeans(args, superpixels, superpixel_features, superpixel_wei
         cl[b], _ = paint(superpixels[b], assign[off:off + n])
         off += n
     return cl, cl == 0, dict(assign=assign, n_iter=it, status=status)
+
+
+# --------------------------------------------------------------------------- felzenszwalb
+def _fz_proto():
+    L = lib()
+    if not hasattr(L, '_fz_ready'):
+        L.orc_fz_gauss_weights.restype = ctypes.c_int
+        L.orc_fz_gauss_weights.argtypes = [_dbl, _P, ctypes.c_int]
+        L.orc_fz_blur.restype = None
+        L.orc_fz_blur.argtypes = [_P, _i64, _i64, _i64, _P, ctypes.c_int, _P]
+        L.orc_fz_edges.restype = _i64
+        L.orc_fz_edges.argtypes = [_P, _i64, _i64, _i64, _P, _P]
+        L.orc_fz_segment.restype = _i64
+        L.orc_fz_segment.argtypes = [_P, _P, _P, _i64, _i64, _dbl, _i64, _P]
+        L.orc_felzenszwalb.restype = _i64
+        L.orc_felzenszwalb.argtypes = [_P, _i64, _i64, _dbl, _dbl, _i64, _P]
+        L._fz_ready = True
+    return L
+
+
+def fz_gauss_weights(sigma):
+    w = np.zeros(64)
+    r = _fz_proto().orc_fz_gauss_weights(sigma, w.ctypes.data, 64)
+    return w[:2 * r + 1].copy(), r
+
+
+def fz_blur(img_hwc, weights=None, sigma=0.8):
+    """scipy.ndimage.gaussian_filter(img, sigma=[s, s, 0]) on an (H, W, C) float64 image."""
+    img = _c(img_hwc, np.float64)
+    H, W, C = img.shape
+    if weights is None:
+        weights, r = fz_gauss_weights(sigma)
+    else:
+        r = (len(weights) - 1) // 2
+    w = _c(weights, np.float64)
+    out = np.empty_like(img)
+    _fz_proto().orc_fz_blur(img.ctypes.data, H, W, C, w.ctypes.data, r, out.ctypes.data)
+    return out
+
+
+def fz_edges(img_hwc):
+    img = _c(img_hwc, np.float64)
+    H, W, C = img.shape
+    costs = np.empty(4 * H * W); edges = np.empty((4 * H * W, 2), np.int64)
+    n = _fz_proto().orc_fz_edges(img.ctypes.data, H, W, C, costs.ctypes.data, edges.ctypes.data)
+    return costs[:n].copy(), edges[:n].copy()
+
+
+def fz_segment(costs, edges, order, npix, scale, min_size):
+    c = _c(costs, np.float64); e = _c(edges, np.int64); o = _c(order, np.int64)
+    labels = np.empty(npix, np.int64)
+    nl = _fz_proto().orc_fz_segment(c.ctypes.data, e.ctypes.data, o.ctypes.data, len(o), npix, scale,
+                                    min_size, labels.ctypes.data)
+    return labels, int(nl)
+
+
+def felzenszwalb(img_chw, scale=300.0, sigma=0.8, min_size=20):
+    """felzenszwalb(img.transpose(1,2,0) / 255., scale, sigma, min_size) — batch_spalign_kmeans.py:303-307."""
+    img = _c(img_chw, np.float32)
+    _, H, W = img.shape
+    out = np.empty((H, W), np.int64)
+    nl = _fz_proto().orc_felzenszwalb(img.ctypes.data, H, W, scale, sigma, min_size, out.ctypes.data)
+    if nl < 0:
+        raise RuntimeError('orc_felzenszwalb failed')
+    return out

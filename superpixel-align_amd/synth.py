@@ -62,3 +62,28 @@ def synth_gt_labels(seed, height, width):
     lab[: int(height * 0.05)] = 0          # void strip (ignored in scoring)
     lab[int(height * 0.95):] = 1           # ego vehicle = void
     return lab
+
+
+def synth_scene(seed, height, width, n_rect=40, noise=5.0, dtype=np.float32, integer_valued=True):
+    """Piecewise-constant 'street scene': random coloured rectangles over a vertical gradient,
+    plus Gaussian noise; CHW, 0..255.  Gives graph-based segmentation (felzenszwalb) many regions
+    with sharp borders, and — with integer_valued and zero noise inside some rectangles — large
+    groups of exactly equal edge costs."""
+    rs = np.random.RandomState(seed + 4242)
+    ys = np.linspace(0.0, 1.0, height)[:, None]
+    img = np.stack([60 + 120 * ys + 0 * np.zeros((1, width)),
+                    90 + 60 * ys + 0 * np.zeros((1, width)),
+                    140 - 70 * ys + 0 * np.zeros((1, width))]).astype(np.float64)
+    for i in range(n_rect):
+        h = rs.randint(max(2, height // 12), max(3, height // 2))
+        w = rs.randint(max(2, width // 12), max(3, width // 2))
+        y0 = rs.randint(0, height - h + 1)
+        x0 = rs.randint(0, width - w + 1)
+        col = rs.uniform(0, 255, size=3)
+        img[:, y0:y0 + h, x0:x0 + w] = col[:, None, None]
+        if i % 4 != 0:                       # three quarters of the rectangles are noisy
+            img[:, y0:y0 + h, x0:x0 + w] += noise * rs.standard_normal((3, h, w))
+    np.clip(img, 0.0, 255.0, out=img)
+    if integer_valued:
+        img = np.floor(img)
+    return img.astype(dtype)

@@ -161,3 +161,28 @@ def test_confusion_matches_chainercv_formula(orc):
     assert r['road_iou'] == iou[1] and r['non_road_iou'] == iou[0]
     lab = np.array([[0, 3, 6, 7], [8, 11, 7, 255]], np.uint8)
     assert np.array_equal(orc.create_label_mask(lab), [[-1, -1, -1, 1], [0, 0, 1, 0]])
+
+
+FZ_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 'fz_s*.npz')))
+
+
+@pytest.mark.parametrize('name', FZ_CASES)
+def test_felzenszwalb_oracle_against_skimage_core(orc, synth, name):
+    """The felzenszwalb restatement vs scikit-image's compiled core run on the oracle's smoothed
+    image with a stable argsort (fixture `pinned`): bit exact.  `plain` is the untouched call."""
+    g = golden(name)
+    seed, H, W, min_size, integer = (int(v) for v in g['meta'])
+    scale, sigma = (float(v) for v in g['params'])
+    img = synth.synth_scene(seed, H, W, integer_valued=bool(integer))
+    labels = orc.felzenszwalb(img, scale, sigma, min_size)
+    assert np.array_equal(labels, g['pinned'].astype(np.int64))
+    # the untouched scikit-image call (machine-dependent exp and tie order): same partition here
+    same = (labels[:, 1:] == labels[:, :-1]) == (g['plain'][:, 1:] == g['plain'][:, :-1])
+    assert same.mean() > 0.99
+    if 'scipy_weights' in g.files:
+        w, r = orc.fz_gauss_weights(sigma)
+        np.testing.assert_allclose(w, g['scipy_weights'], rtol=1e-14)
+        hwc = (img.transpose(1, 2, 0) / np.float32(255.)).astype(np.float64)
+        # summation order of scipy's correlate1d reproduced: bit exact given scipy's weights
+        assert np.array_equal(orc.fz_blur(hwc, weights=g['scipy_weights']), g['scipy_blur'])
+        np.testing.assert_allclose(orc.fz_blur(hwc, sigma=sigma), g['scipy_blur'], rtol=1e-13, atol=1e-15)
