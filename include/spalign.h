@@ -113,6 +113,16 @@ int spa_slic(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t W,
              int32_t n_segments, float compactness, int32_t max_iter,
              int32_t *labels, int32_t *n_labels, void *stream);
 
+/* ---- Felzenszwalb superpixels ------------------------------------------------------------
+ * replaces batch_superpixel(), felzenszwalb branch: batch_spalign_kmeans.py:301-307, i.e.
+ * skimage.segmentation.felzenszwalb(img.transpose(1,2,0) / 255., scale, sigma, min_size) — the
+ * branch every reference launcher uses (scale 300, sigma 0.8, min_size 20).
+ * rgb (B,3,H,W) float32 0..255 -> labels (B,H,W) int32 contiguous ids, n_labels (B) int32.
+ * Equal edge costs are ordered by edge index (numpy's argsort leaves that order unspecified). */
+int spa_felzenszwalb(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t W,
+                     double scale, double sigma, int32_t min_size, int32_t *labels,
+                     int32_t *n_labels, void *stream);
+
 /* ---- per-superpixel descriptors -------------------------------------------------------- */
 
 /* offsets (B+1) int32 = exclusive prefix sum of n_labels (B).  (n_superpixels_per_image,

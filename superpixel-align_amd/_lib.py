@@ -59,7 +59,8 @@ PROTOTYPES = {
     'spa_enforce_connectivity': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p,
                                                 c_p, c_p]),
     'spa_slic': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_p, c_p, c_p]),
-    'spa_segment_offsets': (ctypes.c_int, [c_p, c_p, c_i32, c_p, c_p]),
+    'spa_felzenszwalb': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_f64, c_f64, c_i32, c_p, c_p, c_p]),
+    'spa_segment_offsets':(ctypes.c_int, [c_p, c_p, c_i32, c_p, c_p]),
     'spa_segment_stats': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_p, c_i32, c_f64, c_f64,
                                          c_f64, c_f64, c_p, c_p, c_p, c_p]),
     'spa_pyrandom_create': (ctypes.c_int, [ctypes.c_uint64, ctypes.POINTER(c_p)]),

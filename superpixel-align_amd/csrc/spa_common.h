@@ -66,6 +66,10 @@ enum {
     WS_SBOX,         // bounding boxes of small components
     WS_TODO,         // BFS tier hand-over lists
     WS_ROWMASK,      // SLIC per (centre, row) occupancy bits
+    WS_FZ_KEYS,      // felzenszwalb: edge cost keys (in/out of the radix sort)
+    WS_FZ_VALS,      // felzenszwalb: edge indices (in/out of the radix sort)
+    WS_FZ_STATE,     // felzenszwalb: internal costs + reservation marks
+    WS_FZ_TMP,       // felzenszwalb: radix sort temporary storage
     WS_COUNT
 };
 

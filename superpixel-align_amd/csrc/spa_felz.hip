@@ -1,0 +1,519 @@
+// Felzenszwalb-Huttenlocher graph-based superpixels on gfx950, bit exact with scikit-image's
+// felzenszwalb() as the reference calls it (batch_spalign_kmeans.py:301-307: img/255, scale 300,
+// sigma 0.8, min_size 20) given a canonical order of equal edge costs (edge index).
+//
+// The reference algorithm is a SEQUENTIAL greedy pass over the cost-sorted edges of the
+// 8-connected pixel grid: an edge merges its two components iff its cost is below
+// min(int(A) + k/|A|, int(B) + k/|B|) (thresholds rounded to float32 in the Cython core), where the
+// component state (root = smallest pixel index, size, internal cost) is that left by all earlier
+// edges; a second pass merges components below min_size.  The order dependence is kept exactly
+// with deterministic reservations: the sorted edges are taken in windows; in every round each
+// still-pending edge (1) finds its two roots and evaluates the merge test against the current
+// state, and if it wants to merge, reserves both roots with atomicMin(sorted position); (2) an
+// edge is decided — merge committed, or dropped — only if no earlier edge of the window holds a
+// reservation on either of its components, otherwise it waits for the next round.  An edge is
+// therefore always decided against exactly the state the sequential pass would show it.
+// One persistent cooperative launch per pass handles all images of the batch at once (a group
+// of workgroups per image, agent-scope barrier per group).
+//   smoothing : scipy.ndimage.gaussian_filter(img, [sigma, sigma, 0]) — symmetric correlate1d
+//               summation order, 'reflect' borders, float64
+//   costs     : float64 Euclidean colour distance of the 4 edge families (right, down, down-right,
+//               up-right), keys sorted with a stable LSD radix sort (hipCUB) on the cost bits
+#include <hipcub/hipcub.hpp>
+#include <math.h>
+
+#include "spa_common.h"
+
+#define FZ_THREADS 256
+#define FZ_EPT 4                 // edges per thread per window
+
+struct FzImg {
+    unsigned barrier;            // monotonic arrival counter of this image's workgroup group
+    int cnt[4];                  // ring of group-wide counters (see fz_group_sum)
+    int pad[3];
+};
+
+// ---------------------------------------------------------------------------------------
+// host: scipy.ndimage._gaussian_kernel1d with the deterministic exp of the oracle
+// ---------------------------------------------------------------------------------------
+static double h_det_exp(double t)
+{
+    double kf = floor(t * 1.44269504088896338700e+00 + 0.5);
+    double r = (t - kf * 6.93147180369123816490e-01) - kf * 1.90821492927058770002e-10;
+    double p = 1.0 / 87178291200.0;
+    p = p * r + 1.0 / 6227020800.0;
+    p = p * r + 1.0 / 479001600.0;
+    p = p * r + 1.0 / 39916800.0;
+    p = p * r + 1.0 / 3628800.0;
+    p = p * r + 1.0 / 362880.0;
+    p = p * r + 1.0 / 40320.0;
+    p = p * r + 1.0 / 5040.0;
+    p = p * r + 1.0 / 720.0;
+    p = p * r + 1.0 / 120.0;
+    p = p * r + 1.0 / 24.0;
+    p = p * r + 1.0 / 6.0;
+    p = p * r + 0.5;
+    p = p * r + 1.0;
+    p = p * r + 1.0;
+    int k = (int)kf;
+    unsigned long long b = (unsigned long long)(k + 1023) << 52;
+    double sc;
+    memcpy(&sc, &b, 8);
+    return p * sc;
+}
+
+#define FZ_MAXW 65
+static int fz_weights(double sigma, double *w)
+{
+    int r = (int)(4.0 * sigma + 0.5);
+    if (2 * r + 1 > FZ_MAXW) return -1;
+    double sigma2 = sigma * sigma, sum = 0.0;
+    for (int i = -r; i <= r; ++i) w[i + r] = h_det_exp(-0.5 / sigma2 * (double)(i * i));
+    int n = 2 * r + 1;
+    if (n < 8) {
+        for (int i = 0; i < n; ++i) sum += w[i];
+    } else {      // numpy pairwise summation of a short vector
+        double acc[8];
+        int i;
+        for (i = 0; i < 8; ++i) acc[i] = w[i];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) acc[j] += w[i + j];
+        sum = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+        for (; i < n; ++i) sum += w[i];
+    }
+    for (int i = 0; i < n; ++i) w[i] = w[i] / sum;
+    return r;
+}
+
+struct FzWeights { double w[FZ_MAXW]; int r; };
+
+__device__ __forceinline__ int fz_reflect(int i, int n)
+{
+    if (n == 1) return 0;
+    int period = 2 * n;
+    i = i % period;
+    if (i < 0) i += period;
+    return i < n ? i : period - 1 - i;
+}
+
+// pass 1: x/255 (float32), widen, smooth along y -> planar float64
+__global__ __launch_bounds__(256) void k_fz_blur_y(const float *__restrict__ rgb, double *__restrict__ out,
+                                                   int H, int W, FzWeights fw)
+{
+    const long long npix = (long long)H * W;
+    const long long plane = blockIdx.y;                      // b*3 + c
+    const float *src = rgb + plane * npix;
+    double *dst = out + plane * npix;
+    const double *wc = fw.w + fw.r;
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long long)gridDim.x * 256) {
+        const int y = (int)(p / W), x = (int)(p - (long long)y * W);
+        double tmp = (double)(src[p] / 255.0f) * wc[0];
+        for (int j = -fw.r; j < 0; ++j) {
+            double a = (double)(src[(long long)fz_reflect(y + j, H) * W + x] / 255.0f);
+            double b = (double)(src[(long long)fz_reflect(y - j, H) * W + x] / 255.0f);
+            tmp = tmp + (a + b) * wc[j];
+        }
+        dst[p] = tmp;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fz_blur_x(const double *__restrict__ in, double *__restrict__ out,
+                                                   int H, int W, FzWeights fw)
+{
+    const long long npix = (long long)H * W;
+    const long long plane = blockIdx.y;
+    const double *src = in + plane * npix;
+    double *dst = out + plane * npix;
+    const double *wc = fw.w + fw.r;
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long long)gridDim.x * 256) {
+        const int y = (int)(p / W), x = (int)(p - (long long)y * W);
+        const double *row = src + (long long)y * W;
+        double tmp = row[x] * wc[0];
+        for (int j = -fw.r; j < 0; ++j)
+            tmp = tmp + (row[fz_reflect(x + j, W)] + row[fz_reflect(x - j, W)]) * wc[j];
+        dst[p] = tmp;
+    }
+}
+
+// edge index -> endpoints; families in the reference's concatenation order
+struct FzGeom { int H, W; long long nR, nD, nDR, nE; };
+
+__device__ __forceinline__ void fz_endpoints(const FzGeom &g, long long idx, int &a, int &b)
+{
+    const int W = g.W;
+    if (idx < g.nR) {
+        int y = (int)(idx / (W - 1)), x = (int)(idx % (W - 1)) + 1;
+        a = y * W + x; b = a - 1;
+    } else if (idx < g.nR + g.nD) {
+        long long i = idx - g.nR;
+        int y = (int)(i / W) + 1, x = (int)(i % W);
+        a = y * W + x; b = a - W;
+    } else if (idx < g.nR + g.nD + g.nDR) {
+        long long i = idx - g.nR - g.nD;
+        int y = (int)(i / (W - 1)) + 1, x = (int)(i % (W - 1)) + 1;
+        a = y * W + x; b = a - W - 1;
+    } else {
+        long long i = idx - g.nR - g.nD - g.nDR;
+        int y = (int)(i / (W - 1)), x = (int)(i % (W - 1)) + 1;
+        a = y * W + x; b = a + W - 1;
+    }
+}
+
+// costs = sqrt(((d0*d0) + d1*d1) + d2*d2), float64; key = bit pattern (non-negative doubles order
+// like unsigned integers), value = edge index
+__global__ __launch_bounds__(256) void k_fz_costs(const double *__restrict__ sm, FzGeom g,
+                                                  unsigned long long *__restrict__ keys,
+                                                  unsigned *__restrict__ vals)
+{
+    const int b = blockIdx.y;
+    const long long npix = (long long)g.H * g.W;
+    const double *s0 = sm + (long long)b * 3 * npix, *s1 = s0 + npix, *s2 = s1 + npix;
+    unsigned long long *K = keys + (long long)b * g.nE;
+    unsigned *V = vals + (long long)b * g.nE;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < g.nE; e += (long long)gridDim.x * 256) {
+        int pa, pb;
+        fz_endpoints(g, e, pa, pb);
+        double d0 = s0[pa] - s0[pb], d1 = s1[pa] - s1[pb], d2 = s2[pa] - s2[pb];
+        double s = d0 * d0;
+        s = s + d1 * d1;
+        s = s + d2 * d2;
+        K[e] = (unsigned long long)__double_as_longlong(sqrt(s));
+        V[e] = (unsigned)e;
+    }
+}
+
+__global__ void k_fz_init(int *__restrict__ parent, int *__restrict__ size, double *__restrict__ cint,
+                          unsigned long long *__restrict__ mark, long long total, FzImg *__restrict__ st, int B)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        parent[i] = -1; size[i] = 1; cint[i] = 0.0; mark[i] = ~0ull;
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < B) {
+        st[threadIdx.x].barrier = 0;
+        for (int i = 0; i < 4; ++i) st[threadIdx.x].cnt[i] = 0;
+    }
+}
+
+__device__ __forceinline__ void fz_group_sync(unsigned *ctr, unsigned G, unsigned &epoch, uint32_t *status)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    epoch += 1;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = epoch * G;
+        long long spins = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1ll << 27)) { atomicOr(status, SPA_ST_KMEANS_BARRIER); break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+
+// sum of `local` over all threads of the image's workgroup group (one barrier).  Counter slots
+// are used round-robin; the slot two steps ahead is cleared on the way (it was last read two
+// barriers ago).
+__device__ __forceinline__ int fz_group_sum(FzImg *me, unsigned &slot, int local, bool is_first_thread,
+                                            unsigned G, unsigned &epoch, uint32_t *status)
+{
+    int *c = &me->cnt[slot & 3u];
+    if (local) atomicAdd(c, local);
+    if (is_first_thread) __hip_atomic_store(&me->cnt[(slot + 2u) & 3u], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    fz_group_sync(&me->barrier, G, epoch, status);
+    const int total = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    slot += 1u;
+    return total;
+}
+
+// parent[] convention: -1 = root (self), otherwise the parent pixel (always a smaller index)
+__device__ __forceinline__ int fz_find(const int *P, int i)
+{
+    int p;
+    while ((p = P[i]) >= 0) i = p;
+    return i;
+}
+
+// One greedy pass (mode 0: merge test of the paper; mode 1: min_size clean-up) over the sorted
+// edges of every image; grid = (G, B), workgroups (., b) form the group of image b.
+__global__ __launch_bounds__(FZ_THREADS) void k_fz_pass(const unsigned long long *__restrict__ keys,
+                                                        const unsigned *__restrict__ vals, FzGeom g,
+                                                        int *__restrict__ parent, int *__restrict__ size,
+                                                        double *__restrict__ cint,
+                                                        unsigned long long *__restrict__ mark,
+                                                        FzImg *__restrict__ st, double scale, int min_size,
+                                                        int mode, unsigned round0, uint32_t *__restrict__ status)
+{
+    const int b = blockIdx.y;
+    const unsigned G = gridDim.x;
+    const long long npix = (long long)g.H * g.W;
+    const unsigned long long *K = keys + (long long)b * g.nE;
+    const unsigned *V = vals + (long long)b * g.nE;
+    int *P = parent + (long long)b * npix;
+    int *S = size + (long long)b * npix;
+    double *CI = cint + (long long)b * npix;
+    unsigned long long *M = mark + (long long)b * npix;
+    FzImg *me = st + b;
+    unsigned epoch = me->barrier / G;             // barrier counter persists across launches
+    const long long T = (long long)G * FZ_THREADS;
+    const long long tg = (long long)blockIdx.x * FZ_THREADS + threadIdx.x;
+    unsigned round = round0;
+    unsigned slot = 0;
+
+    for (long long lo = 0; lo < g.nE; lo += T * FZ_EPT) {
+        // path halving for the whole image before each window keeps the trees shallow
+        for (long long p = tg; p < npix; p += T) {
+            int q = P[p];
+            if (q >= 0) {
+                int r = fz_find(P, q);
+                if (r != q) P[p] = r;
+            }
+        }
+        fz_group_sync(&me->barrier, G, epoch, status);
+        bool pend[FZ_EPT];
+        int ea[FZ_EPT], eb[FZ_EPT];
+        double cost[FZ_EPT];
+#pragma unroll
+        for (int u = 0; u < FZ_EPT; ++u) {
+            const long long e = lo + tg + (long long)u * T;     // sorted position
+            pend[u] = e < g.nE;
+            if (pend[u]) {
+                fz_endpoints(g, (long long)V[e], ea[u], eb[u]);
+                cost[u] = __longlong_as_double((long long)K[e]);
+            }
+        }
+        for (;;) {
+            ++round;
+            const unsigned long long tag = (unsigned long long)(~round) << 32;
+            int ra[FZ_EPT], rb[FZ_EPT];
+            bool want[FZ_EPT], resv[FZ_EPT];
+            // ---- phase 1: roots and the merge test against the current state; edges that want
+            // to merge reserve both components with their position in the window
+#pragma unroll
+            for (int u = 0; u < FZ_EPT; ++u) {
+                want[u] = false; resv[u] = false;
+                if (!pend[u]) continue;
+                ra[u] = fz_find(P, ea[u]);
+                rb[u] = fz_find(P, eb[u]);
+                if (ra[u] == rb[u]) { pend[u] = false; continue; }      // same component for ever
+                if (mode == 0) {
+                    const float t0 = (float)(CI[ra[u]] + scale / (double)S[ra[u]]);
+                    const float t1 = (float)(CI[rb[u]] + scale / (double)S[rb[u]]);
+                    want[u] = cost[u] < (double)(t0 < t1 ? t0 : t1);
+                } else {
+                    want[u] = S[ra[u]] < min_size || S[rb[u]] < min_size;
+                }
+                if (want[u]) {
+                    const unsigned long long key = tag | (unsigned long long)(unsigned)(tg + (long long)u * T);
+                    atomicMin(M + ra[u], key);
+                    atomicMin(M + rb[u], key);
+                    resv[u] = true;
+                }
+            }
+            fz_group_sync(&me->barrier, G, epoch, status);
+            // ---- propagation: an edge that does not want to merge NOW may want to once an earlier
+            // reserved edge has changed one of its components, so while it waits it must hold its
+            // components too (later edges must not be decided against a state it might still change)
+            for (;;) {
+                int changed = 0;
+#pragma unroll
+                for (int u = 0; u < FZ_EPT; ++u) {
+                    if (!pend[u] || resv[u]) continue;
+                    const unsigned pos = (unsigned)(tg + (long long)u * T);
+                    const unsigned long long ma = __hip_atomic_load(M + ra[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long mb = __hip_atomic_load(M + rb[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned pa = (ma >> 32) == (tag >> 32) ? (unsigned)ma : 0xFFFFFFFFu;
+                    const unsigned pb = (mb >> 32) == (tag >> 32) ? (unsigned)mb : 0xFFFFFFFFu;
+                    if (pa < pos || pb < pos) {
+                        const unsigned long long key = tag | (unsigned long long)pos;
+                        atomicMin(M + ra[u], key);
+                        atomicMin(M + rb[u], key);
+                        resv[u] = true;
+                        ++changed;
+                    }
+                }
+                if (fz_group_sum(me, slot, changed, tg == 0, G, epoch, status) == 0) break;
+            }
+            // ---- phase 2: decide every edge no earlier reservation can influence
+            int left = 0;
+#pragma unroll
+            for (int u = 0; u < FZ_EPT; ++u) {
+                if (!pend[u]) continue;
+                const unsigned pos = (unsigned)(tg + (long long)u * T);
+                const unsigned long long ma = __hip_atomic_load(M + ra[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long mb = __hip_atomic_load(M + rb[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned pa = (ma >> 32) == (tag >> 32) ? (unsigned)ma : 0xFFFFFFFFu;
+                const unsigned pb = (mb >> 32) == (tag >> 32) ? (unsigned)mb : 0xFFFFFFFFu;
+                if (pa < pos || pb < pos) { ++left; continue; }                  // waits for an earlier edge
+                if (want[u]) {
+                    const int lo_r = min(ra[u], rb[u]), hi_r = max(ra[u], rb[u]);
+                    const int ns = S[ra[u]] + S[rb[u]];
+                    P[hi_r] = lo_r;
+                    S[lo_r] = ns;
+                    if (mode == 0) CI[lo_r] = cost[u];
+                }
+                pend[u] = false;
+            }
+            if (fz_group_sum(me, slot, left, tg == 0, G, epoch, status) == 0) break;
+        }
+    }
+}
+
+// labels = rank of the root among the roots in raster order (np.unique(flat, return_inverse=True)[1])
+__global__ __launch_bounds__(256) void k_fz_count_roots(const int *__restrict__ parent, int npix,
+                                                        int *__restrict__ blk, int nblk)
+{
+    __shared__ int ws[4];
+    const int b = blockIdx.y;
+    const int *P = parent + (long long)b * npix;
+    const int base = blockIdx.x * 1024 + threadIdx.x * 4;
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c += (base + i < npix && P[base + i] < 0) ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) blk[(long long)b * nblk + blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+__global__ __launch_bounds__(256) void k_fz_scan(int *__restrict__ blk, int nblk, int32_t *__restrict__ n_labels)
+{
+    __shared__ int part[256];
+    const int b = blockIdx.x;
+    int *B_ = blk + (long long)b * nblk;
+    const int per = (nblk + 255) / 256;
+    const int lo = threadIdx.x * per, hi = min(nblk, lo + per);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += B_[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int i = 0; i < 256; ++i) { int t = part[i]; part[i] = run; run += t; }
+        n_labels[b] = run;
+    }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (int i = lo; i < hi; ++i) { int t = B_[i]; B_[i] = run; run += t; }
+}
+
+__global__ __launch_bounds__(256) void k_fz_number(const int *__restrict__ parent, int npix,
+                                                   const int *__restrict__ blk, int nblk,
+                                                   int *__restrict__ rank)
+{
+    __shared__ int ws[4];
+    const int b = blockIdx.y;
+    const int *P = parent + (long long)b * npix;
+    int *R = rank + (long long)b * npix;
+    const int base = blockIdx.x * 1024 + threadIdx.x * 4;
+    bool k[4];
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { k[i] = base + i < npix && P[base + i] < 0; c += k[i] ? 1 : 0; }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int inc = c;
+    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) ws[wv] = inc;
+    __syncthreads();
+    int off = blk[(long long)b * nblk + blockIdx.x];
+    for (int i = 0; i < wv; ++i) off += ws[i];
+    int r = off + inc - c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (k[i]) R[base + i] = r++;
+}
+
+__global__ __launch_bounds__(256) void k_fz_relabel(const int *__restrict__ parent,
+                                                    const int *__restrict__ rank, int npix,
+                                                    int32_t *__restrict__ out)
+{
+    const int b = blockIdx.y;
+    const int *P = parent + (long long)b * npix;
+    const int *R = rank + (long long)b * npix;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < npix; p += gridDim.x * 256)
+        out[(long long)b * npix + p] = R[fz_find(P, p)];
+}
+
+extern "C" int spa_felzenszwalb(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t W,
+                                double scale, double sigma, int32_t min_size, int32_t *labels,
+                                int32_t *n_labels, void *stream)
+{
+    SPA_ARG(ctx && rgb && labels && n_labels && B > 0 && H > 1 && W > 1 && sigma > 0.0 && scale > 0.0);
+    SPA_ARG((long long)H * W < (1ll << 28) && B <= 256);
+    hipStream_t s = spa_stream(stream);
+    FzWeights fw;
+    fw.r = fz_weights(sigma, fw.w);
+    SPA_ARG(fw.r >= 0);
+    const long long npix = (long long)H * W;
+    FzGeom g;
+    g.H = H; g.W = W;
+    g.nR = (long long)H * (W - 1); g.nD = (long long)(H - 1) * W; g.nDR = (long long)(H - 1) * (W - 1);
+    g.nE = g.nR + g.nD + 2 * g.nDR;
+    SPA_ARG(g.nE < (1ll << 32));
+
+    // workspaces (the connectivity pass of SLIC is not running at the same time: share its slots)
+    double *sm0, *sm1, *cint;
+    unsigned long long *keys0, *keys1, *mark;
+    unsigned *vals0, *vals1;
+    int *parent, *size, *rank, *blk;
+    FzImg *st;
+    void *tmp;
+    int rc;
+    const size_t planes = (size_t)B * 3 * npix * 8;
+    const int nblk = (int)((npix + 1023) / 1024);
+    if ((rc = spa_ws_reserve(ctx, WS_LAB, 2 * planes, (void **)&sm0)) != SPA_OK) return rc;
+    sm1 = sm0 + (size_t)B * 3 * npix;
+    if ((rc = spa_ws_reserve(ctx, WS_FZ_KEYS, (size_t)B * g.nE * 8 * 2, (void **)&keys0)) != SPA_OK) return rc;
+    keys1 = keys0 + (size_t)B * g.nE;
+    if ((rc = spa_ws_reserve(ctx, WS_FZ_VALS, (size_t)B * g.nE * 4 * 2, (void **)&vals0)) != SPA_OK) return rc;
+    vals1 = vals0 + (size_t)B * g.nE;
+    if ((rc = spa_ws_reserve(ctx, WS_PARENT, (size_t)B * npix * 4, (void **)&parent)) != SPA_OK) return rc;
+    if ((rc = spa_ws_reserve(ctx, WS_SIZE, (size_t)B * npix * 4, (void **)&size)) != SPA_OK) return rc;
+    if ((rc = spa_ws_reserve(ctx, WS_FINAL, (size_t)B * npix * 4, (void **)&rank)) != SPA_OK) return rc;
+    if ((rc = spa_ws_reserve(ctx, WS_FZ_STATE, (size_t)B * npix * 16, (void **)&cint)) != SPA_OK) return rc;
+    mark = (unsigned long long *)(cint + (size_t)B * npix);
+    if ((rc = spa_ws_reserve(ctx, WS_BLK, (size_t)B * 2 * nblk * 4, (void **)&blk)) != SPA_OK) return rc;
+    if ((rc = spa_ws_reserve(ctx, WS_CONNMISC, (size_t)B * sizeof(FzImg) + 256, (void **)&st)) != SPA_OK) return rc;
+    size_t tmp_bytes = 0;
+    hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys0, keys1, vals0, vals1, (int)g.nE, 0, 64, s);
+    if ((rc = spa_ws_reserve(ctx, WS_FZ_TMP, tmp_bytes, &tmp)) != SPA_OK) return rc;
+
+    int gx = (int)((npix + 255) / 256);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(k_fz_blur_y, dim3(gx, B * 3), dim3(256), 0, s, rgb, sm0, H, W, fw);
+    hipLaunchKernelGGL(k_fz_blur_x, dim3(gx, B * 3), dim3(256), 0, s, (const double *)sm0, sm1, H, W, fw);
+    int ge = (int)((g.nE + 255) / 256);
+    if (ge > 2048) ge = 2048;
+    hipLaunchKernelGGL(k_fz_costs, dim3(ge, B), dim3(256), 0, s, (const double *)sm1, g, keys0, vals0);
+    for (int b = 0; b < B; ++b) {
+        SPA_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys0 + (size_t)b * g.nE, keys1 + (size_t)b * g.nE,
+                                                   vals0 + (size_t)b * g.nE, vals1 + (size_t)b * g.nE, (int)g.nE,
+                                                   0, 64, s));
+    }
+    hipLaunchKernelGGL(k_fz_init, dim3(1024), dim3(256), 0, s, parent, size, cint, mark, (long long)B * npix, st, B);
+    // persistent passes: every workgroup of the grid must be resident (one per CU at most)
+    int G = ctx->n_cu / B;
+    if (G < 1) G = 1;
+    long long need = (g.nE + (long long)FZ_THREADS * FZ_EPT - 1) / ((long long)FZ_THREADS * FZ_EPT);
+    if (G > need) G = (int)need;
+    SPA_ARG((long long)G * B <= ctx->n_cu);
+    // scale = float(scale) / 255.
+    const double k = scale / 255.0;
+    hipLaunchKernelGGL(k_fz_pass, dim3(G, B), dim3(FZ_THREADS), 0, s, (const unsigned long long *)keys1,
+                       (const unsigned *)vals1, g, parent, size, cint, mark, st, k, min_size, 0, 0u, ctx->d_status);
+    hipLaunchKernelGGL(k_fz_pass, dim3(G, B), dim3(FZ_THREADS), 0, s, (const unsigned long long *)keys1,
+                       (const unsigned *)vals1, g, parent, size, cint, mark, st, k, min_size, 1, 0x40000000u,
+                       ctx->d_status);
+    hipLaunchKernelGGL(k_fz_count_roots, dim3(nblk, B), dim3(256), 0, s, parent, (int)npix, blk, nblk);
+    hipLaunchKernelGGL(k_fz_scan, dim3(B), dim3(256), 0, s, blk, nblk, n_labels);
+    hipLaunchKernelGGL(k_fz_number, dim3(nblk, B), dim3(256), 0, s, parent, (int)npix, blk, nblk, rank);
+    int gr = (int)((npix + 255) / 256);
+    if (gr > 2048) gr = 2048;
+    hipLaunchKernelGGL(k_fz_relabel, dim3(gr, B), dim3(256), 0, s, parent, rank, (int)npix, labels);
+    SPA_LAUNCH_CHECK();
+    return SPA_OK;
+}

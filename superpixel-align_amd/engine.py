@@ -118,6 +118,17 @@ class Engine(object):
                                  _ptr(labels), _ptr(n_labels), _stream()))
         return labels, n_labels
 
+    def felzenszwalb(self, rgb, scale=300.0, sigma=0.8, min_size=20):
+        """felzenszwalb(img/255, scale, sigma, min_size) for a batch -> labels (B,H,W) i32, n_labels (B)."""
+        rgb = _req(rgb, torch.float32, 'rgb')
+        B, C, H, W = rgb.shape
+        assert C == 3
+        labels = torch.empty((B, H, W), dtype=torch.int32, device=rgb.device)
+        n_labels = torch.empty((B,), dtype=torch.int32, device=rgb.device)
+        check(self._lib.spa_felzenszwalb(self._ctx, _ptr(rgb), B, H, W, scale, sigma, min_size,
+                                         _ptr(labels), _ptr(n_labels), _stream()))
+        return labels, n_labels
+
     # ------------------------------------------------------------------ descriptors
     def segment_offsets(self, n_labels):
         n_labels = _req(n_labels, torch.int32, 'n_labels')
