@@ -48,6 +48,8 @@ def parse():
     p.add_argument('--arch', default='drn_d_22', choices=['drn_d_22', 'drn_c_26'])
     p.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'])
     p.add_argument('--n_slic_segments', type=int, default=200)
+    p.add_argument('--superpixel_method', default='slic', choices=['slic', 'felzenszwalb'],
+                   help="felzenszwalb (scale 300, sigma 0.8, min_size 20) is the reference launchers' setting")
     p.add_argument('--n_clusters', type=int, default=2)
     p.add_argument('--pool_mode', default='mean', choices=['mean', 'anchor'])
     p.add_argument('--drn_sub_batch', type=int, default=10)
@@ -80,9 +82,11 @@ def algorithmic_bytes(kernel, B, H, W, C, fh, fw, n_seg, feat_bytes):
     return per_image.get(kernel, 0) * B
 
 
-def make_batch(synth, B, H, W):
-    """B synthetic images from 4 generated ones (rolled copies are new images for SLIC/DRN)."""
-    base = [synth.synth_image(s, H, W) for s in range(min(4, B))]
+def make_batch(synth, B, H, W, scene=False):
+    """B synthetic images from 4 generated ones (rolled copies are new images for SLIC/DRN).
+    scene=True: piecewise-constant scenes (what graph-based felzenszwalb needs to find regions)."""
+    gen = synth.synth_scene if scene else synth.synth_image
+    base = [gen(s, H, W) for s in range(min(4, B))]
     imgs = np.empty((B, 3, H, W), np.float32)
     gts = np.empty((B, H, W), np.int32)
     gt0 = [synth.synth_gt_labels(s, H, W) for s in range(min(4, B))]
@@ -145,7 +149,8 @@ def main():
     dtype = {'fp32': torch.float32, 'bf16': torch.bfloat16}[a.dtype]
 
     args = types.SimpleNamespace(
-        superpixel_method='slic', n_slic_segments=a.n_slic_segments, n_anchors=10, n_neighbors=4,
+        superpixel_method=a.superpixel_method, n_slic_segments=a.n_slic_segments, n_anchors=10, n_neighbors=4,
+        felzenszwalb_scale=300.0, felzenszwalb_sigma=0.8, felzenszwalb_min_size=20,
         without_pos=False, y_rel_pos=0.75, x_rel_pos=0.5, y_rel_sigma=0.1, x_rel_sigma=0.1,
         gpu=local, n_clusters=a.n_clusters, use_feature_maps=[7], pool_mode=a.pool_mode,
         mean_sampling='nearest', drn_sub_batch=a.drn_sub_batch)
@@ -155,7 +160,7 @@ def main():
     eng = pipe.eng
 
     B, H, W = a.batch, a.height, a.width
-    imgs_h, gts_h = make_batch(spa.synth, B, H, W)
+    imgs_h, gts_h = make_batch(spa.synth, B, H, W, scene=(a.superpixel_method == 'felzenszwalb'))
     imgs = torch.from_numpy(imgs_h).cuda()
     gts = torch.from_numpy(gts_h).cuda()
     conf_total = torch.zeros((B, 4), dtype=torch.int64, device='cuda')
@@ -239,9 +244,11 @@ def main():
         'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if a.dtype == 'fp32' else 'bf16',
         'data': 'synthetic',
-        'config': {'workload': 'BASELINE configs[1] x batch: %s %s features + HIP SLIC(%d)/%s-pool/'
+        'config': {'workload': 'BASELINE configs[1] x batch: %s %s features + HIP %s/%s-pool/'
                                'prior/k-means(k=%d)/paint, %dx%d, %d images per step per GPU, '
-                               'random-init weights' % (a.arch, a.dtype, a.n_slic_segments, a.pool_mode,
+                               'random-init weights' % (a.arch, a.dtype,
+                                                        'SLIC(%d)' % a.n_slic_segments if a.superpixel_method == 'slic'
+                                                        else 'felzenszwalb(300,0.8,20)', a.pool_mode,
                                                         a.n_clusters, H, W, B),
                    'images_per_step_per_gpu': B, 'sharding': 'images (no data-path collective), '
                    'one all_gather of score records'},

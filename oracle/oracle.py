@@ -308,8 +308,9 @@ def confusion(road_mask, gt_mask):
 # --------------------------------------------------------------------------- boundary ops
 def batch_superpixel(args, imgs):
     """:299-313 (SLIC branch)."""
-    if args.superpixel_method != 'slic':
-        raise NotImplementedError('oracle restates the SLIC branch only')
+    if args.superpixel_method == 'felzenszwalb':
+        return np.asarray([felzenszwalb(img, args.felzenszwalb_scale, args.felzenszwalb_sigma,
+                                        args.felzenszwalb_min_size) for img in imgs])
     return np.asarray([slic(img, args.n_slic_segments) for img in imgs])
 
 

@@ -91,11 +91,14 @@ def create_model(args):
 
 
 def batch_superpixel(args, imgs):
-    if args.superpixel_method != 'slic':
-        raise NotImplementedError(
-            "superpixel_method=%r: only 'slic' runs on the MI355X path so far" % args.superpixel_method)
     eng = engine()
-    labels, n_labels = eng.slic(_dev(imgs, torch.float32), args.n_slic_segments)
+    if args.superpixel_method == 'felzenszwalb':
+        labels, n_labels = eng.felzenszwalb(_dev(imgs, torch.float32), args.felzenszwalb_scale,
+                                            args.felzenszwalb_sigma, args.felzenszwalb_min_size)
+    elif args.superpixel_method == 'slic':
+        labels, n_labels = eng.slic(_dev(imgs, torch.float32), args.n_slic_segments)
+    else:
+        raise ValueError('unknown superpixel_method %r' % args.superpixel_method)
     eng.raise_on_status()
     out = labels.cpu().numpy().astype(np.int64)          # np.asarray(list of int64 maps) (:312)
     return _remember(out, labels=labels, n_labels=n_labels)

@@ -57,16 +57,19 @@ class LabelPipeline(object):
     def superpixels(self, imgs_dev):
         """batch_superpixel (:299-313) -> labels (B,H,W) i32, n_labels (B) i32 on the device."""
         a = self.args
-        if a.superpixel_method != 'slic':
-            raise NotImplementedError(
-                "superpixel_method=%r: only 'slic' runs on the MI355X path so far "
-                '(felzenszwalb is the next row of the scope table, SURVEY.md 8f)' % a.superpixel_method)
-        return self.eng.slic(imgs_dev, a.n_slic_segments)
+        if a.superpixel_method == 'slic':
+            return self.eng.slic(imgs_dev, a.n_slic_segments)
+        if a.superpixel_method == 'felzenszwalb':
+            return self.eng.felzenszwalb(imgs_dev, a.felzenszwalb_scale, a.felzenszwalb_sigma,
+                                         a.felzenszwalb_min_size)
+        raise ValueError('unknown superpixel_method %r' % a.superpixel_method)
 
-    def capacity(self, B, H, W):
+    def capacity(self, B, H, W, n_labels):
+        """Rows to allocate for the descriptor matrix.  SLIC has a static bound; felzenszwalb's
+        segment count is data dependent (1 .. H*W/min_size), so the exact total is read back."""
         if self.args.superpixel_method == 'slic':
             return B * _lib.make_plan(H, W, self.args.n_slic_segments).max_labels
-        return B * H * W
+        return max(1, int(n_labels.sum().item()))
 
     def segments(self, imgs_shape, labels, n_labels):
         """Everything of batch_superpixel_align (:316-330) + batch_create_prior (:333-344) that
@@ -74,7 +77,7 @@ class LabelPipeline(object):
         anchor pixels (random.shuffle stream of the reference, :231-234)."""
         a, eng = self.args, self.eng
         B, _, H, W = imgs_shape
-        ncap = self.capacity(B, H, W)
+        ncap = self.capacity(B, H, W, n_labels)
         off = eng.segment_offsets(n_labels)
         count, centroid, prior = eng.segment_stats(
             labels, off, ncap, (a.y_rel_pos, a.x_rel_pos, a.y_rel_sigma, a.x_rel_sigma),

@@ -85,8 +85,12 @@ def test_five_ops_drop_in(mods, orc, synth):
     cl4, _ = ops.batch_weighted_kmeans(a4, sps, feats, w, n_per)
     r4, _, _ = orc.batch_weighted_kmeans(a4, ref_sps, rf, w, rn, nprandom=orc.NpRandom(1111))
     assert np.array_equal(cl4, r4)
-    with pytest.raises(NotImplementedError):
-        ops.batch_superpixel(_args(superpixel_method='felzenszwalb'), imgs)
+    # the felzenszwalb branch (the reference launchers' choice) through the same boundary
+    af = _args(superpixel_method='felzenszwalb', felzenszwalb_scale=300.0, felzenszwalb_sigma=0.8,
+               felzenszwalb_min_size=20)
+    scenes = np.stack([synth.synth_scene(s, 96, 160) for s in (50, 51)])
+    fz = ops.batch_superpixel(af, scenes)
+    assert fz.dtype == np.int64 and np.array_equal(fz, orc.batch_superpixel(af, scenes))
 
 
 @pytest.mark.parametrize('pool_mode,k', [('mean', 2), ('anchor', 2), ('anchor', 4), ('mean', 3)])
@@ -112,6 +116,28 @@ def test_fused_pipeline_end_to_end(mods, orc, synth, pool_mode, k):
     gi = res.info.cpu().tolist()
     assert gi[:3] == [info['n_iter'], info['status'], N]
     assert np.array_equal(res.assign[:N].cpu().numpy(), info['assign'])
+    assert np.array_equal(res.cluster.cpu().numpy(), cl)
+    assert np.array_equal(res.road.cpu().numpy().astype(bool), road)
+
+
+def test_reference_operating_point_felzenszwalb(mods, orc, synth):
+    """What every reference launcher runs (utils/create_random300_labels.sh:14-34): 224x224 input,
+    felzenszwalb(scale 300, sigma 0.8, min_size 20), DRN-C-26 layer8, 10 anchors, k = 4, batch."""
+    args = _args(superpixel_method='felzenszwalb', felzenszwalb_scale=300.0, felzenszwalb_sigma=0.8,
+                 felzenszwalb_min_size=20, n_clusters=4, pool_mode='anchor', arch='drn_c_26')
+    imgs = np.stack([synth.synth_scene(60 + i, 224, 224) for i in range(6)])
+    model = mods.drn.create_drn('drn_c_26', device='cuda')
+    pipe = mods.pipeline.LabelPipeline(args, model, mods.ops.engine())
+    res = pipe.run(imgs)
+    fmap = res.fmap.float().cpu().numpy()
+    sps = orc.batch_superpixel(args, imgs)
+    assert np.array_equal(res.labels.cpu().numpy().astype(np.int64), sps)
+    feats, n_per = orc.batch_superpixel_align(args, imgs, sps, fmap, orc.PyRandom(1111), 'anchor')
+    N = sum(n_per)
+    assert np.array_equal(res.X[:N].cpu().numpy(), feats)
+    prior = orc.batch_create_prior(args, sps)
+    np.testing.assert_allclose(res.prior[:N].cpu().numpy(), prior, rtol=1e-12)
+    cl, road, info = orc.batch_weighted_kmeans(args, sps, feats, prior, n_per, nprandom=orc.NpRandom(1111))
     assert np.array_equal(res.cluster.cpu().numpy(), cl)
     assert np.array_equal(res.road.cpu().numpy().astype(bool), road)
 

@@ -2,10 +2,10 @@
 # Data-parallel label generation for the Cityscapes "random300" list: N_GPUS background processes,
 # contiguous image ranges of size n_data / N_GPUS + 1, one GPU each (the reference's fan-out,
 # utils/create_random300_labels.sh there).  Defaults reproduce the reference launcher's parameters
-# except the superpixel method: the MI355X path implements SLIC (felzenszwalb is a later row).
+# (felzenszwalb superpixels, scale 300, as in the reference; pass "slic" as 2nd argument for SLIC).
 #   usage: bash utils/create_random300_labels.sh N_GPUS [slic|felzenszwalb]
 N_GPUS=${1:-1}
-METHOD=${2:-slic}
+METHOD=${2:-felzenszwalb}
 N_CLUSTERS=4
 BATCHSIZE=30
 OUT=results/estimated_train_random300_labels
