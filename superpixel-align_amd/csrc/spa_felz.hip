@@ -238,6 +238,72 @@ __device__ __forceinline__ int fz_find(const int *P, int i)
     return i;
 }
 
+// ---------------------------------------------------------------------------------------
+// Zero-cost edges.  They sort first, and with scale > 0 every one of them passes the merge test
+// whatever the state (0 < int + k/size), so the sequential pass simply unions the connected
+// components of the zero-cost graph, root = smallest pixel, size = pixel count, internal cost 0.
+// That is order free: done with a lock-free union-find up front.  (Flat regions would otherwise
+// produce reservation chains as long as their rows, because equal costs are ordered by index.)
+// ---------------------------------------------------------------------------------------
+__global__ void k_fz_zero_count(const unsigned long long *__restrict__ keys, long long nE, int *__restrict__ zcount)
+{
+    // first sorted position whose cost is not +0.0 (binary search, one thread per image)
+    const int b = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    const unsigned long long *K = keys + (long long)b * nE;
+    long long lo = 0, hi = nE;
+    while (lo < hi) {
+        long long mid = (lo + hi) >> 1;
+        if (K[mid] == 0ull) lo = mid + 1; else hi = mid;
+    }
+    zcount[b] = (int)lo;
+}
+
+__global__ __launch_bounds__(256) void k_fz_zero_union(const unsigned *__restrict__ vals, FzGeom g,
+                                                       const int *__restrict__ zcount, int *__restrict__ parent)
+{
+    const int b = blockIdx.y;
+    const long long npix = (long long)g.H * g.W;
+    const unsigned *V = vals + (long long)b * g.nE;
+    int *P = parent + (long long)b * npix;
+    const int z = zcount[b];
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < z; e += gridDim.x * 256) {
+        int a, c;
+        fz_endpoints(g, (long long)V[e], a, c);
+        for (;;) {
+            int ra = a, rb = c, p;
+            while ((p = __hip_atomic_load(P + ra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= 0) ra = p;
+            while ((p = __hip_atomic_load(P + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= 0) rb = p;
+            if (ra == rb) break;
+            const int lo_r = min(ra, rb), hi_r = max(ra, rb);
+            if (atomicCAS(P + hi_r, -1, lo_r) == -1) break;      // hi_r was still a root: linked
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fz_zero_sizes(const int *__restrict__ zcount, int *__restrict__ parent,
+                                                       int *__restrict__ size, int npix)
+{
+    const int b = blockIdx.y;
+    if (zcount[b] == 0) return;
+    int *P = parent + (long long)b * npix;
+    int *S = size + (long long)b * npix;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    int r = -1;
+    if (p < npix && P[p] >= 0) {
+        r = fz_find(P, p);
+        P[p] = r;                                  // flatten
+    }
+    unsigned long long todo = __ballot(r >= 0);    // one atomic per distinct root per wave
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int rr = __shfl(r, leader);
+        const unsigned long long same = __ballot(r == rr);
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(S + rr, __popcll(same));
+        todo &= ~same;
+    }
+}
+
 // One greedy pass (mode 0: merge test of the paper; mode 1: min_size clean-up) over the sorted
 // edges of every image; grid = (G, B), workgroups (., b) form the group of image b.
 __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass(const unsigned long long *__restrict__ keys,
@@ -246,7 +312,9 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass(const unsigned long long
                                                         double *__restrict__ cint,
                                                         unsigned long long *__restrict__ mark,
                                                         FzImg *__restrict__ st, double scale, int min_size,
-                                                        int mode, unsigned round0, uint32_t *__restrict__ status)
+                                                        int mode, unsigned round0,
+                                                        const int *__restrict__ zcount,
+                                                        uint32_t *__restrict__ status)
 {
     const int b = blockIdx.y;
     const unsigned G = gridDim.x;
@@ -264,7 +332,7 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass(const unsigned long long
     unsigned round = round0;
     unsigned slot = 0;
 
-    for (long long lo = 0; lo < g.nE; lo += T * FZ_EPT) {
+    for (long long lo = zcount[b]; lo < g.nE; lo += T * FZ_EPT) {   // zero-cost edges: done up front
         // path halving for the whole image before each window keeps the trees shallow
         for (long long p = tg; p < npix; p += T) {
             int q = P[p];
@@ -443,7 +511,21 @@ extern "C" int spa_felzenszwalb(spa_ctx *ctx, const float *rgb, int32_t B, int32
                                 int32_t *n_labels, void *stream)
 {
     SPA_ARG(ctx && rgb && labels && n_labels && B > 0 && H > 1 && W > 1 && sigma > 0.0 && scale > 0.0);
-    SPA_ARG((long long)H * W < (1ll << 28) && B <= 256);
+    SPA_ARG((long long)H * W < (1ll << 28));
+    {
+        // the persistent passes need every workgroup resident: at most n_cu images per launch
+        const int maxB = ctx->n_cu < 64 ? ctx->n_cu : 64;
+        if (B > maxB) {
+            const long long px = (long long)H * W;
+            for (int b0 = 0; b0 < B; b0 += maxB) {
+                const int nb = B - b0 < maxB ? B - b0 : maxB;
+                int rc0 = spa_felzenszwalb(ctx, rgb + (long long)b0 * 3 * px, nb, H, W, scale, sigma, min_size,
+                                           labels + (long long)b0 * px, n_labels + b0, stream);
+                if (rc0 != SPA_OK) return rc0;
+            }
+            return SPA_OK;
+        }
+    }
     hipStream_t s = spa_stream(stream);
     FzWeights fw;
     fw.r = fz_weights(sigma, fw.w);
@@ -477,9 +559,9 @@ extern "C" int spa_felzenszwalb(spa_ctx *ctx, const float *rgb, int32_t B, int32
     if ((rc = spa_ws_reserve(ctx, WS_FZ_STATE, (size_t)B * npix * 16, (void **)&cint)) != SPA_OK) return rc;
     mark = (unsigned long long *)(cint + (size_t)B * npix);
     if ((rc = spa_ws_reserve(ctx, WS_BLK, (size_t)B * 2 * nblk * 4, (void **)&blk)) != SPA_OK) return rc;
-    if ((rc = spa_ws_reserve(ctx, WS_CONNMISC, (size_t)B * sizeof(FzImg) + 256, (void **)&st)) != SPA_OK) return rc;
+    if ((rc = spa_ws_reserve(ctx, WS_CONNMISC, 64 * sizeof(FzImg) + 64 * sizeof(int), (void **)&st)) != SPA_OK) return rc;
     size_t tmp_bytes = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys0, keys1, vals0, vals1, (int)g.nE, 0, 64, s);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys0, keys1, vals0, vals1, (int)g.nE, 0, 64, s);
     if ((rc = spa_ws_reserve(ctx, WS_FZ_TMP, tmp_bytes, &tmp)) != SPA_OK) return rc;
 
     int gx = (int)((npix + 255) / 256);
@@ -495,6 +577,12 @@ extern "C" int spa_felzenszwalb(spa_ctx *ctx, const float *rgb, int32_t B, int32
                                                    0, 64, s));
     }
     hipLaunchKernelGGL(k_fz_init, dim3(1024), dim3(256), 0, s, parent, size, cint, mark, (long long)B * npix, st, B);
+    int *zcount = (int *)((char *)st + 64 * sizeof(FzImg));
+    hipLaunchKernelGGL(k_fz_zero_count, dim3(B), dim3(64), 0, s, (const unsigned long long *)keys1, g.nE, zcount);
+    hipLaunchKernelGGL(k_fz_zero_union, dim3(256, B), dim3(256), 0, s, (const unsigned *)vals1, g,
+                       (const int *)zcount, parent);
+    hipLaunchKernelGGL(k_fz_zero_sizes, dim3((unsigned)((npix + 255) / 256), B), dim3(256), 0, s,
+                       (const int *)zcount, parent, size, (int)npix);
     // persistent passes: every workgroup of the grid must be resident (one per CU at most)
     int G = ctx->n_cu / B;
     if (G < 1) G = 1;
@@ -504,10 +592,10 @@ extern "C" int spa_felzenszwalb(spa_ctx *ctx, const float *rgb, int32_t B, int32
     // scale = float(scale) / 255.
     const double k = scale / 255.0;
     hipLaunchKernelGGL(k_fz_pass, dim3(G, B), dim3(FZ_THREADS), 0, s, (const unsigned long long *)keys1,
-                       (const unsigned *)vals1, g, parent, size, cint, mark, st, k, min_size, 0, 0u, ctx->d_status);
+                       (const unsigned *)vals1, g, parent, size, cint, mark, st, k, min_size, 0, 0u, (const int *)zcount, ctx->d_status);
     hipLaunchKernelGGL(k_fz_pass, dim3(G, B), dim3(FZ_THREADS), 0, s, (const unsigned long long *)keys1,
                        (const unsigned *)vals1, g, parent, size, cint, mark, st, k, min_size, 1, 0x40000000u,
-                       ctx->d_status);
+                       (const int *)zcount, ctx->d_status);
     hipLaunchKernelGGL(k_fz_count_roots, dim3(nblk, B), dim3(256), 0, s, parent, (int)npix, blk, nblk);
     hipLaunchKernelGGL(k_fz_scan, dim3(B), dim3(256), 0, s, blk, nblk, n_labels);
     hipLaunchKernelGGL(k_fz_number, dim3(nblk, B), dim3(256), 0, s, parent, (int)npix, blk, nblk, rank);
