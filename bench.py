@@ -31,6 +31,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# MIOpen's exhaustive find (cudnn.benchmark) otherwise also times its naive reference convolution
+# on every layer shape: ~100 s of start-up per process at 1024x2048 for a solver that never wins
+os.environ.setdefault('MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD', '0')
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 FP32_MATRIX_PEAK_TF = 157.3    # fp32 MFMA peak; bf16 dense 2500

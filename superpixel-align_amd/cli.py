@@ -16,8 +16,11 @@ import os
 import time
 import zipfile
 
-import numpy as np
-import torch
+# skip MIOpen's naive reference convolution during solver search (slow start-up, never selected)
+os.environ.setdefault('MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD', '0')
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 from . import dist as spdist
 from . import ops
