@@ -55,6 +55,7 @@ _COMMON_FLAGS = [
     ('--mean_sampling', dict(type=str, default='nearest', choices=['nearest', 'bilinear'])),
     ('--no_figure', dict(action='store_true', default=False)),
     ('--balanced', dict(action='store_true', default=False)),
+    ('--io_threads', dict(type=int, default=8)),
 ]
 
 
@@ -126,8 +127,12 @@ class ImageList(object):
             img = resize_bicubic_chw(img, self._shape)
         return img.astype(self._dtype)
 
-    def batch(self, lo, hi):
-        return np.stack([self.get(i) for i in range(len(self))[lo:hi]])
+    def batch(self, lo, hi, pool=None):
+        """dataset[lo:hi] stacked (python slice semantics, like concat_examples(dataset[i:end_i]));
+        decoded by `pool` threads when given (PIL and numpy release the GIL)."""
+        idx = list(range(len(self))[lo:hi])
+        imgs = list(pool.map(self.get, idx)) if pool is not None else [self.get(i) for i in idx]
+        return np.stack(imgs)
 
 
 def create_dataset(args):
@@ -188,16 +193,18 @@ def save_npy(args, img_fn, road_mask, clustering_result):
 
 
 def save_figure(args, img, road_mask, label, clustering_result, img_fn):
-    """:361-386 — 2x2 overview figure at 300 dpi (about a second per image: --no_figure)."""
-    import matplotlib
-    matplotlib.use('Agg')
-    import matplotlib.pyplot as plt
-    fig, axes = plt.subplots(2, 2)
-    fig.set_dpi(300)
+    """:361-386 — 2x2 overview figure at 300 dpi (about a second per image: --no_figure).
+    Object-oriented matplotlib API (no pyplot state), so figures can be rendered from worker threads."""
+    from matplotlib import cm
+    from matplotlib.backends.backend_agg import FigureCanvasAgg
+    from matplotlib.figure import Figure
+    fig = Figure(dpi=300)
+    FigureCanvasAgg(fig)
+    axes = fig.subplots(2, 2)
     for ax in axes.ravel():
         ax.axis('off')
     axes[0, 0].imshow(img / 255.)
-    axes[0, 0].imshow(road_mask, alpha=0.4, cmap=plt.cm.Set1_r)
+    axes[0, 0].imshow(road_mask, alpha=0.4, cmap=cm.Set1_r)
     axes[0, 0].set_title('Estimated road mask (input image overlayed)', fontsize=8)
     axes[0, 1].imshow(label == 1)
     axes[0, 1].set_title('Ground truth road mask', fontsize=8)
@@ -205,8 +212,7 @@ def save_figure(args, img, road_mask, label, clustering_result, img_fn):
     axes[1, 0].set_title('All clusters', fontsize=8)
     axes[1, 1].imshow(clustering_result == 0)
     axes[1, 1].set_title('Estimated road mask', fontsize=8)
-    plt.savefig(os.path.join(args.out_dir, os.path.basename(img_fn)), bbox_inches='tight')
-    plt.close(fig)
+    fig.savefig(os.path.join(args.out_dir, os.path.basename(img_fn)), bbox_inches='tight')
 
 
 def result_line(args, img_fn, label_fn, sc, elapsed_times, st_all):
@@ -239,31 +245,54 @@ def main_labelled(argv=None):
     if ws > 1:
         s, e = spdist.shard_range(end - start, ws, rank, args.balanced)
         start, end = start + s, start + e
-    lines, records = [], []
-    for lo, hi in (spdist.batch_ranges(start, end, args.batchsize) if end > start else []):
+    # Host side of the loop: decode/resize of the NEXT batch and the per-image
+    # outputs of the PREVIOUS one (GT decode, nearest resize, two .npy files, figure, scores) run on
+    # worker threads while the GPU labels the current batch.
+    from concurrent.futures import ThreadPoolExecutor
+    workers = ThreadPoolExecutor(max_workers=max(1, args.io_threads))
+    loader = ThreadPoolExecutor(max_workers=1)
+    ranges = spdist.batch_ranges(start, end, args.batchsize) if end > start else []
+
+    def finish(i, rm, cl, n_sp, info, times, st_all):
+        img_fn, label_fn = imgs_ds._paths[i], labels_ds._paths[i]
+        gt = create_label_mask(labels_ds.get(i)[0])
+        if rm.shape != gt.shape:                                       # :470-477
+            rm, cl = resize_nearest(rm, gt.shape), resize_nearest(cl, gt.shape)
+        save_npy(args, img_fn, rm, cl)
+        if not args.no_figure:
+            full = _decode(imgs_ds._open(img_fn) if imgs_ds._open else img_fn)   # :464 reloads the PNG
+            save_figure(args, full, rm, gt, cl, img_fn)
+        sc = score(rm, gt)
+        line = result_line(args, img_fn, label_fn, sc, times, st_all)
+        tn = int(((gt == 0) & (rm == 0)).sum())
+        return i, line, [i, tn, sc['FP'], sc['FN'], sc['TP'], n_sp, int(info[0]), int(info[1])]
+
+    pending = []
+    nxt = loader.submit(imgs_ds.batch, ranges[0][0], ranges[0][1], workers) if ranges else None
+    for bi, (lo, hi) in enumerate(ranges):
         st_all = time.time()
-        imgs = imgs_ds.batch(lo, hi)
+        imgs = nxt.result()
+        if bi + 1 < len(ranges):
+            nxt = loader.submit(imgs_ds.batch, ranges[bi + 1][0], ranges[bi + 1][1], workers)
         res = pipe.run(imgs)
         times = pipe.elapsed_times()
         cluster, road = res.masks_to_host()
         info = res.info.cpu().numpy()
-        idx = list(range(len(imgs_ds)))[lo:hi]
-        for j, i in enumerate(idx):
-            img_fn, label_fn = imgs_ds._paths[i], labels_ds._paths[i]
-            gt = create_label_mask(labels_ds.get(i)[0])
-            rm, cl = road[j], cluster[j]
-            if rm.shape != gt.shape:                                   # :470-477
-                rm, cl = resize_nearest(rm, gt.shape), resize_nearest(cl, gt.shape)
-            save_npy(args, img_fn, rm, cl)
-            if not args.no_figure:
-                full = _decode(imgs_ds._open(img_fn) if imgs_ds._open else img_fn)   # :464 reloads the PNG
-                save_figure(args, full, rm, gt, cl, img_fn)
-            sc = score(rm, gt)
-            line = result_line(args, img_fn, label_fn, sc, times, st_all)
-            lines.append((i, line))
-            tn = int(((gt == 0) & (rm == 0)).sum())
-            records.append([i, tn, sc['FP'], sc['FN'], sc['TP'], int(res.n_labels[j]), int(info[0]), int(info[1])])
-            print('Road IoU:', line['road_iou'], os.path.basename(img_fn))
+        n_sp = res.n_labels.cpu().numpy()
+        # a re-labelled image (last batch shifted back, :539-542) must overwrite its earlier files:
+        # wait for the previous batch's writers before queueing this batch's
+        for f in pending:
+            f.result()
+        for j, i in enumerate(list(range(len(imgs_ds)))[lo:hi]):
+            pending.append(workers.submit(finish, i, road[j], cluster[j], int(n_sp[j]), info, times, st_all))
+    lines, records = [], []
+    for f in pending:
+        i, line, rec = f.result()
+        lines.append((i, line))
+        records.append(rec)
+        print('Road IoU:', line['road_iou'], os.path.basename(line['img_fn']))
+    workers.shutdown()
+    loader.shutdown()
     path = os.path.join(args.out_dir, 'result.json')
     if ws == 1:
         with open(path, 'a') as fp:                                    # reference: append
@@ -305,8 +334,10 @@ def main_labelfree(argv=None):
     os.makedirs(args.out_dir, exist_ok=True)
     start, end = _effective_range(args, len(ds))
     from PIL import Image
+    from concurrent.futures import ThreadPoolExecutor
+    io_pool = ThreadPoolExecutor(max_workers=max(1, args.io_threads))
     for lo, hi in spdist.batch_ranges(start, end, args.batchsize):
-        res = pipe.run(ds.batch(lo, hi))
+        res = pipe.run(ds.batch(lo, hi, io_pool))
         _, road = res.masks_to_host()
         for j, i in enumerate(list(range(len(ds)))[lo:hi]):
             rm = road[j]
