@@ -225,3 +225,12 @@ extern "C" int spa_prof_read(spa_ctx *ctx, int slot, double *total_ms, int *laun
     *launches = ctx->prof_used[slot];
     return SPA_OK;
 }
+
+// diagnostics: copy `bytes` of workspace `which` (offset in bytes) to the host; synchronises
+extern "C" int spa_debug_peek(spa_ctx *ctx, int which, size_t offset, size_t bytes, void *host)
+{
+    SPA_ARG(ctx && host && which >= 0 && which < WS_COUNT && offset + bytes <= ctx->ws_bytes[which]);
+    SPA_HIP(hipDeviceSynchronize());
+    SPA_HIP(hipMemcpy(host, (const char *)ctx->ws[which] + offset, bytes, hipMemcpyDeviceToHost));
+    return SPA_OK;
+}

@@ -9,22 +9,27 @@
 // edges; a second pass merges components below min_size.  The order dependence is kept exactly
 // with deterministic reservations: the sorted edges are taken in windows; in every round each
 // still-pending edge (1) finds its two roots and evaluates the merge test against the current
-// state, and if it wants to merge, reserves both roots with atomicMin(sorted position); (2) an
-// edge is decided — merge committed, or dropped — only if no earlier edge of the window holds a
-// reservation on either of its components, otherwise it waits for the next round.  An edge is
-// therefore always decided against exactly the state the sequential pass would show it.
-// One persistent cooperative launch per pass handles all images of the batch at once (a group
-// of workgroups per image, agent-scope barrier per group).
+// state, and if it wants to merge, reserves both roots with atomicMin(sorted position); (2) edges
+// blocked by an earlier reservation hold their components as well, to a fixed point (they may
+// want to merge once the earlier edge has changed their component); (3) an edge is decided —
+// merge committed, or dropped — only if no earlier edge holds either of its components,
+// otherwise it waits for the next round.  An edge is therefore always decided against exactly
+// the state the sequential pass would show it.  Zero-cost edges (always merge) are unioned up
+// front with a lock-free union-find.  The passes are bound by the number of rounds (chains of
+// dependent merges into a growing component), so each image gets ONE 1024-thread workgroup: a
+// round then costs workgroup barriers (~1 us) rather than agent-scope barriers; the images of
+// the batch proceed in parallel on different CUs.
 //   smoothing : scipy.ndimage.gaussian_filter(img, [sigma, sigma, 0]) — symmetric correlate1d
 //               summation order, 'reflect' borders, float64
 //   costs     : float64 Euclidean colour distance of the 4 edge families (right, down, down-right,
 //               up-right), keys sorted with a stable LSD radix sort (hipCUB) on the cost bits
 #include <hipcub/hipcub.hpp>
 #include <math.h>
+#include <stdlib.h>
 
 #include "spa_common.h"
 
-#define FZ_THREADS 256
+#define FZ_THREADS 1024
 #define FZ_EPT 4                 // edges per thread per window
 
 struct FzImg {
@@ -191,11 +196,16 @@ __global__ void k_fz_init(int *__restrict__ parent, int *__restrict__ size, doub
     if (blockIdx.x == 0 && (int)threadIdx.x < B) {
         st[threadIdx.x].barrier = 0;
         for (int i = 0; i < 4; ++i) st[threadIdx.x].cnt[i] = 0;
+        for (int i = 0; i < 3; ++i) st[threadIdx.x].pad[i] = 0;
     }
 }
 
 __device__ __forceinline__ void fz_group_sync(unsigned *ctr, unsigned G, unsigned &epoch, uint32_t *status)
 {
+    if (G == 1u) {           // the whole image lives in one workgroup: a workgroup barrier is enough
+        __syncthreads();
+        return;
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     epoch += 1;
@@ -221,6 +231,7 @@ __device__ __forceinline__ void fz_group_sync(unsigned *ctr, unsigned G, unsigne
 __device__ __forceinline__ int fz_group_sum(FzImg *me, unsigned &slot, int local, bool is_first_thread,
                                             unsigned G, unsigned &epoch, uint32_t *status)
 {
+    if (G == 1u) return __syncthreads_or(local != 0);     // callers only test the sum against zero
     int *c = &me->cnt[slot & 3u];
     if (local) atomicAdd(c, local);
     if (is_first_thread) __hip_atomic_store(&me->cnt[(slot + 2u) & 3u], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -313,7 +324,7 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass(const unsigned long long
                                                         unsigned long long *__restrict__ mark,
                                                         FzImg *__restrict__ st, double scale, int min_size,
                                                         int mode, unsigned round0,
-                                                        const int *__restrict__ zcount,
+                                                        const int *__restrict__ zcount, int flatten_every,
                                                         uint32_t *__restrict__ status)
 {
     const int b = blockIdx.y;
@@ -331,14 +342,19 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass(const unsigned long long
     const long long tg = (long long)blockIdx.x * FZ_THREADS + threadIdx.x;
     unsigned round = round0;
     unsigned slot = 0;
+    int win = 0;
 
     for (long long lo = zcount[b]; lo < g.nE; lo += T * FZ_EPT) {   // zero-cost edges: done up front
-        // path halving for the whole image before each window keeps the trees shallow
-        for (long long p = tg; p < npix; p += T) {
-            int q = P[p];
-            if (q >= 0) {
-                int r = fz_find(P, q);
-                if (r != q) P[p] = r;
+        if (tg == 0) me->pad[2] += 1;                           // diagnostics: windows
+        // flattening the forest keeps the trees shallow; it costs a sweep over the image, so it is
+        // done every `flatten_every` windows (about once per npix/16 edges)
+        if ((win++ % flatten_every) == 0) {
+            for (long long p = tg; p < npix; p += T) {
+                int q = P[p];
+                if (q >= 0) {
+                    int r = fz_find(P, q);
+                    if (r != q) P[p] = r;
+                }
             }
         }
         fz_group_sync(&me->barrier, G, epoch, status);
@@ -356,6 +372,7 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass(const unsigned long long
         }
         for (;;) {
             ++round;
+            if (tg == 0) me->pad[0] += 1;                       // diagnostics: rounds
             const unsigned long long tag = (unsigned long long)(~round) << 32;
             int ra[FZ_EPT], rb[FZ_EPT];
             bool want[FZ_EPT], resv[FZ_EPT];
@@ -404,6 +421,7 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass(const unsigned long long
                         ++changed;
                     }
                 }
+                if (tg == 0) me->pad[1] += 1;                   // diagnostics: propagation steps
                 if (fz_group_sum(me, slot, changed, tg == 0, G, epoch, status) == 0) break;
             }
             // ---- phase 2: decide every edge no earlier reservation can influence
@@ -584,18 +602,23 @@ extern "C" int spa_felzenszwalb(spa_ctx *ctx, const float *rgb, int32_t B, int32
     hipLaunchKernelGGL(k_fz_zero_sizes, dim3((unsigned)((npix + 255) / 256), B), dim3(256), 0, s,
                        (const int *)zcount, parent, size, (int)npix);
     // persistent passes: every workgroup of the grid must be resident (one per CU at most)
-    int G = ctx->n_cu / B;
-    if (G < 1) G = 1;
-    long long need = (g.nE + (long long)FZ_THREADS * FZ_EPT - 1) / ((long long)FZ_THREADS * FZ_EPT);
-    if (G > need) G = (int)need;
+    // The passes are bound by the number of reservation rounds (chains of dependent merges), not by
+    // work per round: ONE 1024-thread workgroup per image makes a round cost a workgroup barrier
+    // (~1 us) instead of an agent-scope barrier across workgroups (~10 us each, several per round).
+    // SPA_FZ_GROUP overrides (experiments).
+    int G = 1;
+    if (const char *e = getenv("SPA_FZ_GROUP")) G = atoi(e) > 0 ? atoi(e) : 1;
+    if ((long long)G * B > ctx->n_cu) G = ctx->n_cu / B > 0 ? ctx->n_cu / B : 1;
     SPA_ARG((long long)G * B <= ctx->n_cu);
+    long long fe = npix / (16ll * G * FZ_THREADS * FZ_EPT);
+    const int flatten_every = fe < 1 ? 1 : (int)fe;
     // scale = float(scale) / 255.
     const double k = scale / 255.0;
     hipLaunchKernelGGL(k_fz_pass, dim3(G, B), dim3(FZ_THREADS), 0, s, (const unsigned long long *)keys1,
-                       (const unsigned *)vals1, g, parent, size, cint, mark, st, k, min_size, 0, 0u, (const int *)zcount, ctx->d_status);
+                       (const unsigned *)vals1, g, parent, size, cint, mark, st, k, min_size, 0, 0u, (const int *)zcount, flatten_every, ctx->d_status);
     hipLaunchKernelGGL(k_fz_pass, dim3(G, B), dim3(FZ_THREADS), 0, s, (const unsigned long long *)keys1,
                        (const unsigned *)vals1, g, parent, size, cint, mark, st, k, min_size, 1, 0x40000000u,
-                       (const int *)zcount, ctx->d_status);
+                       (const int *)zcount, flatten_every, ctx->d_status);
     hipLaunchKernelGGL(k_fz_count_roots, dim3(nblk, B), dim3(256), 0, s, parent, (int)npix, blk, nblk);
     hipLaunchKernelGGL(k_fz_scan, dim3(B), dim3(256), 0, s, blk, nblk, n_labels);
     hipLaunchKernelGGL(k_fz_number, dim3(nblk, B), dim3(256), 0, s, parent, (int)npix, blk, nblk, rank);
