@@ -70,6 +70,20 @@ int spa_prof_enable(spa_ctx *ctx, int on);
 int spa_prof_slots(void);
 const char *spa_prof_name(int slot);
 int spa_prof_read(spa_ctx *ctx, int slot, double *total_ms_host, int *launches_host);
+/* Diagnostics only: copy `bytes` of internal workspace `which` (byte offset) to the host. */
+int spa_debug_peek(spa_ctx *ctx, int which, size_t offset, size_t bytes, void *host);
+
+/* ---- DRN forward glue (the convolutions themselves stay in PyTorch-ROCm / MIOpen) -----------
+ * spa_drn_normalise: DRN.batch_predict input arithmetic (models/drn.py:319-321): x/255 in float32,
+ *   then (x - mean) and (x / std) in float64 rounded to float32.  x (B,3,H,W) float32 planar ->
+ *   out (B,H,W,3) channels-last, out_dtype 0 = float32, 1 = bfloat16.
+ * spa_bias_act: y = relu?(y + bias [+ residual]) in place on a channels-last activation of `rows`
+ *   pixels x C channels (dtype 0 = float32, 1 = bfloat16; bias/residual in the same dtype): the
+ *   bias add left by folding BatchNorm, the residual add of a BasicBlock and the ReLU in one pass. */
+int spa_drn_normalise(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W, void *out,
+                      int32_t out_dtype, const double *mean3_host, const double *std3_host, void *stream);
+int spa_bias_act(spa_ctx *ctx, void *y, int32_t dtype, int64_t rows, int32_t C, const void *bias,
+                 const void *residual, int32_t relu, void *stream);
 
 /* ---- SLIC superpixels ------------------------------------------------------------------
  * replaces batch_superpixel(), SLIC branch: batch_spalign_kmeans.py:308-311, i.e.

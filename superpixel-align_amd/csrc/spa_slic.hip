@@ -412,8 +412,11 @@ __global__ __launch_bounds__(256) void k_slic_update(const float *__restrict__ l
         gb += s_gtake;
         const int rounds = (npieces + UPD_NG * UPD_PPW - 1) / (UPD_NG * UPD_PPW);
         const int gw = wv - 1;
-        UpdRegs cur, nxt;
-        auto fetch = [&](UpdRegs &R, int rd) {
+        // three rounds in flight per gather wave: labels of round rd+2 are requested, the Lab values
+        // of round rd+1 are requested for the lanes whose label matched (so pixels of neighbouring
+        // segments inside a piece cost 4 bytes, not 16), round rd is compacted
+        UpdRegs cur, nxt, nx2;
+        auto fetch_labels = [&](UpdRegs &R, int rd) {
             const int t0 = (rd * UPD_NG + gw) * UPD_PPW;
 #pragma unroll
             for (int u = 0; u < UPD_PPW; ++u) {
@@ -421,18 +424,29 @@ __global__ __launch_bounds__(256) void k_slic_update(const float *__restrict__ l
                 R.pe[u] = t < npieces ? (unsigned)plist[t] : 0u;
                 const int yy = ybase + (int)(R.pe[u] >> 5), xx = (int)((R.pe[u] & 31u) << 6) + lane;
                 const bool in = (t < npieces) && (xx < W) && (yy < H);
-                const long long p = (long long)yy * W + xx;
-                R.lv[u] = in ? lb[p] : -1;
-                R.vL[u] = in ? pl[p] : 0.0f;
-                R.vA[u] = in ? pl[npix + p] : 0.0f;
-                R.vB[u] = in ? pl[2 * npix + p] : 0.0f;
+                R.lv[u] = in ? lb[(long long)yy * W + xx] : -1;
             }
         };
-        if (wv >= 1 && rounds > 0) fetch(cur, 0);
+        auto fetch_lab = [&](UpdRegs &R) {
+#pragma unroll
+            for (int u = 0; u < UPD_PPW; ++u) {
+                const int yy = ybase + (int)(R.pe[u] >> 5), xx = (int)((R.pe[u] & 31u) << 6) + lane;
+                const long long p = (long long)yy * W + xx;
+                const bool m = (R.lv[u] == k);
+                R.vL[u] = m ? pl[p] : 0.0f;
+                R.vA[u] = m ? pl[npix + p] : 0.0f;
+                R.vB[u] = m ? pl[2 * npix + p] : 0.0f;
+            }
+        };
+        if (wv >= 1 && rounds > 0) {
+            fetch_labels(cur, 0);
+            if (rounds > 1) fetch_labels(nxt, 1);
+            fetch_lab(cur);
+        }
         for (int rd = 0; rd <= rounds; ++rd) {
             if (wv >= 1 && rd < rounds) {
-                // ---- gather: request the next round's pixels, then compact this round's
-                if (rd + 1 < rounds) fetch(nxt, rd + 1);
+                if (rd + 2 < rounds) fetch_labels(nx2, rd + 2);
+                if (rd + 1 < rounds) fetch_lab(nxt);
                 float *sub = ring[rd & 1][gw];
                 int fill = 0;
 #pragma unroll
@@ -457,6 +471,7 @@ __global__ __launch_bounds__(256) void k_slic_update(const float *__restrict__ l
                 }
                 if (lane == 0) ring_cnt[rd & 1][gw] = fill;
                 cur = nxt;
+                nxt = nx2;
             } else if (wv == 0 && rd > 0) {
                 // ---- chain: sub-rings of round rd-1, in order
 #pragma unroll

@@ -56,6 +56,30 @@ def _conv(cin, cout, k, stride=1, dilation=1):
     return nn.Conv2d(cin, cout, k, stride=stride, padding=pad, dilation=dilation, bias=False)
 
 
+_EPILOGUE = {'engine': None}      # set by DRN.prepare() on a GPU: libspalign's fused bias/residual/ReLU
+
+
+def conv_bias_act(conv, bn, x, residual=None, relu=True):
+    """relu?(bn(conv(x)) [+ residual]).  With BatchNorm folded (bn is Identity, conv carries the
+    bias) and the tensors on the GPU in channels-last storage, the bias add, the residual add and
+    the ReLU run as ONE in-place pass of libspalign (spa_bias_act) behind the MIOpen convolution
+    instead of two or three separate elementwise kernels."""
+    eng = _EPILOGUE['engine']
+    if (eng is not None and x.is_cuda and isinstance(bn, nn.Identity) and conv.bias is not None
+            and x.dtype in (torch.float32, torch.bfloat16)):
+        y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation)
+        vec = 4 if y.dtype == torch.float32 else 8
+        if (y.is_contiguous(memory_format=torch.channels_last) and y.shape[1] % vec == 0
+                and (residual is None or residual.is_contiguous(memory_format=torch.channels_last))):
+            return eng.bias_act_(y, conv.bias, residual, relu)
+        y = y + conv.bias.view(1, -1, 1, 1)
+    else:
+        y = bn(conv(x))
+    if residual is not None:
+        y = y + residual
+    return F.relu_(y) if relu else y
+
+
 class BasicBlock(nn.Module):
     """conv-bn-relu-conv-bn (+ residual) - relu; `residual=False` for layers 7/8 of arch C."""
 
@@ -72,11 +96,12 @@ class BasicBlock(nn.Module):
         self.residual = residual
 
     def forward(self, x):
-        y = F.relu_(self.bn1(self.conv1(x)))
-        y = self.bn2(self.conv2(y))
+        y = conv_bias_act(self.conv1, self.bn1, x, None, True)
+        res = None
         if self.residual:
-            y = y + (x if self.downsample is None else self.downsample(x))
-        return F.relu_(y)
+            res = x if self.downsample is None else conv_bias_act(self.downsample[0], self.downsample[1],
+                                                                  x, None, False)
+        return conv_bias_act(self.conv2, self.bn2, y, res, True)
 
 
 class DRN(nn.Module):
@@ -172,18 +197,28 @@ class DRN(nn.Module):
         self.compute_dtype = dtype
         self.to(device=device, dtype=dtype, memory_format=torch.channels_last)
         self.eval()
+        if torch.device(device).type == 'cuda':
+            from .engine import default_engine        # fused glue kernels of libspalign
+            _EPILOGUE['engine'] = default_engine()
         return self
 
     # -- forward ---------------------------------------------------------------------------------
     def forward_maps(self, x):
         """x: normalised (B,3,H,W). Returns the 8 maps of the Chainer convention."""
+        def plain(seq, t):
+            mods = list(seq.children())            # (conv, bn | Identity, relu) triples
+            for i in range(0, len(mods), 3):
+                t = conv_bias_act(mods[i], mods[i + 1], t, None, True)
+            return t
+
         if self.arch == 'C':
-            x = F.relu_(self.bn1(self.conv1(x)))
+            x = conv_bias_act(self.conv1, self.bn1, x, None, True)
         else:
-            x = self.layer0(x)
+            x = plain(self.layer0, x)
         maps = []
         for i in range(1, 9):
-            x = getattr(self, 'layer%d' % i)(x)
+            layer = getattr(self, 'layer%d' % i)
+            x = plain(layer, x) if (self.arch == 'D' and i in (1, 2, 7, 8)) else layer(x)
             maps.append(x)
         return maps
 
@@ -216,8 +251,12 @@ class DRN(nn.Module):
         sub = B if not sub_batch else sub_batch
         outs = None
         for s in range(0, B, sub):
-            xi = self.normalise(x[s:s + sub].float())
-            xi = xi.to(self.compute_dtype).contiguous(memory_format=torch.channels_last)
+            eng = _EPILOGUE['engine']
+            if eng is not None and x.is_cuda:
+                xi = eng.drn_normalise(x[s:s + sub].float().contiguous(), self.compute_dtype)
+            else:
+                xi = self.normalise(x[s:s + sub].float())
+                xi = xi.to(self.compute_dtype).contiguous(memory_format=torch.channels_last)
             _, maps = self.forward(xi)
             if outs is None:
                 outs = [[m] for m in maps]

@@ -76,6 +76,26 @@ class Engine(object):
                 out[self._lib.spa_prof_name(slot).decode()] = (ms.value, n.value)
         return out
 
+    # ------------------------------------------------------------------ DRN glue
+    def drn_normalise(self, x, dtype=torch.float32):
+        """(B,3,H,W) float32 0..255 -> normalised channels-last tensor of `dtype` (one pass)."""
+        x = _req(x, torch.float32, 'x')
+        B, C, H, W = x.shape
+        assert C == 3
+        out = torch.empty((B, 3, H, W), dtype=dtype, device=x.device, memory_format=torch.channels_last)
+        mean = (ctypes.c_double * 3)(0.485, 0.456, 0.406)
+        std = (ctypes.c_double * 3)(0.229, 0.224, 0.225)
+        check(self._lib.spa_drn_normalise(self._ctx, _ptr(x), B, H, W, _ptr(out),
+                                          0 if dtype == torch.float32 else 1, mean, std, _stream()))
+        return out
+
+    def bias_act_(self, y, bias, residual=None, relu=True):
+        """In place y = relu?(y + bias [+ residual]) on a channels-last (B,C,H,W) activation."""
+        B, C, H, W = y.shape
+        check(self._lib.spa_bias_act(self._ctx, _ptr(y), 0 if y.dtype == torch.float32 else 1, B * H * W, C,
+                                     _ptr(bias), _ptr(residual), 1 if relu else 0, _stream()))
+        return y
+
     # ------------------------------------------------------------------ SLIC
     def rgb2lab(self, rgb, ratio=0.1):
         rgb = _req(rgb, torch.float32, 'rgb')
@@ -244,6 +264,17 @@ class Engine(object):
         check(self._lib.spa_confusion(self._ctx, _ptr(road), _ptr(gt), B, road[0].numel(), _ptr(out),
                                       _stream()))
         return out
+
+
+_DEFAULT = None
+
+
+def default_engine():
+    """Process-wide Engine (one spa_ctx per process/GPU)."""
+    global _DEFAULT
+    if _DEFAULT is None:
+        _DEFAULT = Engine()
+    return _DEFAULT
 
 
 class PyRandom(object):

@@ -31,10 +31,8 @@ _DEVCACHE = {}          # id(host array) -> (weakref to it, dict of device tenso
 
 
 def engine():
-    global _ENGINE
-    if _ENGINE is None:
-        _ENGINE = Engine()
-    return _ENGINE
+    from .engine import default_engine
+    return default_engine()
 
 
 def seed(value=1111):
