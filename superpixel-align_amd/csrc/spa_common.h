@@ -66,6 +66,8 @@ enum {
     WS_SBOX,         // bounding boxes of small components
     WS_TODO,         // BFS tier hand-over lists
     WS_ROWMASK,      // SLIC per (centre, row) occupancy bits
+    WS_FINEMASK,     // SLIC per (centre, window row, 64-pixel piece) pixel masks
+    WS_SLIC_ORDER,   // SLIC update: per-XCD longest-first segment lists + queue heads
     WS_FZ_KEYS,      // felzenszwalb: edge cost keys (in/out of the radix sort)
     WS_FZ_VALS,      // felzenszwalb: edge indices (in/out of the radix sort)
     WS_FZ_STATE,     // felzenszwalb: internal costs + reservation marks

@@ -165,6 +165,7 @@ __global__ __launch_bounds__(256) void k_slic_assign(const float *__restrict__ l
                                                      int H, int W, float sw,
                                                      int32_t *__restrict__ labels,
                                                      unsigned long long *__restrict__ rowmask, int HG, int PW,
+                                                     uint32_t *__restrict__ fine, int RW, int PWF,
                                                      uint32_t *__restrict__ status)
 {
     __shared__ uint4 cand[256 * 3];
@@ -269,39 +270,50 @@ __global__ __launch_bounds__(256) void k_slic_assign(const float *__restrict__ l
 #pragma unroll
     for (int i = 0; i < 4; ++i) uncovered = uncovered || (ok[i] && bl[i] < 0);
     if (uncovered) atomicOr(status, SPA_ST_SLIC_UNCOVERED);
-    // occupancy masks of the new segments for the centroid update: the distinct labels of a wave
-    // (8 rows x 32 columns, lane = row*8 + column group) are enumerated with ballots and each
-    // sets one bit — scattered atomics run at a fixed chip-wide rate, so they are kept to one per
-    // (wave, label)
-    {
-        // runs of equal label inside the thread's 4 pixels (static indexing only: a runtime
-        // index into bl[]/ok[] would push the arrays to scratch memory)
-        bool val[4], st[4];
+    // pixel masks of the new segments for the centroid update.  The distinct labels of a wave
+    // (8 rows x 32 columns, lane = row*8 + column group, 4 pixels per lane) are enumerated with
+    // ballots.  For each label the wave leaves
+    //   * fine: one 32-bit word per row, bit (i*8 + column group) = pixel 4*group+i of the row
+    //     carries the label, stored in the label's window-relative table (plain stores: each
+    //     (label, row, 32-pixel half piece) belongs to exactly one wave);
+    //   * coarse: one bit per (row, 64-pixel piece) in the mask word of its (8-row group, piece
+    //     octet) — one atomicOr per (wave, label); scattered atomics run at a fixed chip-wide rate.
+    // The update kernel walks the coarse bits, reads the fine words and never touches the labels.
+    if (fine) {
+        bool val[4], done[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) val[i] = ok[i] && bl[i] >= 0;
+        for (int i = 0; i < 4; ++i) { val[i] = ok[i] && bl[i] >= 0; done[i] = !val[i]; }
+        const int piece = tx0 >> 6;
+        const int half = (tx0 >> 5) & 1;
+        while (true) {
+            const unsigned long long pend = __ballot(!(done[0] && done[1] && done[2] && done[3]));
+            if (!pend) break;
+            const int leader = __ffsll((long long)pend) - 1;
+            const int mine = !done[0] ? bl[0] : (!done[1] ? bl[1] : (!done[2] ? bl[2] : bl[3]));
+            const int ll = __shfl(mine, leader);
+            unsigned long long bi[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) st[i] = val[i] && (i == 0 || !val[i - 1] || bl[i] != bl[i - 1]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int rl = st[i] ? bl[i] : -1;
-            unsigned long long todo = __ballot(rl >= 0);
-            while (todo) {
-                const int leader = __ffsll((long long)todo) - 1;
-                const int ll = __shfl(rl, leader);
-                const bool mine = (rl == ll);
-                const unsigned long long same = __ballot(mine);
-                // occupancy: one bit per (row, 64-pixel piece) of the centre.  A wave covers 8 rows of
-                // one piece, i.e. one byte of the mask word of its (8-row group, piece octet), so one
-                // atomicOr per (wave, label) records all of its rows.
-                const unsigned long long rb =
-                    __ballot(lane < 8 && ((same >> (lane * 8)) & 0xFFull) != 0ull) & 0xFFull;
-                if (lane == leader) {
-                    const int piece = tx0 >> 6;
-                    atomicOr(rowmask + (((long long)b * nC + ll) * HG + ((ty0 >> 3) + wv)) * PW + (piece >> 3),
-                             rb << ((piece & 7) * 8));
-                }
-                todo &= ~same;
+            for (int i = 0; i < 4; ++i) {
+                const bool m = val[i] && bl[i] == ll;
+                bi[i] = __ballot(m);
+                done[i] = done[i] || m;
             }
+            uint32_t rowbits = 0u;
+            if (lane < 8) {
+                const int sh = lane * 8;
+                rowbits = (uint32_t)((bi[0] >> sh) & 0xFFull) | ((uint32_t)((bi[1] >> sh) & 0xFFull) << 8) |
+                          ((uint32_t)((bi[2] >> sh) & 0xFFull) << 16) | ((uint32_t)((bi[3] >> sh) & 0xFFull) << 24);
+                if (rowbits) {
+                    const uint32_t *c = cb + (long long)ll * CEN_WORDS;
+                    const int wy0 = (int)c[6], wx0 = (int)c[8];
+                    const int yy = ty0 + wv * 8 + lane;
+                    fine[((((long long)b * nC + ll) * RW + (yy - wy0)) * PWF + (piece - (wx0 >> 6))) * 2 + half] = rowbits;
+                }
+            }
+            const unsigned long long rb = __ballot(rowbits != 0u) & 0xFFull;
+            if (lane == leader)
+                atomicOr(rowmask + (((long long)b * nC + ll) * HG + ((ty0 >> 3) + wv)) * PW + (piece >> 3),
+                         rb << ((piece & 7) * 8));
         }
     }
     int32_t *out = labels + (long long)b * npix;
@@ -315,60 +327,164 @@ __global__ __launch_bounds__(256) void k_slic_assign(const float *__restrict__ l
 }
 
 // ------------------------------------------------------------------------------------
-// centroid update: one 256-thread workgroup per (image, centre).  Raster-order float32 sums.
+// centroid update: one WAVEFRONT per (image, centre), four independent wavefronts per
+// workgroup, no workgroup barriers.  Raster-order float32 sums.
 //
 // skimage adds the pixels of a segment to float32 accumulators in raster order; float32
-// addition does not commute with regrouping, so the order is kept: lanes 0..4 of wave 0 carry
-// the five running sums (y, x, L, a, b) through the segment's pixels one by one.  Everything
-// around that serial chain is parallel and overlapped with it:
-//   * the assignment sweep left one occupancy bit per (8-row group, 64-pixel piece) of the
-//     segment; wave 1 expands the bits into a raster-ordered piece list in LDS;
-//   * waves 1..3 (gatherers) take 4 pieces each per round: the labels and Lab values of their
-//     pieces are requested together (16 independent loads in flight per lane), the matching
-//     pixels are compacted with ballot + mbcnt, in raster order, into that wave's sub-ring;
-//   * wave 0 (consumer) drains the three sub-rings of the PREVIOUS round in order while the
-//     gatherers fill the other buffer (double buffering, one barrier per round).
-// Thousands of these chains (B * n_centroids workgroups) run concurrently.
+// addition does not commute with regrouping, so the order is kept: lanes 0..4 of the wave carry
+// the five running sums (y, x, L, a, b) through the segment's pixels one by one.  Feeding that
+// serial chain is what the rest of the wave does, and none of it is per-piece scalar work:
+//   * the assignment sweep left, per segment, one coarse bit per (row, 64-pixel piece) and one
+//     fine 64-bit pixel mask per set coarse bit (window-relative table).  The wave expands the
+//     coarse bits into a raster-ordered piece list (LDS) — the label image is never read;
+//   * 64 list entries at a time, lane j owns entry j: it reads (and clears) the entry's fine
+//     mask, and a wave prefix sum of the mask populations gives every entry its place in the
+//     segment's pixel stream.  Each lane then writes the packed (row, x) of its mask's set bits
+//     to that place of an LDS index buffer — as many leading entries as fit the buffer;
+//   * the stream is consumed in rounds of UPD_ROUND pixels: lane i reads index i, loads L, a, b
+//     of that pixel (every lane of every load is a wanted pixel; three statically named register
+//     sets keep two rounds of loads in flight, the schedule is straight-line so that the
+//     compiler's vmcnt waits stay exact) and writes y, x, L, a, b to the wave's staging rows;
+//   * lanes 0..4 then walk the staging rows: four 16-byte LDS reads per 16 dependent adds, the
+//     reads of the next 16 pixels in flight meanwhile.
+// HBM traffic per sweep ~ 12 B/pixel (Lab, plus partially used lines at segment borders) and
+// 8 B per (row, piece) of mask.
 // ------------------------------------------------------------------------------------
-#define UPD_NG 3           // gather waves
-#define UPD_PPW 4          // pieces per gather wave per round
-#define UPD_SUB (UPD_PPW * 64)
-#define UPD_STRIDE (UPD_SUB + 16)   // floats per feature row of a sub-ring (+16: zero pad, read slack)
-#define UPD_PLIST 4096     // piece-list capacity (entries of 16 bits: row in window << 5 | piece)
+#define UPD_WAVES 4                        // independent segments per workgroup
+#define UPD_ROUND 128                      // pixels staged per round (two loads of 64 per plane)
+#define UPD_ROW (UPD_ROUND + 36)           // floats per staging row (+read-ahead slack; 164 % 64 = 36 spreads the 5 rows over LDS banks)
+#define UPD_PCAP 512                       // piece-list capacity (entries: row in window << 5 | piece)
+#define UPD_ICAP 2048                      // index-buffer capacity (pixels)
 
-struct UpdRegs { int lv[UPD_PPW]; float vL[UPD_PPW], vA[UPD_PPW], vB[UPD_PPW]; unsigned pe[UPD_PPW]; };
+// one round in flight: packed (row << 11 | x) and Lab of 2 x 64 stream pixels
+struct UpdRound { unsigned code[2]; float vL[2], vA[2], vB[2]; int fill; };
 
-__global__ __launch_bounds__(256) void k_slic_update(const float *__restrict__ lab,
-                                                     const int32_t *__restrict__ labels,
-                                                     uint32_t *__restrict__ cen, int nC, int H,
-                                                     int W, int s2y, int s2x,
-                                                     unsigned long long *__restrict__ rowmask, int HG, int PW,
-                                                     uint32_t *__restrict__ status)
+#ifdef SPA_UPD_TIMING      // development aid: per-phase wave cycles summed into the words after the queue heads
+#define UPD_T0() unsigned long long t_ = __builtin_readcyclecounter(), tacc_[6] = {0, 0, 0, 0, 0, 0}
+#define UPD_T(i) { const unsigned long long n_ = __builtin_readcyclecounter(); tacc_[i] += n_ - t_; t_ = n_; }
+#define UPD_TFLUSH(q) if (lane == 0) { for (int i_ = 0; i_ < 6; ++i_) atomicAdd((unsigned long long *)(q) + 8 + i_, tacc_[i_]); }
+#else
+#define UPD_T0()
+#define UPD_T(i)
+#define UPD_TFLUSH(q)
+#endif
+
+__device__ __forceinline__ void wave_lds_sync()
 {
-    __shared__ __attribute__((aligned(16))) float ring[2][UPD_NG][UPD_STRIDE * 5];   // [feature][entry]
-    __shared__ int ring_cnt[2][UPD_NG];
-    __shared__ unsigned short plist[UPD_PLIST];
-    __shared__ int s_npieces, s_gtake;
-    const int k = blockIdx.x, b = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const long long npix = (long long)H * W;
-    const float *pl = lab + (long long)b * 3 * npix;
-    const int32_t *lb = labels + (long long)b * npix;
-    uint32_t *c = cen + ((long long)b * nC + k) * CEN_WORDS;
-    const int wy0 = (int)c[6], wy1 = (int)c[7];   // the search window [wy0, wy1) bounds the segment
-    unsigned long long *rm = rowmask + ((long long)b * nC + k) * HG * PW;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 
-    float acc = 0.0f;          // wave 0, lanes 0..4: running sums of y, x, L, a, b
-    unsigned n = 0;            // wave 0: pixel count
+// inclusive prefix sum over the 64 lanes with DPP moves (no LDS round trips)
+__device__ __forceinline__ int upd_wave_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);      // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);      // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);      // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);      // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);      // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);      // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// the sweep stores bit (i*8 + g) for pixel 4*g + i of a 32-pixel half row; back to bit = pixel
+__device__ __forceinline__ unsigned upd_pixel_order(unsigned w)
+{
+    unsigned out = 0u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned v = (w >> (8 * i)) & 0xFFu;
+        v = (v | (v << 12)) & 0x000F000Fu;
+        v = (v | (v << 6)) & 0x03030303u;
+        v = (v | (v << 3)) & 0x11111111u;
+        out |= v << i;
+    }
+    return out;
+}
+
+// Longest-first work lists.  Segment sizes differ by a factor of 3-4 and a segment is one serial
+// chain, so the launch is as long as its unluckiest wave unless the big segments start first:
+// the (image, centre) pairs are split into 8 contiguous ranges (one per XCD, so that neighbouring
+// segments, which share border lines of the Lab image, meet in one L2) and each range is bucket
+// sorted by the pixel count of the previous sweep, largest first.  Persistent waves then pull
+// the next segment of their XCD's list with one atomic each.
+#define UPD_CLASSES 64
+
+__global__ __launch_bounds__(1024) void k_slic_order(const uint32_t *__restrict__ cen, int total,
+                                                     int per_xcd, unsigned mean_px,
+                                                     int *__restrict__ order, int *__restrict__ qhead)
+{
+    __shared__ int hist[UPD_CLASSES];
+    const int x = blockIdx.x, tid = threadIdx.x;
+    const int lo = x * per_xcd, hi = min(total, lo + per_xcd);
+    if (tid < UPD_CLASSES) hist[tid] = 0;
+    __syncthreads();
+    for (int i = lo + tid; i < hi; i += 1024) {
+        const unsigned n = cen[(long long)i * CEN_WORDS + 10];
+        atomicAdd(&hist[UPD_CLASSES - 1 - (int)min((unsigned)(UPD_CLASSES - 1), n * 16u / mean_px)], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int q = 0; q < UPD_CLASSES; ++q) { const int h = hist[q]; hist[q] = run; run += h; }
+        qhead[x] = 0;
+    }
+    __syncthreads();
+    for (int i = lo + tid; i < hi; i += 1024) {
+        const unsigned n = cen[(long long)i * CEN_WORDS + 10];
+        const int pos = atomicAdd(&hist[UPD_CLASSES - 1 - (int)min((unsigned)(UPD_CLASSES - 1), n * 16u / mean_px)], 1);
+        order[lo + pos] = i;
+    }
+}
+
+__global__ __launch_bounds__(256)
+void k_slic_update(const float *__restrict__ lab, uint32_t *__restrict__ cen, int nC, int B, int H,
+                   int W, int s2y, int s2x, unsigned long long *__restrict__ rowmask, int HG, int PW,
+                   unsigned long long *__restrict__ fine, int RW, int PWF, int per_xcd,
+                   const int *__restrict__ order, int *__restrict__ qhead,
+                   uint32_t *__restrict__ status)
+{
+    __shared__ __attribute__((aligned(16))) float stage_s[UPD_WAVES][5 * UPD_ROW];
+    __shared__ unsigned idx_s[UPD_WAVES][UPD_ICAP];
+    __shared__ unsigned short plist_s[UPD_WAVES][UPD_PCAP];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int xcd = (int)(blockIdx.x & 7u);          // workgroups are dealt round-robin to the XCDs
+    const int qlo = xcd * per_xcd, qn = min(B * nC, qlo + per_xcd) - qlo;
+    float *st = stage_s[wv];
+    unsigned *idx = idx_s[wv];
+    unsigned short *plist = plist_s[wv];
+    const unsigned W4 = (unsigned)W * 4u;
+  for (;;) {
+    int qi = 0;
+    if (lane == 0) qi = atomicAdd(qhead + xcd, 1);
+    qi = __builtin_amdgcn_readfirstlane(qi);
+    if (qi >= qn) return;
+    const int seg = __builtin_amdgcn_readfirstlane(order[qlo + qi]);
+    const int b = seg / nC;
+    const int k = seg - b * nC;
+    const unsigned npix = (unsigned)H * (unsigned)W;
+    const float *pL = lab + (long long)b * 3 * npix;        // wave-uniform plane bases
+    const float *pA = pL + npix;
+    const float *pB = pA + npix;
+    uint32_t *c = cen + ((long long)b * nC + k) * CEN_WORDS;
+    const int wy0 = (int)c[6], wy1 = (int)c[7], wx0 = (int)c[8];   // the window the sweep used
+    unsigned long long *rm = rowmask + ((long long)b * nC + k) * HG * PW;
+    unsigned long long *fm = fine + ((long long)b * nC + k) * RW * PWF;
+    const int pc0 = wx0 >> 6;
+
+    float acc = 0.0f;          // lanes 0..4: running sums of y, x, L, a, b
+    unsigned n = 0;            // pixel count
+    UPD_T0();
 
     const int g0 = wy0 >> 3, g1 = (wy1 - 1) >> 3;
     const int ybase = g0 << 3;                    // plist rows are relative to this
     int gb = g0;
     while (gb <= g1) {
-        if (wv == 1) {
-            // piece list in raster order: groups in order, rows in order, pieces in order.
-            // lane g expands group gb+g: PW mask words, byte q of word i = rows of piece 8i+q.
-            // As many whole groups as fit the list are taken (and their masks cleared).
+        // ---- piece list in raster order: groups in order, rows in order, pieces in order.
+        // lane g expands group gb+g: PW mask words, byte q of word i = rows of piece 8i+q.
+        // As many whole groups as fit the list are taken (and their masks cleared).
+        int npieces, gtake;
+        {
             const int gg = gb + lane;
             const bool has = gg <= g1;
             unsigned long long mw[4] = {0ull, 0ull, 0ull, 0ull};
@@ -379,129 +495,197 @@ __global__ __launch_bounds__(256) void k_slic_update(const float *__restrict__ l
                 for (int i = 0; i < 4; ++i)
                     if (i < PW) { mw[i] = w[i]; cntl += __popcll(mw[i]); }
             }
-            int inc = cntl;
-            for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
-            const bool take = has && inc <= UPD_PLIST;
+            const int inc = upd_wave_scan(cntl);
+            const bool take = has && inc <= UPD_PCAP;
             const unsigned long long tm = __ballot(take);
-            const int gtake = __popcll(tm);               // prefix property: lanes 0..gtake-1
-            const int total = gtake ? __shfl(inc, gtake - 1) : 0;
-            if (lane == 0) { s_npieces = total; s_gtake = gtake > 0 ? gtake : 1; }
-            if (take) {
+            gtake = __popcll(tm);                         // prefix property: lanes 0..gtake-1
+            npieces = __builtin_amdgcn_readfirstlane(gtake ? __shfl(inc, gtake - 1) : 0);
+            if (take && cntl) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (i < PW) w[i] = 0ull;                                      // consumed
+                    if (i < PW && mw[i]) w[i] = 0ull;                             // consumed
                 int pos = inc - cntl;
-                if (cntl) {
-                    const int yrel = (gg << 3) - ybase;
-                    for (int r = 0; r < 8; ++r) {
+                const int yrel = (gg << 3) - ybase;
+#pragma unroll 1
+                for (int r = 0; r < 8; ++r) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            unsigned long long bits = (mw[i] >> r) & 0x0101010101010101ull;
-                            while (bits) {
-                                const int q = (__ffsll((long long)bits) - 1) >> 3;
-                                plist[pos++] = (unsigned short)(((yrel + r) << 5) | (i * 8 + q));
-                                bits &= bits - 1ull;
-                            }
+                    for (int i = 0; i < 4; ++i) {
+                        unsigned long long bits = (mw[i] >> r) & 0x0101010101010101ull;
+                        while (bits) {
+                            const int q = (__ffsll((long long)bits) - 1) >> 3;
+                            plist[pos++] = (unsigned short)(((yrel + r) << 5) | (i * 8 + q));
+                            bits &= bits - 1ull;
                         }
                     }
                 }
             }
+            if (gtake == 0) gtake = 1;
         }
-        __syncthreads();
-        const int npieces = s_npieces;
-        gb += s_gtake;
-        const int rounds = (npieces + UPD_NG * UPD_PPW - 1) / (UPD_NG * UPD_PPW);
-        const int gw = wv - 1;
-        // three rounds in flight per gather wave: labels of round rd+2 are requested, the Lab values
-        // of round rd+1 are requested for the lanes whose label matched (so pixels of neighbouring
-        // segments inside a piece cost 4 bytes, not 16), round rd is compacted
-        UpdRegs cur, nxt, nx2;
-        auto fetch_labels = [&](UpdRegs &R, int rd) {
-            const int t0 = (rd * UPD_NG + gw) * UPD_PPW;
-#pragma unroll
-            for (int u = 0; u < UPD_PPW; ++u) {
-                const int t = t0 + u;
-                R.pe[u] = t < npieces ? (unsigned)plist[t] : 0u;
-                const int yy = ybase + (int)(R.pe[u] >> 5), xx = (int)((R.pe[u] & 31u) << 6) + lane;
-                const bool in = (t < npieces) && (xx < W) && (yy < H);
-                R.lv[u] = in ? lb[(long long)yy * W + xx] : -1;
-            }
+        gb += gtake;
+        wave_lds_sync();
+        UPD_T(0)
+
+        if (npieces == 0) continue;
+        // fine masks of list entries e..e+63, one per lane (lanes past the end re-read the last
+        // entry: the load itself is unconditional so that the wait counters stay exact)
+        unsigned long long raw_n;
+        unsigned long long *fa_n;
+        unsigned code_n;
+        auto fetch_masks = [&](int e) {
+            const unsigned pe = (unsigned)plist[min(e + lane, npieces - 1)];
+            const int yrel = (int)(pe >> 5), pc = (int)(pe & 31u);
+            fa_n = fm + (long long)(ybase + yrel - wy0) * PWF + (pc - pc0);
+            raw_n = *fa_n;
+            code_n = ((unsigned)yrel << 11) | ((unsigned)pc << 6);
         };
-        auto fetch_lab = [&](UpdRegs &R) {
-#pragma unroll
-            for (int u = 0; u < UPD_PPW; ++u) {
-                const int yy = ybase + (int)(R.pe[u] >> 5), xx = (int)((R.pe[u] & 31u) << 6) + lane;
-                const long long p = (long long)yy * W + xx;
-                const bool m = (R.lv[u] == k);
-                R.vL[u] = m ? pl[p] : 0.0f;
-                R.vA[u] = m ? pl[npix + p] : 0.0f;
-                R.vB[u] = m ? pl[2 * npix + p] : 0.0f;
+        // ---- the stream of this list: the index buffer is refilled when its last round has been
+        // ISSUED (issued rounds carry their codes in registers), so rounds of the next part are in
+        // flight while the last rounds of this part are summed
+        int e0 = 0;              // next list entry
+        int T = 0, nr = 0;       // pixels / rounds in the index buffer
+        int lr = 0;              // next round of the buffer to issue
+        int inflight = 0;        // live rounds issued and not yet summed
+        if (lane == 0) idx[0] = 0u;                  // a valid code for the loads of idle rounds
+        fetch_masks(0);
+        auto refill = [&]() {
+            // lane j owns list entry e0+j: fine mask in pixel order, place in the stream
+            unsigned mlo = 0u, mhi = 0u;
+            unsigned code0 = code_n;
+            unsigned long long *fa = fa_n;
+            if (e0 + lane < npieces) {
+                mlo = upd_pixel_order((unsigned)raw_n);
+                mhi = upd_pixel_order((unsigned)(raw_n >> 32));
             }
+            const int cnt = __popc(mlo) + __popc(mhi);
+            const int inc = upd_wave_scan(cnt);
+            const bool take = (e0 + lane < npieces) && inc <= UPD_ICAP;
+            const int m = __popcll(__ballot(take));               // >= 1: one entry is at most 64 pixels
+            T = __builtin_amdgcn_readlane(inc, m - 1);
+            if (take) {
+                *fa = 0ull;                                       // cleared for the next sweep
+                // set bits -> packed (row, x), in x order: two 32-bit halves (32-bit bit tricks are
+                // half the vector instructions of 64-bit ones); the loop runs as long as the fullest
+                // mask of the wave needs
+                unsigned *d = idx + (inc - cnt);
+                while (mlo) {
+                    *d++ = code0 + (unsigned)(__ffs((int)mlo) - 1);
+                    mlo &= mlo - 1u;
+                }
+                code0 += 32u;
+                while (mhi) {
+                    *d++ = code0 + (unsigned)(__ffs((int)mhi) - 1);
+                    mhi &= mhi - 1u;
+                }
+            }
+            e0 += m;
+            nr = (T + UPD_ROUND - 1) / UPD_ROUND;
+            lr = 0;
+            wave_lds_sync();
+            fetch_masks(e0);     // the next entries' masks travel while this part of the stream is summed
+            UPD_T(1)
         };
-        if (wv >= 1 && rounds > 0) {
-            fetch_labels(cur, 0);
-            if (rounds > 1) fetch_labels(nxt, 1);
-            fetch_lab(cur);
-        }
-        for (int rd = 0; rd <= rounds; ++rd) {
-            if (wv >= 1 && rd < rounds) {
-                if (rd + 2 < rounds) fetch_labels(nx2, rd + 2);
-                if (rd + 1 < rounds) fetch_lab(nxt);
-                float *sub = ring[rd & 1][gw];
-                int fill = 0;
+        auto issue = [&](UpdRound &R) {
+            if (lr == nr && e0 < npieces) refill();
+            const bool live = lr < nr;
+            R.fill = live ? min(UPD_ROUND, T - lr * UPD_ROUND) : 0;
 #pragma unroll
-                for (int u = 0; u < UPD_PPW; ++u) {
-                    const bool match = (cur.lv[u] == k);
-                    const unsigned long long mm = __ballot(match);
-                    if (match) {
-                        const int yy = ybase + (int)(cur.pe[u] >> 5), xx = (int)((cur.pe[u] & 31u) << 6) + lane;
-                        const int ps = fill + (int)spa_rank_in_mask(mm);
-                        sub[0 * UPD_STRIDE + ps] = (float)yy;
-                        sub[1 * UPD_STRIDE + ps] = (float)xx;
-                        sub[2 * UPD_STRIDE + ps] = cur.vL[u];
-                        sub[3 * UPD_STRIDE + ps] = cur.vA[u];
-                        sub[4 * UPD_STRIDE + ps] = cur.vB[u];
-                    }
-                    fill += __popcll(mm);
+            for (int g = 0; g < 2; ++g) {
+                const int p = g * 64 + lane;
+                // lanes past the end re-read pixel 0 of the buffer (cached) and stage zeros
+                const bool ok = p < R.fill;
+                const unsigned v = idx[ok ? lr * UPD_ROUND + p : 0];
+                const unsigned off = (unsigned)(ybase + (int)(v >> 11)) * W4 + ((v & 2047u) << 2);
+                R.code[g] = ok ? v : 0xFFFFFFFFu;
+                R.vL[g] = *(const float *)((const char *)pL + off);
+                R.vA[g] = *(const float *)((const char *)pA + off);
+                R.vB[g] = *(const float *)((const char *)pB + off);
+            }
+            lr += live ? 1 : 0;
+            inflight += live ? 1 : 0;
+        };
+        auto consume = [&](const UpdRound &R) {
+            const int fill = R.fill;
+            if (fill == 0) return;                         // idle round (its loads hit one cached line)
+            if (fill == UPD_ROUND) {                       // full round: every lane is a pixel
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    float *d = st + g * 64 + lane;
+                    d[0 * UPD_ROW] = (float)(ybase + (int)(R.code[g] >> 11));
+                    d[1 * UPD_ROW] = (float)(int)(R.code[g] & 2047u);
+                    d[2 * UPD_ROW] = R.vL[g];
+                    d[3 * UPD_ROW] = R.vA[g];
+                    d[4 * UPD_ROW] = R.vB[g];
                 }
-                // pad to a multiple of 8 with +0.0f (x + 0.0f == x): the consumer needs no tail loop
-                if (lane < 8) {
+            } else {                                       // last round of a part: zeros behind the end
 #pragma unroll
-                    for (int f = 0; f < 5; ++f) sub[f * UPD_STRIDE + fill + lane] = 0.0f;
-                }
-                if (lane == 0) ring_cnt[rd & 1][gw] = fill;
-                cur = nxt;
-                nxt = nx2;
-            } else if (wv == 0 && rd > 0) {
-                // ---- chain: sub-rings of round rd-1, in order
-#pragma unroll
-                for (int g = 0; g < UPD_NG; ++g) {
-                    const float *sub = ring[(rd - 1) & 1][g];
-                    const int cnt = ring_cnt[(rd - 1) & 1][g];
-                    if (lane < 5) {
-                        // lane f walks feature row f: two 16-byte LDS reads per 8 pixels, issued one
-                        // step ahead of the dependent float32 adds
-                        const float *row = sub + lane * UPD_STRIDE;
-                        const float4 *r4 = (const float4 *)row;
-                        float4 a = r4[0], bq = r4[1];
-                        int j = 0;
-                        for (; j < cnt; j += 8) {
-                            const float4 na = r4[(j >> 2) + 2], nb = r4[(j >> 2) + 3];
-                            acc = acc + a.x; acc = acc + a.y; acc = acc + a.z; acc = acc + a.w;
-                            acc = acc + bq.x; acc = acc + bq.y; acc = acc + bq.z; acc = acc + bq.w;
-                            a = na; bq = nb;
-                        }
-                    }
-                    n += (unsigned)cnt;
+                for (int g = 0; g < 2; ++g) {
+                    const bool ok = R.code[g] != 0xFFFFFFFFu;
+                    float *d = st + g * 64 + lane;
+                    d[0 * UPD_ROW] = ok ? (float)(ybase + (int)(R.code[g] >> 11)) : 0.0f;
+                    d[1 * UPD_ROW] = ok ? (float)(int)(R.code[g] & 2047u) : 0.0f;
+                    d[2 * UPD_ROW] = ok ? R.vL[g] : 0.0f;
+                    d[3 * UPD_ROW] = ok ? R.vA[g] : 0.0f;
+                    d[4 * UPD_ROW] = ok ? R.vB[g] : 0.0f;
                 }
             }
-            __syncthreads();
-        }
+            wave_lds_sync();
+            UPD_T(2)
+            if (lane < 5) {
+                // lane f walks feature row f: four 16-byte LDS reads per 16 dependent adds; the
+                // reads of the next 16 pixels are in flight while this step's adds run (the empty
+                // asm pins the prefetched registers so the compiler keeps the software pipeline)
+                const float4 *r4 = (const float4 *)(st + lane * UPD_ROW);
+                float4 q0 = r4[0], q1 = r4[1], q2 = r4[2], q3 = r4[3];
+                float4 n0, n1, n2, n3;
+#define UPD_ADD16(a0, a1, a2, a3)                                                          \
+    acc = acc + a0.x; acc = acc + a0.y; acc = acc + a0.z; acc = acc + a0.w;                \
+    acc = acc + a1.x; acc = acc + a1.y; acc = acc + a1.z; acc = acc + a1.w;                \
+    acc = acc + a2.x; acc = acc + a2.y; acc = acc + a2.z; acc = acc + a2.w;                \
+    acc = acc + a3.x; acc = acc + a3.y; acc = acc + a3.z; acc = acc + a3.w;
+#define UPD_PIN(a0, a1, a2, a3)                                                            \
+    asm volatile("" : "+v"(a0.x), "+v"(a0.y), "+v"(a0.z), "+v"(a0.w), "+v"(a1.x), "+v"(a1.y), "+v"(a1.z), "+v"(a1.w)); \
+    asm volatile("" : "+v"(a2.x), "+v"(a2.y), "+v"(a2.z), "+v"(a2.w), "+v"(a3.x), "+v"(a3.y), "+v"(a3.z), "+v"(a3.w));
+                for (int j = 0;;) {
+                    n0 = r4[(j >> 2) + 4]; n1 = r4[(j >> 2) + 5]; n2 = r4[(j >> 2) + 6]; n3 = r4[(j >> 2) + 7];
+                    __builtin_amdgcn_sched_barrier(0);
+                    UPD_ADD16(q0, q1, q2, q3)
+                    UPD_PIN(n0, n1, n2, n3)
+                    j += 16;
+                    if (j >= fill) break;
+                    q0 = r4[(j >> 2) + 4]; q1 = r4[(j >> 2) + 5]; q2 = r4[(j >> 2) + 6]; q3 = r4[(j >> 2) + 7];
+                    __builtin_amdgcn_sched_barrier(0);
+                    UPD_ADD16(n0, n1, n2, n3)
+                    UPD_PIN(q0, q1, q2, q3)
+                    j += 16;
+                    if (j >= fill) break;
+                }
+            }
+            n += (unsigned)fill;
+            inflight -= 1;
+            wave_lds_sync();
+            UPD_T(3)
+        };
+
+        // straight-line schedule, no branch around the loads of an issue(): the compiler's vmcnt
+        // accounting stays exact (waits leave the younger loads in flight) only when the number
+        // of loads between an issue and its use is the same on every path.
+        UpdRound r0, r1, r2;
+        issue(r0);
+        issue(r1);
+        do {
+            issue(r2);
+            consume(r0);
+            issue(r0);
+            consume(r1);
+            issue(r1);
+            consume(r2);
+        } while (inflight > 0 || lr < nr || e0 < npieces);
+        UPD_T(4)
     }
-    if (wv != 0) return;
+    UPD_TFLUSH(qhead)
     if (n == 0u) {
-        if (lane == 0) atomicOr(status, SPA_ST_SLIC_EMPTY_SEGMENT);
-        return;
+        if (lane == 0) { atomicOr(status, SPA_ST_SLIC_EMPTY_SEGMENT); c[10] = 0u; }
+        continue;
     }
     float mean = acc / (float)n;      // segments[k, c] /= n_segment_elems[k]
     float cy = __shfl(mean, 0), cx = __shfl(mean, 1);
@@ -514,6 +698,7 @@ __global__ __launch_bounds__(256) void k_slic_update(const float *__restrict__ l
         c[6] = (uint32_t)ny0; c[7] = (uint32_t)ny1; c[8] = (uint32_t)nx0; c[9] = (uint32_t)nx1;
         c[10] = n;
     }
+  }
 }
 
 __global__ void k_slic_export_centres(const uint32_t *__restrict__ cen, float *__restrict__ out,
@@ -550,6 +735,29 @@ extern "C" int spa_slic_core(spa_ctx *ctx, const float *lab, int32_t B, int32_t 
     rc = spa_ws_reserve(ctx, WS_ROWMASK, (size_t)B * nC * HG * PW * 8, (void **)&rowmask);
     if (rc != SPA_OK) return rc;
     SPA_HIP(hipMemsetAsync(rowmask, 0, (size_t)B * nC * HG * PW * 8, s));
+    // fine pixel masks: per (centre, row of its search window, 64-pixel piece of the window) 64 bits
+    const int RW = 2 * s2y + 2;
+    const int PWF = ((2 * s2x + 1) >> 6) + 2;
+    unsigned long long *fine;
+    rc = spa_ws_reserve(ctx, WS_FINEMASK, (size_t)B * nC * RW * PWF * 8, (void **)&fine);
+    if (rc != SPA_OK) return rc;
+    SPA_HIP(hipMemsetAsync(fine, 0, (size_t)B * nC * RW * PWF * 8, s));
+    // update sweep: per-XCD longest-first segment lists pulled by persistent waves
+    const int upd_total = B * nC;
+    const int upd_per_xcd = (upd_total + 7) / 8;
+    int *upd_order;
+    rc = spa_ws_reserve(ctx, WS_SLIC_ORDER, ((size_t)upd_total + 8 + 32) * 4, (void **)&upd_order);
+    if (rc != SPA_OK) return rc;
+    int *upd_qhead = upd_order + upd_total;
+    static int upd_wg_per_cu = 0;
+    if (!upd_wg_per_cu) {
+        SPA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&upd_wg_per_cu, (const void *)k_slic_update, 256, 0));
+        if (upd_wg_per_cu < 1) upd_wg_per_cu = 1;
+    }
+    int upd_grid = upd_wg_per_cu * ctx->n_cu;
+    if (upd_grid > (upd_total + UPD_WAVES - 1) / UPD_WAVES) upd_grid = (upd_total + UPD_WAVES - 1) / UPD_WAVES;
+    upd_grid = (upd_grid + 7) & ~7;
+    const unsigned mean_px = (unsigned)(((long long)H * W) / nC) ? (unsigned)(((long long)H * W) / nC) : 1u;
     hipLaunchKernelGGL(k_slic_init, dim3((nC + 127) / 128, B), dim3(128), 0, s, cen, nC,
                        pl.grid_nx, pl.start_y, pl.start_x, pl.step_y, pl.step_x, s2y, s2x, H, W);
     SPA_LAUNCH_CHECK();
@@ -558,14 +766,20 @@ extern "C" int spa_slic_core(spa_ctx *ctx, const float *lab, int32_t B, int32_t 
     dim3 ga((W + TILE - 1) / TILE, (H + TILE - 1) / TILE, B);
     for (int it = 0; it < max_iter; ++it) {
         { SpaProfScope prof_(ctx, PROF_SLIC_ASSIGN, s);
+        // (the masks of the last sweep would never be read)
+        const bool upd = it + 1 < max_iter || centres;
         hipLaunchKernelGGL(k_slic_assign, ga, dim3(256), 0, s, lab, cen, nC, H, W, sw, labels,
-                           rowmask, HG, PW, ctx->d_status); }
+                           rowmask, HG, PW, upd ? (uint32_t *)fine : (uint32_t *)nullptr, RW, PWF,
+                           ctx->d_status); }
         SPA_LAUNCH_CHECK();
         // the centroids computed after the last sweep never influence the labels
         if (it + 1 < max_iter || centres) {
             SpaProfScope prof_(ctx, PROF_SLIC_UPDATE, s);
-            hipLaunchKernelGGL(k_slic_update, dim3(nC, B), dim3(256), 0, s, lab, labels, cen, nC,
-                               H, W, s2y, s2x, rowmask, HG, PW, ctx->d_status);
+            hipLaunchKernelGGL(k_slic_order, dim3(8), dim3(1024), 0, s, cen, upd_total, upd_per_xcd, mean_px,
+                               upd_order, upd_qhead);
+            hipLaunchKernelGGL(k_slic_update, dim3(upd_grid), dim3(256), 0, s, lab, cen, nC, B,
+                               H, W, s2y, s2x, rowmask, HG, PW, fine, RW, PWF, upd_per_xcd,
+                               (const int *)upd_order, upd_qhead, ctx->d_status);
             SPA_LAUNCH_CHECK();
         }
     }
