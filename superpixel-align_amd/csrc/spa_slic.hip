@@ -159,6 +159,7 @@ __global__ void k_slic_init(uint32_t *__restrict__ cen, int nC, int grid_nx, int
 // Algorithmic HBM bytes per pixel per sweep: 12 (Lab) + 4 (label).
 // ------------------------------------------------------------------------------------
 #define TILE 32
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(256) void k_slic_assign(const float *__restrict__ lab,
                                                      uint32_t *__restrict__ cen, int nC,
@@ -203,6 +204,9 @@ __global__ __launch_bounds__(256) void k_slic_assign(const float *__restrict__ l
     float best[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
     int bl[4] = {-1, -1, -1, -1};
     const float fy = (float)y;
+    const f32x2 pL2[2] = {{pL[0], pL[1]}, {pL[2], pL[3]}}, pA2[2] = {{pA[0], pA[1]}, {pA[2], pA[3]}},
+                pB2[2] = {{pB[0], pB[1]}, {pB[2], pB[3]}};
+    const f32x2 fx2[2] = {{(float)xb, (float)(xb + 1)}, {(float)(xb + 2), (float)(xb + 3)}};
 
     for (int kb = 0; kb < nC; kb += 256) {
         const int k = kb + tid;
@@ -235,7 +239,9 @@ __global__ __launch_bounds__(256) void k_slic_assign(const float *__restrict__ l
         if (row_ok) {
             // straight-line body: the three 16-byte LDS reads of an entry are issued together and
             // the window test is folded into the final comparison (no divergent branches), so the
-            // compiler can overlap the next entry's reads with this entry's arithmetic
+            // compiler can overlap the next entry's reads with this entry's arithmetic.  The
+            // float arithmetic runs on pixel pairs (v_pk_add_f32 / v_pk_mul_f32: two IEEE float32
+            // operations per instruction, each rounded exactly like the scalar one — no FMA).
 #pragma unroll 2
             for (int j = 0; j < total; ++j) {
                 const uint4 e0 = cand[j * 3 + 0], e1 = cand[j * 3 + 1], e2 = cand[j * 3 + 2];
@@ -247,20 +253,25 @@ __global__ __launch_bounds__(256) void k_slic_assign(const float *__restrict__ l
                 const bool rowin = (y >= y0) && (y < y1);
                 const float ty = cy - fy;
                 const float dy = ty * ty;
+                const unsigned xw = (unsigned)(x1 - x0);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int x = xb + i;
-                    const float tx = cx - (float)x;
-                    const float dx = tx * tx;
-                    float dc = (dy + dx) * sw;
-                    const float t0 = pL[i] - cl, t1 = pA[i] - ca, t2 = pB[i] - cbb;
-                    float col = t0 * t0;
+                for (int h = 0; h < 2; ++h) {
+                    const f32x2 tx = f32x2{cx, cx} - fx2[h];
+                    const f32x2 dx = tx * tx;
+                    f32x2 dc = (f32x2{dy, dy} + dx) * f32x2{sw, sw};
+                    const f32x2 t0 = pL2[h] - f32x2{cl, cl}, t1 = pA2[h] - f32x2{ca, ca}, t2 = pB2[h] - f32x2{cbb, cbb};
+                    f32x2 col = t0 * t0;
                     col = col + t1 * t1;
                     col = col + t2 * t2;
                     dc = dc + col;
-                    const bool take = rowin && ok[i] && (x >= x0) && (x < x1) && (best[i] > dc);
-                    best[i] = take ? dc : best[i];
-                    bl[i] = take ? kk : bl[i];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int i = 2 * h + q;
+                        const float d = q ? dc.y : dc.x;
+                        const bool take = rowin && ok[i] && ((unsigned)(xb + i - x0) < xw) && (best[i] > d);
+                        best[i] = take ? d : best[i];
+                        bl[i] = take ? kk : bl[i];
+                    }
                 }
             }
         }
