@@ -523,18 +523,32 @@ __global__ __launch_bounds__(256) void k_conn_bfs_lane(const int *__restrict__ p
 }
 
 // ---------------------------------------------------------------------------------------
-// BFS replay of one small component, LDS tier: the component's bounding box (+1 pixel margin)
-// is staged in LDS as one code word per pixel
-//     INF_KEY      pixel of this component, not yet discovered
-//     CODE_EARLIER pixel of a component with a smaller seed (a candidate for `adjacent`)
-//     CODE_OTHER   anything else
-//     key < CODE_OTHER: pixel of this component, discovered with that (queue index*4+dir) key
-// and the queue holds 16-bit box-local indices, so every step of the replay is a handful of LDS
-// round trips (~100 cycles) instead of L2/HBM round trips (~1-2 us).  Components that do not fit
-// `lds_bytes` are appended to `todo` for the next tier.
+// BFS replay of one small component, LDS tiers: one wavefront per component.  The component's
+// bounding box (+1 pixel margin) is staged in LDS as one BYTE per pixel
+//     BC_OTHER    not a candidate for `adjacent` (a component with a larger seed)
+//     BC_EARLIER  pixel of a component with a smaller seed (a candidate for `adjacent`)
+//     BC_MEMBER   pixel of this component, not yet discovered
+//     BC_DONE     pixel of this component, discovered
+//     BC_CUR + l  pixel of this component that lane l is expanding in this step
+// and the queue is a ring of 16-bit box-local indices (only the current and the next BFS level
+// are alive), so a component costs (box area + ring) bytes of LDS and 10 of the typical
+// 1-2 thousand pixel components replay concurrently per CU; every step of a replay is a handful
+// of LDS round trips.  A pixel reached from several pixels of the same step goes to the smallest
+// (queue index, direction) key, as in the sequential BFS: each claimant looks at the pixel's
+// other neighbours for step-mates with a smaller key (no atomics).  Components whose box or
+// frontier does not fit are appended to `todo` for the next tier.
 // ---------------------------------------------------------------------------------------
-#define CODE_EARLIER 0xFFFFFFFEu
-#define CODE_OTHER 0xFFFFFFFDu
+#define BC_OTHER 0
+#define BC_EARLIER 1
+#define BC_MEMBER 2
+#define BC_DONE 3
+#define BC_CUR 64
+
+__device__ __forceinline__ void conn_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 
 __global__ __launch_bounds__(64) void k_conn_bfs_lds(const int *__restrict__ parent,
                                                      const int *__restrict__ size,
@@ -544,22 +558,20 @@ __global__ __launch_bounds__(64) void k_conn_bfs_lds(const int *__restrict__ par
                                                      int *__restrict__ todo,           // slots that do not fit
                                                      ConnMisc *__restrict__ misc, int tier,
                                                      int *__restrict__ final_, int H, int W,
-                                                     int lds_bytes)
+                                                     int lds_bytes, int ring)          // ring: power of two
 {
     extern __shared__ uint32_t lds_u32[];
     const int b = blockIdx.y;
     const int npix = H * W;
     const int lane = threadIdx.x;
     const int *P = parent + (long long)b * npix;
-    const int *S = size + (long long)b * npix;
     const int *BL = big_list + (long long)b * npix;
     int *F = final_ + (long long)b * npix;
     const int n_items = tier == 0 ? misc[b].n_big : misc[b].n_todo1;
     int *todo_count = tier == 0 ? &misc[b].n_todo1 : &misc[b].n_todo2;
     const int first_kept = misc[b].first_kept;
     const unsigned long long below = (1ull << lane) - 1ull;
-    const int ddx[4] = {1, -1, 0, 0};
-    const int ddy[4] = {0, 0, 1, -1};
+    const int rmask = ring - 1;
 
     for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
         const int slot = list ? list[(long long)b * npix + it] : it;
@@ -568,94 +580,122 @@ __global__ __launch_bounds__(64) void k_conn_bfs_lds(const int *__restrict__ par
             if (lane == 0) F[r] = -1;
             continue;
         }
-        const int sz = S[r];
         bool fits = slot < SBOX_CAP;
-        int y0 = 0, y1 = 0, x0 = 0, x1 = 0, bw = 0, bh = 0, area = 0;
+        int y0 = 0, y1 = 0, x0 = 0, x1 = 0, bw = 0, bh = 0, area = 0, area4 = 0;
         if (fits) {
             const int *bb = sbox + ((long long)b * SBOX_CAP + slot) * 4;
             y0 = max(bb[0] - 1, 0); y1 = min(bb[1] + 1, H - 1);
             x0 = max(bb[2] - 1, 0); x1 = min(bb[3] + 1, W - 1);
             bw = x1 - x0 + 1; bh = y1 - y0 + 1;
             area = bw * bh;
-            fits = area <= 65535 && (long long)area * 4 + (long long)((sz + 1) & ~1) * 2 <= lds_bytes;
+            area4 = (area + 3) & ~3;
+            fits = area <= 65535 && area4 + ring * 2 <= lds_bytes;
         }
-        if (!fits) {
+        bool overflow = false;
+        long long best = -1;            // (key << 32) | box-local index of the outside neighbour
+        if (fits) {
+            unsigned char *code = (unsigned char *)lds_u32;
+            unsigned short *Q = (unsigned short *)(code + area4);
+            conn_wave_sync();
+            // stage the box: 16 pixels per lane and step (16 independent loads in flight per
+            // lane), four packed 32-bit LDS stores
+            for (int i0 = 0; i0 < area4; i0 += 1024) {
+                int rv[16];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = i0 + g * 256 + lane * 4 + u;
+                        const int yy = y0 + i / bw, xx = x0 + i % bw;
+                        rv[g * 4 + u] = i < area ? P[yy * W + xx] : 0x7fffffff;
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint32_t packed = 0u;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int q = rv[g * 4 + u];
+                        const uint32_t c = q == r ? BC_MEMBER : (q < r ? BC_EARLIER : BC_OTHER);
+                        packed |= c << (8 * u);
+                    }
+                    if (i0 + g * 256 + lane * 4 < area4) lds_u32[((i0 + g * 256) >> 2) + lane] = packed;
+                }
+            }
+            const int ry = r / W, rx = r - ry * W;
+            const int rloc = (ry - y0) * bw + (rx - x0);
+            conn_wave_sync();
+            if (lane == 0) { Q[0] = (unsigned short)rloc; code[rloc] = BC_DONE; }
+            conn_wave_sync();
+            int head = 0, tail = 1;
+            const int ddx[4] = {1, -1, 0, 0};
+            const int ddy[4] = {0, 0, 1, -1};
+            while (head < tail) {
+                const int cnt = min(64, tail - head);
+                const bool act = lane < cnt;
+                const int uidx = head + lane;
+                const int u = act ? (int)Q[uidx & rmask] : 0;
+                if (act) code[u] = (unsigned char)(BC_CUR + lane);
+                conn_wave_sync();
+                const int uy = u / bw, ux = u - uy * bw;
+                bool win[4];
+                int v[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int xx = ux + ddx[d], yy = uy + ddy[d];
+                    const bool inb = act && xx >= 0 && xx < bw && yy >= 0 && yy < bh;
+                    v[d] = yy * bw + xx;
+                    win[d] = false;
+                    if (inb) {
+                        const int c = code[v[d]];
+                        if (c == BC_MEMBER) {
+                            // the other pixels that may reach v in this step: v - dd[d2], direction d2
+                            bool lose = false;
+#pragma unroll
+                            for (int d2 = 0; d2 < 4; ++d2) {
+                                if (d2 == d) continue;
+                                const int wx = xx - ddx[d2], wy = yy - ddy[d2];
+                                if (wx >= 0 && wx < bw && wy >= 0 && wy < bh) {
+                                    const int cw = code[wy * bw + wx];
+                                    if (cw >= BC_CUR && (cw - BC_CUR) * 4 + d2 < lane * 4 + d) lose = true;
+                                }
+                            }
+                            win[d] = !lose;
+                        } else if (c == BC_EARLIER) {
+                            const long long key = ((long long)(uidx * 4 + d) << 32) | (unsigned)v[d];
+                            if (key > best) best = key;
+                        }
+                    }
+                }
+                conn_wave_sync();           // every read of this step is done before the winners mark
+                int mywins = 0, before = 0, total = 0;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const unsigned long long m = __ballot(win[d]);
+                    before += __popcll(m & below);
+                    total += __popcll(m);
+                }
+                if (tail + total - (head + cnt) > ring) { overflow = true; break; }
+                const int pos = tail + before;
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+                    if (win[d]) {
+                        Q[(pos + mywins) & rmask] = (unsigned short)v[d];
+                        code[v[d]] = BC_DONE;
+                        ++mywins;
+                    }
+                if (act) code[u] = BC_DONE;
+                conn_wave_sync();
+                head += cnt;
+                tail += total;
+            }
+        }
+        if (!fits || overflow) {
             if (lane == 0) {
-                int k = atomicAdd(todo_count, 1);
+                const int k = atomicAdd(todo_count, 1);
                 todo[(long long)b * npix + k] = slot;
             }
             continue;
-        }
-        uint32_t *code = lds_u32;
-        unsigned short *Q = (unsigned short *)(lds_u32 + area);
-        __syncthreads();
-        // stage the box: coalesced row reads of the component roots, 4 in flight per lane
-        for (int i0 = 0; i0 < area; i0 += 256) {
-            int rv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                int idx = i0 + u * 64 + lane;
-                int yy = y0 + idx / bw, xx = x0 + idx % bw;
-                rv[u] = idx < area ? P[yy * W + xx] : -1;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                int idx = i0 + u * 64 + lane;
-                if (idx < area) code[idx] = rv[u] == r ? INF_KEY : (rv[u] < r ? CODE_EARLIER : CODE_OTHER);
-            }
-        }
-        const int ry = r / W, rx = r - ry * W;
-        const int rloc = (ry - y0) * bw + (rx - x0);
-        if (lane == 0) { Q[0] = (unsigned short)rloc; code[rloc] = 0u; }
-        __syncthreads();
-        int head = 0, tail = 1;
-        long long best = -1;            // (key << 32) | box-local index of the outside neighbour
-        while (head < tail) {
-            const int cnt = min(64, tail - head);
-            const bool act = lane < cnt;
-            const int uidx = head + lane;
-            const int u = act ? (int)Q[uidx] : 0;
-            const int uy = u / bw, ux = u - uy * bw;
-            int v[4];
-            bool cand[4];
-            uint32_t keyd[4];
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                int xx = ux + ddx[d], yy = uy + ddy[d];
-                bool inb = act && xx >= 0 && xx < bw && yy >= 0 && yy < bh;
-                v[d] = yy * bw + xx;
-                keyd[d] = (uint32_t)(uidx * 4 + d);
-                cand[d] = false;
-                if (inb) {
-                    uint32_t c = code[v[d]];
-                    if (c == INF_KEY) cand[d] = true;
-                    else if (c == CODE_EARLIER) {
-                        long long key = ((long long)keyd[d] << 32) | (unsigned)v[d];
-                        if (key > best) best = key;
-                    }
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int d = 0; d < 4; ++d)
-                if (cand[d]) atomicMin(code + v[d], keyd[d]);
-            __syncthreads();
-            int mywins = 0, before = 0, total = 0;
-            bool win[4];
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                win[d] = cand[d] && code[v[d]] == keyd[d];
-                unsigned long long m = __ballot(win[d]);
-                before += __popcll(m & below);
-                total += __popcll(m);
-            }
-            int pos = tail + before;
-#pragma unroll
-            for (int d = 0; d < 4; ++d)
-                if (win[d]) { Q[pos + mywins] = (unsigned short)v[d]; ++mywins; }
-            __syncthreads();
-            head += cnt;
-            tail += total;
         }
         for (int o = 32; o > 0; o >>= 1) {
             long long t = __shfl_xor(best, o);
@@ -664,8 +704,8 @@ __global__ __launch_bounds__(64) void k_conn_bfs_lds(const int *__restrict__ par
         if (lane == 0) {
             int f = -1;
             if (best >= 0) {
-                int loc = (int)(best & 0xFFFFFFFFll);
-                int gy = y0 + loc / bw, gx = x0 + loc % bw;
+                const int loc = (int)(best & 0xFFFFFFFFll);
+                const int gy = y0 + loc / bw, gx = x0 + loc % bw;
                 f = -2 - P[gy * W + gx];
             }
             F[r] = f;
@@ -867,20 +907,20 @@ extern "C" int spa_enforce_connectivity(spa_ctx *ctx, const int32_t *labels_in, 
     if (gb > 1024) gb = 1024;
     hipLaunchKernelGGL(k_small_bbox, dim3(gb, B), dim3(256), 0, s, parent, size, final_, W, npix,
                        min_size, sbox);
-    // BFS replay of the small components: lane tier for the tiny ones, then 40 KB LDS, 156 KB LDS
+    // BFS replay of the small components: lane tier for the tiny ones, then 16 KB LDS, 80 KB LDS
     // and global-memory wave tiers for the rest.  The lists live on the device; surplus
     // workgroups exit at once.
     hipLaunchKernelGGL(k_conn_bfs_lane, dim3(gb, B), dim3(256), 0, s, parent, size, tiny, misc,
                        final_, H, W);
     static bool attr_done = false;
     if (!attr_done) {
-        SPA_HIP(hipFuncSetAttribute((const void *)k_conn_bfs_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        SPA_HIP(hipFuncSetAttribute((const void *)k_conn_bfs_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         attr_done = true;
     }
-    hipLaunchKernelGGL(k_conn_bfs_lds, dim3(1024, B), dim3(64), 40 * 1024, s, parent, size, big, sbox,
-                       (const int *)nullptr, todo1, misc, 0, final_, H, W, 40 * 1024);
-    hipLaunchKernelGGL(k_conn_bfs_lds, dim3(256, B), dim3(64), 156 * 1024, s, parent, size, big, sbox,
-                       (const int *)todo1, todo2, misc, 1, final_, H, W, 156 * 1024);
+    hipLaunchKernelGGL(k_conn_bfs_lds, dim3(1024, B), dim3(64), 16 * 1024, s, parent, size, big, sbox,
+                       (const int *)nullptr, todo1, misc, 0, final_, H, W, 16 * 1024, 1024);
+    hipLaunchKernelGGL(k_conn_bfs_lds, dim3(512, B), dim3(64), 80 * 1024, s, parent, size, big, sbox,
+                       (const int *)todo1, todo2, misc, 1, final_, H, W, 80 * 1024, 4096);
     // (the claim array is all-INF again: k_conn_split releases what it takes)
     hipLaunchKernelGGL(k_conn_bfs, dim3(256, B), dim3(64), 0, s, parent, size, big, (const int *)todo2,
                        misc, claim, queue, final_, H, W);
