@@ -67,6 +67,24 @@ def parse():
     return p.parse_args()
 
 
+# what the PMC counters say holds each kernel below the HBM roofline
+LIMITERS = {
+    'k_slic_assign': 'VALU issue: ~20 candidate centres per pixel x ~17 separately rounded float32 operations '
+                     '(SQ_INSTS_VALU x 4 cycles / SIMD = the whole launch time)',
+    'k_slic_update': 'serial float32 chains (6-cycle dependent add x pixels of the largest segment) + VALU issue',
+}
+
+
+def pmc_traffic(kernel, B, H, W):
+    """HBM bytes per launch measured with the PMC counters (committed summary), or None."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic.json')
+    if (H, W) != (1024, 2048) or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        per_image = json.load(f)['bytes_per_image_per_launch'].get(kernel)
+    return None if per_image is None else int(per_image * B)
+
+
 def algorithmic_bytes(kernel, B, H, W, C, fh, fw, n_seg, feat_bytes):
     """Algorithmic HBM bytes per launch (DESIGN.md 'Kernels'), B images/launch."""
     px = H * W
@@ -232,9 +250,12 @@ def main():
         dom = max(single, key=lambda k: kernels[k]['ms_per_step'])
         ach = kernels[dom]['achieved_GBs']
         roof = {'kernel': dom, 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
+                'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': pmc_traffic(dom, B, H, W),
                 'avg_launch_ms': kernels[dom]['avg_ms'],
-                'algorithmic_bytes_per_launch': algorithmic_bytes(dom, B, H, W, C, fh, fw, n_seg, feat_bytes)}
+                'algorithmic_bytes_per_launch': algorithmic_bytes(dom, B, H, W, C, fh, fw, n_seg, feat_bytes),
+                'traffic_source': 'profiles/pmc_traffic.json: HBM bytes per launch from separate rocprofv3 --pmc '
+                                  'FETCH_SIZE / WRITE_SIZE passes (gfx950 corrections applied), scaled to this batch',
+                'limiter': LIMITERS.get(dom)}
     drn_ms = stage['time_feature_maps'] / a.steps
     flops = drn.flops_per_image(a.arch, H, W) * B
     peak_tf = FP32_MATRIX_PEAK_TF if a.dtype == 'fp32' else BF16_MATRIX_PEAK_TF

@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Turn the raw outputs of tools/make_profiles.sh (under gpurun_out/) into the committed
+summaries under profiles/:  kernel-stats table of the default bench, the bench line, and the
+HBM-traffic table (+ a JSON with per-image traffic that bench.py reports as roofline.traffic)."""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+go = os.path.join(root, 'gpurun_out')
+prof = os.path.join(root, 'profiles')
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r1_final'
+
+# ---- 1. kernel stats of the default bench
+stats = glob.glob(os.path.join(go, 'final_stats', '**', '*kernel_stats.csv'), recursive=True)[0]
+rows = list(csv.DictReader(open(stats)))
+for r in rows:
+    r['short'] = re.sub(r'^void ', '', r['Name']).split('(')[0]
+ours = [r for r in rows if re.match(r'(void )?k_', r['Name'])]
+ours.sort(key=lambda r: -float(r['TotalDurationNs']))
+lines = ['# %s: rocprofv3 --kernel-trace --stats of the default bench' % tag,
+         'command: rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no_cpu_baseline',
+         '(6 timed + 2 warm-up steps of 30 images, 1024x2048, DRN-D-22 fp32, SLIC 200, mean pooling, k=2; '
+         'MIOpen find kernels of the first step are included in the totals)', '',
+         '## libspalign kernels (hand-written HIP)', '',
+         '| kernel | calls | total ms | avg us | min us | max us |', '|---|---|---|---|---|---|']
+for r in ours:
+    lines.append('| %s | %s | %.2f | %.1f | %.1f | %.1f |' % (
+        r['short'], r['Calls'], float(r['TotalDurationNs']) / 1e6, float(r['AverageNs']) / 1e3,
+        float(r['MinNs']) / 1e3, float(r['MaxNs']) / 1e3))
+rows.sort(key=lambda r: -float(r['TotalDurationNs']))
+lines += ['', '## top 12 kernels overall', '', '| kernel | calls | total ms | avg us |', '|---|---|---|---|']
+for r in rows[:12]:
+    lines.append('| %s | %s | %.2f | %.1f |' % (r['short'][:80], r['Calls'], float(r['TotalDurationNs']) / 1e6,
+                                             float(r['AverageNs']) / 1e3))
+open(os.path.join(prof, tag + '_bench_default_kernel_stats.md'), 'w').write('\n'.join(lines) + '\n')
+with open(os.path.join(prof, tag + '_bench_default_kernel_stats.csv'), 'w') as f:
+    w = csv.writer(f)
+    w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'MinNs', 'MaxNs'])
+    for r in rows:
+        if float(r['TotalDurationNs']) > 2e5:
+            w.writerow([r['short'][:120], r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['MinNs'], r['MaxNs']])
+
+# ---- 2. bench lines
+for src, dst in (('final_bench_line.json', tag + '_bench_line.json'),
+                 ('final_stats_bench_line.json', tag + '_bench_line_under_rocprof.json')):
+    txt = [l for l in open(os.path.join(go, src)).read().splitlines() if l.startswith('{')]
+    if txt:
+        open(os.path.join(prof, dst), 'w').write(txt[-1] + '\n')
+
+# ---- 3. HBM traffic (batch 8)
+def table(path):
+    out = {}
+    for l in open(path):
+        m = re.match(r'(\S.*?)\s+(FETCH_SIZE|WRITE_SIZE)\s+launches\s+(\d+)\s+mean\s+([\d.]+)', l)
+        if m:
+            out[m.group(1).strip()] = (int(m.group(3)), float(m.group(4)))
+    return out
+fe, wr = table(os.path.join(go, 'final_pmc_fetch.txt')), table(os.path.join(go, 'final_pmc_write.txt'))
+B = 8
+px = 1024 * 2048
+alg = {'k_rgb2lab': 24 * px, 'k_slic_assign': 16 * px, 'k_slic_update': 16 * px, 'k_paint': 6 * px,
+       'k_pool_mean': 512 * 128 * 256 * 4 + px * 4, 'k_cell_weights': 4 * px + 128 * 256 * 16,
+       'k_conn_relabel': 12 * px, 'k_ccl_merge': 8 * px}
+wide = {'k_rgb2lab', 'k_slic_assign', 'k_paint', 'k_pool_mean', 'k_conn_relabel', 'k_cell_weights',
+        'k_ccl_init', 'k_ccl_flatten', 'k_bbox_count_lds', 'k_seg_moments'}      # 16 B/lane streaming reads
+lines = ['# HBM traffic per launch from PMC counters (%s), batch 8, 1024x2048, MI355X' % tag,
+         'command (one pass per counter, as MI355X_MICROARCH.md prescribes):',
+         '  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 tools/prof_stages.py --batch 8 --reps 2',
+         '  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -- python3 tools/prof_stages.py --batch 8 --reps 2',
+         'FETCH MB = FETCH_SIZE(KB) x 1024, x 2 for the kernels marked * (gfx950 correction: their reads are wide',
+         '16 B/lane streams, whose 128-B requests are tallied at 64 B).  k_slic_update gathers dwords: its requests are',
+         '64 B (checked: TCC_EA0_RDREQ x 64 B = FETCH_SIZE, TCC_EA0_RDREQ_32B = 0), no correction.',
+         'WRITE MB = WRITE_SIZE(KB) x 1024.  "vs alg" = HBM MB / algorithmic MB of DESIGN.md section 4.', '',
+         '```', '%-22s %8s %12s %12s %12s %8s' % ('kernel', 'launches', 'FETCH MB', 'WRITE MB', 'HBM MB', 'vs alg')]
+traffic = {}
+for k in sorted(fe):
+    if not k.startswith('k_') and 'k_kmeans' not in k:
+        continue
+    name = k.replace('void ', '')
+    f_mb = fe[k][1] * 1024 / 1e6 * (2 if name in wide else 1)
+    w_mb = wr.get(k, (0, 0.0))[1] * 1024 / 1e6
+    tot = f_mb + w_mb
+    a = alg.get(name)
+    lines.append('%-22s %8d %11.1f%s %12.1f %12.1f %8s' % (name[:22], fe[k][0], f_mb, '*' if name in wide else ' ',
+                                                          w_mb, tot, ('%.2fx' % (tot * 1e6 / (a * B))) if a else '-'))
+    traffic[name] = tot * 1e6 / B
+lines.append('```')
+open(os.path.join(prof, tag + '_pmc_hbm_traffic_b8.md'), 'w').write('\n'.join(lines) + '\n')
+json.dump({'note': 'HBM bytes per launch PER IMAGE (1024x2048) from the PMC passes of ' + tag +
+                   '_pmc_hbm_traffic_b8.md; bench.py reports roofline.traffic = this x images per launch',
+           'bytes_per_image_per_launch': traffic}, open(os.path.join(prof, 'pmc_traffic.json'), 'w'), indent=1)
+print('\n'.join(lines[-40:]))
