@@ -120,14 +120,28 @@ __global__ __launch_bounds__(KM_THREADS) void k_kmeans(const T *__restrict__ X, 
             double acc[KM_MAXK];
 #pragma unroll
             for (int c = 0; c < KM_MAXK; ++c) acc[c] = 0.0;
-            for (int i = lo; i < hi; ++i) {
-                const int a = asg[i];
-                double wi = 1.0;
-                if (phase > 0) wi = (a == 0) ? w[i] : 1.0 - w[i];
-                const double v = (phase > 0) ? ldx(X, (long long)i * ld + d) * wi
-                                             : ldx(X, (long long)i * ld + d);
+            // the points of the slice in order; 8 rows are requested together so that the
+            // sequential additions do not each wait for their own row
+            for (int i0 = lo; i0 < hi; i0 += 8) {
+                int aa[8];
+                double ww[8], xx[8];
 #pragma unroll
-                for (int c = 0; c < KM_MAXK; ++c) acc[c] = acc[c] + ((a == c) ? v : 0.0);
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + u < hi ? i0 + u : hi - 1;
+                    aa[u] = asg[i];
+                    ww[u] = w[i];
+                    xx[u] = ldx(X, (long long)i * ld + d);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (i0 + u < hi) {
+                        const int a = aa[u];
+                        const double wi = (a == 0) ? ww[u] : 1.0 - ww[u];
+                        const double v = (phase > 0) ? xx[u] * wi : xx[u];
+#pragma unroll
+                        for (int c = 0; c < KM_MAXK; ++c) acc[c] = acc[c] + ((a == c) ? v : 0.0);
+                    }
+                }
             }
 #pragma unroll
             for (int c = 0; c < KM_MAXK; ++c)
@@ -150,18 +164,29 @@ __global__ __launch_bounds__(KM_THREADS) void k_kmeans(const T *__restrict__ X, 
             for (int i = lo + tid; i < hi; i += KM_THREADS) assign[i] = new_assign[i];
         }
         // ---- centres = sum over workgroups in order / denominator; slices of (c, d)
+        // (the additions keep their order, workgroup after workgroup; the LOADS of 16 partials are
+        // issued together, otherwise every addition would wait for its own trip to L2)
         bool empty = false;
-        for (int c = 0; c < k; ++c) {
-            int cn = 0;
-            for (unsigned q = 0; q < G; ++q) cn += part_n[q * k + c];
-            if (cn == 0) empty = true;
+        {
+            int cn_mine = 0;             // lane c < k of every wave: members of cluster c
+            if (lane < k)
+                for (unsigned q = 0; q < G; ++q) cn_mine += part_n[q * k + lane];
+            empty = __ballot(lane < k && cn_mine == 0) != 0ull;
         }
         for (int e = g * KM_THREADS + tid; e < k * D; e += (int)G * KM_THREADS) {
             const int c = e / D, d = e - c * D;
             double s = 0.0, den = 0.0;
-            for (unsigned q = 0; q < G; ++q) {
-                s = s + part[((long long)q * k + c) * D + d];
-                den = den + part_w[q * k + c];
+            for (unsigned q0 = 0; q0 < G; q0 += 16) {
+                double ps[16], pw[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const unsigned q = q0 + u < G ? q0 + u : G - 1;
+                    ps[u] = part[((long long)q * k + c) * D + d];
+                    pw[u] = part_w[q * k + c];
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (q0 + u < G) { s = s + ps[u]; den = den + pw[u]; }
             }
             double v = s / den;                 // 0/0 -> NaN for an empty cluster, like numpy
             if (f32) v = (double)(float)v;      // the reference stores centres in X's dtype
@@ -192,7 +217,8 @@ __global__ __launch_bounds__(KM_THREADS) void k_kmeans(const T *__restrict__ X, 
             }
 #pragma unroll
             for (int c = 0; c < KM_MAXK; ++c)
-                for (int o = 32; o > 0; o >>= 1) dist[c] = dist[c] + __shfl_xor(dist[c], o);
+                if (c < k)
+                    for (int o = 32; o > 0; o >>= 1) dist[c] = dist[c] + __shfl_xor(dist[c], o);
             int best = 0;
             double bd = sqrt(dist[0]);
 #pragma unroll
@@ -229,7 +255,7 @@ extern "C" int spa_kmeans_weighted(spa_ctx *ctx, const void *X, int32_t x_dtype,
         return SPA_ERR_ARG;
     }
     hipStream_t s = spa_stream(stream);
-    int G = (Ncap + 31) / 32;
+    int G = (Ncap + 15) / 16;
     if (G > ctx->n_cu) G = ctx->n_cu;
     if (G < 1) G = 1;
     double *part;
