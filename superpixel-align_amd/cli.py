@@ -74,6 +74,7 @@ def get_args(argv=None):
              ('--label_file_list', dict(type=str, default=None)),
              ('--cityscapes_img_dir', dict(type=str, default=None)),
              ('--cityscapes_label_dir', dict(type=str, default=None)),
+             ('--label_zip', dict(type=str, default=None)),      # extra: write the README's label archive when done
              ('--cityscapes_img_zip', dict(type=str, default=None)),
              ('--cityscapes_label_zip', dict(type=str, default=None)),
              ('--camera_param_dir', dict(type=str, default='data/camera'))]
@@ -190,6 +191,24 @@ def save_npy(args, img_fn, road_mask, clustering_result):
     out_fn = os.path.splitext(os.path.basename(img_fn))[0]
     np.save(os.path.join(args.out_dir, out_fn), road_mask.astype(np.uint8))
     np.save(os.path.join(args.out_dir, out_fn + '_all_cluster'), clustering_result.astype(np.uint8))
+
+
+def write_label_zip(out_dir, zip_path):
+    """The README's packaging step (README.md:135)
+        find <out_dir> -name "*leftImg8bit.npy" | zip -0r <zip_path> -@
+    as a library call: the road masks (not the *_all_cluster.npy files) stored uncompressed under
+    the path names `find` prints, which is what the training stage reads the labels from."""
+    import fnmatch
+    names = []
+    for root, _dirs, files in os.walk(out_dir):
+        for fn in files:
+            if fnmatch.fnmatch(fn, '*leftImg8bit.npy'):
+                names.append(os.path.join(root, fn))
+    names.sort()
+    with zipfile.ZipFile(zip_path, 'w', zipfile.ZIP_STORED, allowZip64=True) as zf:
+        for fn in names:
+            zf.write(fn, arcname=fn)
+    return len(names)
 
 
 def save_figure(args, img, road_mask, label, clustering_result, img_fn):
@@ -320,6 +339,8 @@ def main_labelled(argv=None):
                         line = result_line(args, imgs_ds._paths[i], labels_ds._paths[i], sc, {}, time.time())
                     print(json.dumps(line), file=fp)
         spdist.barrier()
+    if getattr(args, 'label_zip', None) and rank == 0:
+        print('label archive: %d masks -> %s' % (write_label_zip(args.out_dir, args.label_zip), args.label_zip))
     return 0
 
 

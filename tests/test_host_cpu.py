@@ -183,3 +183,36 @@ def test_cli_flags_match_reference_defaults():
     assert a.camera_param_dir == 'data/camera' and a.horizontal_line_filtering is False
     b = cli.get_args_labelfree([])
     assert (b.gpu, b.label_shape, b.img_list_fn) == (-1, [1024, 2048], 'data/demoVideo_fns.txt')
+
+
+def test_label_archive_matches_find_zip_pipeline(tmp_path):
+    """README.md:135 `find <dir> -name "*leftImg8bit.npy" | zip -0r <zip> -@` vs cli.write_label_zip:
+    same member names, stored (not deflated), same payload bytes and CRCs."""
+    import shutil
+    import zipfile
+    if shutil.which('zip') is None:
+        pytest.skip('zip binary not available')
+    out = tmp_path / 'results' / 'estimated_train_labels'
+    out.mkdir(parents=True)
+    rng = np.random.RandomState(5)
+    for city in ('aachen_000000_000019', 'bochum_000000_000313', 'ulm_000094_000019'):
+        np.save(str(out / (city + '_leftImg8bit')), (rng.rand(16, 32) > 0.5).astype(np.uint8))
+        np.save(str(out / (city + '_leftImg8bit_all_cluster')), rng.randint(0, 4, (16, 32)).astype(np.uint8))
+    (out / 'result.json').write_text('{}\n')
+    cwd = os.getcwd()
+    os.chdir(str(tmp_path))
+    try:
+        subprocess.check_call('find results/estimated_train_labels -name "*leftImg8bit.npy" | '
+                              'zip -0r ref.zip -@ > /dev/null', shell=True)
+        n = cli.write_label_zip('results/estimated_train_labels', 'ours.zip')
+    finally:
+        os.chdir(cwd)
+    assert n == 3
+    with zipfile.ZipFile(str(tmp_path / 'ref.zip')) as a, zipfile.ZipFile(str(tmp_path / 'ours.zip')) as b:
+        assert sorted(a.namelist()) == sorted(b.namelist())
+        for name in a.namelist():
+            ia, ib = a.getinfo(name), b.getinfo(name)
+            assert ia.compress_type == ib.compress_type == zipfile.ZIP_STORED
+            assert ia.CRC == ib.CRC and ia.file_size == ib.file_size
+            assert a.read(name) == b.read(name)
+            assert not name.endswith('_all_cluster.npy')
