@@ -137,6 +137,12 @@ int spa_felzenszwalb(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32
                      double scale, double sigma, int32_t min_size, int32_t *labels,
                      int32_t *n_labels, void *stream);
 
+/* the same call on a uint8 image, as superpixel_overlaps.py:294-300 makes it: the values (still
+ * passed as float32 0..255) are divided by 255. in float64, not float32.                      */
+int spa_felzenszwalb_u8(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t W,
+                        double scale, double sigma, int32_t min_size, int32_t *labels,
+                        int32_t *n_labels, void *stream);
+
 /* ---- per-superpixel descriptors -------------------------------------------------------- */
 
 /* offsets (B+1) int32 = exclusive prefix sum of n_labels (B).  (n_superpixels_per_image,
@@ -225,6 +231,14 @@ int spa_kmeans_weighted(spa_ctx *ctx, const void *X, int32_t x_dtype, int64_t ld
 int spa_paint(spa_ctx *ctx, const int32_t *labels, const int32_t *assign,
               const int32_t *offsets, int32_t B, int32_t H, int32_t W,
               uint8_t *cluster, uint8_t *road, void *stream);
+
+/* replaces the refinement loop of superpixel_overlaps.py:353-361: refined[p] = 1 where the
+ * superpixel of p holds more than `threshold` of the image's predicted road pixels
+ * (overlap / float(n_road) > threshold in float64; all zeros when no road was predicted).
+ * labels (B,npix) int32 in [0,max_labels), road (B,npix) uint8 -> refined (B,npix) uint8.     */
+int spa_overlap_refine(spa_ctx *ctx, const int32_t *labels, const uint8_t *road, int32_t B,
+                       int64_t npix, int32_t max_labels, double threshold, uint8_t *refined,
+                       void *stream);
 
 /* save_info() scoring (:398-405): per image confusion of road (B,npix) uint8 against
    gt (B,npix) int32 in {-1 ignore, 0, 1} -> out (B,4) int64 {TN, FP, FN, TP}.             */

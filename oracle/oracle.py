@@ -417,3 +417,61 @@ def felzenszwalb(img_chw, scale=300.0, sigma=0.8, min_size=20):
     if nl < 0:
         raise RuntimeError('orc_felzenszwalb failed')
     return out
+
+
+# --------------------------------------------------------------------------- the paper's baselines
+# (direct_clustering.py, superpixel_overlaps.py — SURVEY.md section 8f-4).  Pure numpy: the
+# problems are small and every step is elementwise or a bincount.
+def pixel_prior(h, w, y_rel_pos=0.75, x_rel_pos=0.5, y_rel_sigma=0.1, x_rel_sigma=0.2):
+    """create_prior(h, w, ...) of direct_clustering.py:188-201 / superpixel_overlaps.py:194-207:
+    the Gaussian location prior per feature pixel (integer centre, sigma relative to the map)."""
+    y0, x0 = int(h * y_rel_pos), int(w * x_rel_pos)
+    sy, sx = h * y_rel_sigma, w * x_rel_sigma
+    ty = (np.arange(h)[:, None] - y0) ** 2 / (2 * sy) ** 2
+    tx = (np.arange(w)[None, :] - x0) ** 2 / (2 * sx) ** 2
+    return np.exp(-(ty + tx))
+
+
+def pixel_matrix(fmap_nchw):
+    """direct_clustering.py:299-306: one row per feature pixel of the batch, the C channels
+    followed by the pixel's (x, y); float32 joined with int32 gives float64."""
+    n, c, h, w = fmap_nchw.shape
+    feats = np.asarray(fmap_nchw).transpose(0, 2, 3, 1).reshape(n * h * w, c)
+    yy, xx = np.divmod(np.arange(h * w), w)
+    xy = np.tile(np.stack([xx, yy], 1), (n, 1)).astype(np.int32)
+    return np.concatenate([feats, xy], axis=1)
+
+
+def direct_clustering(fmap_nchw, k, y_rel_pos=0.75, x_rel_pos=0.5, y_rel_sigma=0.1, x_rel_sigma=0.1,
+                      nprandom=None):
+    """estimate_road_mask of direct_clustering.py:286-322 up to the masks: weighted k-means over
+    all feature pixels of the batch.  -> (cluster ids (n,h,w) int32, road (n,h,w) bool)."""
+    n, c, h, w = fmap_nchw.shape
+    prior = np.tile(pixel_prior(h, w, y_rel_pos, x_rel_pos, y_rel_sigma, x_rel_sigma).reshape(-1), n)
+    assign, _, _ = kmeans(k, pixel_matrix(fmap_nchw), prior, nprandom=nprandom)
+    cl = assign.reshape(n, h, w)
+    return cl, cl == 0
+
+
+def overlap_refine(road_mask, superpixel, threshold):
+    """superpixel_overlaps.py:353-361: a superpixel becomes road when it holds more than
+    `threshold` of all predicted road pixels."""
+    road = np.asarray(road_mask).astype(bool)
+    sp = np.asarray(superpixel)
+    n_road = float(road.sum())
+    out = np.zeros(sp.shape, np.uint8)
+    if n_road > 0:
+        counts = np.bincount(sp[road].ravel(), minlength=int(sp.max()) + 1)
+        out[(counts / n_road > threshold)[sp]] = 1
+    return out
+
+
+def felzenszwalb_u8(img_chw_u8, scale=500.0, sigma=0.9, min_size=20):
+    """felzenszwalb(img.transpose(1,2,0) / 255., ...) on a uint8 image (superpixel_overlaps.py:294-300):
+    the division happens in float64; equal costs in edge-index order (stable sort), as everywhere."""
+    img = np.asarray(img_chw_u8).transpose(1, 2, 0).astype(np.float64) / 255.
+    H, W, _ = img.shape
+    costs, edges = fz_edges(fz_blur(img, sigma=sigma))
+    order = np.argsort(costs, kind='stable')
+    labels, _ = fz_segment(costs, edges, order, H * W, float(scale) / 255., min_size)
+    return labels.reshape(H, W)

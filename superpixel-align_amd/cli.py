@@ -13,6 +13,7 @@ import argparse
 import glob
 import json
 import os
+import sys
 import time
 import zipfile
 
@@ -81,6 +82,28 @@ def get_args(argv=None):
     args = _parser(extra).parse_args(argv)
     args.resize_shape = tuple(args.resize_shape)
     os.makedirs(args.out_dir, exist_ok=True)
+    return args
+
+
+def get_args_direct(argv=None):
+    """direct_clustering.py:38-108 — the labelled driver's flags with --n_clusters 4."""
+    args = get_args(argv)
+    return args
+
+
+def get_args_overlaps(argv=None):
+    """superpixel_overlaps.py:43-115 — plus --overlap_threshold; felzenszwalb 500 / 0.9 and
+    --n_clusters 4 are that script's defaults."""
+    argv = list(sys.argv[1:] if argv is None else argv)
+    pre = argparse.ArgumentParser(add_help=False)
+    pre.add_argument('--overlap_threshold', type=float, default=0.01)
+    known, rest = pre.parse_known_args(argv)
+    defaults = []
+    for flag, val in (('--felzenszwalb_scale', '500.0'), ('--felzenszwalb_sigma', '0.9')):
+        if flag not in rest:
+            defaults += [flag, val]
+    args = get_args(defaults + rest)
+    args.overlap_threshold = known.overlap_threshold
     return args
 
 
@@ -252,14 +275,18 @@ def _effective_range(args, n_data):
     return start, end
 
 
-def main_labelled(argv=None):
-    args = get_args(argv)
+def main_labelled(argv=None, get=None, make_pipe=None, originals=False):
+    """The labelled driver loop.  `get` / `make_pipe` select one of the three scripts that share it
+    (batch_spalign_kmeans.py, direct_clustering.py, superpixel_overlaps.py); `originals`: the
+    pipeline also wants the undecimated uint8 images of the batch (superpixel_overlaps.py:322)."""
+    args = (get or get_args)(argv)
     rank, ws, local = spdist.init()
     if ws > 1:
         args.gpu = local
     imgs_ds, labels_ds = create_dataset(args)
     model = ops.create_model(args)
-    pipe = LabelPipeline(args, model, ops.engine())
+    pipe = make_pipe(args, model, ops.engine()) if make_pipe else LabelPipeline(args, model, ops.engine())
+    orig_ds = ImageList(imgs_ds._paths, None, np.uint8, imgs_ds._open) if originals else None
     start, end = _effective_range(args, len(imgs_ds))
     if ws > 1:
         s, e = spdist.shard_range(end - start, ws, rank, args.balanced)
@@ -276,7 +303,9 @@ def main_labelled(argv=None):
         img_fn, label_fn = imgs_ds._paths[i], labels_ds._paths[i]
         gt = create_label_mask(labels_ds.get(i)[0])
         if rm.shape != gt.shape:                                       # :470-477
-            rm, cl = resize_nearest(rm, gt.shape), resize_nearest(cl, gt.shape)
+            rm = resize_nearest(rm, gt.shape)
+        if cl.shape != gt.shape:
+            cl = resize_nearest(cl, gt.shape)
         save_npy(args, img_fn, rm, cl)
         if not args.no_figure:
             full = _decode(imgs_ds._open(img_fn) if imgs_ds._open else img_fn)   # :464 reloads the PNG
@@ -293,7 +322,7 @@ def main_labelled(argv=None):
         imgs = nxt.result()
         if bi + 1 < len(ranges):
             nxt = loader.submit(imgs_ds.batch, ranges[bi + 1][0], ranges[bi + 1][1], workers)
-        res = pipe.run(imgs)
+        res = pipe.run(imgs, orig_ds.batch(lo, hi, workers)) if originals else pipe.run(imgs)
         times = pipe.elapsed_times()
         cluster, road = res.masks_to_host()
         info = res.info.cpu().numpy()
@@ -342,6 +371,21 @@ def main_labelled(argv=None):
     if getattr(args, 'label_zip', None) and rank == 0:
         print('label archive: %d masks -> %s' % (write_label_zip(args.out_dir, args.label_zip), args.label_zip))
     return 0
+
+
+def main_direct(argv=None):
+    from .baselines import DirectClustering
+    if argv is None and '--n_clusters' not in sys.argv:
+        argv = sys.argv[1:] + ['--n_clusters', '4']                    # direct_clustering.py:44
+    return main_labelled(argv, get_args_direct, lambda a, m, e: DirectClustering(a, m, e, ops._rng()[1]))
+
+
+def main_overlaps(argv=None):
+    from .baselines import SuperpixelOverlaps
+    if argv is None and '--n_clusters' not in sys.argv:
+        argv = sys.argv[1:] + ['--n_clusters', '4']                    # superpixel_overlaps.py:49
+    return main_labelled(argv, get_args_overlaps, lambda a, m, e: SuperpixelOverlaps(a, m, e, ops._rng()[1]),
+                         originals=True)
 
 
 def main_labelfree(argv=None):

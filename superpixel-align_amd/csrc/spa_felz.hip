@@ -102,8 +102,15 @@ __device__ __forceinline__ int fz_reflect(int i, int n)
 }
 
 // pass 1: x/255 (float32), widen, smooth along y -> planar float64
+// `wide` = the caller's image was uint8: the reference divides that by 255. in float64
+// (superpixel_overlaps.py:297-298), a float32 image in float32 (batch_spalign_kmeans.py:303)
+__device__ __forceinline__ double fz_unit(float v, bool wide)
+{
+    return wide ? (double)v / 255.0 : (double)(v / 255.0f);
+}
+
 __global__ __launch_bounds__(256) void k_fz_blur_y(const float *__restrict__ rgb, double *__restrict__ out,
-                                                   int H, int W, FzWeights fw)
+                                                   int H, int W, FzWeights fw, bool wide)
 {
     const long long npix = (long long)H * W;
     const long long plane = blockIdx.y;                      // b*3 + c
@@ -112,10 +119,10 @@ __global__ __launch_bounds__(256) void k_fz_blur_y(const float *__restrict__ rgb
     const double *wc = fw.w + fw.r;
     for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long long)gridDim.x * 256) {
         const int y = (int)(p / W), x = (int)(p - (long long)y * W);
-        double tmp = (double)(src[p] / 255.0f) * wc[0];
+        double tmp = fz_unit(src[p], wide) * wc[0];
         for (int j = -fw.r; j < 0; ++j) {
-            double a = (double)(src[(long long)fz_reflect(y + j, H) * W + x] / 255.0f);
-            double b = (double)(src[(long long)fz_reflect(y - j, H) * W + x] / 255.0f);
+            double a = fz_unit(src[(long long)fz_reflect(y + j, H) * W + x], wide);
+            double b = fz_unit(src[(long long)fz_reflect(y - j, H) * W + x], wide);
             tmp = tmp + (a + b) * wc[j];
         }
         dst[p] = tmp;
@@ -524,9 +531,27 @@ __global__ __launch_bounds__(256) void k_fz_relabel(const int *__restrict__ pare
         out[(long long)b * npix + p] = R[fz_find(P, p)];
 }
 
+static int fz_run(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t W, double scale,
+                  double sigma, int32_t min_size, int32_t *labels, int32_t *n_labels, void *stream,
+                  bool wide);
+
 extern "C" int spa_felzenszwalb(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t W,
                                 double scale, double sigma, int32_t min_size, int32_t *labels,
                                 int32_t *n_labels, void *stream)
+{
+    return fz_run(ctx, rgb, B, H, W, scale, sigma, min_size, labels, n_labels, stream, false);
+}
+
+extern "C" int spa_felzenszwalb_u8(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t W,
+                                   double scale, double sigma, int32_t min_size, int32_t *labels,
+                                   int32_t *n_labels, void *stream)
+{
+    return fz_run(ctx, rgb, B, H, W, scale, sigma, min_size, labels, n_labels, stream, true);
+}
+
+static int fz_run(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t W, double scale,
+                  double sigma, int32_t min_size, int32_t *labels, int32_t *n_labels, void *stream,
+                  bool wide)
 {
     SPA_ARG(ctx && rgb && labels && n_labels && B > 0 && H > 1 && W > 1 && sigma > 0.0 && scale > 0.0);
     SPA_ARG((long long)H * W < (1ll << 28));
@@ -537,8 +562,8 @@ extern "C" int spa_felzenszwalb(spa_ctx *ctx, const float *rgb, int32_t B, int32
             const long long px = (long long)H * W;
             for (int b0 = 0; b0 < B; b0 += maxB) {
                 const int nb = B - b0 < maxB ? B - b0 : maxB;
-                int rc0 = spa_felzenszwalb(ctx, rgb + (long long)b0 * 3 * px, nb, H, W, scale, sigma, min_size,
-                                           labels + (long long)b0 * px, n_labels + b0, stream);
+                int rc0 = fz_run(ctx, rgb + (long long)b0 * 3 * px, nb, H, W, scale, sigma, min_size,
+                                 labels + (long long)b0 * px, n_labels + b0, stream, wide);
                 if (rc0 != SPA_OK) return rc0;
             }
             return SPA_OK;
@@ -584,7 +609,7 @@ extern "C" int spa_felzenszwalb(spa_ctx *ctx, const float *rgb, int32_t B, int32
 
     int gx = (int)((npix + 255) / 256);
     if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL(k_fz_blur_y, dim3(gx, B * 3), dim3(256), 0, s, rgb, sm0, H, W, fw);
+    hipLaunchKernelGGL(k_fz_blur_y, dim3(gx, B * 3), dim3(256), 0, s, rgb, sm0, H, W, fw, wide);
     hipLaunchKernelGGL(k_fz_blur_x, dim3(gx, B * 3), dim3(256), 0, s, (const double *)sm0, sm1, H, W, fw);
     int ge = (int)((g.nE + 255) / 256);
     if (ge > 2048) ge = 2048;

@@ -100,3 +100,69 @@ extern "C" int spa_confusion(spa_ctx *ctx, const uint8_t *road, const int32_t *g
     SPA_LAUNCH_CHECK();
     return SPA_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------
+// superpixel_overlaps.py:353-361 — a superpixel becomes road when it holds more than `threshold`
+// of all predicted road pixels of its image:  overlap / float(n_road) > threshold  (float64).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_overlap_count(const int32_t *__restrict__ labels,
+                                                       const uint8_t *__restrict__ road, long long npix,
+                                                       int max_labels, int *__restrict__ counts,
+                                                       int *__restrict__ n_road, uint32_t *__restrict__ status)
+{
+    const int b = blockIdx.y;
+    const int32_t *L = labels + (long long)b * npix;
+    const uint8_t *R = road + (long long)b * npix;
+    int *C = counts + (long long)b * max_labels;
+    int mine = 0;
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long long)gridDim.x * 256) {
+        if (R[p]) {
+            const int l = L[p];
+            if (l < 0 || l >= max_labels) { atomicOr(status, SPA_ST_LABEL_RANGE); continue; }
+            atomicAdd(C + l, 1);
+            ++mine;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(n_road + b, mine);
+}
+
+__global__ __launch_bounds__(256) void k_overlap_paint(const int32_t *__restrict__ labels, long long npix,
+                                                       int max_labels, const int *__restrict__ counts,
+                                                       const int *__restrict__ n_road, double threshold,
+                                                       uint8_t *__restrict__ refined)
+{
+    const int b = blockIdx.y;
+    const int32_t *L = labels + (long long)b * npix;
+    const int *C = counts + (long long)b * max_labels;
+    const int nr = n_road[b];
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long long)gridDim.x * 256) {
+        const int l = L[p];
+        uint8_t v = 0;
+        if (nr > 0 && l >= 0 && l < max_labels) v = ((double)C[l] / (double)nr > threshold) ? 1 : 0;
+        refined[(long long)b * npix + p] = v;
+    }
+}
+
+extern "C" int spa_overlap_refine(spa_ctx *ctx, const int32_t *labels, const uint8_t *road, int32_t B,
+                                  int64_t npix, int32_t max_labels, double threshold, uint8_t *refined,
+                                  void *stream)
+{
+    SPA_ARG(ctx && labels && road && refined && B > 0 && npix > 0 && max_labels > 0);
+    hipStream_t s = spa_stream(stream);
+    int *counts;
+    const size_t bytes = ((size_t)B * max_labels + B) * sizeof(int);
+    int rc = spa_ws_reserve(ctx, WS_OVERLAP, bytes, (void **)&counts);
+    if (rc != SPA_OK) return rc;
+    int *n_road = counts + (size_t)B * max_labels;
+    SPA_HIP(hipMemsetAsync(counts, 0, bytes, s));
+    int gx = (int)((npix + 255) / 256);
+    if (gx > 2048) gx = 2048;
+    hipLaunchKernelGGL(k_overlap_count, dim3(gx, B), dim3(256), 0, s, labels, road, (long long)npix, max_labels,
+                       counts, n_road, ctx->d_status);
+    hipLaunchKernelGGL(k_overlap_paint, dim3(gx, B), dim3(256), 0, s, labels, (long long)npix, max_labels,
+                       (const int *)counts, (const int *)n_road, threshold, refined);
+    SPA_LAUNCH_CHECK();
+    return SPA_OK;
+}

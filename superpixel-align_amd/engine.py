@@ -138,16 +138,30 @@ class Engine(object):
                                  _ptr(labels), _ptr(n_labels), _stream()))
         return labels, n_labels
 
-    def felzenszwalb(self, rgb, scale=300.0, sigma=0.8, min_size=20):
-        """felzenszwalb(img/255, scale, sigma, min_size) for a batch -> labels (B,H,W) i32, n_labels (B)."""
+    def felzenszwalb(self, rgb, scale=300.0, sigma=0.8, min_size=20, uint8_image=False):
+        """felzenszwalb(img/255, scale, sigma, min_size) for a batch -> labels (B,H,W) i32, n_labels (B).
+        uint8_image: the reference passed a uint8 image, so /255. happens in float64
+        (superpixel_overlaps.py:294-300) instead of float32 (batch_spalign_kmeans.py:301-307)."""
         rgb = _req(rgb, torch.float32, 'rgb')
         B, C, H, W = rgb.shape
         assert C == 3
         labels = torch.empty((B, H, W), dtype=torch.int32, device=rgb.device)
         n_labels = torch.empty((B,), dtype=torch.int32, device=rgb.device)
-        check(self._lib.spa_felzenszwalb(self._ctx, _ptr(rgb), B, H, W, scale, sigma, min_size,
-                                         _ptr(labels), _ptr(n_labels), _stream()))
+        fn = self._lib.spa_felzenszwalb_u8 if uint8_image else self._lib.spa_felzenszwalb
+        check(fn(self._ctx, _ptr(rgb), B, H, W, scale, sigma, min_size, _ptr(labels), _ptr(n_labels), _stream()))
         return labels, n_labels
+
+    def overlap_refine(self, labels, road, max_labels, threshold):
+        """superpixel_overlaps.py:353-361 -> refined (B,H,W) u8 (1 = road)."""
+        labels = _req(labels, torch.int32, 'labels')
+        road = _req(road, torch.uint8, 'road')
+        B = labels.shape[0]
+        npix = labels[0].numel()
+        assert road.shape == labels.shape
+        out = torch.empty(labels.shape, dtype=torch.uint8, device=labels.device)
+        check(self._lib.spa_overlap_refine(self._ctx, _ptr(labels), _ptr(road), B, npix, int(max_labels),
+                                           float(threshold), _ptr(out), _stream()))
+        return out
 
     # ------------------------------------------------------------------ descriptors
     def segment_offsets(self, n_labels):

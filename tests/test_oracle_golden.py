@@ -186,3 +186,24 @@ def test_felzenszwalb_oracle_against_skimage_core(orc, synth, name):
         # summation order of scipy's correlate1d reproduced: bit exact given scipy's weights
         assert np.array_equal(orc.fz_blur(hwc, weights=g['scipy_weights']), g['scipy_blur'])
         np.testing.assert_allclose(orc.fz_blur(hwc, sigma=sigma), g['scipy_blur'], rtol=1e-13, atol=1e-15)
+
+
+# --------------------------------------------------------------------------- baselines (8f-4)
+@pytest.mark.parametrize('tag', ['dc_k2', 'dc_k4', 'dc_k4_512'])
+def test_direct_clustering_restatement_matches_reference(orc, tag):
+    g = golden('baseline_' + tag)
+    h, w = g['prior'].shape
+    # exp differs by an ulp between numpy builds (the fixture was made with numpy 1.26)
+    np.testing.assert_allclose(orc.pixel_prior(h, w, 0.75, 0.5, 0.1, 0.1), g['prior'], rtol=4e-16, atol=0)
+    cl, road = orc.direct_clustering(g['fmap'], int(g['k']), nprandom=orc.NpRandom(1111))
+    assert np.array_equal(cl, g['cluster'])
+    assert np.array_equal(road.astype(np.uint8), g['road'])
+
+
+@pytest.mark.parametrize('tag', ['so_fz_k4', 'so_slic_k2'])
+def test_superpixel_overlaps_restatement_matches_reference(orc, tag):
+    g = golden('baseline_' + tag)
+    cl, road = orc.direct_clustering(g['fmap'], int(g['k']), nprandom=orc.NpRandom(1111))
+    assert np.array_equal(cl, g['cluster'])
+    for i in range(len(cl)):
+        assert np.array_equal(orc.overlap_refine(road[i], g['superpixels'][i], float(g['thr'])), g['refined'][i])
