@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Development aid: felzenszwalb timing at full resolution for several workgroups-per-image
+settings (SPA_FZ_GROUP) and batch sizes.   python tools/fz_fullres.py"""
+import importlib
+import os
+import subprocess
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if len(sys.argv) > 1:
+    import numpy as np
+    import torch
+    spa = importlib.import_module('superpixel-align_amd')
+    eng = importlib.import_module('superpixel-align_amd.engine').default_engine()
+    B = int(sys.argv[1])
+    imgs = torch.from_numpy(np.stack([spa.synth.synth_image(i, 1024, 2048) for i in range(B)])).cuda()
+    eng.felzenszwalb(imgs, 300.0, 0.8, 20)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(2):
+        lab, n = eng.felzenszwalb(imgs, 300.0, 0.8, 20)
+    torch.cuda.synchronize()
+    print('B=%d G=%s: %.1f ms per batch, %.1f ms per image, segments %d' % (
+        B, os.environ.get('SPA_FZ_GROUP', '1'), (time.time() - t0) / 2 * 1e3, (time.time() - t0) / 2 / B * 1e3, int(n[0])))
+else:
+    for B in (1, 8, 30):
+        for G in (1, 2, 4, 8):
+            env = dict(os.environ, SPA_FZ_GROUP=str(G))
+            subprocess.call([sys.executable, __file__, str(B)], env=env)
