@@ -55,7 +55,9 @@ def parse():
                    help="felzenszwalb (scale 300, sigma 0.8, min_size 20) is the reference launchers' setting")
     p.add_argument('--n_clusters', type=int, default=2)
     p.add_argument('--pool_mode', default='mean', choices=['mean', 'anchor'])
-    p.add_argument('--drn_sub_batch', type=int, default=10)
+    p.add_argument('--drn_sub_batch', type=int, default=0,
+                   help='DRN forward in sub-batches of this many images (0 = the whole batch at once: fewest, largest '
+                        'convolution launches; 30 x 1024x2048 fp32 needs ~25 GB of activations)')
     p.add_argument('--no_cpu_baseline', action='store_true')
     p.add_argument('--cpu_sample', type=int, default=1, help='images of the CPU baseline sample')
     p.add_argument('--no_prof', action='store_true', help='do not record per-kernel events')
@@ -174,7 +176,7 @@ def main():
         felzenszwalb_scale=300.0, felzenszwalb_sigma=0.8, felzenszwalb_min_size=20,
         without_pos=False, y_rel_pos=0.75, x_rel_pos=0.5, y_rel_sigma=0.1, x_rel_sigma=0.1,
         gpu=local, n_clusters=a.n_clusters, use_feature_maps=[7], pool_mode=a.pool_mode,
-        mean_sampling='nearest', drn_sub_batch=a.drn_sub_batch)
+        mean_sampling='nearest', drn_sub_batch=a.drn_sub_batch or None)
     model = drn.create_drn(a.arch, device='cuda:%d' % local, dtype=dtype)
     overlap = a.overlap or a.pool_mode == 'anchor'
     pipe = pipeline.LabelPipeline(args, model, overlap=overlap)
