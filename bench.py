@@ -281,7 +281,8 @@ def main():
         'roofline': roof,
         'drn': {'bound': 'mfma', 'achieved': round(drn_tf, 2), 'peak': peak_tf, 'unit': 'TFLOP/s',
                 'frac': round(drn_tf / peak_tf, 4), 'ms_per_step': round(drn_ms, 3),
-                'note': 'DRN forward is PyTorch-ROCm (MIOpen) by design; not a libspalign kernel'},
+                'note': 'DRN forward is PyTorch-ROCm (MIOpen) by design; libspalign adds the fused float32-MFMA stem of '
+                        'DRN-D (normalise + layer0 + layer1, k_drn_stem_d) and the bias/residual/ReLU epilogues'},
         'stage_ms_per_step': dict({k: round(v / a.steps, 3) for k, v in stage.items()},
                                   streams='two: superpixel branch overlaps the DRN forward' if overlap
                                   else 'one'),

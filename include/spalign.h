@@ -85,6 +85,15 @@ int spa_drn_normalise(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_
 int spa_bias_act(spa_ctx *ctx, void *y, int32_t dtype, int64_t rows, int32_t C, const void *bias,
                  const void *residual, int32_t relu, void *stream);
 
+/* The full-resolution stem of DRN-D as one float32-MFMA kernel: input normalisation
+ * (models/drn.py:319-321), layer0 = conv7x7(3->16)+BN+ReLU and layer1 = conv3x3(16->16)+BN+ReLU
+ * (models/drn.py:134-145) with BatchNorm folded into weights and biases.
+ * x (B,3,H,W) float32 planar 0..255; w0 (16,147) = the (16,3,7,7) weight flattened; w1 (16,144) =
+ * the (16,16,3,3) weight permuted to (n, ky, kx, c); b0, b1 (16); y (B,H,W,16) float32 channels-last. */
+int spa_drn_stem_d(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W,
+                   const float *w0, const float *b0, const float *w1, const float *b1,
+                   const double *mean3_host, const double *std3_host, float *y, void *stream);
+
 /* ---- SLIC superpixels ------------------------------------------------------------------
  * replaces batch_superpixel(), SLIC branch: batch_spalign_kmeans.py:308-311, i.e.
  * skimage.segmentation.slic(img.transpose(1,2,0), n_segments) with every other argument

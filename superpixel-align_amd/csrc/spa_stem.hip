@@ -1,0 +1,204 @@
+// The full-resolution stem of DRN-D (models/drn.py:134-145: layer0 = conv7x7(3->16)+BN+ReLU,
+// layer1 = conv3x3(16->16)+BN+ReLU) as ONE kernel, float32 MFMA.
+//
+// Why it is not left to MIOpen like the rest of the network: with 3 / 16 channels the library's
+// implicit-GEMM kernels reach 22-28 % of the float32 matrix peak (8.6 + 6.5 ms per 30 images at
+// 1024x2048), each convolution is followed by a bias/ReLU pass over a 4 GB tensor, and the
+// 16-channel full-resolution intermediate makes one extra trip through HBM.  Here a workgroup
+//   A. stages the (16+8) x (32+8) x 3 input patch of its 16 x 32 output tile in LDS, normalised
+//      on the way in (DRN.batch_predict, models/drn.py:319-321: x/255 float32, then (x - mean)
+//      and (x / std) in float64 rounded to float32), zero outside the image (conv padding);
+//   B. computes layer0 on the 18 x 34 pixels layer1 needs (v_mfma_f32_16x16x4_f32: 16 pixels x
+//      16 channels per instruction, K = 7*7*3 = 147 padded to 148), adds the folded-BN bias,
+//      applies ReLU and keeps the result in LDS (zeros outside the image: layer1's padding);
+//   C. computes layer1 from that LDS tile (K = 3*3*16 = 144), bias, ReLU, and stores the
+//      channels-last float32 map.
+// The float32 MFMA is an exact k-ordered fmaf chain (no reduced precision); HBM traffic is the
+// input once and the output once.
+#include "spa_common.h"
+
+#define ST_TH 16
+#define ST_TW 32
+#define ST_IH (ST_TH + 8)
+#define ST_IW (ST_TW + 8)
+#define ST_IPLANE (ST_IH * ST_IW + 8)        // floats per input channel plane (+8: bank spread)
+#define ST_LH (ST_TH + 2)
+#define ST_LW (ST_TW + 2)
+#define ST_LP (ST_LH * ST_LW)                // layer0 pixels per tile (612)
+#define ST_PS 17                             // floats per layer0 pixel in LDS (16 channels + 1: bank spread)
+#define ST_K0 148                            // 147 padded to a multiple of 4
+#define ST_S0 (ST_K0 / 4)                    // MFMA steps of layer0 (37)
+#define ST_S1 (144 / 4)                      // MFMA steps of layer1 (36)
+#define ST_PF 8                              // LDS read-ahead, in MFMA steps
+
+typedef float stem_f4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void k_drn_stem_d(const float *__restrict__ xn, int B, int H, int W,
+                                                    const float *__restrict__ w0,    // [16][147]  (n, c*49+ky*7+kx)
+                                                    const float *__restrict__ b0,    // [16]
+                                                    const float *__restrict__ w1,    // [16][144]  (n, (ky*3+kx)*16+c)
+                                                    const float *__restrict__ b1,    // [16]
+                                                    float *__restrict__ y)
+{
+    __shared__ float in_s[3 * ST_IPLANE];
+    __shared__ float l0_s[ST_LP * ST_PS + 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int m = lane & 15, g = lane >> 4;
+    const long long npix = (long long)H * W;
+    const int tiles_x = (W + ST_TW - 1) / ST_TW, tiles_y = (H + ST_TH - 1) / ST_TH;
+    const int n_tiles = tiles_x * tiles_y * B;
+
+    // layer0 operands of this lane: B[k = 4s + g][n = m] and the LDS offset of input element k
+    float wq[ST_S0];
+    int koff[ST_S0];
+#pragma unroll
+    for (int s = 0; s < ST_S0; ++s) {
+        const int k = 4 * s + g;
+        const bool valid = k < 147;
+        const int c = k / 49, rem = k - c * 49, ky = rem / 7, kx = rem - ky * 7;
+        koff[s] = valid ? c * ST_IPLANE + ky * ST_IW + kx : 0;
+        wq[s] = valid ? w0[m * 147 + k] : 0.0f;
+    }
+    const float bias0 = b0[m];
+    // layer1 operands: B[k = 4s + g][n = m], k = (ky*3 + kx)*16 + c
+    float wr[ST_S1];
+#pragma unroll
+    for (int s = 0; s < ST_S1; ++s) wr[s] = w1[m * 144 + 4 * s + g];
+    const float bias1 = b1[m];
+
+    // persistent workgroups: the operand registers above are set up once, then tile after tile
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int b = tile / (tiles_x * tiles_y), tr = tile - b * (tiles_x * tiles_y);
+    const int ty0 = (tr / tiles_x) * ST_TH, tx0 = (tr % tiles_x) * ST_TW;
+    const float *src = xn + (long long)b * npix * 3;
+    // ---- A: input patch (already normalised, channels-last), origin (ty0 - 4, tx0 - 4); zero
+    // outside the image (conv padding).  All loads are issued before the first value is used.
+    {
+        constexpr int NE = 3 * ST_IH * ST_IW, NU = (NE + 255) / 256;
+        float raw[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int e = tid + u * 256;                 // e = (iy * ST_IW + ix) * 3 + c
+            const int pix = e / 3, c = e - pix * 3;
+            const int iy = pix / ST_IW, ix = pix - iy * ST_IW;
+            const int gy = ty0 - 4 + iy, gx = tx0 - 4 + ix;
+            const bool in = e < NE && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            raw[u] = in ? src[((long long)gy * W + gx) * 3 + c] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int e = tid + u * 256;
+            if (e < NE) {
+                const int pix = e / 3, c = e - pix * 3;
+                in_s[c * ST_IPLANE + pix] = raw[u];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- B: layer0 on the 18 x 34 region (origin (ty0 - 1, tx0 - 1)), two 16-pixel tiles at a time
+    for (int t = wv; t < (ST_LP + 15) / 16; t += 8) {
+        const int t2 = t + 4;
+        const bool two = t2 < (ST_LP + 15) / 16;
+        int pa = t * 16 + m, pb = t2 * 16 + m;
+        if (pa > ST_LP - 1) pa = ST_LP - 1;
+        if (pb > ST_LP - 1) pb = ST_LP - 1;
+        const int basea = (pa / ST_LW) * ST_IW + (pa % ST_LW);
+        const int baseb = (pb / ST_LW) * ST_IW + (pb % ST_LW);
+        stem_f4 acca = {0.0f, 0.0f, 0.0f, 0.0f}, accb = {0.0f, 0.0f, 0.0f, 0.0f};
+        // the A operands come from LDS ST_PF steps ahead of the MFMA that uses them (a ring of
+        // registers with compile-time indices), so the matrix pipe does not wait for LDS latency
+        float ra[ST_PF], rb[ST_PF];
+#pragma unroll
+        for (int s = 0; s < ST_PF; ++s) { ra[s] = in_s[basea + koff[s]]; rb[s] = in_s[baseb + koff[s]]; }
+#pragma unroll
+        for (int s = 0; s < ST_S0; ++s) {
+            const float aa = ra[s % ST_PF], ab = rb[s % ST_PF];
+            if (s + ST_PF < ST_S0) {
+                ra[s % ST_PF] = in_s[basea + koff[s + ST_PF]];
+                rb[s % ST_PF] = in_s[baseb + koff[s + ST_PF]];
+            }
+            __builtin_amdgcn_sched_barrier(0);        // keep the reads ST_PF steps ahead of their use
+            acca = __builtin_amdgcn_mfma_f32_16x16x4f32(aa, wq[s], acca, 0, 0, 0);
+            accb = __builtin_amdgcn_mfma_f32_16x16x4f32(ab, wq[s], accb, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // D[row = 4g + j][col = m]: row = pixel of the tile, col = channel
+            const int qa = t * 16 + 4 * g + j;
+            if (qa < ST_LP) {
+                const int r = qa / ST_LW, q = qa - r * ST_LW;
+                const int gy = ty0 - 1 + r, gx = tx0 - 1 + q;
+                const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                l0_s[qa * ST_PS + m] = in ? fmaxf(acca[j] + bias0, 0.0f) : 0.0f;
+            }
+            const int qb = t2 * 16 + 4 * g + j;
+            if (two && qb < ST_LP) {
+                const int r = qb / ST_LW, q = qb - r * ST_LW;
+                const int gy = ty0 - 1 + r, gx = tx0 - 1 + q;
+                const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                l0_s[qb * ST_PS + m] = in ? fmaxf(accb[j] + bias0, 0.0f) : 0.0f;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- C: layer1 on the 16 x 32 tile: 32 tiles of 16 pixels (row t>>1, columns (t&1)*16 ..)
+    for (int t = wv; t < 32; t += 8) {
+        const int t2 = t + 4;
+        const int rowa = t >> 1, cola = (t & 1) * 16, rowb = t2 >> 1, colb = (t2 & 1) * 16;
+        const float *pa = l0_s + (rowa * ST_LW + cola + m) * ST_PS + g;
+        const float *pb = l0_s + (rowb * ST_LW + colb + m) * ST_PS + g;
+        stem_f4 acca = {0.0f, 0.0f, 0.0f, 0.0f}, accb = {0.0f, 0.0f, 0.0f, 0.0f};
+        float ra[ST_PF], rb[ST_PF];
+#define ST_OFF1(s) ((((s) >> 2) / 3 * ST_LW + ((s) >> 2) % 3) * ST_PS + ((s) & 3) * 4)     // compile-time constant
+#pragma unroll
+        for (int s = 0; s < ST_PF; ++s) { ra[s] = pa[ST_OFF1(s)]; rb[s] = pb[ST_OFF1(s)]; }
+#pragma unroll
+        for (int s = 0; s < ST_S1; ++s) {
+            const float aa = ra[s % ST_PF], ab = rb[s % ST_PF];
+            if (s + ST_PF < ST_S1) {
+                ra[s % ST_PF] = pa[ST_OFF1(s + ST_PF)];
+                rb[s % ST_PF] = pb[ST_OFF1(s + ST_PF)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acca = __builtin_amdgcn_mfma_f32_16x16x4f32(aa, wr[s], acca, 0, 0, 0);
+            accb = __builtin_amdgcn_mfma_f32_16x16x4f32(ab, wr[s], accb, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int mm = 4 * g + j;
+            int gy = ty0 + rowa, gx = tx0 + cola + mm;
+            if (gy < H && gx < W)
+                y[(((long long)b * H + gy) * W + gx) * 16 + m] = fmaxf(acca[j] + bias1, 0.0f);
+            gy = ty0 + rowb; gx = tx0 + colb + mm;
+            if (gy < H && gx < W)
+                y[(((long long)b * H + gy) * W + gx) * 16 + m] = fmaxf(accb[j] + bias1, 0.0f);
+        }
+    }
+    __syncthreads();         // the next tile overwrites both LDS tiles
+    }
+}
+
+extern "C" int spa_drn_stem_d(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W,
+                              const float *w0, const float *b0, const float *w1, const float *b1,
+                              const double *mean3_host, const double *std3_host, float *y, void *stream)
+{
+    SPA_ARG(ctx && x && w0 && b0 && w1 && b1 && mean3_host && std3_host && y && B > 0 && H > 0 && W > 0);
+    // exact input normalisation (models/drn.py:319-321) into a channels-last workspace, then the stem
+    float *xn;
+    int rc = spa_ws_reserve(ctx, WS_STEM_IN, (size_t)B * H * W * 3 * sizeof(float), (void **)&xn);
+    if (rc != SPA_OK) return rc;
+    rc = spa_drn_normalise(ctx, x, B, H, W, xn, 0, mean3_host, std3_host, stream);
+    if (rc != SPA_OK) return rc;
+    const long long n_tiles = (long long)((W + ST_TW - 1) / ST_TW) * ((H + ST_TH - 1) / ST_TH) * B;
+    SPA_ARG(n_tiles < (1ll << 31));
+    long long grid = 3ll * ctx->n_cu;                      // 3 resident workgroups per CU (LDS)
+    if (grid > n_tiles) grid = n_tiles;
+    hipLaunchKernelGGL(k_drn_stem_d, dim3((unsigned)grid), dim3(256), 0, spa_stream(stream), (const float *)xn, B, H, W,
+                       w0, b0, w1, b1, y);
+    SPA_LAUNCH_CHECK();
+    return SPA_OK;
+}

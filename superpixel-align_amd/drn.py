@@ -134,6 +134,8 @@ class DRN(nn.Module):
         self.fc = nn.Conv2d(ch[7], num_classes, 1) if with_fc else None
         self.folded = False
         self.compute_dtype = torch.float32
+        self.use_fused_stem = True      # arch D, float32, folded BN, on the GPU: libspalign's stem kernel
+        self._stem = None
         for m in self.modules():           # the reference's random init (models/drn.py:176-184)
             if isinstance(m, nn.Conv2d):
                 n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
@@ -197,26 +199,40 @@ class DRN(nn.Module):
         self.compute_dtype = dtype
         self.to(device=device, dtype=dtype, memory_format=torch.channels_last)
         self.eval()
+        self._stem = None
         if torch.device(device).type == 'cuda':
             from .engine import default_engine        # fused glue kernels of libspalign
             _EPILOGUE['engine'] = default_engine()
+            if self.arch == 'D' and self.folded and dtype == torch.float32:
+                # operands of libspalign's fused stem kernel (normalise + layer0 + layer1)
+                c0, c1 = self.layer0[0], self.layer1[0]
+                self._stem = (c0.weight.detach().float().reshape(16, 147).contiguous(),
+                              c0.bias.detach().float().contiguous(),
+                              c1.weight.detach().float().permute(0, 2, 3, 1).reshape(16, 144).contiguous(),
+                              c1.bias.detach().float().contiguous())
         return self
 
     # -- forward ---------------------------------------------------------------------------------
-    def forward_maps(self, x):
-        """x: normalised (B,3,H,W). Returns the 8 maps of the Chainer convention."""
+    def forward_maps(self, x, layer1_out=None):
+        """x: normalised (B,3,H,W) (or None with `layer1_out`, the fused stem's output).
+        Returns the 8 maps of the Chainer convention."""
         def plain(seq, t):
             mods = list(seq.children())            # (conv, bn | Identity, relu) triples
             for i in range(0, len(mods), 3):
                 t = conv_bias_act(mods[i], mods[i + 1], t, None, True)
             return t
 
-        if self.arch == 'C':
+        first = 1
+        maps = []
+        if layer1_out is not None:             # the fused stem already produced layer1's output
+            x = layer1_out
+            maps.append(x)
+            first = 2
+        elif self.arch == 'C':
             x = conv_bias_act(self.conv1, self.bn1, x, None, True)
         else:
             x = plain(self.layer0, x)
-        maps = []
-        for i in range(1, 9):
+        for i in range(first, 9):
             layer = getattr(self, 'layer%d' % i)
             x = plain(layer, x) if (self.arch == 'D' and i in (1, 2, 7, 8)) else layer(x)
             maps.append(x)
@@ -252,12 +268,16 @@ class DRN(nn.Module):
         outs = None
         for s in range(0, B, sub):
             eng = _EPILOGUE['engine']
-            if eng is not None and x.is_cuda:
-                xi = eng.drn_normalise(x[s:s + sub].float().contiguous(), self.compute_dtype)
+            if eng is not None and x.is_cuda and getattr(self, '_stem', None) is not None and self.use_fused_stem:
+                l1 = eng.drn_stem_d(x[s:s + sub].float().contiguous(), *self._stem)
+                maps = self.forward_maps(None, layer1_out=l1)
             else:
-                xi = self.normalise(x[s:s + sub].float())
-                xi = xi.to(self.compute_dtype).contiguous(memory_format=torch.channels_last)
-            _, maps = self.forward(xi)
+                if eng is not None and x.is_cuda:
+                    xi = eng.drn_normalise(x[s:s + sub].float().contiguous(), self.compute_dtype)
+                else:
+                    xi = self.normalise(x[s:s + sub].float())
+                    xi = xi.to(self.compute_dtype).contiguous(memory_format=torch.channels_last)
+                _, maps = self.forward(xi)
             if outs is None:
                 outs = [[m] for m in maps]
             else:

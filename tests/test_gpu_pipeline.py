@@ -204,3 +204,22 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['value'] > 0
     assert d['quality']['records_gathered'] == 4             # 2 ranks x 2 images
     assert d['roofline']['bound'] == 'hbm' and 'cpu_baseline' not in d
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 96), (1, 100, 75), (3, 33, 130)])
+def test_fused_drn_d_stem_matches_convolution_path(mods, shape):
+    """libspalign's float32-MFMA stem kernel (normalise + layer0 + layer1 of DRN-D) against the
+    MIOpen convolutions + separate epilogues it replaces: float32 rounding-level agreement on
+    layer1's output and on the final map, including image sizes that are not tile multiples."""
+    B, H, W = shape
+    model = mods.drn.create_drn('drn_d_22', None, device='cuda', dtype=torch.float32, seed=3)
+    assert model._stem is not None
+    x = torch.rand(B, 3, H, W, device='cuda') * 255
+    model.use_fused_stem = False
+    _, ref = model.batch_predict(x)
+    ref = [m.clone() for m in ref]
+    model.use_fused_stem = True
+    _, got = model.batch_predict(x)
+    for i in (0, 1, 7):
+        scale = float(ref[i].abs().max())
+        assert float((got[i] - ref[i]).abs().max()) <= 2e-5 * scale
