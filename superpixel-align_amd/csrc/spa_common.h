@@ -81,7 +81,8 @@ enum {
 // kernels bench.py prices against the roofline
 enum {
     PROF_RGB2LAB = 0, PROF_SLIC_ASSIGN, PROF_SLIC_UPDATE, PROF_CONNECT, PROF_STATS,
-    PROF_CELL_WEIGHTS, PROF_POOL_MEAN, PROF_POOL_ANCHOR, PROF_KMEANS, PROF_PAINT, PROF_SLOTS
+    PROF_CELL_WEIGHTS, PROF_POOL_MEAN, PROF_POOL_ANCHOR, PROF_KMEANS, PROF_PAINT,
+    PROF_DRN_STEM, PROF_DRN_BIAS_ACT, PROF_SLOTS
 };
 
 struct spa_ctx {

@@ -118,6 +118,7 @@ extern "C" int spa_bias_act(spa_ctx *ctx, void *y, int32_t dtype, int64_t rows, 
     const int vec = dtype == 0 ? 4 : 8;
     SPA_ARG(C % vec == 0);
     SPA_ARG((((uintptr_t)y | (uintptr_t)bias | (uintptr_t)residual) & 15) == 0);
+    SpaProfScope prof_(ctx, PROF_DRN_BIAS_ACT, spa_stream(stream));
     const long long n = rows * C / vec;
     long long gx = (n + 255) / 256;
     if (gx > 4096) gx = 4096;

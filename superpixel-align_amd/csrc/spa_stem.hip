@@ -188,6 +188,7 @@ extern "C" int spa_drn_stem_d(spa_ctx *ctx, const float *x, int32_t B, int32_t H
 {
     SPA_ARG(ctx && x && w0 && b0 && w1 && b1 && mean3_host && std3_host && y && B > 0 && H > 0 && W > 0);
     // exact input normalisation (models/drn.py:319-321) into a channels-last workspace, then the stem
+    SpaProfScope prof_(ctx, PROF_DRN_STEM, spa_stream(stream));
     float *xn;
     int rc = spa_ws_reserve(ctx, WS_STEM_IN, (size_t)B * H * W * 3 * sizeof(float), (void **)&xn);
     if (rc != SPA_OK) return rc;

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .engine import Engine, NpRandom, PyRandom
+from .engine import Engine, default_engine, NpRandom, PyRandom
 
 
 class BatchResult(object):
@@ -35,7 +35,7 @@ class LabelPipeline(object):
                  overlap=True):
         self.args = args
         self.model = model
-        self.eng = engine or Engine()
+        self.eng = engine or default_engine()     # one spa_ctx per process: the DRN glue kernels use it too
         self.pool_mode = pool_mode or getattr(args, 'pool_mode', 'anchor')
         self.mean_sampling = mean_sampling or getattr(args, 'mean_sampling', 'nearest')
         # the reference seeds both generators once per process (batch_spalign_kmeans.py:33-34);
