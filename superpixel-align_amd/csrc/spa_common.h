@@ -94,7 +94,13 @@ struct spa_ctx {
     int prof_on;
     hipEvent_t *prof_ev[PROF_SLOTS];   // pairs (start, stop)
     int prof_cap[PROF_SLOTS], prof_used[PROF_SLOTS];
+    // side streams for independent kernels of one call (fork/join with events; created on first use)
+    hipStream_t aux[2];
+    hipEvent_t ev_fork, ev_join[2];
+    int aux_ready;
 };
+
+int spa_aux_streams(spa_ctx *ctx);
 
 void spa_prof_mark(spa_ctx *ctx, int slot, int end, hipStream_t s);
 struct SpaProfScope {

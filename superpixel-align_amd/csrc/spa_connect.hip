@@ -26,10 +26,12 @@ struct ConnMisc {
     int first_kept;    // smallest kept root (npix if none)
     int qalloc;        // BFS queue allocation cursor
     int n_kept;        // number of kept components
-    int n_todo1;       // small components that did not fit the 40 KB LDS tier
-    int n_todo2;       // ... nor the 156 KB tier (handled in global memory)
+    int n_todo1;       // big-small components of the 80 KB LDS tier
+    int n_todo2;       // ... of the global-memory tier (too large for LDS, or a ring overflow)
     int n_big;         // small components with more than LANE_MAX pixels
     int n_over;        // components larger than max_size (cut in BFS order by the reference)
+    int n_a;           // big-small components of the 16 KB LDS tier
+    int pad_[3];
 };
 
 __device__ __forceinline__ int ld_i32(const int *p)
@@ -544,6 +546,44 @@ __global__ __launch_bounds__(256) void k_conn_bfs_lane(const int *__restrict__ p
 #define BC_DONE 3
 #define BC_CUR 64
 
+// tier of every big-small component, from its bounding box alone (the tiers then run concurrently
+// on separate streams): 16 KB LDS, 80 KB LDS, or global memory
+#define BFS_LDS_A (16 * 1024)
+#define BFS_RING_A 1024
+#define BFS_LDS_B (80 * 1024)
+#define BFS_RING_B 4096
+
+__global__ __launch_bounds__(256) void k_conn_classify(const int *__restrict__ big_list,
+                                                       const int *__restrict__ sbox,
+                                                       ConnMisc *__restrict__ misc, int *__restrict__ final_,
+                                                       int *__restrict__ list_a, int *__restrict__ list_b,
+                                                       int *__restrict__ list_g, int H, int W)
+{
+    const int b = blockIdx.y;
+    const long long npix = (long long)H * W;
+    const int n_big = misc[b].n_big;
+    const int first_kept = misc[b].first_kept;
+    for (int slot = blockIdx.x * 256 + threadIdx.x; slot < n_big; slot += gridDim.x * 256) {
+        const int r = big_list[b * npix + slot];
+        if (r < first_kept) { final_[b * npix + r] = -1; continue; }   // before the first kept component: label 0
+        int tier = 2;
+        if (slot < SBOX_CAP) {
+            const int *bb = sbox + ((long long)b * SBOX_CAP + slot) * 4;
+            const int y0 = max(bb[0] - 1, 0), y1 = min(bb[1] + 1, H - 1);
+            const int x0 = max(bb[2] - 1, 0), x1 = min(bb[3] + 1, W - 1);
+            const long long area = (long long)(x1 - x0 + 1) * (y1 - y0 + 1);
+            const long long area4 = (area + 3) & ~3ll;
+            if (area <= 65535) {
+                if (area4 + BFS_RING_A * 2 <= BFS_LDS_A) tier = 0;
+                else if (area4 + BFS_RING_B * 2 <= BFS_LDS_B) tier = 1;
+            }
+        }
+        if (tier == 0) list_a[b * npix + atomicAdd(&misc[b].n_a, 1)] = slot;
+        else if (tier == 1) list_b[b * npix + atomicAdd(&misc[b].n_todo1, 1)] = slot;
+        else list_g[b * npix + atomicAdd(&misc[b].n_todo2, 1)] = slot;
+    }
+}
+
 __device__ __forceinline__ void conn_wave_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -567,8 +607,8 @@ __global__ __launch_bounds__(64) void k_conn_bfs_lds(const int *__restrict__ par
     const int *P = parent + (long long)b * npix;
     const int *BL = big_list + (long long)b * npix;
     int *F = final_ + (long long)b * npix;
-    const int n_items = tier == 0 ? misc[b].n_big : misc[b].n_todo1;
-    int *todo_count = tier == 0 ? &misc[b].n_todo1 : &misc[b].n_todo2;
+    const int n_items = tier == 0 ? misc[b].n_a : misc[b].n_todo1;
+    int *todo_count = &misc[b].n_todo2;          // what fits no LDS tier after all goes to the global tier
     const int first_kept = misc[b].first_kept;
     const unsigned long long below = (1ull << lane) - 1ull;
     const int rmask = ring - 1;
@@ -849,7 +889,7 @@ __global__ void k_conn_init_misc(ConnMisc *misc, int B, int npix)
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B) {
         misc[b].n_small = 0; misc[b].first_kept = npix; misc[b].qalloc = 0; misc[b].n_kept = 0;
-        misc[b].n_todo1 = 0; misc[b].n_todo2 = 0; misc[b].n_big = 0; misc[b].n_over = 0;
+        misc[b].n_todo1 = 0; misc[b].n_todo2 = 0; misc[b].n_big = 0; misc[b].n_over = 0; misc[b].n_a = 0;
     }
 }
 
@@ -876,8 +916,11 @@ extern "C" int spa_enforce_connectivity(spa_ctx *ctx, const int32_t *labels_in, 
     big = tiny + (size_t)B * npix;
     if ((rc = spa_ws_reserve(ctx, WS_BLK, (size_t)B * 2 * nblk * 4, (void **)&blk)) != SPA_OK) return rc;
     if ((rc = spa_ws_reserve(ctx, WS_SBOX, (size_t)B * SBOX_CAP * 16, (void **)&sbox)) != SPA_OK) return rc;
-    if ((rc = spa_ws_reserve(ctx, WS_TODO, 2 * img, (void **)&todo1)) != SPA_OK) return rc;
+    int *todo0;
+    if ((rc = spa_ws_reserve(ctx, WS_TODO, 3 * img, (void **)&todo1)) != SPA_OK) return rc;
     todo2 = todo1 + (size_t)B * npix;
+    todo0 = todo2 + (size_t)B * npix;
+    if ((rc = spa_aux_streams(ctx)) != SPA_OK) return rc;
     if ((rc = spa_ws_reserve(ctx, WS_CONNMISC, (size_t)B * sizeof(ConnMisc), (void **)&misc)) != SPA_OK) return rc;
 
     SpaProfScope prof_(ctx, PROF_CONNECT, s);
@@ -907,20 +950,31 @@ extern "C" int spa_enforce_connectivity(spa_ctx *ctx, const int32_t *labels_in, 
     if (gb > 1024) gb = 1024;
     hipLaunchKernelGGL(k_small_bbox, dim3(gb, B), dim3(256), 0, s, parent, size, final_, W, npix,
                        min_size, sbox);
-    // BFS replay of the small components: lane tier for the tiny ones, then 16 KB LDS, 80 KB LDS
-    // and global-memory wave tiers for the rest.  The lists live on the device; surplus
-    // workgroups exit at once.
-    hipLaunchKernelGGL(k_conn_bfs_lane, dim3(gb, B), dim3(256), 0, s, parent, size, tiny, misc,
-                       final_, H, W);
+    // BFS replay of the small components.  The tiers are independent of each other (a component
+    // only reads the roots of its neighbours), so they run concurrently: the lane tier (<= 32 pixels,
+    // one thread each) on a side stream, the 80 KB LDS tier on another, the 16 KB LDS tier here;
+    // what fits no LDS tier (or overflows a frontier ring) goes to the global-memory wave tier after
+    // the join.  Each tier is bound by its slowest replay (a thin 5 000-pixel component is ~1 ms of
+    // dependent LDS steps), not by throughput.
     static bool attr_done = false;
     if (!attr_done) {
-        SPA_HIP(hipFuncSetAttribute((const void *)k_conn_bfs_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        SPA_HIP(hipFuncSetAttribute((const void *)k_conn_bfs_lds, hipFuncAttributeMaxDynamicSharedMemorySize, BFS_LDS_B));
         attr_done = true;
     }
-    hipLaunchKernelGGL(k_conn_bfs_lds, dim3(1024, B), dim3(64), 16 * 1024, s, parent, size, big, sbox,
-                       (const int *)nullptr, todo1, misc, 0, final_, H, W, 16 * 1024, 1024);
-    hipLaunchKernelGGL(k_conn_bfs_lds, dim3(512, B), dim3(64), 80 * 1024, s, parent, size, big, sbox,
-                       (const int *)todo1, todo2, misc, 1, final_, H, W, 80 * 1024, 4096);
+    hipLaunchKernelGGL(k_conn_classify, dim3(8, B), dim3(256), 0, s, big, sbox, misc, final_, todo0, todo1, todo2, H, W);
+    SPA_HIP(hipEventRecord(ctx->ev_fork, s));
+    SPA_HIP(hipStreamWaitEvent(ctx->aux[0], ctx->ev_fork, 0));
+    SPA_HIP(hipStreamWaitEvent(ctx->aux[1], ctx->ev_fork, 0));
+    hipLaunchKernelGGL(k_conn_bfs_lds, dim3(256, B), dim3(64), BFS_LDS_B, ctx->aux[1], parent, size, big, sbox,
+                       (const int *)todo1, todo2, misc, 1, final_, H, W, BFS_LDS_B, BFS_RING_B);
+    hipLaunchKernelGGL(k_conn_bfs_lane, dim3(gb, B), dim3(256), 0, ctx->aux[0], parent, size, tiny, misc,
+                       final_, H, W);
+    hipLaunchKernelGGL(k_conn_bfs_lds, dim3(1024, B), dim3(64), BFS_LDS_A, s, parent, size, big, sbox,
+                       (const int *)todo0, todo2, misc, 0, final_, H, W, BFS_LDS_A, BFS_RING_A);
+    SPA_HIP(hipEventRecord(ctx->ev_join[0], ctx->aux[0]));
+    SPA_HIP(hipEventRecord(ctx->ev_join[1], ctx->aux[1]));
+    SPA_HIP(hipStreamWaitEvent(s, ctx->ev_join[0], 0));
+    SPA_HIP(hipStreamWaitEvent(s, ctx->ev_join[1], 0));
     // (the claim array is all-INF again: k_conn_split releases what it takes)
     hipLaunchKernelGGL(k_conn_bfs, dim3(256, B), dim3(64), 0, s, parent, size, big, (const int *)todo2,
                        misc, claim, queue, final_, H, W);

@@ -55,6 +55,10 @@ extern "C" void spa_ctx_destroy(spa_ctx *ctx)
     for (int i = 0; i < WS_COUNT; ++i)
         if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
+    if (ctx->aux_ready) {
+        for (int i = 0; i < 2; ++i) { (void)hipStreamDestroy(ctx->aux[i]); (void)hipEventDestroy(ctx->ev_join[i]); }
+        (void)hipEventDestroy(ctx->ev_fork);
+    }
     free(ctx);
 }
 
@@ -223,6 +227,19 @@ extern "C" int spa_prof_read(spa_ctx *ctx, int slot, double *total_ms, int *laun
     }
     *total_ms = t;
     *launches = ctx->prof_used[slot];
+    return SPA_OK;
+}
+
+// side streams: created once per context; spa_ctx_destroy releases them
+int spa_aux_streams(spa_ctx *ctx)
+{
+    if (ctx->aux_ready) return SPA_OK;
+    for (int i = 0; i < 2; ++i) {
+        SPA_HIP(hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking));
+        SPA_HIP(hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming));
+    }
+    SPA_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    ctx->aux_ready = 1;
     return SPA_OK;
 }
 

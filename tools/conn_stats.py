@@ -40,7 +40,7 @@ labels, n_labels = eng.slic(imgs, a.n)
 torch.cuda.synchronize()
 plan = lib_mod.make_plan(H, W, a.n)
 print('min_size', plan.min_size, 'max_size', plan.max_size)
-misc = peek('WS_CONNMISC', 0, 8 * a.batch, np.int32).reshape(a.batch, 8)
+misc = peek('WS_CONNMISC', 0, 12 * a.batch, np.int32).reshape(a.batch, 12)[:, :8]
 npix = H * W
 for b in range(a.batch):
     n_small, first_kept, qalloc, n_kept, n_todo1, n_todo2, n_big, n_over = misc[b]
