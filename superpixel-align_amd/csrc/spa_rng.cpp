@@ -149,12 +149,27 @@ extern "C" int spa_pyrandom_shuffle_select_host(spa_pyrandom *r, const int32_t *
             for (int a = 0; a < A; ++a) ranks[(int64_t)t * A + a] = 0;
             if (n <= 0) continue;
             int32_t *j_of = d.data() + off[t - s];
-            for (int32_t i = n - 1; i >= 1; --i) {
-                const uint32_t m = (uint32_t)i + 1u;
-                const int sh = __builtin_clz(m);           // 32 - bit_length(m)
-                uint32_t v = r->g.next() >> sh;
-                while (v >= m) v = r->g.next() >> sh;
-                j_of[i] = (int32_t)v;
+            // randbelow(i + 1) for i = n-1 .. 1: top bit_length(i+1) bits of a 32-bit output, redrawn
+            // while >= i+1.  Branch-free over the generator's output block: every candidate is
+            // stored at j_of[i] (a rejected one is overwritten by the next try for the same i) and
+            // i steps down only on acceptance; the shift is constant while i+1 stays in (2^(k-1), 2^k].
+            int32_t i = n - 1;
+            while (i >= 1) {
+                const int sh = __builtin_clz((uint32_t)i + 1u);          // 32 - bit_length(i + 1)
+                const int32_t band_lo = (int32_t)(0x80000000u >> sh) - 1;  // bit_length(i + 1) stays k while i >= 2^(k-1) - 1
+                const int32_t stop = band_lo > 1 ? band_lo : 1;
+                while (i >= stop) {
+                    if (r->g.idx >= 624) r->g.refill();
+                    const uint32_t *o = r->g.out + r->g.idx;
+                    const int avail = 624 - r->g.idx;
+                    int used = 0;
+                    while (used < avail && i >= stop) {
+                        const uint32_t v = o[used++] >> sh;
+                        j_of[i] = (int32_t)v;
+                        i -= (int32_t)(v <= (uint32_t)i);
+                    }
+                    r->g.idx += used;
+                }
             }
         }
         // ---- phase 2 of the previous group must be done before its buffers are reused next time
