@@ -33,6 +33,13 @@
 
 typedef float stem_f4 __attribute__((ext_vector_type(4)));
 
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global store
+// in flight (vmcnt(0)), i.e. for the previous tile's output to reach memory
+__device__ __forceinline__ void stem_lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __global__ __launch_bounds__(256) void k_drn_stem_d(const float *__restrict__ xn, int B, int H, int W,
                                                     const float *__restrict__ w0,    // [16][147]  (n, c*49+ky*7+kx)
                                                     const float *__restrict__ b0,    // [16]
@@ -66,35 +73,46 @@ __global__ __launch_bounds__(256) void k_drn_stem_d(const float *__restrict__ xn
     for (int s = 0; s < ST_S1; ++s) wr[s] = w1[m * 144 + 4 * s + g];
     const float bias1 = b1[m];
 
-    // persistent workgroups: the operand registers above are set up once, then tile after tile
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int b = tile / (tiles_x * tiles_y), tr = tile - b * (tiles_x * tiles_y);
-    const int ty0 = (tr / tiles_x) * ST_TH, tx0 = (tr % tiles_x) * ST_TW;
-    const float *src = xn + (long long)b * npix * 3;
     // ---- A: input patch (already normalised, channels-last), origin (ty0 - 4, tx0 - 4); zero
-    // outside the image (conv padding).  All loads are issued before the first value is used.
-    {
-        constexpr int NE = 3 * ST_IH * ST_IW, NU = (NE + 255) / 256;
-        float raw[NU];
+    // outside the image (conv padding).  The loads of a tile are issued one tile ahead (while the
+    // previous tile's layer1 runs) and straight-line: every thread loads from a clamped (always
+    // valid) address and zeroes the value afterwards — a branch around a load would make each load
+    // wait for the one before it.
+    constexpr int NE = 3 * ST_IH * ST_IW, NU = (NE + 255) / 256;
+    float raw[NU];
+    auto patch_load = [&](int tile) {
+        const int b = tile / (tiles_x * tiles_y), tr = tile - b * (tiles_x * tiles_y);
+        const int ty0 = (tr / tiles_x) * ST_TH, tx0 = (tr % tiles_x) * ST_TW;
+        const float *src = xn + (long long)b * npix * 3;
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             const int e = tid + u * 256;                 // e = (iy * ST_IW + ix) * 3 + c
             const int pix = e / 3, c = e - pix * 3;
             const int iy = pix / ST_IW, ix = pix - iy * ST_IW;
             const int gy = ty0 - 4 + iy, gx = tx0 - 4 + ix;
-            const bool in = e < NE && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            raw[u] = in ? src[((long long)gy * W + gx) * 3 + c] : 0.0f;
+            const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+            const unsigned off = ((unsigned)cy * (unsigned)W + (unsigned)cx) * 12u + (unsigned)c * 4u;
+            raw[u] = *(const float *)((const char *)src + off);
         }
+    };
+    if ((int)blockIdx.x < n_tiles) patch_load(blockIdx.x);
+
+    // persistent workgroups: the operand registers above are set up once, then tile after tile
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int b = tile / (tiles_x * tiles_y), tr = tile - b * (tiles_x * tiles_y);
+    const int ty0 = (tr / tiles_x) * ST_TH, tx0 = (tr % tiles_x) * ST_TW;
+    {
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             const int e = tid + u * 256;
-            if (e < NE) {
-                const int pix = e / 3, c = e - pix * 3;
-                in_s[c * ST_IPLANE + pix] = raw[u];
-            }
+            const int pix = e / 3, c = e - pix * 3;
+            const int iy = pix / ST_IW, ix = pix - iy * ST_IW;
+            const int gy = ty0 - 4 + iy, gx = tx0 - 4 + ix;
+            const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            if (e < NE) in_s[c * ST_IPLANE + pix] = in ? raw[u] : 0.0f;
         }
     }
-    __syncthreads();
+    stem_lds_barrier();
 
     // ---- B: layer0 on the 18 x 34 region (origin (ty0 - 1, tx0 - 1)), two 16-pixel tiles at a time
     for (int t = wv; t < (ST_LP + 15) / 16; t += 8) {
@@ -142,7 +160,8 @@ __global__ __launch_bounds__(256) void k_drn_stem_d(const float *__restrict__ xn
             }
         }
     }
-    __syncthreads();
+    stem_lds_barrier();
+    if (tile + (int)gridDim.x < n_tiles) patch_load(tile + (int)gridDim.x);     // next tile's input travels under layer1
 
     // ---- C: layer1 on the 16 x 32 tile: 32 tiles of 16 pixels (row t>>1, columns (t&1)*16 ..)
     for (int t = wv; t < 32; t += 8) {
@@ -178,7 +197,7 @@ __global__ __launch_bounds__(256) void k_drn_stem_d(const float *__restrict__ xn
                 y[(((long long)b * H + gy) * W + gx) * 16 + m] = fmaxf(accb[j] + bias1, 0.0f);
         }
     }
-    __syncthreads();         // the next tile overwrites both LDS tiles
+    stem_lds_barrier();         // the next tile overwrites both LDS tiles
     }
 }
 
@@ -196,6 +215,7 @@ extern "C" int spa_drn_stem_d(spa_ctx *ctx, const float *x, int32_t B, int32_t H
     if (rc != SPA_OK) return rc;
     const long long n_tiles = (long long)((W + ST_TW - 1) / ST_TW) * ((H + ST_TH - 1) / ST_TH) * B;
     SPA_ARG(n_tiles < (1ll << 31));
+    SPA_ARG((long long)H * W * 12 < (1ll << 32));            // 32-bit byte offsets inside one image
     long long grid = 3ll * ctx->n_cu;                      // 3 resident workgroups per CU (LDS)
     if (grid > n_tiles) grid = n_tiles;
     hipLaunchKernelGGL(k_drn_stem_d, dim3((unsigned)grid), dim3(256), 0, spa_stream(stream), (const float *)xn, B, H, W,
