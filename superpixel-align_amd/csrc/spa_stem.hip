@@ -33,6 +33,13 @@
 
 typedef float stem_f4 __attribute__((ext_vector_type(4)));
 
+__device__ __forceinline__ unsigned short stem_bf16(float f)      // round to nearest even
+{
+    const unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x0040u);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
 // workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global store
 // in flight (vmcnt(0)), i.e. for the previous tile's output to reach memory
 __device__ __forceinline__ void stem_lds_barrier()
@@ -45,8 +52,10 @@ __global__ __launch_bounds__(256) void k_drn_stem_d(const float *__restrict__ xn
                                                     const float *__restrict__ b0,    // [16]
                                                     const float *__restrict__ w1,    // [16][144]  (n, (ky*3+kx)*16+c)
                                                     const float *__restrict__ b1,    // [16]
-                                                    float *__restrict__ y)
+                                                    void *__restrict__ yout, int out_bf16)
 {
+    float *__restrict__ y = (float *)yout;
+    unsigned short *__restrict__ yh = (unsigned short *)yout;
     __shared__ float in_s[3 * ST_IPLANE];
     __shared__ float l0_s[ST_LP * ST_PS + 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -190,11 +199,17 @@ __global__ __launch_bounds__(256) void k_drn_stem_d(const float *__restrict__ xn
         for (int j = 0; j < 4; ++j) {
             const int mm = 4 * g + j;
             int gy = ty0 + rowa, gx = tx0 + cola + mm;
-            if (gy < H && gx < W)
-                y[(((long long)b * H + gy) * W + gx) * 16 + m] = fmaxf(acca[j] + bias1, 0.0f);
+            if (gy < H && gx < W) {
+                const float v = fmaxf(acca[j] + bias1, 0.0f);
+                const long long o = (((long long)b * H + gy) * W + gx) * 16 + m;
+                if (out_bf16) yh[o] = stem_bf16(v); else y[o] = v;
+            }
             gy = ty0 + rowb; gx = tx0 + colb + mm;
-            if (gy < H && gx < W)
-                y[(((long long)b * H + gy) * W + gx) * 16 + m] = fmaxf(accb[j] + bias1, 0.0f);
+            if (gy < H && gx < W) {
+                const float v = fmaxf(accb[j] + bias1, 0.0f);
+                const long long o = (((long long)b * H + gy) * W + gx) * 16 + m;
+                if (out_bf16) yh[o] = stem_bf16(v); else y[o] = v;
+            }
         }
     }
     stem_lds_barrier();         // the next tile overwrites both LDS tiles
@@ -203,9 +218,11 @@ __global__ __launch_bounds__(256) void k_drn_stem_d(const float *__restrict__ xn
 
 extern "C" int spa_drn_stem_d(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W,
                               const float *w0, const float *b0, const float *w1, const float *b1,
-                              const double *mean3_host, const double *std3_host, float *y, void *stream)
+                              const double *mean3_host, const double *std3_host, void *y, int32_t out_dtype,
+                              void *stream)
 {
     SPA_ARG(ctx && x && w0 && b0 && w1 && b1 && mean3_host && std3_host && y && B > 0 && H > 0 && W > 0);
+    SPA_ARG(out_dtype == 0 || out_dtype == 1);
     // exact input normalisation (models/drn.py:319-321) into a channels-last workspace, then the stem
     SpaProfScope prof_(ctx, PROF_DRN_STEM, spa_stream(stream));
     float *xn;
@@ -219,7 +236,7 @@ extern "C" int spa_drn_stem_d(spa_ctx *ctx, const float *x, int32_t B, int32_t H
     long long grid = 3ll * ctx->n_cu;                      // 3 resident workgroups per CU (LDS)
     if (grid > n_tiles) grid = n_tiles;
     hipLaunchKernelGGL(k_drn_stem_d, dim3((unsigned)grid), dim3(256), 0, spa_stream(stream), (const float *)xn, B, H, W,
-                       w0, b0, w1, b1, y);
+                       w0, b0, w1, b1, y, (int)out_dtype);
     SPA_LAUNCH_CHECK();
     return SPA_OK;
 }

@@ -203,7 +203,7 @@ class DRN(nn.Module):
         if torch.device(device).type == 'cuda':
             from .engine import default_engine        # fused glue kernels of libspalign
             _EPILOGUE['engine'] = default_engine()
-            if self.arch == 'D' and self.folded and dtype == torch.float32:
+            if self.arch == 'D' and self.folded and dtype in (torch.float32, torch.bfloat16):
                 # operands of libspalign's fused stem kernel (normalise + layer0 + layer1)
                 c0, c1 = self.layer0[0], self.layer1[0]
                 self._stem = (c0.weight.detach().float().reshape(16, 147).contiguous(),
@@ -269,7 +269,7 @@ class DRN(nn.Module):
         for s in range(0, B, sub):
             eng = _EPILOGUE['engine']
             if eng is not None and x.is_cuda and getattr(self, '_stem', None) is not None and self.use_fused_stem:
-                l1 = eng.drn_stem_d(x[s:s + sub].float().contiguous(), *self._stem)
+                l1 = eng.drn_stem_d(x[s:s + sub].float().contiguous(), *self._stem, dtype=self.compute_dtype)
                 maps = self.forward_maps(None, layer1_out=l1)
             else:
                 if eng is not None and x.is_cuda:

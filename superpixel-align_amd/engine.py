@@ -89,20 +89,21 @@ class Engine(object):
                                           0 if dtype == torch.float32 else 1, mean, std, _stream()))
         return out
 
-    def drn_stem_d(self, x, w0, b0, w1p, b1):
-        """DRN-D stem in one kernel: raw (B,3,H,W) float32 0..255 -> layer1 output (B,16,H,W)
-        float32 in channels-last storage.  w0 (16,147), w1p (16,144) in (n, ky, kx, c) order."""
+    def drn_stem_d(self, x, w0, b0, w1p, b1, dtype=torch.float32):
+        """DRN-D stem in one kernel: raw (B,3,H,W) float32 0..255 -> layer1 output (B,16,H,W) of
+        `dtype` (float32 arithmetic) in channels-last storage.  w0 (16,147), w1p (16,144) in
+        (n, ky, kx, c) order."""
         x = _req(x, torch.float32, 'x')
         B, C, H, W = x.shape
         assert C == 3
         for t, shape in ((w0, (16, 147)), (b0, (16,)), (w1p, (16, 144)), (b1, (16,))):
             _req(t, torch.float32, 'stem weights')
             assert tuple(t.shape) == shape
-        out = torch.empty((B, 16, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        out = torch.empty((B, 16, H, W), dtype=dtype, device=x.device, memory_format=torch.channels_last)
         mean = (ctypes.c_double * 3)(0.485, 0.456, 0.406)
         std = (ctypes.c_double * 3)(0.229, 0.224, 0.225)
         check(self._lib.spa_drn_stem_d(self._ctx, _ptr(x), B, H, W, _ptr(w0), _ptr(b0), _ptr(w1p), _ptr(b1),
-                                       mean, std, _ptr(out), _stream()))
+                                       mean, std, _ptr(out), 0 if dtype == torch.float32 else 1, _stream()))
         return out
 
     def bias_act_(self, y, bias, residual=None, relu=True):

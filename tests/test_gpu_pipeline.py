@@ -223,3 +223,24 @@ def test_fused_drn_d_stem_matches_convolution_path(mods, shape):
     for i in (0, 1, 7):
         scale = float(ref[i].abs().max())
         assert float((got[i] - ref[i]).abs().max()) <= 2e-5 * scale
+
+
+def test_fused_stem_in_bf16_mode(mods):
+    """bf16 network: the stem kernel computes in float32 and stores bf16; compared with the bf16
+    MIOpen path it replaces, against the float32 network as the common reference."""
+    B, H, W = 2, 64, 96
+    ref_model = mods.drn.create_drn('drn_d_22', None, device='cuda', dtype=torch.float32, seed=5)
+    model = mods.drn.create_drn('drn_d_22', None, device='cuda', dtype=torch.bfloat16, seed=5)
+    x = torch.rand(B, 3, H, W, device='cuda') * 255
+    _, ref = ref_model.batch_predict(x)
+    model.use_fused_stem = False
+    _, plain = model.batch_predict(x)
+    plain = [m.float() for m in plain]
+    model.use_fused_stem = True
+    _, fused = model.batch_predict(x)
+    assert fused[0].dtype == torch.bfloat16
+    for i in (0, 7):
+        scale = float(ref[i].abs().max())
+        e_plain = float((plain[i] - ref[i]).abs().max()) / scale
+        e_fused = float((fused[i].float() - ref[i]).abs().max()) / scale
+        assert e_fused <= max(1.25 * e_plain, 2e-2), (i, e_fused, e_plain)
