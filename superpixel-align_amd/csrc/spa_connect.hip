@@ -442,16 +442,28 @@ __global__ __launch_bounds__(256) void k_small_bbox(const int *__restrict__ pare
             if (sz >= min_size || sz <= LANE_MAX) r = -1;
             y = p / W; x = p - y * W;
         }
+        // first pixel of the wave and whether its 64 pixels stay inside one row and the image
+        const int pw = p0 + (threadIdx.x & ~63);
+        const int wy = pw / W, wx = pw - wy * W;
+        const bool one_row = (wx + 63 < W) && (pw + 63 < npix);
         unsigned long long todo = __ballot(r >= 0);
         while (todo) {
             int leader = __ffsll((long long)todo) - 1;
             int rr = __shfl(r, leader);
             unsigned long long same = __ballot(r == rr);
             bool mine = (r == rr);
-            int ya = mine ? y : 0x7fffffff, yb = mine ? y : -1, xa = mine ? x : 0x7fffffff, xb = mine ? x : -1;
-            for (int o = 32; o > 0; o >>= 1) {
-                ya = min(ya, __shfl_xor(ya, o)); yb = max(yb, __shfl_xor(yb, o));
-                xa = min(xa, __shfl_xor(xa, o)); xb = max(xb, __shfl_xor(xb, o));
+            int ya, yb, xa, xb;
+            if (one_row) {
+                // the wave's 64 pixels lie in one image row: the extent of the root's lanes is the
+                // extent of its pixels (no cross-lane reduction)
+                const int first = __ffsll((long long)same) - 1, last = 63 - __clzll((long long)same);
+                ya = yb = wy; xa = wx + first; xb = wx + last;
+            } else {
+                ya = mine ? y : 0x7fffffff; yb = mine ? y : -1; xa = mine ? x : 0x7fffffff; xb = mine ? x : -1;
+                for (int o = 32; o > 0; o >>= 1) {
+                    ya = min(ya, __shfl_xor(ya, o)); yb = max(yb, __shfl_xor(yb, o));
+                    xa = min(xa, __shfl_xor(xa, o)); xb = max(xb, __shfl_xor(xb, o));
+                }
             }
             if (lane == leader) {
                 int slot = F[rr];
