@@ -26,12 +26,13 @@ struct ConnMisc {
     int first_kept;    // smallest kept root (npix if none)
     int qalloc;        // BFS queue allocation cursor
     int n_kept;        // number of kept components
-    int n_todo1;       // big-small components of the 80 KB LDS tier
+    int n_todo1;       // big-small components of the 48 KB LDS tier
     int n_todo2;       // ... of the global-memory tier (too large for LDS, or a ring overflow)
     int n_big;         // small components with more than LANE_MAX pixels
     int n_over;        // components larger than max_size (cut in BFS order by the reference)
     int n_a;           // big-small components of the 16 KB LDS tier
-    int pad_[3];
+    int n_c;           // ... of the 80 KB LDS tier (rare: boxes above 40 K pixels)
+    int pad_[2];
 };
 
 __device__ __forceinline__ int ld_i32(const int *p)
@@ -562,14 +563,16 @@ __global__ __launch_bounds__(256) void k_conn_bfs_lane(const int *__restrict__ p
 // on separate streams): 16 KB LDS, 80 KB LDS, or global memory
 #define BFS_LDS_A (16 * 1024)
 #define BFS_RING_A 1024
-#define BFS_LDS_B (80 * 1024)
+#define BFS_LDS_B (48 * 1024)
 #define BFS_RING_B 4096
+#define BFS_LDS_C (80 * 1024)
 
 __global__ __launch_bounds__(256) void k_conn_classify(const int *__restrict__ big_list,
                                                        const int *__restrict__ sbox,
                                                        ConnMisc *__restrict__ misc, int *__restrict__ final_,
                                                        int *__restrict__ list_a, int *__restrict__ list_b,
-                                                       int *__restrict__ list_g, int H, int W)
+                                                       int *__restrict__ list_c, int *__restrict__ list_g,
+                                                       int H, int W)
 {
     const int b = blockIdx.y;
     const long long npix = (long long)H * W;
@@ -578,7 +581,7 @@ __global__ __launch_bounds__(256) void k_conn_classify(const int *__restrict__ b
     for (int slot = blockIdx.x * 256 + threadIdx.x; slot < n_big; slot += gridDim.x * 256) {
         const int r = big_list[b * npix + slot];
         if (r < first_kept) { final_[b * npix + r] = -1; continue; }   // before the first kept component: label 0
-        int tier = 2;
+        int tier = 3;
         if (slot < SBOX_CAP) {
             const int *bb = sbox + ((long long)b * SBOX_CAP + slot) * 4;
             const int y0 = max(bb[0] - 1, 0), y1 = min(bb[1] + 1, H - 1);
@@ -588,10 +591,12 @@ __global__ __launch_bounds__(256) void k_conn_classify(const int *__restrict__ b
             if (area <= 65535) {
                 if (area4 + BFS_RING_A * 2 <= BFS_LDS_A) tier = 0;
                 else if (area4 + BFS_RING_B * 2 <= BFS_LDS_B) tier = 1;
+                else if (area4 + BFS_RING_B * 2 <= BFS_LDS_C) tier = 2;
             }
         }
         if (tier == 0) list_a[b * npix + atomicAdd(&misc[b].n_a, 1)] = slot;
         else if (tier == 1) list_b[b * npix + atomicAdd(&misc[b].n_todo1, 1)] = slot;
+        else if (tier == 2) list_c[b * npix + atomicAdd(&misc[b].n_c, 1)] = slot;
         else list_g[b * npix + atomicAdd(&misc[b].n_todo2, 1)] = slot;
     }
 }
@@ -619,11 +624,14 @@ __global__ __launch_bounds__(64) void k_conn_bfs_lds(const int *__restrict__ par
     const int *P = parent + (long long)b * npix;
     const int *BL = big_list + (long long)b * npix;
     int *F = final_ + (long long)b * npix;
-    const int n_items = tier == 0 ? misc[b].n_a : misc[b].n_todo1;
+    const int n_items = tier == 0 ? misc[b].n_a : (tier == 1 ? misc[b].n_todo1 : misc[b].n_c);
     int *todo_count = &misc[b].n_todo2;          // what fits no LDS tier after all goes to the global tier
     const int first_kept = misc[b].first_kept;
     const unsigned long long below = (1ull << lane) - 1ull;
     const int rmask = ring - 1;
+    // the replays of the larger tiers are the critical path of the pass (few, long, serial): let their
+    // instructions issue ahead of the many short waves that share the SIMD
+    if (tier > 0) __builtin_amdgcn_s_setprio(3);
 
     for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
         const int slot = list ? list[(long long)b * npix + it] : it;
@@ -901,7 +909,7 @@ __global__ void k_conn_init_misc(ConnMisc *misc, int B, int npix)
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B) {
         misc[b].n_small = 0; misc[b].first_kept = npix; misc[b].qalloc = 0; misc[b].n_kept = 0;
-        misc[b].n_todo1 = 0; misc[b].n_todo2 = 0; misc[b].n_big = 0; misc[b].n_over = 0; misc[b].n_a = 0;
+        misc[b].n_todo1 = 0; misc[b].n_todo2 = 0; misc[b].n_big = 0; misc[b].n_over = 0; misc[b].n_a = 0; misc[b].n_c = 0;
     }
 }
 
@@ -928,10 +936,11 @@ extern "C" int spa_enforce_connectivity(spa_ctx *ctx, const int32_t *labels_in, 
     big = tiny + (size_t)B * npix;
     if ((rc = spa_ws_reserve(ctx, WS_BLK, (size_t)B * 2 * nblk * 4, (void **)&blk)) != SPA_OK) return rc;
     if ((rc = spa_ws_reserve(ctx, WS_SBOX, (size_t)B * SBOX_CAP * 16, (void **)&sbox)) != SPA_OK) return rc;
-    int *todo0;
-    if ((rc = spa_ws_reserve(ctx, WS_TODO, 3 * img, (void **)&todo1)) != SPA_OK) return rc;
+    int *todo0, *todo3;
+    if ((rc = spa_ws_reserve(ctx, WS_TODO, 4 * img, (void **)&todo1)) != SPA_OK) return rc;
     todo2 = todo1 + (size_t)B * npix;
     todo0 = todo2 + (size_t)B * npix;
+    todo3 = todo0 + (size_t)B * npix;
     if ((rc = spa_aux_streams(ctx)) != SPA_OK) return rc;
     if ((rc = spa_ws_reserve(ctx, WS_CONNMISC, (size_t)B * sizeof(ConnMisc), (void **)&misc)) != SPA_OK) return rc;
 
@@ -964,16 +973,17 @@ extern "C" int spa_enforce_connectivity(spa_ctx *ctx, const int32_t *labels_in, 
                        min_size, sbox);
     // BFS replay of the small components.  The tiers are independent of each other (a component
     // only reads the roots of its neighbours), so they run concurrently: the lane tier (<= 32 pixels,
-    // one thread each) on a side stream, the 80 KB LDS tier on another, the 16 KB LDS tier here;
+    // one thread each) and the rare 80 KB LDS tier on a side stream, the 48 KB LDS tier on another,
+    // the 16 KB LDS tier here;
     // what fits no LDS tier (or overflows a frontier ring) goes to the global-memory wave tier after
     // the join.  Each tier is bound by its slowest replay (a thin 5 000-pixel component is ~1 ms of
     // dependent LDS steps), not by throughput.
     static bool attr_done = false;
     if (!attr_done) {
-        SPA_HIP(hipFuncSetAttribute((const void *)k_conn_bfs_lds, hipFuncAttributeMaxDynamicSharedMemorySize, BFS_LDS_B));
+        SPA_HIP(hipFuncSetAttribute((const void *)k_conn_bfs_lds, hipFuncAttributeMaxDynamicSharedMemorySize, BFS_LDS_C));
         attr_done = true;
     }
-    hipLaunchKernelGGL(k_conn_classify, dim3(8, B), dim3(256), 0, s, big, sbox, misc, final_, todo0, todo1, todo2, H, W);
+    hipLaunchKernelGGL(k_conn_classify, dim3(8, B), dim3(256), 0, s, big, sbox, misc, final_, todo0, todo1, todo3, todo2, H, W);
     SPA_HIP(hipEventRecord(ctx->ev_fork, s));
     SPA_HIP(hipStreamWaitEvent(ctx->aux[0], ctx->ev_fork, 0));
     SPA_HIP(hipStreamWaitEvent(ctx->aux[1], ctx->ev_fork, 0));
@@ -981,6 +991,8 @@ extern "C" int spa_enforce_connectivity(spa_ctx *ctx, const int32_t *labels_in, 
                        (const int *)todo1, todo2, misc, 1, final_, H, W, BFS_LDS_B, BFS_RING_B);
     hipLaunchKernelGGL(k_conn_bfs_lane, dim3(gb, B), dim3(256), 0, ctx->aux[0], parent, size, tiny, misc,
                        final_, H, W);
+    hipLaunchKernelGGL(k_conn_bfs_lds, dim3(64, B), dim3(64), BFS_LDS_C, ctx->aux[0], parent, size, big, sbox,
+                       (const int *)todo3, todo2, misc, 2, final_, H, W, BFS_LDS_C, BFS_RING_B);
     hipLaunchKernelGGL(k_conn_bfs_lds, dim3(1024, B), dim3(64), BFS_LDS_A, s, parent, size, big, sbox,
                        (const int *)todo0, todo2, misc, 0, final_, H, W, BFS_LDS_A, BFS_RING_A);
     SPA_HIP(hipEventRecord(ctx->ev_join[0], ctx->aux[0]));

@@ -234,8 +234,12 @@ extern "C" int spa_prof_read(spa_ctx *ctx, int slot, double *total_ms, int *laun
 int spa_aux_streams(spa_ctx *ctx)
 {
     if (ctx->aux_ready) return SPA_OK;
+    // aux[1] carries the few long, LDS-hungry replays of a call: highest priority, so that its
+    // workgroups are placed before the many small ones of the other streams fill the CUs
+    int prio_lo = 0, prio_hi = 0;
+    SPA_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
     for (int i = 0; i < 2; ++i) {
-        SPA_HIP(hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking));
+        SPA_HIP(hipStreamCreateWithPriority(&ctx->aux[i], hipStreamNonBlocking, i == 1 ? prio_hi : prio_lo));
         SPA_HIP(hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming));
     }
     SPA_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
