@@ -58,6 +58,10 @@ def parse():
     p.add_argument('--drn_sub_batch', type=int, default=0,
                    help='DRN forward in sub-batches of this many images (0 = the whole batch at once: fewest, largest '
                         'convolution launches; 30 x 1024x2048 fp32 needs ~25 GB of activations)')
+    p.add_argument('--drn_streams', type=int, default=1,
+                   help='parts of the batch run on side streams inside the DRN forward (epilogue passes of one part '
+                        'under the convolutions of the other): 2 shortens the forward by 2 %% but the label kernels '
+                        'that follow run slower by as much (measured), so the default is 1')
     p.add_argument('--no_cpu_baseline', action='store_true')
     p.add_argument('--cpu_sample', type=int, default=1, help='images of the CPU baseline sample')
     p.add_argument('--no_prof', action='store_true', help='do not record per-kernel events')
@@ -176,7 +180,7 @@ def main():
         felzenszwalb_scale=300.0, felzenszwalb_sigma=0.8, felzenszwalb_min_size=20,
         without_pos=False, y_rel_pos=0.75, x_rel_pos=0.5, y_rel_sigma=0.1, x_rel_sigma=0.1,
         gpu=local, n_clusters=a.n_clusters, use_feature_maps=[7], pool_mode=a.pool_mode,
-        mean_sampling='nearest', drn_sub_batch=a.drn_sub_batch or None)
+        mean_sampling='nearest', drn_sub_batch=a.drn_sub_batch or None, drn_streams=a.drn_streams)
     model = drn.create_drn(a.arch, device='cuda:%d' % local, dtype=dtype)
     overlap = a.overlap or a.pool_mode == 'anchor'
     pipe = pipeline.LabelPipeline(args, model, overlap=overlap)

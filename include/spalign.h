@@ -90,11 +90,12 @@ int spa_bias_act(spa_ctx *ctx, void *y, int32_t dtype, int64_t rows, int32_t C, 
  * (models/drn.py:134-145) with BatchNorm folded into weights and biases.
  * x (B,3,H,W) float32 planar 0..255; w0 (16,147) = the (16,3,7,7) weight flattened; w1 (16,144) =
  * the (16,16,3,3) weight permuted to (n, ky, kx, c); b0, b1 (16); y (B,H,W,16) channels-last,
- * out_dtype 0 = float32, 1 = bfloat16 (the arithmetic is float32 either way).                      */
+ * out_dtype 0 = float32, 1 = bfloat16 (the arithmetic is float32 either way).  xn_scratch: B*H*W*3
+ * floats for the normalised image, or NULL to use the context's workspace (then one call at a time). */
 int spa_drn_stem_d(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W,
                    const float *w0, const float *b0, const float *w1, const float *b1,
                    const double *mean3_host, const double *std3_host, void *y, int32_t out_dtype,
-                   void *stream);
+                   float *xn_scratch, void *stream);
 
 /* ---- SLIC superpixels ------------------------------------------------------------------
  * replaces batch_superpixel(), SLIC branch: batch_spalign_kmeans.py:308-311, i.e.

@@ -219,14 +219,15 @@ __global__ __launch_bounds__(256) void k_drn_stem_d(const float *__restrict__ xn
 extern "C" int spa_drn_stem_d(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W,
                               const float *w0, const float *b0, const float *w1, const float *b1,
                               const double *mean3_host, const double *std3_host, void *y, int32_t out_dtype,
-                              void *stream)
+                              float *xn_scratch, void *stream)
 {
     SPA_ARG(ctx && x && w0 && b0 && w1 && b1 && mean3_host && std3_host && y && B > 0 && H > 0 && W > 0);
     SPA_ARG(out_dtype == 0 || out_dtype == 1);
     // exact input normalisation (models/drn.py:319-321) into a channels-last workspace, then the stem
     SpaProfScope prof_(ctx, PROF_DRN_STEM, spa_stream(stream));
-    float *xn;
-    int rc = spa_ws_reserve(ctx, WS_STEM_IN, (size_t)B * H * W * 3 * sizeof(float), (void **)&xn);
+    float *xn = xn_scratch;          // caller-owned scratch lets several calls run on different streams
+    int rc = SPA_OK;
+    if (!xn) rc = spa_ws_reserve(ctx, WS_STEM_IN, (size_t)B * H * W * 3 * sizeof(float), (void **)&xn);
     if (rc != SPA_OK) return rc;
     rc = spa_drn_normalise(ctx, x, B, H, W, xn, 0, mean3_host, std3_host, stream);
     if (rc != SPA_OK) return rc;

@@ -252,10 +252,29 @@ class DRN(nn.Module):
         x = (x.double() / std).float()
         return x
 
+    def _forward_chunk(self, xc):
+        """One sub-batch: raw (b,3,H,W) float32 0..255 -> the 8 maps."""
+        eng = _EPILOGUE['engine']
+        if eng is not None and xc.is_cuda and getattr(self, '_stem', None) is not None and self.use_fused_stem:
+            l1 = eng.drn_stem_d(xc.float().contiguous(), *self._stem, dtype=self.compute_dtype)
+            return self.forward_maps(None, layer1_out=l1)
+        if eng is not None and xc.is_cuda:
+            xi = eng.drn_normalise(xc.float().contiguous(), self.compute_dtype)
+        else:
+            xi = self.normalise(xc.float())
+            xi = xi.to(self.compute_dtype).contiguous(memory_format=torch.channels_last)
+        return self.forward(xi)[1]
+
     @torch.no_grad()
-    def batch_predict(self, x, sub_batch=None):
+    def batch_predict(self, x, sub_batch=None, need=None, streams=1):
         """x: (B,3,H,W) float32 RGB 0..255 (numpy or tensor). -> (logits or None, [8 maps]).
 
+        need: indices of the maps the caller will use (the others come back as None: for the
+        default --use_feature_maps 7 that avoids keeping / concatenating 38 GB of activations per
+        batch of 30 full-size images).  streams: run that many parts of the batch on side streams
+        — the memory-bound epilogue passes of one part then run under the MFMA-bound convolutions
+        of another (2 parts of 15: the forward is 2 % shorter than with one part of 30, but in the
+        full pipeline the label kernels that follow lose as much, so callers leave it at 1).
         Unlike the reference's --gpu -1 path the input array is never modified (the GPU path
         of the reference copies it too, which is the behaviour the launchers rely on)."""
         dev = next(self.parameters()).device
@@ -264,26 +283,40 @@ class DRN(nn.Module):
             x = x.to(dev, non_blocking=True)
         assert x.ndim == 4 and x.shape[1] == 3
         B = x.shape[0]
-        sub = B if not sub_batch else sub_batch
-        outs = None
-        for s in range(0, B, sub):
-            eng = _EPILOGUE['engine']
-            if eng is not None and x.is_cuda and getattr(self, '_stem', None) is not None and self.use_fused_stem:
-                l1 = eng.drn_stem_d(x[s:s + sub].float().contiguous(), *self._stem, dtype=self.compute_dtype)
-                maps = self.forward_maps(None, layer1_out=l1)
-            else:
-                if eng is not None and x.is_cuda:
-                    xi = eng.drn_normalise(x[s:s + sub].float().contiguous(), self.compute_dtype)
-                else:
-                    xi = self.normalise(x[s:s + sub].float())
-                    xi = xi.to(self.compute_dtype).contiguous(memory_format=torch.channels_last)
-                _, maps = self.forward(xi)
-            if outs is None:
-                outs = [[m] for m in maps]
-            else:
-                for o, m in zip(outs, maps):
-                    o.append(m)
-        maps = [o[0] if len(o) == 1 else torch.cat(o, 0) for o in outs]
+        keep = set(range(8)) if need is None else set(int(i) for i in need)
+
+        def pick(maps):
+            return [m if i in keep else None for i, m in enumerate(maps)]
+
+        parts = []
+        if streams > 1 and x.is_cuda and B >= 2 * streams and not sub_batch:
+            if len(getattr(self, '_side', ())) < streams:
+                self._side = [torch.cuda.Stream(device=dev) for _ in range(streams)]
+            cur = torch.cuda.current_stream(dev)
+            per = (B + streams - 1) // streams
+            for i in range(streams):
+                lo, hi = i * per, min(B, (i + 1) * per)
+                if lo >= hi:
+                    break
+                st = self._side[i]
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    xc = x[lo:hi]
+                    xc.record_stream(st)
+                    parts.append(pick(self._forward_chunk(xc)))
+            for i in range(len(parts)):
+                cur.wait_stream(self._side[i])
+                for m in parts[i]:
+                    if m is not None:
+                        m.record_stream(cur)
+        else:
+            sub = B if not sub_batch else sub_batch
+            for s in range(0, B, sub):
+                parts.append(pick(self._forward_chunk(x[s:s + sub])))
+        maps = []
+        for i in range(8):
+            col = [p[i] for p in parts]
+            maps.append(None if col[0] is None else (col[0] if len(col) == 1 else torch.cat(col, 0)))
         return None, maps
 
     class _XP(object):

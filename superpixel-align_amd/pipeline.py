@@ -48,7 +48,9 @@ class LabelPipeline(object):
     # ---------------------------------------------------------------- stages
     def features(self, imgs_dev):
         """model.batch_predict + F.concat(use_maps) (:431-435) -> (B, C, fh, fw), channels-last."""
-        _, maps = self.model.batch_predict(imgs_dev, getattr(self.args, 'drn_sub_batch', None))
+        _, maps = self.model.batch_predict(imgs_dev, getattr(self.args, 'drn_sub_batch', None),
+                                           need=self.args.use_feature_maps,
+                                           streams=getattr(self.args, 'drn_streams', 1))
         use = [maps[i] for i in self.args.use_feature_maps]
         if len(use) == 1:
             return use[0]
