@@ -17,7 +17,8 @@
 #include "spa_common.h"
 
 #define KM_MAXK 8
-#define KM_THREADS 256
+#define KM_THREADS 1024      // 16 waves per workgroup: more points of the slice in flight per barrier interval
+#define KM_COMB 4096          // doubles of LDS for staging partial sums (>= workgroups * clusters)
 
 struct KmShared {
     unsigned barrier;      // monotonic arrival counter
@@ -49,6 +50,22 @@ __device__ __forceinline__ void grid_sync(unsigned *ctr, unsigned G, unsigned &e
     __syncthreads();
 }
 
+// sum of n LDS doubles at stride `stride`, in index order; 16 reads are issued together so that the
+// ordered additions do not each wait for an LDS round trip
+__device__ __forceinline__ double km_ordered_sum(const double *p, int n, int stride)
+{
+    double s = 0.0;
+    for (int q0 = 0; q0 < n; q0 += 16) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = p[(q0 + u < n ? q0 + u : n - 1) * stride];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (q0 + u < n) s = s + v[u];
+    }
+    return s;
+}
+
 template <typename T>
 __device__ __forceinline__ double ldx(const T *X, long long i) { return (double)X[i]; }
 
@@ -71,6 +88,8 @@ __global__ __launch_bounds__(KM_THREADS) void k_kmeans(const T *__restrict__ X, 
                                                        uint32_t *__restrict__ status)
 {
     extern __shared__ double lds_c[];          // k * D centres
+    __shared__ double comb[KM_COMB];          // partials staged for the ordered combination
+    __shared__ double den_s[KM_MAXK];
     const unsigned G = gridDim.x;
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     unsigned epoch = 0;
@@ -113,39 +132,61 @@ __global__ __launch_bounds__(KM_THREADS) void k_kmeans(const T *__restrict__ X, 
     int it = 0, st = 1;
     // phase == 0: unweighted means of the initial assignment (:150-151); afterwards the
     // weighted update (:163-171)
+#ifdef SPA_KM_TIMING
+    unsigned long long kt_[6] = {0, 0, 0, 0, 0, 0}, kt0_ = __builtin_readcyclecounter();
+#define KM_T(i) { unsigned long long n_ = __builtin_readcyclecounter(); kt_[i] += n_ - kt0_; kt0_ = n_; }
+#else
+#define KM_T(i)
+#endif
     for (int phase = 0;; ++phase) {
         // ---- partial sums of this workgroup's slice, thread t owns dimensions t, t+256, ...
         const int32_t *asg = new_assign;
-        for (int d = tid; d < D; d += KM_THREADS) {
-            double acc[KM_MAXK];
+        for (int d0 = tid; d0 < D; d0 += 3 * KM_THREADS) {
+            // this thread's (up to) three dimensions d0, d0+KM_THREADS, d0+2*KM_THREADS; the points of the slice in
+            // order, 8 rows of all three dimensions requested together so that the ordered
+            // additions do not each wait for their own row
+            double acc[3][KM_MAXK];
 #pragma unroll
-            for (int c = 0; c < KM_MAXK; ++c) acc[c] = 0.0;
-            // the points of the slice in order; 8 rows are requested together so that the
-            // sequential additions do not each wait for their own row
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int c = 0; c < KM_MAXK; ++c) acc[j][c] = 0.0;
             for (int i0 = lo; i0 < hi; i0 += 8) {
                 int aa[8];
-                double ww[8], xx[8];
+                double ww[8], xx[3][8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int i = i0 + u < hi ? i0 + u : hi - 1;
                     aa[u] = asg[i];
                     ww[u] = w[i];
-                    xx[u] = ldx(X, (long long)i * ld + d);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const int d = d0 + j * KM_THREADS;
+                        xx[j][u] = ldx(X, (long long)i * ld + (d < D ? d : D - 1));
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     if (i0 + u < hi) {
                         const int a = aa[u];
                         const double wi = (a == 0) ? ww[u] : 1.0 - ww[u];
-                        const double v = (phase > 0) ? xx[u] * wi : xx[u];
 #pragma unroll
-                        for (int c = 0; c < KM_MAXK; ++c) acc[c] = acc[c] + ((a == c) ? v : 0.0);
+                        for (int j = 0; j < 3; ++j) {
+                            const double v = (phase > 0) ? xx[j][u] * wi : xx[j][u];
+#pragma unroll
+                            for (int c = 0; c < KM_MAXK; ++c) acc[j][c] = acc[j][c] + ((a == c) ? v : 0.0);
+                        }
                     }
                 }
             }
 #pragma unroll
-            for (int c = 0; c < KM_MAXK; ++c)
-                if (c < k) part[((long long)g * k + c) * D + d] = acc[c];
+            for (int j = 0; j < 3; ++j) {
+                const int d = d0 + j * KM_THREADS;
+                if (d < D) {
+#pragma unroll
+                    for (int c = 0; c < KM_MAXK; ++c)
+                        if (c < k) part[((long long)g * k + c) * D + d] = acc[j][c];
+                }
+            }
         }
         if (tid < k) {
             double sw = 0.0;
@@ -155,7 +196,9 @@ __global__ __launch_bounds__(KM_THREADS) void k_kmeans(const T *__restrict__ X, 
             part_w[g * k + tid] = sw;
             part_n[g * k + tid] = cn;
         }
+        KM_T(0)
         grid_sync(&sh->barrier, G, epoch, status);
+        KM_T(1)
 
         // ---- convergence test of the sweep that produced new_assign (:158-159)
         if (phase > 0) {
@@ -163,36 +206,56 @@ __global__ __launch_bounds__(KM_THREADS) void k_kmeans(const T *__restrict__ X, 
             if (ch == 0) { st = 0; break; }
             for (int i = lo + tid; i < hi; i += KM_THREADS) assign[i] = new_assign[i];
         }
-        // ---- centres = sum over workgroups in order / denominator; slices of (c, d)
-        // (the additions keep their order, workgroup after workgroup; the LOADS of 16 partials are
-        // issued together, otherwise every addition would wait for its own trip to L2)
+        // ---- centres = sum over workgroups in order / denominator.  Workgroup g owns a slice of the
+        // (cluster, dimension) elements.  The additions keep their order, workgroup after workgroup,
+        // but the partials are fetched by ALL threads at once into LDS and then summed from there:
+        // one trip to L2 per pass instead of one per addition.
         bool empty = false;
         {
+            int *cnt_s = (int *)comb;                       // member counts, staged like the sums below
+            for (int idx = tid; idx < k * (int)G; idx += KM_THREADS) cnt_s[idx] = part_n[idx];
+            __syncthreads();
             int cn_mine = 0;             // lane c < k of every wave: members of cluster c
-            if (lane < k)
-                for (unsigned q = 0; q < G; ++q) cn_mine += part_n[q * k + lane];
-            empty = __ballot(lane < k && cn_mine == 0) != 0ull;
-        }
-        for (int e = g * KM_THREADS + tid; e < k * D; e += (int)G * KM_THREADS) {
-            const int c = e / D, d = e - c * D;
-            double s = 0.0, den = 0.0;
-            for (unsigned q0 = 0; q0 < G; q0 += 16) {
-                double ps[16], pw[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const unsigned q = q0 + u < G ? q0 + u : G - 1;
-                    ps[u] = part[((long long)q * k + c) * D + d];
-                    pw[u] = part_w[q * k + c];
-                }
-#pragma unroll
-                for (int u = 0; u < 16; ++u)
-                    if (q0 + u < G) { s = s + ps[u]; den = den + pw[u]; }
+            if (lane < k) {
+#pragma unroll 16
+                for (unsigned q = 0; q < G; ++q) cn_mine += cnt_s[q * k + lane];
             }
-            double v = s / den;                 // 0/0 -> NaN for an empty cluster, like numpy
-            if (f32) v = (double)(float)v;      // the reference stores centres in X's dtype
-            centres[e] = v;
+            empty = __ballot(lane < k && cn_mine == 0) != 0ull;
+            __syncthreads();
         }
+        {
+            const int nE = k * D;
+            const int per_e = (nE + (int)G - 1) / (int)G;
+            const int e0 = min(nE, g * per_e), e1 = min(nE, e0 + per_e);
+            const int EC = KM_COMB / (int)G > 0 ? KM_COMB / (int)G : 1;    // elements per pass
+            // denominators: sum of part_w over workgroups, in order, per cluster
+            for (int idx = tid; idx < k * (int)G; idx += KM_THREADS) comb[idx] = part_w[idx];   // [q][c]
+            __syncthreads();
+            if (tid < k) {
+                den_s[tid] = km_ordered_sum(comb + tid, (int)G, k);
+            }
+            __syncthreads();
+            for (int eb = e0; eb < e1; eb += EC) {
+                const int ne = min(EC, e1 - eb);
+                for (int idx = tid; idx < ne * (int)G; idx += KM_THREADS) {
+                    const int el = idx / (int)G, q = idx - el * (int)G;
+                    const int e = eb + el, c = e / D, d = e - c * D;
+                    comb[idx] = part[((long long)q * k + c) * D + d];
+                }
+                __syncthreads();
+                for (int t = tid; t < ne; t += KM_THREADS) {
+                    const int e = eb + t, c = e / D;
+                    const double sm = km_ordered_sum(comb + t * (int)G, (int)G, 1);
+                    double v = sm / den_s[c];            // 0/0 -> NaN for an empty cluster, like numpy
+                    if (f32) v = (double)(float)v;      // the reference stores centres in X's dtype
+                    centres[e] = v;
+                }
+                __syncthreads();
+            }
+        }
+        KM_T(2)
         grid_sync(&sh->barrier, G, epoch, status);
+        KM_T(3)
         if (phase > 0 && empty) { st = 2; break; }      // (:173-181) after the update
         if (it >= max_iter) { st = 1; break; }
         for (int e = tid; e < k * D; e += KM_THREADS) lds_c[e] = centres[e];
@@ -201,7 +264,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_kmeans(const T *__restrict__ X, 
         // ---- assignment sweep (:155-157): one wavefront per point, lanes over dimensions
         ++it;
         int local_changed = 0;
-        for (int i = lo + wv; i < hi; i += 4) {
+        for (int i = lo + wv; i < hi; i += KM_THREADS / 64) {
             double dist[KM_MAXK];
 #pragma unroll
             for (int c = 0; c < KM_MAXK; ++c) dist[c] = 0.0;
@@ -237,7 +300,11 @@ __global__ __launch_bounds__(KM_THREADS) void k_kmeans(const T *__restrict__ X, 
         if (lane == 0 && local_changed)
             __hip_atomic_fetch_add(&changed[it], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
+        KM_T(4)
     }
+#ifdef SPA_KM_TIMING
+    if (g == 0 && tid == 0) printf("kmeans cycles (workgroup 0): partial sums %llu | barrier %llu | centres %llu | barrier %llu | sweep %llu ; iterations %d, G %u\n", kt_[0], kt_[1], kt_[2], kt_[3], kt_[4], it, G);
+#endif
     if (g == 0 && tid == 0) { info[0] = it; info[1] = st; info[2] = N; info[3] = 0; }
 }
 
