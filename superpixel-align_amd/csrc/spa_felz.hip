@@ -354,7 +354,7 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass(const unsigned long long
     for (long long lo = zcount[b]; lo < g.nE; lo += T * FZ_EPT) {   // zero-cost edges: done up front
         if (tg == 0) me->pad[2] += 1;                           // diagnostics: windows
         // flattening the forest keeps the trees shallow; it costs a sweep over the image, so it is
-        // done every `flatten_every` windows (about once per npix/16 edges)
+        // done every `flatten_every` windows (about once per npix/4 edges)
         if ((win++ % flatten_every) == 0) {
             for (long long p = tg; p < npix; p += T) {
                 int q = P[p];
@@ -635,7 +635,9 @@ static int fz_run(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t 
     if (const char *e = getenv("SPA_FZ_GROUP")) G = atoi(e) > 0 ? atoi(e) : 1;
     if ((long long)G * B > ctx->n_cu) G = ctx->n_cu / B > 0 ? ctx->n_cu / B : 1;
     SPA_ARG((long long)G * B <= ctx->n_cu);
-    long long fe = npix / (16ll * G * FZ_THREADS * FZ_EPT);
+    long long fdiv = 4;          // about 4 sweeps per image worth of edges (measured: 2-4 best, 16+ slower)
+    if (const char *e = getenv("SPA_FZ_FLATTEN_DIV")) fdiv = atoi(e) > 0 ? atoi(e) : 4;       // experiments
+    long long fe = npix / (fdiv * G * FZ_THREADS * FZ_EPT);
     const int flatten_every = fe < 1 ? 1 : (int)fe;
     // scale = float(scale) / 255.
     const double k = scale / 255.0;
