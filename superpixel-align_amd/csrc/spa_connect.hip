@@ -281,7 +281,7 @@ __global__ void k_conn_reset_qalloc(ConnMisc *misc, int B)
 // ---------------------------------------------------------------------------------------
 #define SCAN_PX 1024
 #define SBOX_CAP 65536      // big-small components with an index below this get a bounding box
-#define LANE_MAX 32
+#define LANE_MAX 16
 
 __device__ __forceinline__ void load4_roots(const int *P, int base, int npix, bool aligned, int pv[4])
 {
