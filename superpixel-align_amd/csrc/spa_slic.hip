@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void k_slic_assign(const float *__restrict__ l
             // compiler can overlap the next entry's reads with this entry's arithmetic.  The
             // float arithmetic runs on pixel pairs (v_pk_add_f32 / v_pk_mul_f32: two IEEE float32
             // operations per instruction, each rounded exactly like the scalar one — no FMA).
-#pragma unroll 2
+#pragma unroll 1
             for (int j = 0; j < total; ++j) {
                 const uint4 e0 = cand[j * 3 + 0], e1 = cand[j * 3 + 1], e2 = cand[j * 3 + 2];
                 const int y0 = (int)e1.z, y1 = (int)e1.w, x0 = (int)e2.x, x1 = (int)e2.y;
