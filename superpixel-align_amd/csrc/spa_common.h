@@ -70,6 +70,7 @@ enum {
     WS_SLIC_ORDER,   // SLIC update: per-XCD longest-first segment lists + queue heads
     WS_OVERLAP,      // superpixel_overlaps baseline: road pixels per (image, superpixel)
     WS_STEM_IN,      // DRN-D stem: normalised channels-last input image
+    WS_SRGB_LUT,     // sRGB companding of the 256 integer channel values
     WS_FZ_KEYS,      // felzenszwalb: edge cost keys (in/out of the radix sort)
     WS_FZ_VALS,      // felzenszwalb: edge indices (in/out of the radix sort)
     WS_FZ_STATE,     // felzenszwalb: internal costs + reservation marks

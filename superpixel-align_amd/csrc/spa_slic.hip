@@ -28,18 +28,51 @@ __device__ __forceinline__ float lab_f(float s)
     return (float)7.787 * s + (float)(16.0 / 116.0);
 }
 
-__device__ __forceinline__ void rgb2lab_px(float r, float g, float b, float ratio, float &L,
-                                           float &A, float &Bc)
+// sRGB companding of one channel value, exactly as the reference evaluates it
+__device__ __forceinline__ float srgb_linear(float a)
+{
+    if (a > (float)0.04045) {
+        float u = (a + (float)0.055) / (float)1.055;
+        return (float)spa_det_exp(2.4 * spa_det_log_pos((double)u));
+    }
+    return a / (float)12.92;
+}
+
+// the 256 values a decoded 8-bit image can take (the reference passes 0..255 floats, unscaled):
+// one table per context, filled by this very function, so a table hit is bit-identical to the
+// evaluation it replaces and halves the transcendental work for such images
+__global__ void k_srgb_lut(float *__restrict__ lut)
+{
+    lut[threadIdx.x] = srgb_linear((float)threadIdx.x);
+}
+
+// does the image look like a decoded 8-bit one?  (a sample of the first image; the table path
+// still checks every value, so a wrong guess costs time, never correctness)
+__global__ void k_srgb_probe(const float *__restrict__ rgb, long long n, float *__restrict__ lut)
+{
+    const long long step = n / 4096 > 0 ? n / 4096 : 1;
+    bool ok = true;
+    for (int u = 0; u < 16; ++u) {
+        const long long i = ((long long)threadIdx.x * 16 + u) * step;
+        if (i < n) { const float a = rgb[i]; ok = ok && a >= 0.0f && a <= 255.0f && (float)(int)a == a; }
+    }
+    const int all = __syncthreads_and(ok ? 1 : 0);
+    if (threadIdx.x == 0) ((int *)lut)[256] = all;
+}
+
+template <bool TABLE>
+__device__ __forceinline__ void rgb2lab_px(float r, float g, float b, float ratio,
+                                           const float *__restrict__ lut, float &L, float &A, float &Bc)
 {
     float v[3] = {r, g, b};
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        float a = v[c];
-        if (a > (float)0.04045) {
-            float u = (a + (float)0.055) / (float)1.055;
-            v[c] = (float)spa_det_exp(2.4 * spa_det_log_pos((double)u));
+        const float a = v[c];
+        if (TABLE) {
+            const int ai = (int)a;
+            v[c] = (a >= 0.0f && a <= 255.0f && (float)ai == a) ? lut[ai] : srgb_linear(a);
         } else {
-            v[c] = a / (float)12.92;
+            v[c] = srgb_linear(a);
         }
     }
     float X = (float)0.412453 * v[0];
@@ -59,13 +92,11 @@ __device__ __forceinline__ void rgb2lab_px(float r, float g, float b, float rati
     Bc = ((float)200.0 * (fy - fz)) * ratio;
 }
 
-__global__ __launch_bounds__(256) void k_rgb2lab(const float *__restrict__ rgb,
-                                                 float *__restrict__ lab, long long npix,
-                                                 float ratio, int vec4)
+template <bool TABLE>
+__device__ __forceinline__ void rgb2lab_sweep(const float *__restrict__ src, float *__restrict__ dst,
+                                              long long npix, float ratio, int vec4,
+                                              const float *__restrict__ lut)
 {
-    const int b = blockIdx.y;
-    const float *src = rgb + (long long)b * 3 * npix;
-    float *dst = lab + (long long)b * 3 * npix;
     long long stride = (long long)gridDim.x * blockDim.x;
     if (vec4) {
         long long n4 = npix >> 2;
@@ -74,10 +105,10 @@ __global__ __launch_bounds__(256) void k_rgb2lab(const float *__restrict__ rgb,
             float4 g = ((const float4 *)(src + npix))[i];
             float4 bl = ((const float4 *)(src + 2 * npix))[i];
             float4 L, A, Bc;
-            rgb2lab_px(r.x, g.x, bl.x, ratio, L.x, A.x, Bc.x);
-            rgb2lab_px(r.y, g.y, bl.y, ratio, L.y, A.y, Bc.y);
-            rgb2lab_px(r.z, g.z, bl.z, ratio, L.z, A.z, Bc.z);
-            rgb2lab_px(r.w, g.w, bl.w, ratio, L.w, A.w, Bc.w);
+            rgb2lab_px<TABLE>(r.x, g.x, bl.x, ratio, lut, L.x, A.x, Bc.x);
+            rgb2lab_px<TABLE>(r.y, g.y, bl.y, ratio, lut, L.y, A.y, Bc.y);
+            rgb2lab_px<TABLE>(r.z, g.z, bl.z, ratio, lut, L.z, A.z, Bc.z);
+            rgb2lab_px<TABLE>(r.w, g.w, bl.w, ratio, lut, L.w, A.w, Bc.w);
             ((float4 *)dst)[i] = L;
             ((float4 *)(dst + npix))[i] = A;
             ((float4 *)(dst + 2 * npix))[i] = Bc;
@@ -85,12 +116,23 @@ __global__ __launch_bounds__(256) void k_rgb2lab(const float *__restrict__ rgb,
     } else {
         for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += stride) {
             float L, A, Bc;
-            rgb2lab_px(src[i], src[npix + i], src[2 * npix + i], ratio, L, A, Bc);
+            rgb2lab_px<TABLE>(src[i], src[npix + i], src[2 * npix + i], ratio, lut, L, A, Bc);
             dst[i] = L;
             dst[npix + i] = A;
             dst[2 * npix + i] = Bc;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_rgb2lab(const float *__restrict__ rgb,
+                                                 float *__restrict__ lab, long long npix,
+                                                 float ratio, int vec4, const float *__restrict__ lut)
+{
+    const int b = blockIdx.y;
+    const float *src = rgb + (long long)b * 3 * npix;
+    float *dst = lab + (long long)b * 3 * npix;
+    if (((const int *)lut)[256]) rgb2lab_sweep<true>(src, dst, npix, ratio, vec4, lut);     // wave-uniform
+    else rgb2lab_sweep<false>(src, dst, npix, ratio, vec4, lut);
 }
 
 extern "C" int spa_rgb2lab(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t W,
@@ -102,9 +144,15 @@ extern "C" int spa_rgb2lab(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H,
     long long work = vec4 ? npix / 4 : npix;
     int gx = (int)((work + 255) / 256);
     if (gx > 2048) gx = 2048;
+    float *lut;
+    const bool fresh = ctx->ws_bytes[WS_SRGB_LUT] == 0;
+    int rc = spa_ws_reserve(ctx, WS_SRGB_LUT, 257 * sizeof(float), (void **)&lut);
+    if (rc != SPA_OK) return rc;
+    if (fresh) hipLaunchKernelGGL(k_srgb_lut, dim3(1), dim3(256), 0, spa_stream(stream), lut);
+    hipLaunchKernelGGL(k_srgb_probe, dim3(1), dim3(256), 0, spa_stream(stream), rgb, 3 * npix, lut);
     { SpaProfScope prof_(ctx, PROF_RGB2LAB, spa_stream(stream));
     hipLaunchKernelGGL(k_rgb2lab, dim3(gx, B), dim3(256), 0, spa_stream(stream), rgb, lab, npix,
-                       ratio, vec4); }
+                       ratio, vec4, (const float *)lut); }
     SPA_LAUNCH_CHECK();
     return SPA_OK;
 }
