@@ -129,7 +129,13 @@ def test_baseline_drivers_on_synthetic_pngs(orc, synth, tmp_path):
     for name, main, extra in (('dc', cli.main_direct, []),
                               ('so', cli.main_overlaps, ['--overlap_threshold', '0.02'])):
         out = tmp_path / name
-        assert main(common + extra + ['--out_dir', str(out)]) == 0
+        zip_path = tmp_path / (name + '_labels.zip')
+        assert main(common + extra + ['--out_dir', str(out), '--label_zip', str(zip_path)]) == 0
+        import zipfile
+        with zipfile.ZipFile(str(zip_path)) as zf:            # README.md:135 label archive, written by the driver
+            members = zf.namelist()
+            assert len(members) == n and all(m.endswith('leftImg8bit.npy') for m in members)
+            assert all(zf.getinfo(m).compress_type == zipfile.ZIP_STORED for m in members)
         lines = [json.loads(l) for l in open(out / 'result.json')]
         assert len(lines) == n
         for l in lines:
