@@ -412,10 +412,16 @@ __global__ __launch_bounds__(256) void k_slic_assign(const float *__restrict__ l
 #define UPD_WAVES 4                        // independent segments per workgroup
 #define UPD_ROUND 128                      // pixels staged per round (two loads of 64 per plane)
 #define UPD_ROW (UPD_ROUND + 36)           // floats per staging row (+read-ahead slack; 164 % 64 = 36 spreads the 5 rows over LDS banks)
-#define UPD_PCAP 512                       // piece-list capacity (entries: row in window << 5 | piece)
+#define UPD_PCAP 512                       // piece-list capacity (entries: row in window << 8 | piece)
+#define UPD_PWMAX 8                        // occupancy words per 8-row group: 8 x 8 pieces x 64 pixels = 4096 pixels
+#define UPD_XBITS 12                       // stream codes: row in window << 12 | x
 #define UPD_ICAP 2048                      // index-buffer capacity (pixels)
 
-// one round in flight: packed (row << 11 | x) and Lab of 2 x 64 stream pixels
+// one round in flight: packed (row << UPD_XBITS | x) and Lab of 2 x 64 stream pixels
+template <int PWM> struct UpdEntry;
+template <> struct UpdEntry<4> { typedef unsigned short type; static constexpr int piece_bits = 5; };
+template <> struct UpdEntry<8> { typedef unsigned type; static constexpr int piece_bits = 8; };
+
 struct UpdRound { unsigned code[2]; float vL[2], vA[2], vB[2]; int fill; };
 
 #ifdef SPA_UPD_TIMING      // development aid: per-phase wave cycles summed into the words after the queue heads
@@ -496,6 +502,9 @@ __global__ __launch_bounds__(1024) void k_slic_order(const uint32_t *__restrict_
     }
 }
 
+// PWM = occupancy words per 8-row group the image width needs: 4 (<= 2048 pixels, 16-bit list entries)
+// or 8 (<= 4096 pixels, 32-bit list entries)
+template <int PWM>
 __global__ __launch_bounds__(256)
 void k_slic_update(const float *__restrict__ lab, uint32_t *__restrict__ cen, int nC, int B, int H,
                    int W, int s2y, int s2x, unsigned long long *__restrict__ rowmask, int HG, int PW,
@@ -505,13 +514,15 @@ void k_slic_update(const float *__restrict__ lab, uint32_t *__restrict__ cen, in
 {
     __shared__ __attribute__((aligned(16))) float stage_s[UPD_WAVES][5 * UPD_ROW];
     __shared__ unsigned idx_s[UPD_WAVES][UPD_ICAP];
-    __shared__ unsigned short plist_s[UPD_WAVES][UPD_PCAP];
+    typedef typename UpdEntry<PWM>::type entry_t;
+    constexpr int PB = UpdEntry<PWM>::piece_bits;
+    __shared__ entry_t plist_s[UPD_WAVES][UPD_PCAP];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int xcd = (int)(blockIdx.x & 7u);          // workgroups are dealt round-robin to the XCDs
     const int qlo = xcd * per_xcd, qn = min(B * nC, qlo + per_xcd) - qlo;
     float *st = stage_s[wv];
     unsigned *idx = idx_s[wv];
-    unsigned short *plist = plist_s[wv];
+    entry_t *plist = plist_s[wv];
     const unsigned W4 = (unsigned)W * 4u;
   for (;;) {
     int qi = 0;
@@ -546,12 +557,14 @@ void k_slic_update(const float *__restrict__ lab, uint32_t *__restrict__ cen, in
         {
             const int gg = gb + lane;
             const bool has = gg <= g1;
-            unsigned long long mw[4] = {0ull, 0ull, 0ull, 0ull};
+            unsigned long long mw[PWM];
+#pragma unroll
+            for (int i = 0; i < PWM; ++i) mw[i] = 0ull;
             int cntl = 0;
             unsigned long long *w = rm + (long long)gg * PW;
             if (has) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < PWM; ++i)
                     if (i < PW) { mw[i] = w[i]; cntl += __popcll(mw[i]); }
             }
             const int inc = upd_wave_scan(cntl);
@@ -561,18 +574,18 @@ void k_slic_update(const float *__restrict__ lab, uint32_t *__restrict__ cen, in
             npieces = __builtin_amdgcn_readfirstlane(gtake ? __shfl(inc, gtake - 1) : 0);
             if (take && cntl) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < PWM; ++i)
                     if (i < PW && mw[i]) w[i] = 0ull;                             // consumed
                 int pos = inc - cntl;
                 const int yrel = (gg << 3) - ybase;
 #pragma unroll 1
                 for (int r = 0; r < 8; ++r) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
+                    for (int i = 0; i < PWM; ++i) {
                         unsigned long long bits = (mw[i] >> r) & 0x0101010101010101ull;
                         while (bits) {
                             const int q = (__ffsll((long long)bits) - 1) >> 3;
-                            plist[pos++] = (unsigned short)(((yrel + r) << 5) | (i * 8 + q));
+                            plist[pos++] = (entry_t)(((unsigned)(yrel + r) << PB) | (unsigned)(i * 8 + q));
                             bits &= bits - 1ull;
                         }
                     }
@@ -592,10 +605,10 @@ void k_slic_update(const float *__restrict__ lab, uint32_t *__restrict__ cen, in
         unsigned code_n;
         auto fetch_masks = [&](int e) {
             const unsigned pe = (unsigned)plist[min(e + lane, npieces - 1)];
-            const int yrel = (int)(pe >> 5), pc = (int)(pe & 31u);
+            const int yrel = (int)(pe >> PB), pc = (int)(pe & ((1u << PB) - 1u));
             fa_n = fm + (long long)(ybase + yrel - wy0) * PWF + (pc - pc0);
             raw_n = *fa_n;
-            code_n = ((unsigned)yrel << 11) | ((unsigned)pc << 6);
+            code_n = ((unsigned)yrel << UPD_XBITS) | ((unsigned)pc << 6);
         };
         // ---- the stream of this list: the index buffer is refilled when its last round has been
         // ISSUED (issued rounds carry their codes in registers), so rounds of the next part are in
@@ -653,7 +666,7 @@ void k_slic_update(const float *__restrict__ lab, uint32_t *__restrict__ cen, in
                 // lanes past the end re-read pixel 0 of the buffer (cached) and stage zeros
                 const bool ok = p < R.fill;
                 const unsigned v = idx[ok ? lr * UPD_ROUND + p : 0];
-                const unsigned off = (unsigned)(ybase + (int)(v >> 11)) * W4 + ((v & 2047u) << 2);
+                const unsigned off = (unsigned)(ybase + (int)(v >> UPD_XBITS)) * W4 + ((v & ((1u << UPD_XBITS) - 1u)) << 2);
                 R.code[g] = ok ? v : 0xFFFFFFFFu;
                 R.vL[g] = *(const float *)((const char *)pL + off);
                 R.vA[g] = *(const float *)((const char *)pA + off);
@@ -669,8 +682,8 @@ void k_slic_update(const float *__restrict__ lab, uint32_t *__restrict__ cen, in
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
                     float *d = st + g * 64 + lane;
-                    d[0 * UPD_ROW] = (float)(ybase + (int)(R.code[g] >> 11));
-                    d[1 * UPD_ROW] = (float)(int)(R.code[g] & 2047u);
+                    d[0 * UPD_ROW] = (float)(ybase + (int)(R.code[g] >> UPD_XBITS));
+                    d[1 * UPD_ROW] = (float)(int)(R.code[g] & ((1u << UPD_XBITS) - 1u));
                     d[2 * UPD_ROW] = R.vL[g];
                     d[3 * UPD_ROW] = R.vA[g];
                     d[4 * UPD_ROW] = R.vB[g];
@@ -680,8 +693,8 @@ void k_slic_update(const float *__restrict__ lab, uint32_t *__restrict__ cen, in
                 for (int g = 0; g < 2; ++g) {
                     const bool ok = R.code[g] != 0xFFFFFFFFu;
                     float *d = st + g * 64 + lane;
-                    d[0 * UPD_ROW] = ok ? (float)(ybase + (int)(R.code[g] >> 11)) : 0.0f;
-                    d[1 * UPD_ROW] = ok ? (float)(int)(R.code[g] & 2047u) : 0.0f;
+                    d[0 * UPD_ROW] = ok ? (float)(ybase + (int)(R.code[g] >> UPD_XBITS)) : 0.0f;
+                    d[1 * UPD_ROW] = ok ? (float)(int)(R.code[g] & ((1u << UPD_XBITS) - 1u)) : 0.0f;
                     d[2 * UPD_ROW] = ok ? R.vL[g] : 0.0f;
                     d[3 * UPD_ROW] = ok ? R.vA[g] : 0.0f;
                     d[4 * UPD_ROW] = ok ? R.vB[g] : 0.0f;
@@ -786,8 +799,8 @@ extern "C" int spa_slic_core(spa_ctx *ctx, const float *lab, int32_t B, int32_t 
     rc = spa_ws_reserve(ctx, WS_CENTRES, (size_t)B * nC * CEN_WORDS * 4, (void **)&cen);
     if (rc != SPA_OK) return rc;
     const int s2y = 2 * pl.win_step_y, s2x = 2 * pl.win_step_x;
-    SPA_ARG(W <= 2048);      // occupancy masks: <= 32 pieces of 64 pixels per row (piece-list encoding)
-    SPA_ARG(4 * pl.win_step_y + 24 < 2048);   // piece-list rows are 11-bit offsets into the search window
+    SPA_ARG(W <= 64 * 8 * UPD_PWMAX);         // occupancy words: <= 64 pieces of 64 pixels per row
+    SPA_ARG(4 * pl.win_step_y + 24 < (1 << 19)); // stream codes keep the row in the upper 20 bits
     const int HG = (H + 7) / 8;
     const int PW = (((W + 63) / 64) + 7) / 8;      // mask words per (centre, 8-row group)
     unsigned long long *rowmask;
@@ -810,7 +823,7 @@ extern "C" int spa_slic_core(spa_ctx *ctx, const float *lab, int32_t B, int32_t 
     int *upd_qhead = upd_order + upd_total;
     static int upd_wg_per_cu = 0;
     if (!upd_wg_per_cu) {
-        SPA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&upd_wg_per_cu, (const void *)k_slic_update, 256, 0));
+        SPA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&upd_wg_per_cu, (const void *)k_slic_update<8>, 256, 0));
         if (upd_wg_per_cu < 1) upd_wg_per_cu = 1;
     }
     int upd_grid = upd_wg_per_cu * ctx->n_cu;
@@ -836,9 +849,14 @@ extern "C" int spa_slic_core(spa_ctx *ctx, const float *lab, int32_t B, int32_t 
             SpaProfScope prof_(ctx, PROF_SLIC_UPDATE, s);
             hipLaunchKernelGGL(k_slic_order, dim3(8), dim3(1024), 0, s, cen, upd_total, upd_per_xcd, mean_px,
                                upd_order, upd_qhead);
-            hipLaunchKernelGGL(k_slic_update, dim3(upd_grid), dim3(256), 0, s, lab, cen, nC, B,
-                               H, W, s2y, s2x, rowmask, HG, PW, fine, RW, PWF, upd_per_xcd,
-                               (const int *)upd_order, upd_qhead, ctx->d_status);
+            if (PW <= 4 && 4 * pl.win_step_y + 24 < 2048)
+                hipLaunchKernelGGL(k_slic_update<4>, dim3(upd_grid), dim3(256), 0, s, lab, cen, nC, B,
+                                   H, W, s2y, s2x, rowmask, HG, PW, fine, RW, PWF, upd_per_xcd,
+                                   (const int *)upd_order, upd_qhead, ctx->d_status);
+            else
+                hipLaunchKernelGGL(k_slic_update<8>, dim3(upd_grid), dim3(256), 0, s, lab, cen, nC, B,
+                                   H, W, s2y, s2x, rowmask, HG, PW, fine, RW, PWF, upd_per_xcd,
+                                   (const int *)upd_order, upd_qhead, ctx->d_status);
             SPA_LAUNCH_CHECK();
         }
     }

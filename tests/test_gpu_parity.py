@@ -106,7 +106,8 @@ def test_connectivity_stress_golden(eng, orc, name):
 @pytest.mark.parametrize('seed,H,W,n', [(1, 40, 56, 6), (2, 33, 65, 5), (3, 17, 300, 9), (4, 300, 17, 9),
                                         (5, 64, 64, 64), (6, 128, 128, 400), (7, 250, 250, 3),
                                         (8, 480, 640, 100), (11, 512, 1024, 800), (10, 1024, 2048, 400),
-                                        (3, 256, 512, 1000), (4, 256, 512, 8), (6, 64, 2048, 40), (7, 300, 70, 25)])
+                                        (3, 256, 512, 1000), (4, 256, 512, 8), (6, 64, 2048, 40), (7, 300, 70, 25),
+                                        (3, 96, 4000, 60), (5, 200, 4096, 120), (6, 128, 2049, 40)])
 def test_slic_edge_shapes(eng, orc, synth, seed, H, W, n):
     """Odd widths (no float4 path), one-seed grids, more seeds than fit, n up to 800, full size."""
     img = synth.synth_image(seed, H, W)
