@@ -130,7 +130,9 @@ void orc_np_shuffle_i64(void *state, int64_t *a, int64_t n)
 
 /* ----------------------------------------------------------------------- */
 /* numpy pairwise summation (add.reduce along a contiguous axis):           */
-/* result = a[0] + pairwise(a[1:])                                          */
+/* result = identity 0 + pairwise(a[0:n]) — probed against numpy 1.26.4 and */
+/* 2.2.6 add.reduce on 1-D and last-axis reductions, and pinned by the      */
+/* near-tie fixtures tests/golden/kmeans_tie.npz                            */
 /* ----------------------------------------------------------------------- */
 static double pairwise_sum(const double *a, int64_t n)
 {
@@ -156,7 +158,7 @@ static double pairwise_sum(const double *a, int64_t n)
 static double np_sum(const double *a, int64_t n)
 {
     if (n == 0) return 0.0;
-    return a[0] + pairwise_sum(a + 1, n - 1);
+    return pairwise_sum(a, n);
 }
 
 static int cmp_double(const void *a, const void *b)
@@ -165,79 +167,115 @@ static int cmp_double(const void *a, const void *b)
     return (x > y) - (x < y);
 }
 
+/* float32 twin of pairwise_sum (numpy FLOAT_pairwise_sum: same blocking, float accumulators) */
+static float pairwise_sum_f(const float *a, int64_t n)
+{
+    if (n < 8) {
+        float r = 0.0f;
+        for (int64_t i = 0; i < n; ++i) r += a[i];
+        return r;
+    } else if (n <= 128) {
+        float r[8];
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        int64_t i;
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+        float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    } else {
+        int64_t n2 = n / 2;
+        n2 -= n2 % 8;
+        return pairwise_sum_f(a, n2) + pairwise_sum_f(a + n2, n - n2);
+    }
+}
+
 /*
  * kmeans(k, X, weights, n_iter=1000)   (:136-183)
- *   X (N, D) float64 row-major, w (N) float64.
+ *   X (N, D) row-major in T = float64 (descriptors with the position appended) or float32
+ *   (--without_pos), w (N) float64.  The arithmetic follows numpy's for that dtype:
+ *     - initial centres X[assign == i].mean(axis=0): sequential axis-0 sum IN T, divided by the
+ *       count in T;
+ *     - distances linalg.norm(X[:,None,:] - centers[None], axis=2): difference, square, pairwise
+ *       add.reduce and sqrt all IN T;
+ *     - update (X[m] * wj[m,None]).sum(0) / wj[m].sum(): products and sequential axis-0 sum in
+ *       float64 (float32 * float64 promotes), float64 pairwise weight sum, float64 division, and
+ *       the result is stored into the T centre array (rounded to float32 when T is float32).
  *   init_other: the shuffled `idx` vector for the points with w <= threshold (:147-149);
  *               NULL means k == 2 semantics (all ones).  Callers that emulate numpy's
  *               global RNG build it with orc_np_shuffle_i64.
  *   assign (N) int32 out; returns number of loop iterations executed (the iteration that
  *   detects convergence counts), status: 0 converged, 1 hit n_iter, 2 stopped on empty cluster.
  */
-int64_t orc_kmeans(int64_t k, const double *X, int64_t N, int64_t D, const double *w,
-                   const int64_t *init_other, int64_t n_iter, int32_t *assign, int32_t *status)
-{
-    double *sorted = (double *)malloc((size_t)N * sizeof(double));
-    memcpy(sorted, w, (size_t)N * sizeof(double));
-    qsort(sorted, (size_t)N, sizeof(double), cmp_double);
-    double thr = sorted[N / 2];
-    free(sorted);
-    int64_t m = 0;
-    for (int64_t i = 0; i < N; ++i) {
-        if (w[i] > thr) assign[i] = 0;
-        else { assign[i] = init_other ? (int32_t)init_other[m] : (int32_t)(m % (k - 1) + 1); ++m; }
-    }
-    double *centers = (double *)malloc((size_t)k * D * sizeof(double));
-    double *tmp = (double *)malloc((size_t)(D > N ? D : N) * sizeof(double));
-    int32_t *na = (int32_t *)malloc((size_t)N * sizeof(int32_t));
-    /* centers = stack([X[assign == i].mean(axis=0)])  — axis-0 reduce: sequential row adds */
-    for (int64_t c = 0; c < k; ++c) {
-        int64_t cnt = 0;
-        for (int64_t d = 0; d < D; ++d) centers[c * D + d] = 0.0;
-        for (int64_t i = 0; i < N; ++i) if (assign[i] == c) {
-            for (int64_t d = 0; d < D; ++d) centers[c * D + d] += X[i * D + d];
-            ++cnt;
-        }
-        for (int64_t d = 0; d < D; ++d)
-            centers[c * D + d] = cnt ? centers[c * D + d] / (double)cnt : NAN;
-    }
-    int64_t it = 0; *status = 1;
-    for (; it < n_iter; ) {
-        ++it;
-        int same = 1;
-        for (int64_t i = 0; i < N; ++i) {
-            int best = 0; double bd = 0.0;
-            for (int64_t c = 0; c < k; ++c) {
-                for (int64_t d = 0; d < D; ++d) { double t = X[i * D + d] - centers[c * D + d]; tmp[d] = t * t; }
-                double dist = sqrt(np_sum(tmp, D));
-                /* np.argmin: first minimum; a NaN is "smaller" than everything (first NaN wins) */
-                if (c == 0) { best = 0; bd = dist; }
-                else if (!isnan(bd) && (isnan(dist) || dist < bd)) { best = (int)c; bd = dist; }
-            }
-            na[i] = best;
-            if (na[i] != assign[i]) same = 0;
-        }
-        if (same) { *status = 0; break; }
-        memcpy(assign, na, (size_t)N * sizeof(int32_t));
-        /* centers[j] = (X[m] * wj[m,None]).sum(0) / wj[m].sum(),  w0 = w, wj = 1 - w */
-        int empty = 0;
-        for (int64_t c = 0; c < k; ++c) {
-            int64_t cnt = 0;
-            for (int64_t d = 0; d < D; ++d) centers[c * D + d] = 0.0;
-            for (int64_t i = 0; i < N; ++i) if (assign[i] == c) {
-                double wi = (c == 0) ? w[i] : 1.0 - w[i];
-                for (int64_t d = 0; d < D; ++d) centers[c * D + d] += X[i * D + d] * wi;
-                tmp[cnt++] = wi;
-            }
-            double ws = np_sum(tmp, cnt);
-            for (int64_t d = 0; d < D; ++d) centers[c * D + d] = centers[c * D + d] / ws;
-            if (cnt == 0) empty = 1;
-        }
-        if (empty) { *status = 2; break; }
-    }
-    free(centers); free(tmp); free(na);
-    return it;
+#define ORC_DEFINE_KMEANS(NAME, T, PWSUM, SQRT)                                                   \
+int64_t NAME(int64_t k, const T *X, int64_t N, int64_t D, const double *w,                        \
+             const int64_t *init_other, int64_t n_iter, int32_t *assign, int32_t *status)         \
+{                                                                                                 \
+    double *sorted = (double *)malloc((size_t)N * sizeof(double));                                \
+    memcpy(sorted, w, (size_t)N * sizeof(double));                                                \
+    qsort(sorted, (size_t)N, sizeof(double), cmp_double);                                         \
+    double thr = sorted[N / 2];                                                                   \
+    free(sorted);                                                                                 \
+    int64_t m = 0;                                                                                \
+    for (int64_t i = 0; i < N; ++i) {                                                             \
+        if (w[i] > thr) assign[i] = 0;                                                            \
+        else { assign[i] = init_other ? (int32_t)init_other[m] : (int32_t)(m % (k - 1) + 1); ++m; } \
+    }                                                                                             \
+    T *centers = (T *)malloc((size_t)k * D * sizeof(T));                                          \
+    double *acc = (double *)malloc((size_t)D * sizeof(double));                                   \
+    T *tmp = (T *)malloc((size_t)D * sizeof(T));                                                  \
+    double *tw = (double *)malloc((size_t)N * sizeof(double));                                    \
+    int32_t *na = (int32_t *)malloc((size_t)N * sizeof(int32_t));                                 \
+    for (int64_t c = 0; c < k; ++c) {                                                             \
+        int64_t cnt = 0;                                                                          \
+        for (int64_t d = 0; d < D; ++d) centers[c * D + d] = (T)0;                                \
+        for (int64_t i = 0; i < N; ++i) if (assign[i] == c) {                                     \
+            for (int64_t d = 0; d < D; ++d) centers[c * D + d] = centers[c * D + d] + X[i * D + d]; \
+            ++cnt;                                                                                \
+        }                                                                                         \
+        for (int64_t d = 0; d < D; ++d)                                                           \
+            centers[c * D + d] = cnt ? centers[c * D + d] / (T)cnt : (T)NAN;                      \
+    }                                                                                             \
+    int64_t it = 0; *status = 1;                                                                  \
+    for (; it < n_iter; ) {                                                                       \
+        ++it;                                                                                     \
+        int same = 1;                                                                             \
+        for (int64_t i = 0; i < N; ++i) {                                                         \
+            int best = 0; T bd = (T)0;                                                            \
+            for (int64_t c = 0; c < k; ++c) {                                                     \
+                for (int64_t d = 0; d < D; ++d) { T t = X[i * D + d] - centers[c * D + d]; tmp[d] = t * t; } \
+                T dist = SQRT(PWSUM(tmp, D));                                                     \
+                /* np.argmin: first minimum; a NaN is "smaller" than everything (first NaN wins) */ \
+                if (c == 0) { best = 0; bd = dist; }                                              \
+                else if (!isnan(bd) && (isnan(dist) || dist < bd)) { best = (int)c; bd = dist; }  \
+            }                                                                                     \
+            na[i] = best;                                                                         \
+            if (na[i] != assign[i]) same = 0;                                                     \
+        }                                                                                         \
+        if (same) { *status = 0; break; }                                                         \
+        memcpy(assign, na, (size_t)N * sizeof(int32_t));                                          \
+        /* centers[j] = (X[m] * wj[m,None]).sum(0) / wj[m].sum(),  w0 = w, wj = 1 - w */          \
+        int empty = 0;                                                                            \
+        for (int64_t c = 0; c < k; ++c) {                                                         \
+            int64_t cnt = 0;                                                                      \
+            for (int64_t d = 0; d < D; ++d) acc[d] = 0.0;                                         \
+            for (int64_t i = 0; i < N; ++i) if (assign[i] == c) {                                 \
+                double wi = (c == 0) ? w[i] : 1.0 - w[i];                                         \
+                for (int64_t d = 0; d < D; ++d) acc[d] += (double)X[i * D + d] * wi;              \
+                tw[cnt++] = wi;                                                                   \
+            }                                                                                     \
+            double ws = np_sum(tw, cnt);                                                          \
+            for (int64_t d = 0; d < D; ++d) centers[c * D + d] = (T)(acc[d] / ws);                \
+            if (cnt == 0) empty = 1;                                                              \
+        }                                                                                         \
+        if (empty) { *status = 2; break; }                                                        \
+    }                                                                                             \
+    free(centers); free(acc); free(tmp); free(tw); free(na);                                      \
+    return it;                                                                                    \
 }
+
+ORC_DEFINE_KMEANS(orc_kmeans, double, np_sum, sqrt)
+ORC_DEFINE_KMEANS(orc_kmeans_f32, float, pairwise_sum_f, sqrtf)
 
 /* paint (:193-199): cluster[p] = assign[offset + labels[p]]; road = cluster == 0 */
 void orc_paint(const int32_t *labels, int64_t npix, const int32_t *assign_img,

@@ -66,6 +66,8 @@ def lib():
         L.orc_np_shuffle_i64.argtypes = [_P, _P, _i64]
         L.orc_kmeans.restype = _i64
         L.orc_kmeans.argtypes = [_i64, _P, _i64, _i64, _P, _P, _i64, _P, _P]
+        L.orc_kmeans_f32.restype = _i64
+        L.orc_kmeans_f32.argtypes = [_i64, _P, _i64, _i64, _P, _P, _i64, _P, _P]
         L.orc_paint.restype = None
         L.orc_paint.argtypes = [_P, _i64, _P, _P, _P]
         L.orc_confusion.restype = None
@@ -259,7 +261,8 @@ def mean_pool(fmap_chw, labels, mode='nearest', S=None):
 # --------------------------------------------------------------------------- k-means
 def kmeans(k, X, weights, n_iter=1000, nprandom=None):
     """kmeans() :136-183. Returns (assign int32, iterations, status)."""
-    X = _c(X, np.float64); w = _c(weights, np.float64)
+    f32 = np.asarray(X).dtype == np.float32        # --without_pos descriptors: numpy computes in float32
+    X = _c(X, np.float32 if f32 else np.float64); w = _c(weights, np.float64)
     N, D = X.shape
     init_other = None
     ptr = None
@@ -270,8 +273,8 @@ def kmeans(k, X, weights, n_iter=1000, nprandom=None):
         (nprandom or NpRandom()).shuffle(init_other)
         ptr = init_other.ctypes.data
     assign = np.zeros(N, np.int32); status = np.zeros(1, np.int32)
-    it = lib().orc_kmeans(k, X.ctypes.data, N, D, w.ctypes.data, ptr, n_iter,
-                          assign.ctypes.data, status.ctypes.data)
+    fn = lib().orc_kmeans_f32 if f32 else lib().orc_kmeans
+    it = fn(k, X.ctypes.data, N, D, w.ctypes.data, ptr, n_iter, assign.ctypes.data, status.ctypes.data)
     return assign, int(it), int(status[0])
 
 

@@ -13,7 +13,7 @@ import types
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, golden
+from conftest import GOLDEN, golden, kmeans_tie_cases
 
 
 def _sha(a):
@@ -39,6 +39,12 @@ def test_rng_streams(orc):
         assert np.array_equal(a[:32], g['np_%d' % n])
 
 
+# pixels (of H*W) that differ from skimage.slic() run from RGB: the reference's float32 pow/cbrt are
+# numpy SVML kernels, up to 9 ulp from the correctly rounded value and machine dependent, whereas
+# the oracle and the HIP kernel evaluate ONE deterministic definition
+E2E_MISMATCH = {'slic_s0_1024x2048_n200': 63, 'slic_s0_512x1024_n200': 7, 'slic_s0_64x128_n20': 0,
+                'slic_s1_128x256_n100': 18, 'slic_s2_256x512_n100': 14, 'slic_s3_96x96_n30': 210,
+                'slic_s4_224x224_n100': 2, 'slic_s5_100x37_n12': 0}
 SLIC_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 'slic_s*.npz')))
 
 
@@ -64,8 +70,9 @@ def test_slic_core_and_connectivity_bit_exact(orc, synth, name):
     # machine dependent in the reference: numpy float32 pow is up to 9 ulp off on this host)
     full = orc.slic(img, n)
     assert np.array_equal(full, post)
-    agree = (full == g['e2e_skimage']).mean()
-    assert agree > 0.95, agree
+    # measured per fixture: pixels where the deterministic-Lab result differs from the untouched
+    # skimage.slic() call of batch_spalign_kmeans.py:311 on this host (0 .. 210 pixels)
+    assert int((full != g['e2e_skimage']).sum()) == E2E_MISMATCH[name], name
 
 
 def test_lab_within_tolerance_of_skimage(orc, synth):
@@ -83,6 +90,33 @@ def test_connectivity_stress(orc, name):
     mn, mx = (int(v) for v in g['meta'])
     post, _ = orc.enforce_connectivity(g['seg'].astype(np.int64), mn, mx)
     assert np.array_equal(post, g['post'].astype(np.int64))
+
+
+MEANPOOL_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 'meanpool_*.npz')))
+
+
+def assert_pooled_close(got, ref):
+    """north_star: 'pooled feature vectors within 1e-4 relative' — per descriptor, relative to its
+    largest component (a component that cancels to ~0 has no meaningful relative error of its own);
+    the float32 sums differ in order only, so the measured distance is ~5e-6."""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    assert got.shape == ref.shape
+    scale = np.abs(ref).max(axis=1, keepdims=True)
+    assert (np.abs(got - ref) <= 1e-4 * scale).all(), float((np.abs(got - ref) / scale).max())
+    assert (np.abs(got - ref) / scale).max() < 2e-5
+
+
+@pytest.mark.parametrize('name', MEANPOOL_CASES)
+@pytest.mark.parametrize('mode', ['nearest', 'bilinear'])
+def test_mean_pool_against_notebook_cell4(orc, name, mode):
+    """Mean mode vs the NumPy restatement of notebooks/Superpixel_Align.ipynb cell 4
+    (oracle/gen_golden_meanpool.py): ALL superpixels, nearest and corner-aligned bilinear."""
+    g = golden(name)
+    labels = g['labels'].astype(np.int32)
+    out = orc.mean_pool(g['fmap'], labels, mode)
+    assert out.shape[0] == g['counts'].size
+    assert_pooled_close(out, g['mean_' + mode])
+    assert np.array_equal(np.bincount(labels.ravel()), g['counts'])
 
 
 def _args(**kw):
@@ -163,6 +197,19 @@ def test_confusion_matches_chainercv_formula(orc):
     assert np.array_equal(orc.create_label_mask(lab), [[-1, -1, -1, 1], [0, 0, 1, 0]])
 
 
+def test_kmeans_near_ties_follow_numpy_rounding(orc):
+    """40 inputs that sit on the decision boundary of the reference's kmeans to within the rounding
+    noise of its distance sums (pairs that differ in the last bit of one parameter and flip one
+    assignment): the oracle must round exactly like numpy — sequential axis-0 centre sums, pairwise
+    add.reduce of the squared differences, float32 arithmetic for float32 descriptors."""
+    n = 0
+    for name, k, X, w, expect, idx in kmeans_tie_cases():
+        a, it, st = orc.kmeans(k, X, w, nprandom=orc.NpRandom(1111))
+        assert np.array_equal(a, expect), name
+        n += 1
+    assert n == 40
+
+
 FZ_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 'fz_s*.npz')))
 
 
@@ -176,9 +223,8 @@ def test_felzenszwalb_oracle_against_skimage_core(orc, synth, name):
     img = synth.synth_scene(seed, H, W, integer_valued=bool(integer))
     labels = orc.felzenszwalb(img, scale, sigma, min_size)
     assert np.array_equal(labels, g['pinned'].astype(np.int64))
-    # the untouched scikit-image call (machine-dependent exp and tie order): same partition here
-    same = (labels[:, 1:] == labels[:, :-1]) == (g['plain'][:, 1:] == g['plain'][:, :-1])
-    assert same.mean() > 0.99
+    # the untouched scikit-image call (machine-dependent exp and tie order): identical on all fixtures
+    assert np.array_equal(labels, g['plain'].astype(np.int64))
     if 'scipy_weights' in g.files:
         w, r = orc.fz_gauss_weights(sigma)
         np.testing.assert_allclose(w, g['scipy_weights'], rtol=1e-14)
