@@ -275,17 +275,31 @@ def _effective_range(args, n_data):
     return start, end
 
 
-def main_labelled(argv=None, get=None, make_pipe=None, originals=False):
+def append_result_line(path, line):
+    """:407-422 — one JSON object per image, appended with ONE write on an O_APPEND descriptor: lines of
+    the N processes the bash launchers start (utils/create_*_labels.sh) cannot interleave mid-line, and
+    every finished image is on disk before the next batch runs."""
+    data = (json.dumps(line) + '\n').encode()
+    fd = os.open(path, os.O_WRONLY | os.O_APPEND | os.O_CREAT, 0o644)
+    try:
+        os.write(fd, data)
+    finally:
+        os.close(fd)
+
+
+def main_labelled(argv=None, get=None, make_pipe=None, originals=False, make_model=None):
     """The labelled driver loop.  `get` / `make_pipe` select one of the three scripts that share it
     (batch_spalign_kmeans.py, direct_clustering.py, superpixel_overlaps.py); `originals`: the
-    pipeline also wants the undecimated uint8 images of the batch (superpixel_overlaps.py:322)."""
+    pipeline also wants the undecimated uint8 images of the batch (superpixel_overlaps.py:322);
+    `make_model`: factory replacing create_model (tests of the host logic inject a stub)."""
     args = (get or get_args)(argv)
     rank, ws, local = spdist.init()
     if ws > 1:
         args.gpu = local
     imgs_ds, labels_ds = create_dataset(args)
-    model = ops.create_model(args)
-    pipe = make_pipe(args, model, ops.engine()) if make_pipe else LabelPipeline(args, model, ops.engine())
+    model = (make_model or ops.create_model)(args)
+    pipe = make_pipe(args, model, None if make_model else ops.engine()) if make_pipe \
+        else LabelPipeline(args, model, ops.engine())
     orig_ds = ImageList(imgs_ds._paths, None, np.uint8, imgs_ds._open) if originals else None
     start, end = _effective_range(args, len(imgs_ds))
     if ws > 1:
@@ -297,7 +311,10 @@ def main_labelled(argv=None, get=None, make_pipe=None, originals=False):
     from concurrent.futures import ThreadPoolExecutor
     workers = ThreadPoolExecutor(max_workers=max(1, args.io_threads))
     loader = ThreadPoolExecutor(max_workers=1)
-    ranges = spdist.batch_ranges(start, end, args.batchsize) if end > start else []
+    # a range shorter than one batch that starts at image 0 makes the reference slice dataset[-k:end],
+    # which is empty, and crash in concat_examples; here that range is labelled as one smaller batch
+    ranges = [(max(lo, 0), hi) for lo, hi in spdist.batch_ranges(start, end, args.batchsize)] if end > start else []
+    path = os.path.join(args.out_dir, 'result.json')
 
     def finish(i, rm, cl, n_sp, info, times, st_all):
         img_fn, label_fn = imgs_ds._paths[i], labels_ds._paths[i]
@@ -313,60 +330,76 @@ def main_labelled(argv=None, get=None, make_pipe=None, originals=False):
         sc = score(rm, gt)
         line = result_line(args, img_fn, label_fn, sc, times, st_all)
         tn = int(((gt == 0) & (rm == 0)).sum())
-        return i, line, [i, tn, sc['FP'], sc['FN'], sc['TP'], n_sp, int(info[0]), int(info[1])]
+        timers = dict(times, elapsed_time=line['elapsed_time'], gpu=args.gpu)
+        return i, line, [i, tn, sc['FP'], sc['FN'], sc['TP'], n_sp, int(info[0]), int(info[1])] \
+            + spdist.pack_timers(timers)
+
+    records = []
+    own = {}
+
+    def drain(futs):
+        """Collect finished images; a single process appends their result.json lines NOW (the
+        reference appends one line per image as it goes, :407-422), so a failure in a later batch
+        loses nothing already computed.  Under torchrun rank 0 writes after the gather instead."""
+        for f in futs:
+            i, line, rec = f.result()
+            records.append(rec)
+            own[i] = line
+            if ws == 1:
+                append_result_line(path, line)
+            print('Road IoU:', line['road_iou'], os.path.basename(line['img_fn']))
 
     pending = []
-    nxt = loader.submit(imgs_ds.batch, ranges[0][0], ranges[0][1], workers) if ranges else None
-    for bi, (lo, hi) in enumerate(ranges):
-        st_all = time.time()
-        imgs = nxt.result()
-        if bi + 1 < len(ranges):
-            nxt = loader.submit(imgs_ds.batch, ranges[bi + 1][0], ranges[bi + 1][1], workers)
-        res = pipe.run(imgs, orig_ds.batch(lo, hi, workers)) if originals else pipe.run(imgs)
-        times = pipe.elapsed_times()
-        cluster, road = res.masks_to_host()
-        info = res.info.cpu().numpy()
-        n_sp = res.n_labels.cpu().numpy()
-        # a re-labelled image (last batch shifted back, :539-542) must overwrite its earlier files:
-        # wait for the previous batch's writers before queueing this batch's
-        for f in pending:
-            f.result()
-        for j, i in enumerate(list(range(len(imgs_ds)))[lo:hi]):
-            pending.append(workers.submit(finish, i, road[j], cluster[j], int(n_sp[j]), info, times, st_all))
-    lines, records = [], []
-    for f in pending:
-        i, line, rec = f.result()
-        lines.append((i, line))
-        records.append(rec)
-        print('Road IoU:', line['road_iou'], os.path.basename(line['img_fn']))
-    workers.shutdown()
-    loader.shutdown()
-    path = os.path.join(args.out_dir, 'result.json')
-    if ws == 1:
-        with open(path, 'a') as fp:                                    # reference: append
-            for _, line in lines:
-                print(json.dumps(line), file=fp)
-    else:
-        # one collective: fixed-size records; rank 0 rewrites the lines it did not produce from
-        # the gathered scores (file names come from the shared lists)
+    try:
+        nxt = loader.submit(imgs_ds.batch, ranges[0][0], ranges[0][1], workers) if ranges else None
+        for bi, (lo, hi) in enumerate(ranges):
+            st_all = time.time()
+            imgs = nxt.result()
+            if bi + 1 < len(ranges):
+                nxt = loader.submit(imgs_ds.batch, ranges[bi + 1][0], ranges[bi + 1][1], workers)
+            res = pipe.run(imgs, orig_ds.batch(lo, hi, workers)) if originals else pipe.run(imgs)
+            times = pipe.elapsed_times()
+            cluster, road = res.masks_to_host()
+            info = res.info.cpu().numpy()
+            n_sp = res.n_labels.cpu().numpy()
+            # a re-labelled image (last batch shifted back, :539-542) must overwrite its earlier files:
+            # wait for the previous batch's writers before queueing this batch's
+            done, pending = pending, []
+            drain(done)
+            for j, i in enumerate(list(range(len(imgs_ds)))[lo:hi]):
+                pending.append(workers.submit(finish, i, road[j], cluster[j], int(n_sp[j]), info, times, st_all))
+    finally:
+        # whatever was computed before an error (corrupt PNG, device status, OOM) still reaches disk
+        ok = [f for f in pending if f.exception() is None]
+        bad = [f for f in pending if f.exception() is not None]
+        drain(ok)
+        workers.shutdown()
+        loader.shutdown()
+    if bad:
+        raise bad[0].exception()
+    if ws > 1:
+        # one collective: fixed-size records (scores + the stage timers of the image's batch); rank 0
+        # rebuilds the lines it did not produce from them (file names come from the shared lists)
         allrec = spdist.gather_records(np.array(records, np.int64).reshape(-1, spdist.RECORD_WIDTH))
-        own = dict(lines)
         if rank == 0:
-            with open(path, 'a') as fp:
-                for r in allrec:                                        # rank order == index order
-                    i = int(r[0])
-                    if i in own:
-                        line = own[i]
-                    else:
-                        TP, FP, FN, TN = int(r[4]), int(r[2]), int(r[3]), int(r[1])
-                        conf = np.array([[TN, FP], [FN, TP]], np.float64)
-                        with np.errstate(divide='ignore', invalid='ignore'):
-                            iou = np.diag(conf) / (conf.sum(1) + conf.sum(0) - np.diag(conf))
-                        sc = dict(road_iou=float(iou[1]), non_road_iou=float(iou[0]),
-                                  precision=float(TP / (TP + FP)) if TP + FP else None,
-                                  recall=float(TP / (TP + FN)) if TP + FN else None, TP=TP, FP=FP, FN=FN)
-                        line = result_line(args, imgs_ds._paths[i], labels_ds._paths[i], sc, {}, time.time())
-                    print(json.dumps(line), file=fp)
+            order = np.argsort(allrec[:, 0], kind='stable') if len(allrec) else []
+            for r in allrec[order]:                                     # index order
+                i = int(r[0])
+                if i in own:
+                    line = own[i]
+                else:
+                    TP, FP, FN, TN = int(r[4]), int(r[2]), int(r[3]), int(r[1])
+                    conf = np.array([[TN, FP], [FN, TP]], np.float64)
+                    with np.errstate(divide='ignore', invalid='ignore'):
+                        iou = np.diag(conf) / (conf.sum(1) + conf.sum(0) - np.diag(conf))
+                    sc = dict(road_iou=float(iou[1]), non_road_iou=float(iou[0]),
+                              precision=float(TP / (TP + FP)) if TP + FP else None,
+                              recall=float(TP / (TP + FN)) if TP + FN else None, TP=TP, FP=FP, FN=FN)
+                    timers = spdist.unpack_timers(r)
+                    line = result_line(args, imgs_ds._paths[i], labels_ds._paths[i], sc, {}, time.time())
+                    line['gpu'] = int(timers.pop('gpu', args.gpu))
+                    line.update(timers)                                  # time_* and elapsed_time of its rank
+                append_result_line(path, line)
         spdist.barrier()
     if getattr(args, 'label_zip', None) and rank == 0:
         print('label archive: %d masks -> %s' % (write_label_zip(args.out_dir, args.label_zip), args.label_zip))
@@ -402,6 +435,7 @@ def main_labelfree(argv=None):
     from concurrent.futures import ThreadPoolExecutor
     io_pool = ThreadPoolExecutor(max_workers=max(1, args.io_threads))
     for lo, hi in spdist.batch_ranges(start, end, args.batchsize):
+        lo = max(lo, 0)                     # see main_labelled: a range shorter than one batch
         res = pipe.run(ds.batch(lo, hi, io_pool))
         _, road = res.masks_to_host()
         for j, i in enumerate(list(range(len(ds)))[lo:hi]):

@@ -15,9 +15,26 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-# one record per processed image: index, TN, FP, FN, TP, n_superpixels, kmeans_iters, kmeans_status
+# one record per processed image: index, TN, FP, FN, TP, n_superpixels, kmeans_iters, kmeans_status,
+# then the stage timers of its batch (result.json's time_* keys, batch_spalign_kmeans.py:428-458, and
+# elapsed_time, :421) as float64 bit patterns carried in the same int64 row, so that the lines rank 0
+# writes for images of other ranks have the same schema as its own
 RECORD_FIELDS = ('index', 'TN', 'FP', 'FN', 'TP', 'n_superpixels', 'kmeans_iters', 'kmeans_status')
-RECORD_WIDTH = len(RECORD_FIELDS)
+TIMER_FIELDS = ('time_superpixel', 'time_roialign', 'time_prior', 'time_kmeans', 'time_feature_maps',
+                'elapsed_time', 'gpu')
+RECORD_WIDTH = len(RECORD_FIELDS) + len(TIMER_FIELDS)
+
+
+def pack_timers(times):
+    """{timer key: seconds} -> len(TIMER_FIELDS) int64 words (float64 bit patterns; missing = NaN)."""
+    v = np.array([float(times.get(k, np.nan)) for k in TIMER_FIELDS], np.float64)
+    return v.view(np.int64).tolist()
+
+
+def unpack_timers(row):
+    """Inverse of pack_timers on one gathered record row; timers that were not recorded are dropped."""
+    v = np.asarray(row[len(RECORD_FIELDS):RECORD_WIDTH], np.int64).view(np.float64)
+    return {k: float(x) for k, x in zip(TIMER_FIELDS, v) if not np.isnan(x)}
 
 
 def world():
@@ -36,8 +53,14 @@ def init(backend=None):
             # a single-GPU box); production uses nccl (= RCCL over xGMI)
             backend = os.environ.get('SPA_DIST_BACKEND') or \
                 ('nccl' if torch.cuda.is_available() else 'gloo')
-        if backend == 'nccl':
-            torch.cuda.set_device(local)
+        if torch.cuda.is_available():
+            # bind this process to its GPU and create its spa_ctx BEFORE the process group exists:
+            # RCCL then initialises on the device the label kernels already use, and no rank ever
+            # touches device 0 by accident (SPA_BENCH_SAME_DEVICE: several ranks share GPU 0 in tests)
+            dev = 0 if os.environ.get('SPA_BENCH_SAME_DEVICE') == '1' else local
+            torch.cuda.set_device(dev)
+            from .engine import default_engine
+            default_engine()
         dist.init_process_group(backend, rank=rank, world_size=ws)
     return rank, ws, local
 

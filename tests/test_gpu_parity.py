@@ -11,7 +11,7 @@ import importlib
 import numpy as np
 import pytest
 
-from conftest import golden
+from conftest import golden, kmeans_tie_cases
 
 pytestmark = pytest.mark.gpu
 
@@ -237,6 +237,21 @@ def test_kmeans_engineered(eng, orc):
     ao, it, st = orc.kmeans(5, g['Xe'], g['we'], nprandom=orc.NpRandom(5))
     assert info.cpu().tolist()[:2] == [it, st]
     eng.raise_on_status()
+
+
+def test_kmeans_near_ties(eng):
+    """Inputs bisected onto the reference's decision boundary (tests/golden/kmeans_tie.npz): the
+    kernel's sums must round exactly like numpy's (sequential axis-0 centre sums, pairwise
+    add.reduce distances, float32 arithmetic for float32 descriptors) to get all 40 right."""
+    wrong = []
+    for name, k, X, w, expect, idx in kmeans_tie_cases():
+        n = dev(np.array([X.shape[0]], np.int32))
+        init = dev(idx) if k > 2 else None
+        a, info = eng.kmeans(dev(X), dev(w), n, k, init_other=init)
+        if not np.array_equal(a.cpu().numpy(), expect):
+            wrong.append(name)
+    eng.raise_on_status()
+    assert not wrong, wrong
 
 
 @pytest.mark.parametrize('sampling', ['nearest', 'bilinear'])

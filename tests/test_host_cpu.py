@@ -216,3 +216,136 @@ def test_label_archive_matches_find_zip_pipeline(tmp_path):
             assert ia.CRC == ib.CRC and ia.file_size == ib.file_size
             assert a.read(name) == b.read(name)
             assert not name.endswith('_all_cluster.npy')
+
+
+# --------------------------------------------------------------------------- the labelled driver, N ranks
+_CLI_WORKER = r'''
+import importlib, os, sys, time, numpy as np, torch
+sys.path.insert(0, %r)
+cli = importlib.import_module('superpixel-align_amd.cli')
+
+
+class StubResult(object):
+    def __init__(self, imgs):
+        # "road" = bright pixels of the red channel; three fake clusters
+        self.road = (imgs[:, 0] > 127).astype(np.uint8)
+        self.cluster = np.where(self.road == 1, 0, 1 + (imgs[:, 1] > 127)).astype(np.uint8)
+        self.info = torch.tensor([3, 0, 7, 0], dtype=torch.int32)
+        self.n_labels = torch.full((imgs.shape[0],), 5, dtype=torch.int32)
+
+    def masks_to_host(self):
+        return self.cluster, self.road
+
+
+class StubPipe(object):
+    """Stands in for LabelPipeline (no GPU here): the host logic around it is what is under test."""
+    def __init__(self, args, model, engine):
+        self.fail_at = int(os.environ.get('FAIL_AT_BATCH', '-1'))
+        self.n = 0
+
+    def run(self, imgs):
+        if self.n == self.fail_at:
+            raise RuntimeError('injected failure in batch %%d' %% self.n)
+        self.n += 1
+        return StubResult(imgs)
+
+    def elapsed_times(self):
+        return {'time_superpixel': 0.25, 'time_roialign': 0.5, 'time_prior': 0.0, 'time_kmeans': 0.125,
+                'time_feature_maps': 1.0}
+
+
+sys.exit(cli.main_labelled(sys.argv[1:], make_pipe=StubPipe, make_model=lambda a: None))
+'''
+
+
+def _make_png_dataset(tmp_path, n, H=16, W=24):
+    from PIL import Image
+    rs = np.random.RandomState(11)
+    imgs, labs = [], []
+    for i in range(n):
+        fn = tmp_path / ('city_%06d_000019_leftImg8bit.png' % i)
+        Image.fromarray(rs.randint(0, 256, size=(H, W, 3)).astype(np.uint8)).save(str(fn))
+        ln = tmp_path / ('city_%06d_000019_gtFine_labelIds.png' % i)
+        Image.fromarray(rs.randint(0, 12, size=(H, W)).astype(np.uint8)).save(str(ln))
+        imgs.append(str(fn)); labs.append(str(ln))
+    (tmp_path / 'imgs.txt').write_text('\n'.join(imgs) + '\n')
+    (tmp_path / 'labels.txt').write_text('\n'.join(labs) + '\n')
+    return imgs, labs
+
+
+def _run_cli_ranks(tmp_path, ws, extra, port, env_extra=None):
+    script = tmp_path / 'cli_worker.py'
+    script.write_text(_CLI_WORKER % ROOT)
+    out = tmp_path / ('out_ws%d_%d' % (ws, port))
+    argv = ['--img_file_list', str(tmp_path / 'imgs.txt'), '--label_file_list', str(tmp_path / 'labels.txt'),
+            '--out_dir', str(out), '--resize_shape', '16', '24', '--no_figure', '--io_threads', '2'] + extra
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), SPA_DIST_BACKEND='gloo',
+               **(env_extra or {}))
+    procs = []
+    for r in range(ws):
+        e = dict(env, RANK=str(r), WORLD_SIZE=str(ws), LOCAL_RANK=str(r)) if ws > 1 else env
+        procs.append(subprocess.Popen([sys.executable, str(script)] + argv, env=e,
+                                      stdout=subprocess.DEVNULL, stderr=subprocess.PIPE))
+    rcs = [p.wait(timeout=180) for p in procs]
+    lines = []
+    if (out / 'result.json').exists():
+        lines = [json.loads(l) for l in (out / 'result.json').read_text().splitlines()]
+    return rcs, lines, out, [p.stderr.read().decode() for p in procs]
+
+
+@pytest.mark.parametrize('ws,extra,n', [(2, [], 11), (4, [], 11), (4, ['--balanced'], 11), (4, [], 3)])
+def test_labelled_driver_under_n_ranks_gloo(tmp_path, ws, extra, n):
+    """cli.main_labelled end to end on N gloo ranks with a stub pipeline: the reference partition
+    (step = n // N + 1, so 3 images on 4 ranks leave rank 3 with an EMPTY shard), --balanced, one
+    gather, rank 0 writes result.json in index order with one schema for every row."""
+    imgs, labs = _make_png_dataset(tmp_path, n)
+    rcs, lines, out, err = _run_cli_ranks(tmp_path, ws, ['--batchsize', '2'] + extra, 29580 + ws + len(extra) + n)
+    assert rcs == [0] * ws, err
+    # every image once per batch it appears in; shards in rank order -> indices non-decreasing
+    idx = [imgs.index(l['img_fn']) for l in lines]
+    assert idx == sorted(idx) and set(idx) == set(range(n))
+    shards = [dist.shard_range(n, ws, r, balanced=bool(extra)) for r in range(ws)]
+    expect = []
+    for s, e in shards:
+        for lo, hi in (dist.batch_ranges(s, e, 2) if e > s else []):
+            expect += list(range(n))[max(lo, 0):hi]
+    assert sorted(expect) == idx                                   # incl. the shifted-back duplicates
+    keys = set(lines[0])
+    assert {'img_fn', 'label_fn', 'road_iou', 'TP', 'FP', 'FN', 'time_superpixel', 'time_roialign',
+            'time_prior', 'time_kmeans', 'elapsed_time', 'gpu', 'n_clusters'} <= keys
+    assert all(set(l) == keys for l in lines)                      # rows of other ranks: same schema
+    assert all(l['time_roialign'] == 0.5 for l in lines)
+    owner = {i: r for r, (s, e) in enumerate(shards) for i in range(s, e)}
+    if n > ws:
+        assert all(l['gpu'] == owner[imgs.index(l['img_fn'])] for l in lines)
+    # scores match a host recomputation, and every image has its two .npy files
+    from PIL import Image
+    for l in lines:
+        im = np.asarray(Image.open(l['img_fn']))
+        gt = cli.create_label_mask(np.asarray(Image.open(l['label_fn'])))
+        sc = cli.score((im[:, :, 0] > 127).astype(np.uint8), gt)
+        assert (l['TP'], l['FP'], l['FN']) == (sc['TP'], sc['FP'], sc['FN'])
+        base = os.path.splitext(os.path.basename(l['img_fn']))[0]
+        assert np.load(out / (base + '.npy')).dtype == np.uint8 and (out / (base + '_all_cluster.npy')).exists()
+
+
+def test_labelled_driver_keeps_finished_images_on_failure(tmp_path):
+    """A failure in batch 2 must not lose the result.json lines of batches 0 and 1 (the reference
+    appends one line per image as it goes, batch_spalign_kmeans.py:407-422)."""
+    imgs, labs = _make_png_dataset(tmp_path, 8)
+    rcs, lines, out, err = _run_cli_ranks(tmp_path, 1, ['--batchsize', '3'], 29571, {'FAIL_AT_BATCH': '2'})
+    assert rcs[0] != 0 and 'injected failure' in err[0]
+    assert [imgs.index(l['img_fn']) for l in lines] == [0, 1, 2, 3, 4, 5]
+
+
+def test_result_lines_from_concurrent_processes_do_not_interleave(tmp_path):
+    """The bash launchers start N processes that append to ONE result.json: every line must be
+    written by a single write() on an O_APPEND descriptor."""
+    path = str(tmp_path / 'result.json')
+    code = ("import importlib,sys;sys.path.insert(0,%r);cli=importlib.import_module('superpixel-align_amd.cli');"
+            "[cli.append_result_line(%r,{'p':int(sys.argv[1]),'i':i,'pad':'x'*9000}) for i in range(200)]"
+            % (ROOT, path))
+    procs = [subprocess.Popen([sys.executable, '-c', code, str(p)]) for p in range(4)]
+    assert [p.wait(timeout=120) for p in procs] == [0] * 4
+    rows = [json.loads(l) for l in open(path)]                     # any torn line fails to parse
+    assert len(rows) == 800 and sorted((r['p'], r['i']) for r in rows) == [(p, i) for p in range(4) for i in range(200)]
