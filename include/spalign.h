@@ -42,7 +42,7 @@ extern "C" {
 #define SPA_ERR_CAPACITY (-5) /* caller-provided capacity too small                     */
 
 /* bits of the device status word (spa_status) */
-#define SPA_ST_SLIC_EMPTY_SEGMENT 0x01u  /* a seed lost all pixels: skimage divides 0/0 there   */
+#define SPA_ST_SLIC_EMPTY_SEGMENT 0x01u  /* informational: a seed lost all pixels; NaN centre, dead afterwards (as skimage) */
 #define SPA_ST_SLIC_UNCOVERED 0x02u      /* a pixel fell outside every 2S search window         */
 #define SPA_ST_CONN_OVERSIZE 0x04u       /* a component reached max_size: handled by the slow exact path */
 #define SPA_ST_POOL_SLOT_OVERFLOW 0x08u  /* > SPA_CELL_SLOTS superpixels touch one feature pixel */

@@ -13,13 +13,16 @@ _LIB = None
 
 SPA_OK = 0
 STATUS_BITS = {
-    0x01: 'SLIC: a seed lost all of its pixels (scikit-image divides 0/0 there)',
+    0x01: 'SLIC: a seed lost all of its pixels (NaN centre, dead for the rest of the sweeps, as in scikit-image)',
     0x02: 'SLIC: a pixel fell outside every 2S search window',
-    0x04: 'connectivity: a component reached max_size (BFS-order cut not supported on the GPU path)',
+    0x04: 'connectivity: a component reached max_size (cut in BFS order by the exact replay path)',
     0x08: 'mean pooling: more than 16 superpixels touch one feature pixel',
     0x10: 'k-means: grid barrier timed out',
     0x20: 'a superpixel label outside [0, n_labels) was met',
 }
+
+# informational bits: the condition is handled exactly like the reference handles it; never an error
+INFO_BITS = 0x01 | 0x04
 
 c_i32 = ctypes.c_int32
 c_i64 = ctypes.c_int64

@@ -756,7 +756,18 @@ void k_slic_update(const float *__restrict__ lab, uint32_t *__restrict__ cen, in
     }
     UPD_TFLUSH(qhead)
     if (n == 0u) {
-        if (lane == 0) { atomicOr(status, SPA_ST_SLIC_EMPTY_SEGMENT); c[10] = 0u; }
+        // the seed lost all its pixels: scikit-image's 0/0 gives it a NaN centre, a NaN distance never
+        // wins `distance > dist_center`, and the NaN -> index casts that size its window yield an empty
+        // range (x86-64), so it stays dead for the remaining sweeps (tests/golden/slic_starve_*.npz).
+        // Here: NaN centre + empty window (never a candidate of any tile, no pixel ever again); the
+        // status bit is informational.
+        if (lane == 0) {
+            atomicOr(status, SPA_ST_SLIC_EMPTY_SEGMENT);
+            const uint32_t qnan = 0x7fc00000u;
+            c[0] = qnan; c[1] = qnan; c[2] = qnan; c[3] = qnan; c[4] = qnan;
+            c[6] = 0u; c[7] = 0u; c[8] = 0u; c[9] = 0u;
+            c[10] = 0u;
+        }
         continue;
     }
     float mean = acc / (float)n;      // segments[k, c] /= n_segment_elems[k]
@@ -780,7 +791,7 @@ __global__ void k_slic_export_centres(const uint32_t *__restrict__ cen, float *_
     if (i >= total) return;
     const uint32_t *c = cen + i * CEN_WORDS;
     float *o = out + i * 6;
-    o[0] = 0.0f;
+    o[0] = (c[0] == 0x7fc00000u && c[7] == 0u) ? __uint_as_float(0x7fc00000u) : 0.0f;   // dead seed: z is 0/0 too
     o[1] = __uint_as_float(c[0]); o[2] = __uint_as_float(c[1]);
     o[3] = __uint_as_float(c[2]); o[4] = __uint_as_float(c[3]); o[5] = __uint_as_float(c[4]);
 }

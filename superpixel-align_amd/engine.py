@@ -56,8 +56,12 @@ class Engine(object):
         check(self._lib.spa_status(self._ctx, ctypes.byref(v), _stream()))
         return v.value
 
-    def raise_on_status(self, ignore=0):
-        st = self.status() & ~ignore
+    def raise_on_status(self, ignore=_lib.INFO_BITS):
+        """Raise on latched error bits.  Informational bits (a starved SLIC seed, an oversize
+        component: both handled as scikit-image handles them) are collected in `self.last_info`."""
+        st = self.status()
+        self.last_info = st & _lib.INFO_BITS
+        st &= ~ignore
         if st:
             msgs = [m for bit, m in _lib.STATUS_BITS.items() if st & bit]
             raise SpalignError('device status 0x%x: %s' % (st, '; '.join(msgs)))

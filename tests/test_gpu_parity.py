@@ -239,6 +239,29 @@ def test_kmeans_engineered(eng, orc):
     eng.raise_on_status()
 
 
+@pytest.mark.parametrize('name', ['slic_starve_s0_24x40_n30', 'slic_starve_s2_40x64_n30',
+                                  'slic_starve_s5_32x32_n60', 'slic_starve_s6_40x64_n60'])
+def test_slic_starved_seeds(eng, orc, name):
+    """A seed that loses all its pixels gets a NaN centre and stays dead, as in scikit-image
+    (fixtures from the compiled core); the status bit is informational, nothing raises."""
+    g = golden(name)
+    seed, H, W, n, nC, mn, mx = (int(v) for v in g['meta'])
+    lab = orc.rgb2lab_scaled(g['img'])
+    labels, centres = eng.slic_core(dev(lab.transpose(2, 0, 1)[None]), n, want_centres=True)
+    assert np.array_equal(labels[0].cpu().numpy(), g['pre'].astype(np.int32))
+    c = centres[0].cpu().numpy()
+    assert np.array_equal(np.nonzero(np.isnan(c).any(axis=1))[0], g['dead'])
+    assert np.array_equal(np.isnan(c), np.isnan(g['centres']))
+    alive = ~np.isnan(c).any(axis=1)
+    assert np.array_equal(c[alive].view(np.int32), g['centres'][alive].view(np.int32))
+    # the whole slic() call from RGB, connectivity included, and the drivers' status check
+    full, n_labels = eng.slic(dev(g['img'][None]), n)
+    assert np.array_equal(full[0].cpu().numpy(), g['post'].astype(np.int32))
+    assert int(n_labels[0]) == int(g['post'].max()) + 1
+    eng.raise_on_status()
+    assert eng.last_info & 0x01
+
+
 def test_kmeans_near_ties(eng):
     """Inputs bisected onto the reference's decision boundary (tests/golden/kmeans_tie.npz): the
     kernel's sums must round exactly like numpy's (sequential axis-0 centre sums, pairwise

@@ -45,7 +45,7 @@ def test_rng_streams(orc):
 E2E_MISMATCH = {'slic_s0_1024x2048_n200': 63, 'slic_s0_512x1024_n200': 7, 'slic_s0_64x128_n20': 0,
                 'slic_s1_128x256_n100': 18, 'slic_s2_256x512_n100': 14, 'slic_s3_96x96_n30': 210,
                 'slic_s4_224x224_n100': 2, 'slic_s5_100x37_n12': 0}
-SLIC_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 'slic_s*.npz')))
+SLIC_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 'slic_s[0-9]_*.npz')))
 
 
 @pytest.mark.parametrize('name', SLIC_CASES)
@@ -73,6 +73,25 @@ def test_slic_core_and_connectivity_bit_exact(orc, synth, name):
     # measured per fixture: pixels where the deterministic-Lab result differs from the untouched
     # skimage.slic() call of batch_spalign_kmeans.py:311 on this host (0 .. 210 pixels)
     assert int((full != g['e2e_skimage']).sum()) == E2E_MISMATCH[name], name
+
+
+STARVE_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 'slic_starve_*.npz')))
+
+
+@pytest.mark.parametrize('name', STARVE_CASES)
+def test_slic_starved_seeds_follow_skimage(orc, name):
+    """Seeds that lose all their pixels (blocky noisy images): scikit-image gives them a 0/0 = NaN
+    centre and they never win a pixel again; labels and every centre (NaN rows included) match."""
+    g = golden(name)
+    seed, H, W, n, nC, mn, mx = (int(v) for v in g['meta'])
+    pre, centres = orc.slic_core(orc.rgb2lab_scaled(g['img']), n)
+    assert np.array_equal(pre, g['pre'].astype(np.int64))
+    assert np.array_equal(np.nonzero(np.isnan(centres).any(axis=1))[0], g['dead'])
+    assert np.isnan(centres[g['dead']]).all() and np.array_equal(np.isnan(centres), np.isnan(g['centres']))
+    alive = ~np.isnan(centres).any(axis=1)
+    assert np.array_equal(centres[alive], g['centres'][alive])
+    post, _ = orc.enforce_connectivity(pre, mn, mx)
+    assert np.array_equal(post, g['post'].astype(np.int64))
 
 
 def test_lab_within_tolerance_of_skimage(orc, synth):
