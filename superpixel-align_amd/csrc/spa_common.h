@@ -99,6 +99,10 @@ struct spa_ctx {
     hipStream_t aux[2];
     hipEvent_t ev_fork, ev_join[2];
     int aux_ready;
+    // per-context (= per-device) one-time kernel attributes and cached occupancy answers
+    int km_attr_done[2];
+    int conn_attr_done;
+    int upd_wg_per_cu;
 };
 
 int spa_aux_streams(spa_ctx *ctx);

@@ -978,10 +978,9 @@ extern "C" int spa_enforce_connectivity(spa_ctx *ctx, const int32_t *labels_in, 
     // what fits no LDS tier (or overflows a frontier ring) goes to the global-memory wave tier after
     // the join.  Each tier is bound by its slowest replay (a thin 5 000-pixel component is ~1 ms of
     // dependent LDS steps), not by throughput.
-    static bool attr_done = false;
-    if (!attr_done) {
+    if (!ctx->conn_attr_done) {        // per context = per device
         SPA_HIP(hipFuncSetAttribute((const void *)k_conn_bfs_lds, hipFuncAttributeMaxDynamicSharedMemorySize, BFS_LDS_C));
-        attr_done = true;
+        ctx->conn_attr_done = 1;
     }
     hipLaunchKernelGGL(k_conn_classify, dim3(8, B), dim3(256), 0, s, big, sbox, misc, final_, todo0, todo1, todo3, todo2, H, W);
     SPA_HIP(hipEventRecord(ctx->ev_fork, s));

@@ -1,33 +1,72 @@
-// Weighted k-means of the reference (batch_spalign_kmeans.py:136-183) as ONE persistent launch.
+// Weighted k-means of the reference (batch_spalign_kmeans.py:136-183) as ONE persistent launch whose
+// arithmetic is numpy's, operation for operation.
 //
-// The reference issues ~10 CuPy kernels and k host synchronisations per Lloyd iteration; the
-// problem itself is tiny (N = a few thousand superpixels of a batch, D = 514, k <= 8), so it
-// is latency bound.  Here one cooperative grid (<= one 256-thread workgroup per CU, all
-// co-resident) keeps the centres in LDS and runs every phase — median threshold of the prior
-// (:144), initial assignment (:141-149), unweighted initial centres (:150-151), assignment
-// (:155-157), convergence test (:158-159), weighted centre update (:163-171), empty-cluster
-// exit (:173-181) — separated by an agent-scope grid barrier, with the convergence flag and the
-// iteration count kept on the device.
+// The reference issues ~10 CuPy/NumPy kernels and k host synchronisations per Lloyd iteration; the
+// problem itself is tiny (N = a few thousand superpixels of a batch, D = 514, k <= 8), so it is latency
+// bound.  Here one grid (one 1024-thread workgroup per CU at most, all co-resident) runs every phase —
+// median threshold of the prior (:144), initial assignment (:141-149), unweighted initial centres
+// (:150-151), assignment (:155-157), convergence test (:158-159), weighted centre update (:163-171),
+// empty-cluster exit (:173-181) — separated by an agent-scope grid barrier, with the convergence flag
+// and the iteration count kept on the device.
 //
-// Determinism: every sum has a fixed order (per-workgroup sequential partial sums over a
-// contiguous slice of points, then a sequential sum over workgroups), so assignments do not
-// depend on scheduling.  Distances are sqrt of float64 sums like the reference's linalg.norm;
-// argmin takes the first minimum and lets a NaN distance win (numpy semantics, which is what
-// makes an initially empty cluster swallow every point).
+// Rounding is part of the contract (tests/golden/kmeans_tie.npz holds inputs that sit on the
+// reference's decision boundary to within the rounding noise of its sums), so every sum keeps numpy's
+// order:
+//   * distances, linalg.norm(X[:,None,:] - centers[None], axis=2): difference, square and sqrt in X's
+//     dtype; the D squares are added by numpy's PAIRWISE add.reduce: blocks of <= 128 elements, eight
+//     strided accumulators r[j] += a[i+j] per block combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)),
+//     the n % 8 tail added one by one, blocks combined by the recursive halving n2 = (n/2) - (n/2)%8.
+//     One wave per point: lane (q, j) carries accumulator j of block q (16 dependent adds), the eight
+//     accumulators meet in a xor-butterfly (1, 2, 4: exactly the bracket above, addition being
+//     commutative), and the block sums are combined by a small stack program built on the host.
+//   * centres, X[assign == c].mean(axis=0) and (X * w[:,None]).sum(0) / w.sum(): axis-0 reductions are
+//     SEQUENTIAL row additions in numpy, so each (cluster, column) is one serial chain over the
+//     cluster's members in index order.  A chain workgroup owns one cluster and 64 columns: all 16
+//     waves gather the next member rows (products x*w already rounded) into LDS, two chunks of loads
+//     in flight, while wave 0 adds the previous chunk row by row.  w.sum() is numpy's pairwise sum of
+//     the member weights (a separate workgroup per cluster).  float32 descriptors (--without_pos):
+//     initial means and distances in float32, weighted sums in float64, centres rounded to float32.
+//   * argmin takes the first minimum and lets a NaN distance win (numpy semantics, which is what makes
+//     an initially empty cluster swallow every point).
+// The median threshold is an 8-pass radix select (no O(N^2) ranking); the k > 2 initial assignment
+// uses an ordered prefix count of the points at or below the threshold.
 #include "spa_common.h"
 #include <stdlib.h>
 
 #define KM_MAXK 8
-#define KM_THREADS 1024      // 16 waves per workgroup: more points of the slice in flight per barrier interval
-#define KM_COMB 4096          // doubles of LDS for staging partial sums (>= workgroups * clusters)
+#define KM_THREADS 1024       // 16 waves per workgroup
+#define KM_WAVES (KM_THREADS / 64)
+#define KM_ROWS 128           // member rows per chain chunk (8 per wave)
+#define KM_MAXLEAF 48         // blocks of the pairwise tree over D (>= 57 elements each: D <= 2736 always fits)
+#define KM_CHUNK_BYTES (KM_ROWS * 64 * 8)
 
 struct KmShared {
     unsigned barrier;      // monotonic arrival counter
-    int n_changed;         // per-iteration flags live in `changed[]`
-    int thr_set;
-    int pad;
+    int pad0, pad1, pad2;
     double thr;
 };
+
+// numpy's pairwise summation tree over D elements, built on the host
+struct KmTree {
+    int nleaf, nops;
+    short leaf_start[KM_MAXLEAF], leaf_n[KM_MAXLEAF];
+    short ops[2 * KM_MAXLEAF];           // >= 0: push block sum; -1: pop two, push their sum
+};
+
+static bool km_build_tree(KmTree &t, int start, int n)
+{
+    if (n <= 128) {
+        if (t.nleaf >= KM_MAXLEAF) return false;
+        t.leaf_start[t.nleaf] = (short)start; t.leaf_n[t.nleaf] = (short)n;
+        t.ops[t.nops++] = (short)t.nleaf++;
+        return true;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    if (!km_build_tree(t, start, n2) || !km_build_tree(t, start + n2, n - n2)) return false;
+    t.ops[t.nops++] = -1;
+    return true;
+}
 
 __device__ __forceinline__ void grid_sync(unsigned *ctr, unsigned G, unsigned &epoch,
                                           uint32_t *status)
@@ -51,24 +90,145 @@ __device__ __forceinline__ void grid_sync(unsigned *ctr, unsigned G, unsigned &e
     __syncthreads();
 }
 
-// sum of n LDS doubles at stride `stride`, in index order; 16 reads are issued together so that the
-// ordered additions do not each wait for an LDS round trip
-__device__ __forceinline__ double km_ordered_sum(const double *p, int n, int stride)
+// LDS written and read back by the same wave
+__device__ __forceinline__ void km_wave_lds_sync()
 {
-    double s = 0.0;
-    for (int q0 = 0; q0 < n; q0 += 16) {
-        double v[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = p[(q0 + u < n ? q0 + u : n - 1) * stride];
-#pragma unroll
-        for (int u = 0; u < 16; ++u)
-            if (q0 + u < n) s = s + v[u];
-    }
-    return s;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <typename T>
-__device__ __forceinline__ double ldx(const T *X, long long i) { return (double)X[i]; }
+// order-preserving key of a double (ascending)
+__device__ __forceinline__ unsigned long long km_key(double v)
+{
+    unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
+}
+__device__ __forceinline__ double km_unkey(unsigned long long u)
+{
+    unsigned long long b = (u >> 63) ? (u & 0x7fffffffffffffffULL) : ~u;
+    return __longlong_as_double((long long)b);
+}
+
+// ordered exclusive rank of `flag` over the workgroup's threads; *total = number of flags.
+// scr: KM_WAVES + 1 ints of LDS.  Two workgroup barriers.
+__device__ __forceinline__ int km_wg_rank(bool flag, int *scr, int &total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(flag);
+    __syncthreads();                          // scr free to overwrite
+    if (lane == 0) scr[wv] = __popcll(m);
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < KM_WAVES; ++i) {
+        const int c = scr[i];
+        if (i < wv) off += c;
+        tot += c;
+    }
+    total = tot;
+    return off + (int)spa_rank_in_mask(m);
+}
+
+// numpy's pairwise sum of wl[0..n) (float64) by ONE wave: lanes 0..7 are the eight accumulators of the
+// current block; the recursion is emulated with an explicit (wave-uniform) stack.
+__device__ double km_pairwise_wave(const double *__restrict__ wl, int n)
+{
+    const int lane = threadIdx.x & 63, j = lane & 7;
+    int fs[40], fn[40], fst[40];
+    double fv[40];
+    int sp = 1;
+    fs[0] = 0; fn[0] = n; fst[0] = 0;
+    double ret = 0.0;
+    while (sp > 0) {
+        const int t = sp - 1;
+        if (fst[t] == 0) {
+            const int s0 = fs[t], nn = fn[t];
+            if (nn <= 128) {
+                double res = 0.0;
+                int i = 0;
+                if (nn >= 8) {
+                    double r = wl[s0 + j];
+                    for (i = 8; i < nn - (nn % 8); i += 8) r = r + wl[s0 + i + j];
+                    r = r + __shfl_xor(r, 1);
+                    r = r + __shfl_xor(r, 2);
+                    r = r + __shfl_xor(r, 4);
+                    res = r;
+                }
+                for (; i < nn; ++i) res = res + wl[s0 + i];
+                ret = res;
+                sp -= 1;
+            } else {
+                int n2 = nn / 2;
+                n2 -= n2 % 8;
+                fst[t] = 1;
+                fs[sp] = s0; fn[sp] = n2; fst[sp] = 0;
+                sp += 1;
+            }
+        } else if (fst[t] == 1) {
+            int n2 = fn[t] / 2;
+            n2 -= n2 % 8;
+            fv[t] = ret;
+            fst[t] = 2;
+            fs[sp] = fs[t] + n2; fn[sp] = fn[t] - n2; fst[sp] = 0;
+            sp += 1;
+        } else {
+            ret = fv[t] + ret;
+            sp -= 1;
+        }
+    }
+    return ret;
+}
+
+// Ordered list of the members of cluster c: indices (and their update weights) in index order.
+// All KM_THREADS threads; 8 consecutive points per thread and tile.  Returns the member count.
+__device__ int km_member_list(const int32_t *__restrict__ asg, const double *__restrict__ w, int N, int c,
+                              bool weighted, int32_t *__restrict__ ml, double *__restrict__ wl, int *scr)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int base = 0;
+    for (int t0 = 0; t0 < N; t0 += KM_THREADS * 8) {
+        const int i0 = t0 + tid * 8;
+        int a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = (i0 + u < N) ? asg[i0 + u] : -1;
+        int cnt = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cnt += (a[u] == c) ? 1 : 0;
+        // inclusive scan of cnt over the wave, then over the waves
+        int inc = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(inc, o);
+            if (lane >= o) inc += v;
+        }
+        __syncthreads();
+        if (lane == 63) scr[wv] = inc;
+        __syncthreads();
+        int off = 0, tot = 0;
+#pragma unroll
+        for (int i = 0; i < KM_WAVES; ++i) {
+            const int v = scr[i];
+            if (i < wv) off += v;
+            tot += v;
+        }
+        int pos = base + off + inc - cnt;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (a[u] == c) {
+                const int i = i0 + u;
+                ml[pos] = i;
+                if (wl) wl[pos] = weighted ? ((c == 0) ? w[i] : 1.0 - w[i]) : 1.0;
+                pos += 1;
+            }
+        }
+        base += tot;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                         // the list is read by other waves of this workgroup
+    return base;
+}
 
 // info: {iterations, status, N, -}
 template <typename T>
@@ -79,18 +239,32 @@ __global__ __launch_bounds__(KM_THREADS) void k_kmeans(const T *__restrict__ X, 
                                                        const long long *__restrict__ init_other,
                                                        int32_t *__restrict__ assign,
                                                        int32_t *__restrict__ new_assign,
-                                                       double *__restrict__ part,      // [G][k][D]
-                                                       double *__restrict__ part_w,    // [G][k]
-                                                       int *__restrict__ part_n,       // [G][k]
-                                                       double *__restrict__ centres,   // [k][D]
+                                                       double *__restrict__ sums,      // [k][D]
+                                                       double *__restrict__ wsum,      // [k]
+                                                       int *__restrict__ cnt_c,        // [k]
+                                                       int *__restrict__ part_n,       // [G]
+                                                       int32_t *__restrict__ mlist,    // [regions][Ncap]
+                                                       double *__restrict__ wlist,     // [regions][Ncap]
                                                        int *__restrict__ changed,      // [max_iter+2]
                                                        KmShared *__restrict__ sh,
                                                        int32_t *__restrict__ info,
-                                                       uint32_t *__restrict__ status)
+                                                       uint32_t *__restrict__ status,
+                                                       const KmTree tree)
 {
-    extern __shared__ double lds_c[];          // k * D centres
-    __shared__ double comb[KM_COMB];          // partials staged for the ordered combination
-    __shared__ double den_s[KM_MAXK];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    // [0, k*D*8): centres (T) | then KM_CHUNK_BYTES shared by the chain buffer and the sweep scratch
+    T *lds_c = (T *)lds_raw;
+    unsigned char *scratch = lds_raw + (((size_t)k * D * sizeof(double) + 15) & ~(size_t)15);
+    double *chunk = (double *)scratch;                           // [KM_ROWS][64]
+    // sweep scratch (aliases the chain buffer): stacks [wave][k][16] (16 KB), block sums [wave][nleaf][k]
+    T *stk = (T *)scratch;
+    T *leafsum = (T *)(scratch + (size_t)KM_WAVES * KM_MAXK * 16 * sizeof(double));
+    __shared__ int scr[KM_WAVES + 4];
+    __shared__ short tl_start[KM_MAXLEAF], tl_n[KM_MAXLEAF], tl_ops[2 * KM_MAXLEAF];
+    __shared__ unsigned hist[256];
+    __shared__ unsigned long long sel_prefix;
+    __shared__ int sel_rank;
+
     const unsigned G = gridDim.x;
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     unsigned epoch = 0;
@@ -99,199 +273,287 @@ __global__ __launch_bounds__(KM_THREADS) void k_kmeans(const T *__restrict__ X, 
     const int per = (N + (int)G - 1) / (int)G;
     const int lo = min(N, g * per), hi = min(N, lo + per);
     const bool f32 = sizeof(T) == 4;
+    const int nblk = (D + 63) / 64;
+    const int n_chain = k * nblk, n_task = n_chain + k;
+    // member-list region of this workgroup (only workgroups g < n_task ever run an update task)
+    int32_t *ml = mlist + (long long)min(g, n_task - 1) * Ncap;
+    double *wl = wlist + (long long)min(g, n_task - 1) * Ncap;
+    const int nleaf = tree.nleaf, nops = tree.nops;
+    for (int i = tid; i < KM_MAXLEAF; i += KM_THREADS) { tl_start[i] = tree.leaf_start[i]; tl_n[i] = tree.leaf_n[i]; }
+    for (int i = tid; i < 2 * KM_MAXLEAF; i += KM_THREADS) tl_ops[i] = tree.ops[i];
 
-    // ---- prior threshold: sort(weights)[N // 2] by stable rank counting (:144)
-    const int target = N / 2;
-    for (int i = lo + tid; i < hi; i += KM_THREADS) {
-        const double wi = w[i];
-        int rank = 0;
-        for (int j = 0; j < N; ++j) {
-            double wj = w[j];
-            rank += (wj < wi || (wj == wi && j < i)) ? 1 : 0;
+    // ---- prior threshold sort(weights)[N // 2] (:144): radix select, most significant byte first
+    if (g == 0) {
+        if (tid == 0) { sel_prefix = 0ull; sel_rank = N / 2; }
+        for (int pass = 0; pass < 8; ++pass) {
+            const int shift = 56 - 8 * pass;
+            for (int i = tid; i < 256; i += KM_THREADS) hist[i] = 0u;
+            __syncthreads();
+            const unsigned long long pre = sel_prefix;
+            for (int i = tid; i < N; i += KM_THREADS) {
+                const unsigned long long key = km_key(w[i]);
+                const bool match = pass == 0 || (key >> (shift + 8)) == (pre >> (shift + 8));
+                if (match) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int r = sel_rank;
+                unsigned b = 0;
+                for (; b < 256u; ++b) {
+                    const int c = (int)hist[b];
+                    if (r < c) break;
+                    r -= c;
+                }
+                sel_rank = r;
+                sel_prefix = pre | ((unsigned long long)b << shift);
+            }
+            __syncthreads();
         }
-        if (rank == target) sh->thr = wi;
+        if (tid == 0) sh->thr = km_unkey(sel_prefix);
     }
     grid_sync(&sh->barrier, G, epoch, status);
     const double thr = __hip_atomic_load(&sh->thr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
-    // ---- initial assignment (:141-149)
-    for (int i = lo + tid; i < hi; i += KM_THREADS) {
-        int a = 0;
-        if (!(w[i] > thr)) {
-            if (k == 2) a = 1;
-            else {
-                int m = 0;                       // index among the points with w <= thr
-                for (int j = 0; j < i; ++j) m += (w[j] <= thr) ? 1 : 0;
-                a = init_other ? (int)init_other[m] : (m % (k - 1) + 1);
-            }
+    // ---- initial assignment (:141-149).  k > 2: the points at or below the threshold take the entries
+    // of the (shuffled) index vector in index order -> ordered prefix count over the whole array
+    if (k == 2) {
+        for (int i = lo + tid; i < hi; i += KM_THREADS) {
+            const int a = (w[i] > thr) ? 0 : 1;
+            assign[i] = a;
+            new_assign[i] = a;
         }
-        assign[i] = a;
-        new_assign[i] = a;
+    } else {
+        int mine = 0;
+        for (int i = lo + tid; i < hi; i += KM_THREADS) mine += (w[i] > thr) ? 0 : 1;
+        for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+        __syncthreads();
+        if (lane == 0) scr[wv] = mine;
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int i = 0; i < KM_WAVES; ++i) t += scr[i];
+            part_n[g] = t;
+        }
+        grid_sync(&sh->barrier, G, epoch, status);
+        int base = 0;
+        for (int q = lane; q < g; q += 64) base += part_n[q];
+        for (int o = 32; o > 0; o >>= 1) base += __shfl_xor(base, o);
+        for (int i0 = lo; i0 < hi; i0 += KM_THREADS) {
+            const int i = i0 + tid;
+            const bool other = i < hi && !(w[i] > thr);
+            int tot;
+            const int m = base + km_wg_rank(other, scr, tot);
+            if (i < hi) {
+                const int a = other ? (init_other ? (int)init_other[m] : (m % (k - 1) + 1)) : 0;
+                assign[i] = a;
+                new_assign[i] = a;
+            }
+            base += tot;
+        }
     }
-    __syncthreads();
+    // the first update reads new_assign of every slice
+    grid_sync(&sh->barrier, G, epoch, status);
 
     int it = 0, st = 1;
-    // phase == 0: unweighted means of the initial assignment (:150-151); afterwards the
-    // weighted update (:163-171)
-#ifdef SPA_KM_TIMING
-    unsigned long long kt_[6] = {0, 0, 0, 0, 0, 0}, kt0_ = __builtin_readcyclecounter();
-#define KM_T(i) { unsigned long long n_ = __builtin_readcyclecounter(); kt_[i] += n_ - kt0_; kt0_ = n_; }
-#else
-#define KM_T(i)
-#endif
     for (int phase = 0;; ++phase) {
-        // ---- partial sums of this workgroup's slice, thread t owns dimensions t, t+256, ...
-        const int32_t *asg = new_assign;
-        for (int d0 = tid; d0 < D; d0 += 3 * KM_THREADS) {
-            // this thread's (up to) three dimensions d0, d0+KM_THREADS, d0+2*KM_THREADS; the points of the slice in
-            // order, 8 rows of all three dimensions requested together so that the ordered
-            // additions do not each wait for their own row
-            double acc[3][KM_MAXK];
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-#pragma unroll
-                for (int c = 0; c < KM_MAXK; ++c) acc[j][c] = 0.0;
-            for (int i0 = lo; i0 < hi; i0 += 8) {
-                int aa[8];
-                double ww[8], xx[3][8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int i = i0 + u < hi ? i0 + u : hi - 1;
-                    aa[u] = asg[i];
-                    ww[u] = w[i];
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        const int d = d0 + j * KM_THREADS;
-                        xx[j][u] = ldx(X, (long long)i * ld + (d < D ? d : D - 1));
-                    }
+        // ================= centre sums of `new_assign`: phase 0 unweighted means in T (:150-151),
+        // afterwards weighted float64 sums (:163-171)
+        for (int u = g; u < n_task; u += (int)G) {
+            if (u >= n_chain) {
+                // ---- member count and w.sum() of one cluster
+                const int c = u - n_chain;
+                const int cnt = km_member_list(new_assign, w, N, c, phase > 0, ml, wl, scr);
+                if (wv == 0) {
+                    const double ws = (phase > 0) ? km_pairwise_wave(wl, cnt) : 0.0;
+                    if (lane == 0) { wsum[c] = ws; cnt_c[c] = cnt; }
                 }
+                __syncthreads();
+                continue;
+            }
+            // ---- one cluster x 64 columns: sequential sums over the members in index order
+            const int c = u / nblk, blk = u - c * nblk;
+            const int col = blk * 64 + lane;
+            const bool colok = col < D;
+            const int cnt = km_member_list(new_assign, w, N, c, phase > 0, ml, wl, scr);
+            const int nchunk = (cnt + KM_ROWS - 1) / KM_ROWS;
+            double accd = 0.0;
+            float accf = 0.0f;
+            double ra[8], rb[8];
+            // rows wv*8 .. wv*8+7 of chunk q -> registers (products already rounded)
+            auto gather = [&](int q, double (&r)[8]) {
+                const int r0 = q * KM_ROWS + wv * 8;
+                int idx = 0;
+                double wj = 0.0;
+                if (lane < 8 && r0 + lane < cnt) { idx = ml[r0 + lane]; wj = wl[r0 + lane]; }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (i0 + u < hi) {
-                        const int a = aa[u];
-                        const double wi = (a == 0) ? ww[u] : 1.0 - ww[u];
+                for (int e = 0; e < 8; ++e) {
+                    const int ie = __shfl(idx, e);
+                    const double we = __shfl(wj, e);
+                    double v = 0.0;
+                    if (colok && r0 + e < cnt) {
+                        const double x = (double)X[(long long)ie * ld + col];
+                        v = (phase > 0) ? x * we : x;
+                    }
+                    r[e] = v;
+                }
+            };
+            auto store = [&](const double (&r)[8]) {
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) {
-                            const double v = (phase > 0) ? xx[j][u] * wi : xx[j][u];
+                for (int e = 0; e < 8; ++e) chunk[(wv * 8 + e) * 64 + lane] = r[e];
+            };
+            auto chain = [&](int q) {
+                if (wv != 0) return;
+                const int rows = min(KM_ROWS, cnt - q * KM_ROWS);
+                for (int r0 = 0; r0 < rows; r0 += 16) {
+                    double v[16];
 #pragma unroll
-                            for (int c = 0; c < KM_MAXK; ++c) acc[j][c] = acc[j][c] + ((a == c) ? v : 0.0);
+                    for (int e = 0; e < 16; ++e) v[e] = chunk[(r0 + e) * 64 + lane];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        if (r0 + e < rows) {
+                            if (f32 && phase == 0) accf = accf + (float)v[e];
+                            else accd = accd + v[e];
                         }
                     }
                 }
-            }
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int d = d0 + j * KM_THREADS;
-                if (d < D) {
-#pragma unroll
-                    for (int c = 0; c < KM_MAXK; ++c)
-                        if (c < k) part[((long long)g * k + c) * D + d] = acc[j][c];
+            };
+            if (nchunk > 0) {
+                gather(0, ra);
+                store(ra);
+                if (nchunk > 1) gather(1, ra);
+                __syncthreads();
+                for (int q = 0; q < nchunk; q += 2) {
+                    // LDS = chunk q, ra = chunk q+1
+                    if (q + 2 < nchunk) gather(q + 2, rb);
+                    chain(q);
+                    __syncthreads();
+                    if (q + 1 >= nchunk) break;
+                    store(ra);
+                    __syncthreads();
+                    // LDS = chunk q+1, rb = chunk q+2
+                    if (q + 3 < nchunk) gather(q + 3, ra);
+                    chain(q + 1);
+                    __syncthreads();
+                    if (q + 2 >= nchunk) break;
+                    store(rb);
+                    __syncthreads();
                 }
             }
+            if (wv == 0 && colok) sums[(long long)c * D + col] = (f32 && phase == 0) ? (double)accf : accd;
+            __syncthreads();
         }
-        if (tid < k) {
-            double sw = 0.0;
-            int cn = 0;
-            for (int i = lo; i < hi; ++i)
-                if (asg[i] == tid) { sw = sw + ((phase > 0) ? ((tid == 0) ? w[i] : 1.0 - w[i]) : 1.0); ++cn; }
-            part_w[g * k + tid] = sw;
-            part_n[g * k + tid] = cn;
-        }
-        KM_T(0)
         grid_sync(&sh->barrier, G, epoch, status);
-        KM_T(1)
 
-        // ---- convergence test of the sweep that produced new_assign (:158-159)
-        if (phase > 0) {
-            const int ch = __hip_atomic_load(&changed[it], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (ch == 0) { st = 0; break; }
-            for (int i = lo + tid; i < hi; i += KM_THREADS) assign[i] = new_assign[i];
-        }
-        // ---- centres = sum over workgroups in order / denominator.  Workgroup g owns a slice of the
-        // (cluster, dimension) elements.  The additions keep their order, workgroup after workgroup,
-        // but the partials are fetched by ALL threads at once into LDS and then summed from there:
-        // one trip to L2 per pass instead of one per addition.
+        // ================= centres = sums / denominator, into LDS (every workgroup)
         bool empty = false;
-        {
-            int *cnt_s = (int *)comb;                       // member counts, staged like the sums below
-            for (int idx = tid; idx < k * (int)G; idx += KM_THREADS) cnt_s[idx] = part_n[idx];
-            __syncthreads();
-            int cn_mine = 0;             // lane c < k of every wave: members of cluster c
-            if (lane < k) {
-#pragma unroll 16
-                for (unsigned q = 0; q < G; ++q) cn_mine += cnt_s[q * k + lane];
+        for (int c = 0; c < k; ++c) empty = empty || (cnt_c[c] == 0);
+        for (int e = tid; e < k * D; e += KM_THREADS) {
+            const int c = e / D;
+            T v;
+            if (phase == 0) {
+                // X[assign == c].mean(axis=0): sum in T, divided by the count in T; 0/0 = NaN
+                v = (T)sums[e] / (T)cnt_c[c];
+            } else {
+                v = (T)(sums[e] / wsum[c]);       // 0/0 -> NaN for an empty cluster, like numpy
             }
-            empty = __ballot(lane < k && cn_mine == 0) != 0ull;
-            __syncthreads();
+            lds_c[e] = v;
         }
-        {
-            const int nE = k * D;
-            const int per_e = (nE + (int)G - 1) / (int)G;
-            const int e0 = min(nE, g * per_e), e1 = min(nE, e0 + per_e);
-            const int EC = KM_COMB / (int)G > 0 ? KM_COMB / (int)G : 1;    // elements per pass
-            // denominators: sum of part_w over workgroups, in order, per cluster
-            for (int idx = tid; idx < k * (int)G; idx += KM_THREADS) comb[idx] = part_w[idx];   // [q][c]
-            __syncthreads();
-            if (tid < k) {
-                den_s[tid] = km_ordered_sum(comb + tid, (int)G, k);
-            }
-            __syncthreads();
-            for (int eb = e0; eb < e1; eb += EC) {
-                const int ne = min(EC, e1 - eb);
-                for (int idx = tid; idx < ne * (int)G; idx += KM_THREADS) {
-                    const int el = idx / (int)G, q = idx - el * (int)G;
-                    const int e = eb + el, c = e / D, d = e - c * D;
-                    comb[idx] = part[((long long)q * k + c) * D + d];
-                }
-                __syncthreads();
-                for (int t = tid; t < ne; t += KM_THREADS) {
-                    const int e = eb + t, c = e / D;
-                    const double sm = km_ordered_sum(comb + t * (int)G, (int)G, 1);
-                    double v = sm / den_s[c];            // 0/0 -> NaN for an empty cluster, like numpy
-                    if (f32) v = (double)(float)v;      // the reference stores centres in X's dtype
-                    centres[e] = v;
-                }
-                __syncthreads();
-            }
-        }
-        KM_T(2)
-        grid_sync(&sh->barrier, G, epoch, status);
-        KM_T(3)
+        __syncthreads();
         if (phase > 0 && empty) { st = 2; break; }      // (:173-181) after the update
         if (it >= max_iter) { st = 1; break; }
-        for (int e = tid; e < k * D; e += KM_THREADS) lds_c[e] = centres[e];
-        __syncthreads();
 
-        // ---- assignment sweep (:155-157): one wavefront per point, lanes over dimensions
+        // ================= assignment sweep (:155-157): one wave per point
         ++it;
         int local_changed = 0;
-        for (int i = lo + wv; i < hi; i += KM_THREADS / 64) {
-            double dist[KM_MAXK];
+        const int q8 = lane >> 3, j = lane & 7;
+        T *ls = leafsum + (size_t)wv * nleaf * KM_MAXK;
+        T *sk = stk + (size_t)wv * KM_MAXK * 16;
+        for (int i = lo + wv; i < hi; i += KM_WAVES) {
+            const T *xr = X + (long long)i * ld;
+            for (int lg = 0; lg < nleaf; lg += 8) {
+                const int q = lg + q8;
+                const bool act = q < nleaf;
+                const int s0 = act ? (int)tl_start[q] : 0;
+                const int n = act ? (int)tl_n[q] : 0;
+                const int steps = n >> 3;
+                T acc[KM_MAXK];
 #pragma unroll
-            for (int c = 0; c < KM_MAXK; ++c) dist[c] = 0.0;
-            for (int d = lane; d < D; d += 64) {
-                const double x = ldx(X, (long long)i * ld + d);
+                for (int c = 0; c < KM_MAXK; ++c) acc[c] = (T)0;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    T xv[8];                // eight elements of this lane's accumulator in flight
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const int tt = h * 8 + t;
+                        xv[t] = xr[(tt < steps) ? s0 + 8 * tt + j : 0];
+                    }
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const int tt = h * 8 + t;
+                        const int d = (tt < steps) ? s0 + 8 * tt + j : 0;
+#pragma unroll
+                        for (int c = 0; c < KM_MAXK; ++c) {
+                            if (c < k) {
+                                const T df = xv[t] - lds_c[c * D + d];
+                                const T sq = df * df;
+                                const T nv = (tt == 0) ? sq : acc[c] + sq;
+                                acc[c] = (tt < steps) ? nv : acc[c];
+                            }
+                        }
+                    }
+                }
 #pragma unroll
                 for (int c = 0; c < KM_MAXK; ++c) {
                     if (c < k) {
-                        double t = f32 ? (double)((float)x - (float)lds_c[c * D + d]) : x - lds_c[c * D + d];
-                        dist[c] = dist[c] + t * t;
+                        T r = acc[c];
+                        r = r + __shfl_xor(r, 1);
+                        r = r + __shfl_xor(r, 2);
+                        r = r + __shfl_xor(r, 4);
+                        acc[c] = (steps > 0) ? r : (T)0;
                     }
                 }
-            }
+                // the n % 8 tail (and a whole block shorter than 8), one by one
+                const int tail0 = steps * 8;
+                for (int e = tail0; e < n; ++e) {
+                    const T x = xr[s0 + e];
 #pragma unroll
-            for (int c = 0; c < KM_MAXK; ++c)
-                if (c < k)
-                    for (int o = 32; o > 0; o >>= 1) dist[c] = dist[c] + __shfl_xor(dist[c], o);
-            int best = 0;
-            double bd = sqrt(dist[0]);
-#pragma unroll
-            for (int c = 1; c < KM_MAXK; ++c) {
-                if (c < k) {
-                    double dc = sqrt(dist[c]);
-                    // np.argmin: first minimum; a NaN beats everything and the first NaN stays
-                    if (!(bd != bd) && ((dc != dc) || dc < bd)) { best = c; bd = dc; }
+                    for (int c = 0; c < KM_MAXK; ++c) {
+                        if (c < k) {
+                            const T df = x - lds_c[c * D + s0 + e];
+                            acc[c] = acc[c] + df * df;
+                        }
+                    }
                 }
+                if (act && j == 0) {
+#pragma unroll
+                    for (int c = 0; c < KM_MAXK; ++c)
+                        if (c < k) ls[q * KM_MAXK + c] = acc[c];
+                }
+            }
+            km_wave_lds_sync();
+            // block sums -> total, lane c = cluster c, numpy's recursion as a stack program
+            T dist = (T)0;
+            if (lane < k) {
+                int sp = 0;
+                for (int o = 0; o < nops; ++o) {
+                    const int op = (int)tl_ops[o];
+                    if (op >= 0) { sk[lane * 16 + sp] = ls[op * KM_MAXK + lane]; sp += 1; }
+                    else {
+                        const T b = sk[lane * 16 + sp - 1], a = sk[lane * 16 + sp - 2];
+                        sk[lane * 16 + sp - 2] = a + b;
+                        sp -= 1;
+                    }
+                }
+                dist = sk[lane * 16];
+                dist = f32 ? (T)sqrtf((float)dist) : (T)sqrt((double)dist);
+            }
+            km_wave_lds_sync();
+            int best = 0;
+            T bd = __shfl(dist, 0);
+            for (int c = 1; c < k; ++c) {
+                const T dc = __shfl(dist, c);
+                // np.argmin: first minimum; a NaN beats everything and the first NaN stays
+                if (!(bd != bd) && ((dc != dc) || dc < bd)) { best = c; bd = dc; }
             }
             if (lane == 0) {
                 new_assign[i] = best;
@@ -300,12 +562,13 @@ __global__ __launch_bounds__(KM_THREADS) void k_kmeans(const T *__restrict__ X, 
         }
         if (lane == 0 && local_changed)
             __hip_atomic_fetch_add(&changed[it], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        KM_T(4)
+        grid_sync(&sh->barrier, G, epoch, status);
+
+        // ================= convergence test of the sweep (:158-159)
+        const int ch = __hip_atomic_load(&changed[it], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ch == 0) { st = 0; break; }
+        for (int i = lo + tid; i < hi; i += KM_THREADS) assign[i] = new_assign[i];
     }
-#ifdef SPA_KM_TIMING
-    if (g == 0 && tid == 0) printf("kmeans cycles (workgroup 0): partial sums %llu | barrier %llu | centres %llu | barrier %llu | sweep %llu ; iterations %d, G %u\n", kt_[0], kt_[1], kt_[2], kt_[3], kt_[4], it, G);
-#endif
     if (g == 0 && tid == 0) { info[0] = it; info[1] = st; info[2] = N; info[3] = 0; }
 }
 
@@ -317,53 +580,61 @@ extern "C" int spa_kmeans_weighted(spa_ctx *ctx, const void *X, int32_t x_dtype,
     SPA_ARG(ctx && X && w && n_ptr && assign && info);
     SPA_ARG(k >= 2 && k <= KM_MAXK && D > 0 && Ncap > 0 && max_iter >= 0 && ld >= D);
     SPA_ARG(x_dtype == 0 || x_dtype == 1);
-    const size_t lds = (size_t)k * D * sizeof(double);
-    if (lds > 120 * 1024) {
-        spa_set_error("k*D = %d*%d centres do not fit LDS", k, D);
+    const size_t lds = (((size_t)k * D * sizeof(double) + 15) & ~(size_t)15) + KM_CHUNK_BYTES;
+    KmTree tree;
+    memset(&tree, 0, sizeof(tree));
+    if (lds > 150 * 1024 || !km_build_tree(tree, 0, D)) {
+        spa_set_error("k*D = %d*%d centres do not fit LDS next to the chain buffer", k, D);
         return SPA_ERR_ARG;
     }
     hipStream_t s = spa_stream(stream);
-    int kdiv = 64;               // points per workgroup (measured: 64 best at N ~ 5 000; two grid barriers per sweep dominate)
-    if (const char *e = getenv("SPA_KM_DIV")) kdiv = atoi(e) > 0 ? atoi(e) : 64;                 // experiments
+    const int nblk = (D + 63) / 64;
+    const int n_task = k * nblk + k;
+    int kdiv = 32;               // points per workgroup of the sweep (16 waves: two points per wave)
+    if (const char *e = getenv("SPA_KM_DIV")) kdiv = atoi(e) > 0 ? atoi(e) : kdiv;               // experiments
     int G = (Ncap + kdiv - 1) / kdiv;
+    if (G < n_task) G = n_task;
     if (G > ctx->n_cu) G = ctx->n_cu;
     if (G < 1) G = 1;
-    double *part;
+    // member lists: one region per workgroup that runs update tasks
+    const int regions = G < n_task ? G : n_task;
+    char *lists;
     char *misc;
     int rc;
-    const size_t part_bytes = (size_t)G * k * D * 8;
-    if ((rc = spa_ws_reserve(ctx, WS_KM_PART, part_bytes, (void **)&part)) != SPA_OK) return rc;
-    // misc: part_w [G*k] f64 | centres [k*D] f64 | KmShared | part_n [G*k] i32 |
+    const size_t list_bytes = (size_t)regions * Ncap * (4 + 8);
+    if ((rc = spa_ws_reserve(ctx, WS_KM_PART, list_bytes, (void **)&lists)) != SPA_OK) return rc;
+    // misc: sums [k*D] f64 | wsum [k] f64 | KmShared | cnt_c [k] i32 | part_n [G] i32 |
     //       changed [max_iter+2] i32 | new_assign [Ncap] i32
-    size_t o_pw = 0, o_cen = o_pw + (size_t)G * k * 8, o_sh = o_cen + (size_t)k * D * 8;
-    size_t o_pn = o_sh + 64, o_ch = o_pn + (size_t)G * k * 4;
+    size_t o_sum = 0, o_ws = o_sum + (size_t)k * D * 8, o_sh = o_ws + (size_t)KM_MAXK * 8;
+    size_t o_cn = o_sh + 64, o_pn = o_cn + (size_t)KM_MAXK * 4, o_ch = o_pn + (size_t)G * 4;
     size_t o_na = o_ch + (size_t)(max_iter + 2) * 4;
     o_na = (o_na + 15) & ~(size_t)15;
     size_t total = o_na + (size_t)Ncap * 4;
     if ((rc = spa_ws_reserve(ctx, WS_KM_MISC, total, (void **)&misc)) != SPA_OK) return rc;
-    SPA_HIP(hipMemsetAsync(misc + o_sh, 0, o_na - o_sh, s));   // barrier, thr, part_n, changed
+    SPA_HIP(hipMemsetAsync(misc + o_sh, 0, o_na - o_sh, s));   // barrier, thr, counters, changed
     SpaProfScope prof_(ctx, PROF_KMEANS, s);
-    static bool attr_done[2] = {false, false};
+    double *wlist = (double *)lists;
+    int32_t *mlist = (int32_t *)(lists + (size_t)regions * Ncap * 8);
     if (x_dtype == 1) {
-        if (!attr_done[1]) {
-            SPA_HIP(hipFuncSetAttribute((const void *)k_kmeans<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
-            attr_done[1] = true;
+        if (!ctx->km_attr_done[1]) {
+            SPA_HIP(hipFuncSetAttribute((const void *)k_kmeans<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            ctx->km_attr_done[1] = 1;
         }
         hipLaunchKernelGGL(k_kmeans<double>, dim3(G), dim3(KM_THREADS), lds, s, (const double *)X,
                            (long long)ld, D, w, n_ptr, Ncap, k, max_iter, (const long long *)init_other,
-                           assign, (int32_t *)(misc + o_na), part, (double *)(misc + o_pw),
-                           (int *)(misc + o_pn), (double *)(misc + o_cen), (int *)(misc + o_ch),
-                           (KmShared *)(misc + o_sh), info, ctx->d_status);
+                           assign, (int32_t *)(misc + o_na), (double *)(misc + o_sum), (double *)(misc + o_ws),
+                           (int *)(misc + o_cn), (int *)(misc + o_pn), mlist, wlist, (int *)(misc + o_ch),
+                           (KmShared *)(misc + o_sh), info, ctx->d_status, tree);
     } else {
-        if (!attr_done[0]) {
-            SPA_HIP(hipFuncSetAttribute((const void *)k_kmeans<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
-            attr_done[0] = true;
+        if (!ctx->km_attr_done[0]) {
+            SPA_HIP(hipFuncSetAttribute((const void *)k_kmeans<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            ctx->km_attr_done[0] = 1;
         }
         hipLaunchKernelGGL(k_kmeans<float>, dim3(G), dim3(KM_THREADS), lds, s, (const float *)X,
                            (long long)ld, D, w, n_ptr, Ncap, k, max_iter, (const long long *)init_other,
-                           assign, (int32_t *)(misc + o_na), part, (double *)(misc + o_pw),
-                           (int *)(misc + o_pn), (double *)(misc + o_cen), (int *)(misc + o_ch),
-                           (KmShared *)(misc + o_sh), info, ctx->d_status);
+                           assign, (int32_t *)(misc + o_na), (double *)(misc + o_sum), (double *)(misc + o_ws),
+                           (int *)(misc + o_cn), (int *)(misc + o_pn), mlist, wlist, (int *)(misc + o_ch),
+                           (KmShared *)(misc + o_sh), info, ctx->d_status, tree);
     }
     SPA_LAUNCH_CHECK();
     return SPA_OK;

@@ -832,12 +832,11 @@ extern "C" int spa_slic_core(spa_ctx *ctx, const float *lab, int32_t B, int32_t 
     rc = spa_ws_reserve(ctx, WS_SLIC_ORDER, ((size_t)upd_total + 8 + 32) * 4, (void **)&upd_order);
     if (rc != SPA_OK) return rc;
     int *upd_qhead = upd_order + upd_total;
-    static int upd_wg_per_cu = 0;
-    if (!upd_wg_per_cu) {
-        SPA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&upd_wg_per_cu, (const void *)k_slic_update<8>, 256, 0));
-        if (upd_wg_per_cu < 1) upd_wg_per_cu = 1;
+    if (!ctx->upd_wg_per_cu) {         // per context = per device
+        SPA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->upd_wg_per_cu, (const void *)k_slic_update<8>, 256, 0));
+        if (ctx->upd_wg_per_cu < 1) ctx->upd_wg_per_cu = 1;
     }
-    int upd_grid = upd_wg_per_cu * ctx->n_cu;
+    int upd_grid = ctx->upd_wg_per_cu * ctx->n_cu;
     if (upd_grid > (upd_total + UPD_WAVES - 1) / UPD_WAVES) upd_grid = (upd_total + UPD_WAVES - 1) / UPD_WAVES;
     upd_grid = (upd_grid + 7) & ~7;
     const unsigned mean_px = (unsigned)(((long long)H * W) / nC) ? (unsigned)(((long long)H * W) / nC) : 1u;

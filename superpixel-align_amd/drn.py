@@ -56,7 +56,9 @@ def _conv(cin, cout, k, stride=1, dilation=1):
     return nn.Conv2d(cin, cout, k, stride=stride, padding=pad, dilation=dilation, bias=False)
 
 
-_EPILOGUE = {'engine': None}      # set by DRN.prepare() on a GPU: libspalign's fused bias/residual/ReLU
+# set by DRN.prepare() on a GPU: libspalign's fused bias/residual/ReLU; 'bytes' accumulates the algorithmic
+# HBM bytes of its launches (read y + write y [+ read residual]) for bench.py's roofline entry
+_EPILOGUE = {'engine': None, 'bytes': 0, 'launches': 0}
 
 
 def conv_bias_act(conv, bn, x, residual=None, relu=True):
@@ -71,6 +73,8 @@ def conv_bias_act(conv, bn, x, residual=None, relu=True):
         vec = 4 if y.dtype == torch.float32 else 8
         if (y.is_contiguous(memory_format=torch.channels_last) and y.shape[1] % vec == 0
                 and (residual is None or residual.is_contiguous(memory_format=torch.channels_last))):
+            _EPILOGUE['bytes'] += y.numel() * y.element_size() * (3 if residual is not None else 2)
+            _EPILOGUE['launches'] += 1
             return eng.bias_act_(y, conv.bias, residual, relu)
         y = y + conv.bias.view(1, -1, 1, 1)
     else:

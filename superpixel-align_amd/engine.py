@@ -16,8 +16,8 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
-def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 def _req(t, dtype, what):
@@ -38,6 +38,11 @@ class Engine(object):
         check(self._lib.spa_ctx_create(self.device.index, ctypes.byref(h)))
         self._ctx = h
 
+    def _s(self):
+        """The launch stream: torch's current stream of THIS engine's device (a spa_ctx is bound to one
+        device; torch's current device may be another one)."""
+        return _stream(self.device)
+
     def close(self):
         if getattr(self, '_ctx', None):
             self._lib.spa_ctx_destroy(self._ctx)
@@ -53,7 +58,7 @@ class Engine(object):
     def status(self):
         """Read and clear the latched device status bits (synchronises the stream)."""
         v = ctypes.c_uint32(0)
-        check(self._lib.spa_status(self._ctx, ctypes.byref(v), _stream()))
+        check(self._lib.spa_status(self._ctx, ctypes.byref(v), self._s()))
         return v.value
 
     def raise_on_status(self, ignore=_lib.INFO_BITS):
@@ -90,7 +95,7 @@ class Engine(object):
         mean = (ctypes.c_double * 3)(0.485, 0.456, 0.406)
         std = (ctypes.c_double * 3)(0.229, 0.224, 0.225)
         check(self._lib.spa_drn_normalise(self._ctx, _ptr(x), B, H, W, _ptr(out),
-                                          0 if dtype == torch.float32 else 1, mean, std, _stream()))
+                                          0 if dtype == torch.float32 else 1, mean, std, self._s()))
         return out
 
     def drn_stem_d(self, x, w0, b0, w1p, b1, dtype=torch.float32):
@@ -109,14 +114,14 @@ class Engine(object):
         scratch = torch.empty((B, H, W, 3), dtype=torch.float32, device=x.device)    # per call: stream safe
         check(self._lib.spa_drn_stem_d(self._ctx, _ptr(x), B, H, W, _ptr(w0), _ptr(b0), _ptr(w1p), _ptr(b1),
                                        mean, std, _ptr(out), 0 if dtype == torch.float32 else 1, _ptr(scratch),
-                                       _stream()))
+                                       self._s()))
         return out
 
     def bias_act_(self, y, bias, residual=None, relu=True):
         """In place y = relu?(y + bias [+ residual]) on a channels-last (B,C,H,W) activation."""
         B, C, H, W = y.shape
         check(self._lib.spa_bias_act(self._ctx, _ptr(y), 0 if y.dtype == torch.float32 else 1, B * H * W, C,
-                                     _ptr(bias), _ptr(residual), 1 if relu else 0, _stream()))
+                                     _ptr(bias), _ptr(residual), 1 if relu else 0, self._s()))
         return y
 
     # ------------------------------------------------------------------ SLIC
@@ -125,7 +130,7 @@ class Engine(object):
         B, C, H, W = rgb.shape
         assert C == 3
         lab = torch.empty_like(rgb)
-        check(self._lib.spa_rgb2lab(self._ctx, _ptr(rgb), B, H, W, ratio, _ptr(lab), _stream()))
+        check(self._lib.spa_rgb2lab(self._ctx, _ptr(rgb), B, H, W, ratio, _ptr(lab), self._s()))
         return lab
 
     def slic_core(self, lab, n_segments, max_iter=10, want_centres=False):
@@ -138,7 +143,7 @@ class Engine(object):
             nC = _lib.make_plan(H, W, n_segments).n_centroids
             centres = torch.empty((B, nC, 6), dtype=torch.float32, device=lab.device)
         check(self._lib.spa_slic_core(self._ctx, _ptr(lab), B, H, W, n_segments, max_iter,
-                                      _ptr(labels), _ptr(centres), _stream()))
+                                      _ptr(labels), _ptr(centres), self._s()))
         return (labels, centres) if want_centres else labels
 
     def enforce_connectivity(self, labels, min_size, max_size):
@@ -147,7 +152,7 @@ class Engine(object):
         out = torch.empty_like(labels)
         n_labels = torch.empty((B,), dtype=torch.int32, device=labels.device)
         check(self._lib.spa_enforce_connectivity(self._ctx, _ptr(labels), B, H, W, min_size, max_size,
-                                                 _ptr(out), _ptr(n_labels), _stream()))
+                                                 _ptr(out), _ptr(n_labels), self._s()))
         return out, n_labels
 
     def slic(self, rgb, n_segments, compactness=10.0, max_iter=10):
@@ -158,7 +163,7 @@ class Engine(object):
         labels = torch.empty((B, H, W), dtype=torch.int32, device=rgb.device)
         n_labels = torch.empty((B,), dtype=torch.int32, device=rgb.device)
         check(self._lib.spa_slic(self._ctx, _ptr(rgb), B, H, W, n_segments, compactness, max_iter,
-                                 _ptr(labels), _ptr(n_labels), _stream()))
+                                 _ptr(labels), _ptr(n_labels), self._s()))
         return labels, n_labels
 
     def felzenszwalb(self, rgb, scale=300.0, sigma=0.8, min_size=20, uint8_image=False):
@@ -171,7 +176,7 @@ class Engine(object):
         labels = torch.empty((B, H, W), dtype=torch.int32, device=rgb.device)
         n_labels = torch.empty((B,), dtype=torch.int32, device=rgb.device)
         fn = self._lib.spa_felzenszwalb_u8 if uint8_image else self._lib.spa_felzenszwalb
-        check(fn(self._ctx, _ptr(rgb), B, H, W, scale, sigma, min_size, _ptr(labels), _ptr(n_labels), _stream()))
+        check(fn(self._ctx, _ptr(rgb), B, H, W, scale, sigma, min_size, _ptr(labels), _ptr(n_labels), self._s()))
         return labels, n_labels
 
     def overlap_refine(self, labels, road, max_labels, threshold):
@@ -183,7 +188,7 @@ class Engine(object):
         assert road.shape == labels.shape
         out = torch.empty(labels.shape, dtype=torch.uint8, device=labels.device)
         check(self._lib.spa_overlap_refine(self._ctx, _ptr(labels), _ptr(road), B, npix, int(max_labels),
-                                           float(threshold), _ptr(out), _stream()))
+                                           float(threshold), _ptr(out), self._s()))
         return out
 
     # ------------------------------------------------------------------ descriptors
@@ -191,7 +196,7 @@ class Engine(object):
         n_labels = _req(n_labels, torch.int32, 'n_labels')
         B = n_labels.numel()
         off = torch.empty((B + 1,), dtype=torch.int32, device=n_labels.device)
-        check(self._lib.spa_segment_offsets(self._ctx, _ptr(n_labels), B, _ptr(off), _stream()))
+        check(self._lib.spa_segment_offsets(self._ctx, _ptr(n_labels), B, _ptr(off), self._s()))
         return off
 
     def segment_stats(self, labels, offsets, ncap, prior_params=None, want_centroid=True):
@@ -206,7 +211,7 @@ class Engine(object):
         yp, xp, ys, xs = prior_params if prior_params else (0.75, 0.5, 0.1, 0.1)
         check(self._lib.spa_segment_stats(self._ctx, _ptr(labels), B, H, W, _ptr(offsets), ncap,
                                           yp, xp, ys, xs, _ptr(count), _ptr(centroid), _ptr(prior),
-                                          _stream()))
+                                          self._s()))
         return count, centroid, prior
 
     def select_anchor_pixels(self, labels, offsets, ncap, ranks, n_valid):
@@ -218,7 +223,7 @@ class Engine(object):
         anchors = torch.zeros((ncap, A, 2), dtype=torch.int32, device=labels.device)
         check(self._lib.spa_select_anchor_pixels(self._ctx, _ptr(labels), B, H, W, _ptr(offsets), ncap,
                                                  _ptr(ranks), _ptr(n_valid), A, _ptr(anchors),
-                                                 _stream()))
+                                                 self._s()))
         return anchors
 
     @staticmethod
@@ -252,7 +257,7 @@ class Engine(object):
         check(self._lib.spa_pool_anchor(self._ctx, _ptr(fmap), ctypes.byref(d), B, img_h,
                                         _ptr(offsets), ncap, _ptr(anchors), _ptr(n_valid), A,
                                         n_neighbors, _ptr(centroid), 1 if append_pos else 0, _ptr(X),
-                                        1 if append_pos else 0, D, _stream()))
+                                        1 if append_pos else 0, D, self._s()))
         return X
 
     def pool_mean(self, fmap, labels, offsets, ncap, count, sampling='nearest', centroid=None,
@@ -266,7 +271,7 @@ class Engine(object):
                                       _ptr(offsets), ncap, _ptr(count),
                                       {'nearest': 0, 'bilinear': 1}[sampling], _ptr(centroid),
                                       1 if append_pos else 0, _ptr(X), 1 if append_pos else 0, D,
-                                      _stream()))
+                                      self._s()))
         return X
 
     # ------------------------------------------------------------------ k-means + paint
@@ -280,7 +285,7 @@ class Engine(object):
         info = torch.zeros((4,), dtype=torch.int32, device=X.device)
         check(self._lib.spa_kmeans_weighted(self._ctx, _ptr(X), 0 if X.dtype == torch.float32 else 1,
                                             D, D, _ptr(w), _ptr(n_ptr), ncap, k, max_iter,
-                                            _ptr(init_other), _ptr(assign), _ptr(info), _stream()))
+                                            _ptr(init_other), _ptr(assign), _ptr(info), self._s()))
         return assign, info
 
     def paint(self, labels, assign, offsets):
@@ -289,7 +294,7 @@ class Engine(object):
         cluster = torch.empty((B, H, W), dtype=torch.uint8, device=labels.device)
         road = torch.empty((B, H, W), dtype=torch.uint8, device=labels.device)
         check(self._lib.spa_paint(self._ctx, _ptr(labels), _ptr(assign), _ptr(offsets), B, H, W,
-                                  _ptr(cluster), _ptr(road), _stream()))
+                                  _ptr(cluster), _ptr(road), self._s()))
         return cluster, road
 
     def confusion(self, road, gt):
@@ -299,7 +304,7 @@ class Engine(object):
         B = road.shape[0]
         out = torch.zeros((B, 4), dtype=torch.int64, device=road.device)
         check(self._lib.spa_confusion(self._ctx, _ptr(road), _ptr(gt), B, road[0].numel(), _ptr(out),
-                                      _stream()))
+                                      self._s()))
         return out
 
 

@@ -196,3 +196,96 @@ class LabelPipeline(object):
         The prior is computed inside the segment-statistics pass: its share is reported under
         time_roialign and time_prior is 0."""
         return {k: v / 1000.0 for k, v in self.stage_ms().items()}
+
+
+class HostStream(object):
+    """Host memory to host memory, double buffered (SURVEY.md 8d's timed region: "from batch tensor
+    resident in pinned host memory to masks in host memory").
+
+    Two device input buffers and two pinned output buffers; the upload of batch s+1 (h2d stream) and
+    the download of batch s's two uint8 masks (d2h stream) run under the kernels of the neighbouring
+    batches, so PCIe (25 MB up + 4 MB down per 1024x2048 image) never sits on the critical path as
+    long as a step takes longer than its own transfers.
+
+        hs = HostStream(pipe, B, H, W)
+        for cluster, road, res in hs.process(batches):   # batches: iterable of pinned (B,3,H,W) f32
+            ...            # cluster / road: numpy views of pinned memory, valid until the next-but-one yield
+
+    `after(res)` may enqueue extra device work on the compute stream per batch (bench: confusion)."""
+
+    def __init__(self, pipe, B, H, W, after=None):
+        self.pipe, self.after = pipe, after
+        dev = pipe.eng.device
+        self.dev = dev
+        self.inp = [torch.empty((B, 3, H, W), dtype=torch.float32, device=dev) for _ in range(2)]
+        self.out = [(torch.empty((B, H, W), dtype=torch.uint8).pin_memory(),
+                     torch.empty((B, H, W), dtype=torch.uint8).pin_memory()) for _ in range(2)]
+        self.h2d = torch.cuda.Stream(device=dev)
+        self.d2h = torch.cuda.Stream(device=dev)
+        self.up_done = [torch.cuda.Event() for _ in range(2)]       # inp[i] holds its batch
+        self.in_free = [torch.cuda.Event() for _ in range(2)]       # kernels reading inp[i] finished
+        self.down_done = [torch.cuda.Event() for _ in range(2)]     # out[i] holds its masks
+        self.staging = None
+
+    def pinned_batch(self, B=None):
+        """A pinned (B,3,H,W) float32 array for the decode workers to fill in place."""
+        shape = tuple(self.inp[0].shape) if B is None else (B,) + tuple(self.inp[0].shape[1:])
+        return torch.empty(shape, dtype=torch.float32).pin_memory()
+
+    def _upload(self, slot, batch):
+        t = torch.as_tensor(batch)
+        if not t.is_pinned():
+            # pageable memory: stage through a pinned buffer (a host memcpy; the drivers decode straight
+            # into pinned_batch() arrays instead)
+            if self.staging is None or self.staging.shape != t.shape:
+                self.staging = torch.empty(t.shape, dtype=torch.float32).pin_memory()
+            self.h2d.synchronize()
+            self.staging.copy_(t)
+            t = self.staging
+        with torch.cuda.stream(self.h2d):
+            self.h2d.wait_event(self.in_free[slot])
+            self.inp[slot][:t.shape[0]].copy_(t, non_blocking=True)
+            self.up_done[slot].record(self.h2d)
+        return t.shape[0]
+
+    def process(self, batches):
+        main = torch.cuda.current_stream(self.dev)
+        it = iter(batches)
+        for ev in self.in_free:
+            ev.record(main)
+        nxt = next(it, None)
+        if nxt is None:
+            return
+        nb = self._upload(0, nxt)
+        s = 0
+        prev = None                                   # (slot, result, n) whose download is in flight
+        while nxt is not None:
+            slot = s & 1
+            cur_n = nb
+            nxt = next(it, None)
+            if nxt is not None:
+                nb = self._upload(slot ^ 1, nxt)      # under this batch's kernels
+            main.wait_event(self.up_done[slot])
+            res = self.pipe.run(self.inp[slot][:cur_n], check_status=False)
+            if self.after is not None:
+                self.after(res)
+            self.in_free[slot].record(main)
+            done = torch.cuda.Event()
+            done.record(main)
+            with torch.cuda.stream(self.d2h):
+                self.d2h.wait_event(done)
+                oc, orr = self.out[slot]
+                oc[:cur_n].copy_(res.cluster, non_blocking=True)
+                orr[:cur_n].copy_(res.road, non_blocking=True)
+                res.cluster.record_stream(self.d2h)
+                res.road.record_stream(self.d2h)
+                self.down_done[slot].record(self.d2h)
+            if prev is not None:
+                pslot, pres, pn = prev
+                self.down_done[pslot].synchronize()
+                yield self.out[pslot][0][:pn].numpy(), self.out[pslot][1][:pn].numpy(), pres
+            prev = (slot, res, cur_n)
+            s += 1
+        pslot, pres, pn = prev
+        self.down_done[pslot].synchronize()
+        yield self.out[pslot][0][:pn].numpy(), self.out[pslot][1][:pn].numpy(), pres
