@@ -8,16 +8,24 @@
 One "step" = one pass of the hot path over one batch of synthetic 1024x2048 RGB images that is
 already resident in HBM: DRN features (PyTorch-ROCm/MIOpen) -> HIP SLIC -> per-superpixel pooling
 -> location prior -> weighted k-means -> painted road masks -> per-image confusion counts
-(BASELINE.json configs[1]: DRN-D-22 fp32, SLIC 200 superpixels, k = 2).  With N > 1 every rank
-labels its own batches (images shard with no data-path collective; weak scaling) and the
-per-image score records are exchanged by one RCCL all_gather at the end of the timed region,
-the native replacement of the reference's shared result.json append.
+(BASELINE.json configs[1]: DRN-D-22 fp32, SLIC 200 superpixels, k = 2).  Three distinct batches
+rotate through the steps.  With N > 1 every rank labels its own batches (images shard with no
+data-path collective; weak scaling) and the per-image score records are exchanged by one RCCL
+all_gather at the end of the timed region, the native replacement of the reference's shared
+result.json append.
 
-Prints ONE JSON line on rank 0 (see README/DESIGN for the fields).  `roofline` prices the
-dominant hand-written HIP kernel of libspalign (HIP events on its launch stream, recorded during
-the timed region) against the HBM roof; `drn` reports the MFMA side of the step (the DRN forward
-is PyTorch-ROCm by design); `cpu_baseline` times the CPU oracle (+ the same DRN on the host
-cores through PyTorch) on a bounded sample of the same workload, rank 0 at N = 1 only.
+Prints ONE JSON line on rank 0 (see README/DESIGN for the fields).  `value` is the device-resident
+rate (inputs in HBM when the timed region starts).  `host_to_host` is SURVEY.md 8d's region, timed
+in a second loop of the same length: batches in pinned host memory -> masks in pinned host memory
+through pipeline.HostStream (uploads and downloads double buffered on copy streams under the
+kernels).  `kernels` holds one roofline-shaped entry per hand-written kernel family of libspalign
+(HIP events on the launch stream, recorded during the timed region): HBM-bound ones against 8 TB/s
+with their algorithmic bytes, the float32-MFMA stem against the fp32 matrix peak; `roofline` is the
+family with the most time per step, whichever it is.  `drn` reports the MFMA side of the step (the
+big convolutions are PyTorch-ROCm / MIOpen).  `cpu_baseline` times, on the host cores, the C
+restatement (oracle, single thread and all cores with images sharded over threads), the same DRN
+through PyTorch-CPU and BASELINE.json's named comparator (NumPy pooling + scipy.cluster.vq.kmeans2)
+on a bounded sample, rank 0 at N = 1 only.
 """
 import argparse
 import importlib
@@ -63,7 +71,10 @@ def parse():
                         'under the convolutions of the other): 2 shortens the forward by 2 %% but the label kernels '
                         'that follow run slower by as much (measured), so the default is 1')
     p.add_argument('--no_cpu_baseline', action='store_true')
-    p.add_argument('--cpu_sample', type=int, default=1, help='images of the CPU baseline sample')
+    p.add_argument('--cpu_sample', type=int, default=1, help='images of the PyTorch-CPU DRN sample')
+    p.add_argument('--cpu_threads', type=int, default=16, help='threads (= images) of the all-cores oracle row')
+    p.add_argument('--no_host_loop', action='store_true', help='skip the pinned-host to pinned-host loop')
+    p.add_argument('--n_batches', type=int, default=3, help='distinct batches rotating through the steps')
     p.add_argument('--no_prof', action='store_true', help='do not record per-kernel events')
     p.add_argument('--overlap', action='store_true',
                    help='run the superpixel branch on a second stream under the DRN forward (+5%% '
@@ -104,19 +115,26 @@ def algorithmic_bytes(kernel, B, H, W, C, fh, fw, n_seg, feat_bytes):
         'k_pool_mean': C * fh * fw * feat_bytes + n_seg * C * 4,
         'k_pool_anchor': n_seg * 10 * 4 * C * feat_bytes + n_seg * C * 8,
         'k_paint': px * (4 + 1 + 1),
+        'k_drn_stem_d(+normalise)': px * (12 + 16 * feat_bytes),     # raw image in, layer1 map out
         'k_kmeans': 0,
     }
     return per_image.get(kernel, 0) * B
 
 
-def make_batch(synth, B, H, W, scene=False):
+def stem_flops(B, H, W):
+    """2 * MACs of the fused DRN-D stem: conv7x7 3->16 (K = 147) + conv3x3 16->16 (K = 144)."""
+    return 2.0 * (147 + 144) * 16 * H * W * B
+
+
+def make_batch(synth, B, H, W, scene=False, seed0=0, out=None):
     """B synthetic images from 4 generated ones (rolled copies are new images for SLIC/DRN).
-    scene=True: piecewise-constant scenes (what graph-based felzenszwalb needs to find regions)."""
+    scene=True: piecewise-constant scenes (what graph-based felzenszwalb needs to find regions).
+    seed0: first generator seed (different batches use different seeds); out: array to fill."""
     gen = synth.synth_scene if scene else synth.synth_image
-    base = [gen(s, H, W) for s in range(min(4, B))]
-    imgs = np.empty((B, 3, H, W), np.float32)
+    base = [gen(seed0 + s, H, W) for s in range(min(4, B))]
+    imgs = np.empty((B, 3, H, W), np.float32) if out is None else out
     gts = np.empty((B, H, W), np.int32)
-    gt0 = [synth.synth_gt_labels(s, H, W) for s in range(min(4, B))]
+    gt0 = [synth.synth_gt_labels(seed0 + s, H, W) for s in range(min(4, B))]
     for b in range(B):
         shift = 37 * (b // 4)
         imgs[b] = np.roll(base[b % 4], shift, axis=2)
@@ -126,35 +144,81 @@ def make_batch(synth, B, H, W, scene=False):
 
 
 def cpu_baseline(a, synth, n_img):
-    """The oracle (kind "port") + the same DRN on the host through PyTorch, on n_img images."""
+    """SURVEY.md 8d's CPU rows on the host cores of this box, on a bounded sample of the same workload:
+      drn       : the same DRN, PyTorch-CPU float32 on all cores, n_img image(s);
+      port_1t   : the C restatement (oracle: Lab, SLIC, connectivity, pooling, prior, k-means, paint),
+                  ONE thread, one image;
+      port_all  : the same with images sharded over `cpu_threads` threads (one image per thread);
+      comparator: BASELINE.json's named CPU path as far as this box has it — NumPy pooling
+                  (label x cell count matrix @ feature matrix) + scipy.cluster.vq.kmeans2(k) on the
+                  oracle's SLIC labels (scikit-image does not travel to the GPU box).
+    `value` = images/s of the whole path on all cores = 1 / (drn s/image + port_all s/image)."""
     import torch
+    from concurrent.futures import ThreadPoolExecutor
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import oracle as orc
     drn = importlib.import_module('superpixel-align_amd.drn')
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
     H, W = a.height, a.width
-    imgs = np.stack([synth.synth_image(100 + i, H, W) for i in range(n_img)])
+    nthr = max(1, min(a.cpu_threads, cores))
     args = types.SimpleNamespace(superpixel_method='slic', n_slic_segments=a.n_slic_segments,
                                  n_anchors=10, n_neighbors=4, without_pos=False, y_rel_pos=0.75,
                                  x_rel_pos=0.5, y_rel_sigma=0.1, x_rel_sigma=0.1, n_clusters=a.n_clusters)
-    model = drn.create_drn(a.arch, device='cpu', dtype=torch.float32)
     orc.lib()
+    with ThreadPoolExecutor(nthr) as ex:
+        imgs = np.stack(list(ex.map(lambda i: synth.synth_image(100 + i, H, W), range(max(n_img, nthr)))))
+    model = drn.create_drn(a.arch, device='cpu', dtype=torch.float32)
     t0 = time.time()
     with torch.no_grad():
         fm = [model.batch_predict(imgs[i:i + 1])[1][7].float().numpy() for i in range(n_img)]
-    fmaps = np.concatenate(fm, 0)
-    t1 = time.time()
-    sps = orc.batch_superpixel(args, imgs)
-    feats, n_per = orc.batch_superpixel_align(args, imgs, sps, fmaps, orc.PyRandom(1111),
-                                              a.pool_mode, 'nearest')
-    prior = orc.batch_create_prior(args, sps)
-    orc.batch_weighted_kmeans(args, sps, feats, prior, n_per)
-    t2 = time.time()
-    return {'value': n_img / (t2 - t0), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
-            'sample': '%d synthetic %dx%d image(s): PyTorch-CPU %s fp32 forward on %d threads (%.1f s) '
-                      '+ single-threaded C oracle SLIC/pool(%s)/prior/k-means/paint (%.1f s)'
-                      % (n_img, H, W, a.arch, cores, t1 - t0, a.pool_mode, t2 - t1)}
+    t_drn = (time.time() - t0) / n_img
+    fmap = fm[0][0]                                   # (C, fh, fw); reused by every image of the port rows
+
+    def rest(i):                                      # everything behind the DRN for ONE image
+        one = imgs[i:i + 1]
+        sps = orc.batch_superpixel(args, one)
+        feats, n_per = orc.batch_superpixel_align(args, one, sps, fmap[None], orc.PyRandom(1111),
+                                                  a.pool_mode, 'nearest')
+        prior = orc.batch_create_prior(args, sps)
+        orc.batch_weighted_kmeans(args, sps, feats, prior, n_per)
+        return sps[0]
+
+    t0 = time.time()
+    sp0 = rest(0)
+    t_1t = time.time() - t0
+    t0 = time.time()
+    with ThreadPoolExecutor(nthr) as ex:
+        list(ex.map(rest, range(nthr)))
+    t_all = (time.time() - t0) / nthr                 # seconds per image with nthr images in flight
+
+    # BASELINE.json's comparator: NumPy pooling + scipy k-means on given labels
+    comp = None
+    try:
+        from scipy.cluster.vq import kmeans2
+        t0 = time.time()
+        C, fh, fw = fmap.shape
+        S = int(sp0.max()) + 1
+        ys = (np.arange(H) * fh // H)[:, None]
+        xs = (np.arange(W) * fw // W)[None, :]
+        pair = sp0.astype(np.int64) * (fh * fw) + (ys * fw + xs)
+        Wt = np.bincount(pair.ravel(), minlength=S * fh * fw).reshape(S, fh * fw).astype(np.float32)
+        pooled = (Wt @ fmap.reshape(C, -1).T) / Wt.sum(axis=1, keepdims=True)
+        kmeans2(pooled.astype(np.float64), a.n_clusters, minit='points', seed=1111)
+        comp = time.time() - t0
+    except Exception as exc:                          # scipy missing or too old: report, do not fail
+        comp = repr(exc)
+    return {'value': round(1.0 / (t_drn + t_all), 4), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': '%d synthetic %dx%d image(s) through PyTorch-CPU %s fp32 on %d threads; the C restatement '
+                      '(SLIC %d / pool(%s) / prior / k-means / paint) on 1 image with 1 thread and on %d images '
+                      'with %d threads; value = 1 / (DRN s/image + all-cores restatement s/image)'
+                      % (n_img, H, W, a.arch, cores, a.n_slic_segments, a.pool_mode, nthr, nthr),
+            'rows': {'drn_pytorch_cpu_s_per_image': round(t_drn, 3),
+                     'port_1_thread_s_per_image': round(t_1t, 3),
+                     'port_all_cores_s_per_image': round(t_all, 3), 'port_all_cores_threads': nthr,
+                     'comparator_numpy_pool_scipy_kmeans2_s_per_image': comp if isinstance(comp, str) else round(comp, 3),
+                     'comparator_note': 'NumPy pooling + scipy.cluster.vq.kmeans2 on the restatement\'s SLIC labels '
+                                        '(scikit-image SLIC, 1.8-3.8 s/image in the build container, is not on this box)'}}
 
 
 def main():
@@ -187,31 +251,45 @@ def main():
     eng = pipe.eng
 
     B, H, W = a.batch, a.height, a.width
-    imgs_h, gts_h = make_batch(spa.synth, B, H, W, scene=(a.superpixel_method == 'felzenszwalb'))
-    imgs = torch.from_numpy(imgs_h).cuda()
-    gts = torch.from_numpy(gts_h).cuda()
+    NB = max(1, a.n_batches)
+    # distinct batches in pinned host memory (the host loop's source) and their device copies
+    host, gts = [], []
+    for nb in range(NB):
+        pin = torch.empty((B, 3, H, W), dtype=torch.float32).pin_memory()
+        _, g = make_batch(spa.synth, B, H, W, scene=(a.superpixel_method == 'felzenszwalb'),
+                          seed0=1000 * rank + 4 * nb, out=pin.numpy())
+        host.append(pin)
+        gts.append(torch.from_numpy(g).cuda())
+    dev = [h.cuda() for h in host]
     conf_total = torch.zeros((B, 4), dtype=torch.int64, device='cuda')
+    cur = [0]
 
-    def step():
-        res = pipe.run(imgs, check_status=False)
-        conf_total.add_(eng.confusion(res.road, gts))
+    def score(res):
+        conf_total.add_(eng.confusion(res.road, gts[cur[0] % NB]))
+
+    def step(s):
+        cur[0] = s
+        res = pipe.run(dev[s % NB], check_status=False)
+        score(res)
         return res
 
-    for _ in range(a.warmup):
-        res = step()
+    for s in range(a.warmup):
+        res = step(s)
     eng.raise_on_status()
     torch.cuda.synchronize()
     conf_total.zero_()
     if not a.no_prof:
         eng.prof_enable(True)
     stage = {'time_feature_maps': 0.0, 'time_superpixel': 0.0, 'time_roialign': 0.0, 'time_kmeans': 0.0}
+    drn._EPILOGUE['bytes'] = 0
+    drn._EPILOGUE['launches'] = 0
 
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     evs = []
-    for _ in range(a.steps):
-        res = step()
+    for s in range(a.steps):
+        res = step(a.warmup + s)
         evs.append(dict(pipe._ev))             # device events, read after the timed region
     # the result.json reduction: one all_gather of per-image records
     info = res.info.cpu().numpy()
@@ -227,6 +305,7 @@ def main():
     torch.cuda.synchronize()
     dt = dist.max_over_ranks(time.perf_counter() - t0)
     eng.raise_on_status()
+    bias_bytes, bias_launches = drn._EPILOGUE['bytes'], drn._EPILOGUE['launches']
 
     for e in evs:
         pipe._ev = e
@@ -236,6 +315,36 @@ def main():
     prof = eng.prof_read() if not a.no_prof else {}
     eng.prof_enable(False)
 
+    # ---- SURVEY.md 8d's region: pinned host memory -> masks in pinned host memory, double buffered
+    h2h = None
+    if not a.no_host_loop:
+        first = [a.warmup]
+        hs = pipeline.HostStream(pipe, B, H, W,
+                                 after=lambda r, s: conf_total.add_(eng.confusion(r.road, gts[(first[0] + s) % NB])))
+        order = [host[(a.warmup + s) % NB] for s in range(a.steps + 1)]
+
+        def feed(seq):
+            for hb in seq:
+                yield hb
+        for _ in hs.process(feed(order[:1])):   # warm the copy streams and buffers
+            pass
+        first[0] = a.warmup + 1
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n_out = 0
+        for cluster_h, road_h, _r in hs.process(feed(order[1:])):
+            n_out += int(road_h.shape[0])
+        dist.barrier()
+        torch.cuda.synchronize()
+        dt_h = dist.max_over_ranks(time.perf_counter() - t1)
+        eng.raise_on_status()
+        h2h = {'value': round(ws * B * a.steps / dt_h, 3), 'unit': 'images/sec',
+               'ms_per_step': round(dt_h / a.steps * 1e3, 3), 'images_downloaded': n_out * ws,
+               'pcie_bytes_per_step': B * (3 * H * W * 4 + 2 * H * W),
+               'region': 'batches in pinned host memory -> cluster + road masks in pinned host memory; uploads '
+                         '(h2d stream) and downloads (d2h stream) double buffered under the kernels'}
+
     if rank != 0:
         return
     total_images = ws * B * a.steps
@@ -243,31 +352,45 @@ def main():
     fh, fw = res.fmap.shape[2], res.fmap.shape[3]
     n_seg = float(n_sp.mean())
     feat_bytes = 4 if a.dtype == 'fp32' else 2
+    peak_tf = FP32_MATRIX_PEAK_TF if a.dtype == 'fp32' else BF16_MATRIX_PEAK_TF
     kernels = {}
     for name, (ms, n) in prof.items():
         avg = ms / n
-        ab = algorithmic_bytes(name, B, H, W, C, fh, fw, n_seg, feat_bytes)
-        kernels[name] = {'launches_per_step': n / a.steps, 'avg_ms': round(avg, 4),
-                         'ms_per_step': round(ms / a.steps, 3),
-                         'achieved_GBs': round(ab / (avg * 1e-3) / 1e9, 1) if ab else None}
+        ent = {'launches_per_step': n / a.steps, 'avg_ms': round(avg, 4), 'ms_per_step': round(ms / a.steps, 3)}
+        if name.startswith('k_drn_stem_d'):
+            # the fused stem is float32 MFMA arithmetic whatever the storage dtype of the network
+            tf = stem_flops(B, H, W) / (avg * 1e-3) / 1e12
+            ent.update(bound='mfma', achieved=round(tf, 2), peak=FP32_MATRIX_PEAK_TF, unit='TFLOP/s',
+                       frac=round(tf / FP32_MATRIX_PEAK_TF, 4), flops_per_launch=stem_flops(B, H, W))
+        else:
+            if name.startswith('k_bias_act'):
+                ab = bias_bytes / max(1, bias_launches)          # average over the 23 layers' shapes
+            else:
+                ab = algorithmic_bytes(name, B, H, W, C, fh, fw, n_seg, feat_bytes)
+            gbs = ab / (avg * 1e-3) / 1e9 if ab else None
+            ent.update(bound='hbm' if ab else 'latency', achieved=round(gbs, 1) if gbs else None, peak=HBM_PEAK_GBS,
+                       unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4) if gbs else None,
+                       algorithmic_bytes_per_launch=int(ab), traffic=pmc_traffic(name, B, H, W))
+        ent['achieved_GBs'] = ent['achieved'] if ent.get('unit') == 'GB/s' else None
+        if name in LIMITERS:
+            ent['limiter'] = LIMITERS[name]
+        kernels[name] = ent
+    # headline roofline: the hand-written kernel family with the most time per step — no name filter
     roof = None
-    # roofline kernel: the longest-running kernel of the label path SURVEY.md 8(d) prices (the DRN glue
-    # kernels of libspalign are listed in `kernels` with their time, and accounted under `drn`)
-    single = [k for k in kernels if not k.endswith('(all)') and kernels[k]['achieved_GBs']
-              and not k.startswith(('k_drn', 'k_bias_act'))]
-    if single:
-        dom = max(single, key=lambda k: kernels[k]['ms_per_step'])
-        ach = kernels[dom]['achieved_GBs']
-        roof = {'kernel': dom, 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': pmc_traffic(dom, B, H, W),
-                'avg_launch_ms': kernels[dom]['avg_ms'],
-                'algorithmic_bytes_per_launch': algorithmic_bytes(dom, B, H, W, C, fh, fw, n_seg, feat_bytes),
+    if kernels:
+        dom = max(kernels, key=lambda k: kernels[k]['ms_per_step'])
+        e = kernels[dom]
+        roof = {'kernel': dom, 'bound': e['bound'], 'achieved': e['achieved'], 'peak': e['peak'], 'unit': e['unit'],
+                'frac': e['frac'], 'traffic': e.get('traffic'), 'avg_launch_ms': e['avg_ms'],
+                'ms_per_step': e['ms_per_step'],
+                'algorithmic_bytes_per_launch': e.get('algorithmic_bytes_per_launch'),
+                'flops_per_launch': e.get('flops_per_launch'),
                 'traffic_source': 'profiles/pmc_traffic.json: HBM bytes per launch from separate rocprofv3 --pmc '
                                   'FETCH_SIZE / WRITE_SIZE passes (gfx950 corrections applied), scaled to this batch',
-                'limiter': LIMITERS.get(dom)}
+                'limiter': e.get('limiter'),
+                'selection': 'largest ms_per_step among all hand-written kernel families of libspalign (see `kernels`)'}
     drn_ms = stage['time_feature_maps'] / a.steps
     flops = drn.flops_per_image(a.arch, H, W) * B
-    peak_tf = FP32_MATRIX_PEAK_TF if a.dtype == 'fp32' else BF16_MATRIX_PEAK_TF
     drn_tf = flops / (drn_ms * 1e-3) / 1e12
     tp = allrec[:, 4].sum(); fp = allrec[:, 2].sum(); fn = allrec[:, 3].sum()
     out = {
@@ -279,16 +402,16 @@ def main():
         'data': 'synthetic',
         'config': {'workload': 'BASELINE configs[1] x batch: %s %s features + HIP %s/%s-pool/'
                                'prior/k-means(k=%d)/paint, %dx%d, %d images per step per GPU, '
-                               'random-init weights' % (a.arch, a.dtype,
-                                                        'SLIC(%d)' % a.n_slic_segments if a.superpixel_method == 'slic'
-                                                        else 'felzenszwalb(300,0.8,20)', a.pool_mode,
-                                                        a.n_clusters, H, W, B),
+                               '%d distinct batches rotating, random-init weights'
+                               % (a.arch, a.dtype, 'SLIC(%d)' % a.n_slic_segments if a.superpixel_method == 'slic'
+                                  else 'felzenszwalb(300,0.8,20)', a.pool_mode, a.n_clusters, H, W, B, NB),
                    'images_per_step_per_gpu': B, 'sharding': 'images (no data-path collective), '
                    'one all_gather of score records'},
         'roofline': roof,
+        'host_to_host': h2h,
         'drn': {'bound': 'mfma', 'achieved': round(drn_tf, 2), 'peak': peak_tf, 'unit': 'TFLOP/s',
                 'frac': round(drn_tf / peak_tf, 4), 'ms_per_step': round(drn_ms, 3),
-                'note': 'DRN forward is PyTorch-ROCm (MIOpen) by design; libspalign adds the fused float32-MFMA stem of '
+                'note': 'the big convolutions are PyTorch-ROCm (MIOpen); libspalign adds the fused float32-MFMA stem of '
                         'DRN-D (normalise + layer0 + layer1, k_drn_stem_d) and the bias/residual/ReLU epilogues'},
         'stage_ms_per_step': dict({k: round(v / a.steps, 3) for k, v in stage.items()},
                                   streams='two: superpixel branch overlaps the DRN forward' if overlap

@@ -211,7 +211,8 @@ class HostStream(object):
         for cluster, road, res in hs.process(batches):   # batches: iterable of pinned (B,3,H,W) f32
             ...            # cluster / road: numpy views of pinned memory, valid until the next-but-one yield
 
-    `after(res)` may enqueue extra device work on the compute stream per batch (bench: confusion)."""
+    `after(res, s)` may enqueue extra device work on the compute stream for the s-th batch of the
+    call (bench: confusion counts)."""
 
     def __init__(self, pipe, B, H, W, after=None):
         self.pipe, self.after = pipe, after
@@ -268,7 +269,7 @@ class HostStream(object):
             main.wait_event(self.up_done[slot])
             res = self.pipe.run(self.inp[slot][:cur_n], check_status=False)
             if self.after is not None:
-                self.after(res)
+                self.after(res, s)
             self.in_free[slot].record(main)
             done = torch.cuda.Event()
             done.record(main)

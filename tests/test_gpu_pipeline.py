@@ -203,7 +203,35 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['value'] > 0
     assert d['quality']['records_gathered'] == 4             # 2 ranks x 2 images
-    assert d['roofline']['bound'] == 'hbm' and 'cpu_baseline' not in d
+    assert d['roofline']['bound'] in ('hbm', 'mfma', 'latency') and 'cpu_baseline' not in d
+    assert d['roofline']['ms_per_step'] == max(k['ms_per_step'] for k in d['kernels'].values())
+    h = d['host_to_host']                                    # SURVEY 8d's region, second timed loop
+    assert h['value'] > 0 and h['images_downloaded'] == 2 * 2 * 2
+
+
+def test_host_stream_matches_device_resident_path(mods, synth):
+    """pipeline.HostStream (pinned host batches -> masks in pinned host memory, uploads and downloads
+    double buffered on copy streams) returns exactly what the device-resident path returns, batch
+    after batch, for pinned and for pageable inputs and a short last batch."""
+    args = _args(pool_mode='mean', n_slic_segments=40)
+    H, W, B = 96, 160, 3
+    model = mods.drn.create_drn('drn_d_22', device='cuda')
+    pipe = mods.pipeline.LabelPipeline(args, model, mods.ops.engine())
+    batches = [synth.synth_batch([70 + 3 * s + i for i in range(B)], H, W) for s in range(5)]
+    batches[4] = batches[4][:2]                              # the driver's last batch may be short
+    expect = []
+    for b in batches:
+        r = pipe.run(b)
+        expect.append((r.cluster.cpu().numpy(), r.road.cpu().numpy()))
+    hs = mods.pipeline.HostStream(pipe, B, H, W)
+    seen = []
+    feed = [torch.from_numpy(b).pin_memory() if i % 2 == 0 else b for i, b in enumerate(batches)]
+    for cl, road, res in hs.process(iter(feed)):
+        seen.append((cl.copy(), road.copy()))
+    assert len(seen) == len(expect)
+    for (c0, r0), (c1, r1) in zip(expect, seen):
+        assert np.array_equal(c0, c1) and np.array_equal(r0, r1)
+    pipe.eng.raise_on_status()
 
 
 @pytest.mark.parametrize('shape', [(2, 64, 96), (1, 100, 75), (3, 33, 130)])
