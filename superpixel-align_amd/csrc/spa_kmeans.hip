@@ -34,11 +34,13 @@
 #include <stdlib.h>
 
 #define KM_MAXK 8
-#define KM_THREADS 1024       // 16 waves per workgroup
+#define KM_THREADS 512        // 8 waves per workgroup (256 registers per lane: nothing spills to scratch,
+                              // whose reloads would drain the global loads in flight through vmcnt)
 #define KM_WAVES (KM_THREADS / 64)
-#define KM_ROWS 128           // member rows per chain chunk (8 per wave)
+#define KM_GROWS 8            // rows per gather wave and chunk
+#define KM_ROWS (KM_GROWS * (KM_WAVES - 1))   // member rows per chain chunk (waves 1..7 gather; wave 0 adds)
 #define KM_MAXLEAF 48         // blocks of the pairwise tree over D (>= 57 elements each: D <= 2736 always fits)
-#define KM_CHUNK_BYTES (KM_ROWS * 64 * 8)
+#define KM_CHUNK_BYTES (128 * 64 * 8)
 
 struct KmShared {
     unsigned barrier;      // monotonic arrival counter
@@ -50,22 +52,29 @@ struct KmShared {
 struct KmTree {
     int nleaf, nops;
     short leaf_start[KM_MAXLEAF], leaf_n[KM_MAXLEAF];
-    short ops[2 * KM_MAXLEAF];           // >= 0: push block sum; -1: pop two, push their sum
+    short ops[2 * KM_MAXLEAF];           // nops pairs (lane a, lane b): lane a += lane b, in numpy's order
 };
 
-static bool km_build_tree(KmTree &t, int start, int n)
+static inline int km_leaf_lane(int q) { return (q & 7) * 8 + (q >> 3); }
+
+// returns the index of the first block of the subtree (its lane receives the subtree's sum), -1 on overflow
+static int km_build_tree(KmTree &t, int start, int n)
 {
     if (n <= 128) {
-        if (t.nleaf >= KM_MAXLEAF) return false;
+        if (t.nleaf >= KM_MAXLEAF) return -1;
         t.leaf_start[t.nleaf] = (short)start; t.leaf_n[t.nleaf] = (short)n;
-        t.ops[t.nops++] = (short)t.nleaf++;
-        return true;
+        return t.nleaf++;
     }
     int n2 = n / 2;
     n2 -= n2 % 8;
-    if (!km_build_tree(t, start, n2) || !km_build_tree(t, start + n2, n - n2)) return false;
-    t.ops[t.nops++] = -1;
-    return true;
+    const int a = km_build_tree(t, start, n2);
+    if (a < 0) return -1;
+    const int b = km_build_tree(t, start + n2, n - n2);
+    if (b < 0) return -1;
+    t.ops[2 * t.nops] = (short)km_leaf_lane(a);
+    t.ops[2 * t.nops + 1] = (short)km_leaf_lane(b);
+    t.nops += 1;
+    return a;
 }
 
 __device__ __forceinline__ void grid_sync(unsigned *ctr, unsigned G, unsigned &epoch,
@@ -90,6 +99,15 @@ __device__ __forceinline__ void grid_sync(unsigned *ctr, unsigned G, unsigned &e
     __syncthreads();
 }
 
+// workgroup barrier that orders LDS only: global loads issued before it stay in flight across it
+// (__syncthreads() waits vmcnt(0) here, which would put every gather's memory latency on the chain's path)
+__device__ __forceinline__ void km_lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // LDS written and read back by the same wave
 __device__ __forceinline__ void km_wave_lds_sync()
 {
@@ -97,6 +115,19 @@ __device__ __forceinline__ void km_wave_lds_sync()
     __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// value of a wave-uniform lane (v_readlane: no LDS round trip)
+__device__ __forceinline__ int km_readlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ float km_readlane(float v, int l)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+__device__ __forceinline__ double km_readlane(double v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
 }
 
 // order-preserving key of a double (ascending)
@@ -133,13 +164,14 @@ __device__ __forceinline__ int km_wg_rank(bool flag, int *scr, int &total)
 
 // numpy's pairwise sum of wl[0..n) (float64) by ONE wave: lanes 0..7 are the eight accumulators of the
 // current block; the recursion is emulated with an explicit (wave-uniform) stack.
-__device__ double km_pairwise_wave(const double *__restrict__ wl, int n)
+__device__ double km_pairwise_wave(const double *wl, int n, int *fs, double *fv)
 {
+    // fs: 3 * 40 ints of LDS (start, length, stage of the pending calls), fv: 40 doubles (left sums)
     const int lane = threadIdx.x & 63, j = lane & 7;
-    int fs[40], fn[40], fst[40];
-    double fv[40];
+    int *fn = fs + 40, *fst = fs + 80;
     int sp = 1;
-    fs[0] = 0; fn[0] = n; fst[0] = 0;
+    if (lane == 0) { fs[0] = 0; fn[0] = n; fst[0] = 0; }
+    km_wave_lds_sync();
     double ret = 0.0;
     while (sp > 0) {
         const int t = sp - 1;
@@ -162,21 +194,20 @@ __device__ double km_pairwise_wave(const double *__restrict__ wl, int n)
             } else {
                 int n2 = nn / 2;
                 n2 -= n2 % 8;
-                fst[t] = 1;
-                fs[sp] = s0; fn[sp] = n2; fst[sp] = 0;
+                if (lane == 0) { fst[t] = 1; fs[sp] = s0; fn[sp] = n2; fst[sp] = 0; }
                 sp += 1;
             }
         } else if (fst[t] == 1) {
-            int n2 = fn[t] / 2;
+            const int s0 = fs[t], nn = fn[t];
+            int n2 = nn / 2;
             n2 -= n2 % 8;
-            fv[t] = ret;
-            fst[t] = 2;
-            fs[sp] = fs[t] + n2; fn[sp] = fn[t] - n2; fst[sp] = 0;
+            if (lane == 0) { fv[t] = ret; fst[t] = 2; fs[sp] = s0 + n2; fn[sp] = nn - n2; fst[sp] = 0; }
             sp += 1;
         } else {
             ret = fv[t] + ret;
             sp -= 1;
         }
+        km_wave_lds_sync();
     }
     return ret;
 }
@@ -231,7 +262,7 @@ __device__ int km_member_list(const int32_t *__restrict__ asg, const double *__r
 }
 
 // info: {iterations, status, N, -}
-template <typename T>
+template <typename T, int KM>
 __global__ __launch_bounds__(KM_THREADS) void k_kmeans(const T *__restrict__ X, long long ld, int D,
                                                        const double *__restrict__ w,
                                                        const int32_t *__restrict__ n_ptr, int Ncap,
@@ -256,14 +287,13 @@ __global__ __launch_bounds__(KM_THREADS) void k_kmeans(const T *__restrict__ X, 
     T *lds_c = (T *)lds_raw;
     unsigned char *scratch = lds_raw + (((size_t)k * D * sizeof(double) + 15) & ~(size_t)15);
     double *chunk = (double *)scratch;                           // [KM_ROWS][64]
-    // sweep scratch (aliases the chain buffer): stacks [wave][k][16] (16 KB), block sums [wave][nleaf][k]
-    T *stk = (T *)scratch;
-    T *leafsum = (T *)(scratch + (size_t)KM_WAVES * KM_MAXK * 16 * sizeof(double));
     __shared__ int scr[KM_WAVES + 4];
     __shared__ short tl_start[KM_MAXLEAF], tl_n[KM_MAXLEAF], tl_ops[2 * KM_MAXLEAF];
     __shared__ unsigned hist[256];
     __shared__ unsigned long long sel_prefix;
     __shared__ int sel_rank;
+    __shared__ int pw_fs[120];
+    __shared__ double pw_fv[40];
 
     const unsigned G = gridDim.x;
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -355,6 +385,12 @@ __global__ __launch_bounds__(KM_THREADS) void k_kmeans(const T *__restrict__ X, 
     grid_sync(&sh->barrier, G, epoch, status);
 
     int it = 0, st = 1;
+#ifdef SPA_KM_TIMING
+    unsigned long long kt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, kt0_ = __builtin_readcyclecounter();
+#define KM_T(i) { unsigned long long n_ = __builtin_readcyclecounter(); kt_[i] += n_ - kt0_; kt0_ = n_; }
+#else
+#define KM_T(i)
+#endif
     for (int phase = 0;; ++phase) {
         // ================= centre sums of `new_assign`: phase 0 unweighted means in T (:150-151),
         // afterwards weighted float64 sums (:163-171)
@@ -363,8 +399,14 @@ __global__ __launch_bounds__(KM_THREADS) void k_kmeans(const T *__restrict__ X, 
                 // ---- member count and w.sum() of one cluster
                 const int c = u - n_chain;
                 const int cnt = km_member_list(new_assign, w, N, c, phase > 0, ml, wl, scr);
+                // the pairwise pass is one wave walking the weights block by block: give it LDS latency
+                const bool in_lds = cnt <= KM_CHUNK_BYTES / 8;
+                if (phase > 0 && in_lds) {
+                    for (int i = tid; i < cnt; i += KM_THREADS) chunk[i] = wl[i];
+                    __syncthreads();
+                }
                 if (wv == 0) {
-                    const double ws = (phase > 0) ? km_pairwise_wave(wl, cnt) : 0.0;
+                    const double ws = (phase > 0) ? km_pairwise_wave(in_lds ? chunk : wl, cnt, pw_fs, pw_fv) : 0.0;
                     if (lane == 0) { wsum[c] = ws; cnt_c[c] = cnt; }
                 }
                 __syncthreads();
@@ -374,42 +416,57 @@ __global__ __launch_bounds__(KM_THREADS) void k_kmeans(const T *__restrict__ X, 
             const int c = u / nblk, blk = u - c * nblk;
             const int col = blk * 64 + lane;
             const bool colok = col < D;
+            KM_T(5)
             const int cnt = km_member_list(new_assign, w, N, c, phase > 0, ml, wl, scr);
+            KM_T(6)
             const int nchunk = (cnt + KM_ROWS - 1) / KM_ROWS;
             double accd = 0.0;
             float accf = 0.0f;
-            double ra[8], rb[8];
-            // rows wv*8 .. wv*8+7 of chunk q -> registers (products already rounded)
-            auto gather = [&](int q, double (&r)[8]) {
-                const int r0 = q * KM_ROWS + wv * 8;
-                int idx = 0;
-                double wj = 0.0;
-                if (lane < 8 && r0 + lane < cnt) { idx = ml[r0 + lane]; wj = wl[r0 + lane]; }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int ie = __shfl(idx, e);
-                    const double we = __shfl(wj, e);
-                    double v = 0.0;
-                    if (colok && r0 + e < cnt) {
-                        const double x = (double)X[(long long)ie * ld + col];
-                        v = (phase > 0) ? x * we : x;
-                    }
-                    r[e] = v;
-                }
+            // Two register sets (raw values + weights of 8 rows each) = two chunks of loads in flight.
+            // The list entries (index, weight) of a chunk are fetched one gather ahead; the row loads are
+            // unconditional (clamped index): a branch around a load makes the compiler wait for each load
+            // separately instead of keeping the eight in flight; the products are formed only when the set
+            // is written to LDS, so a gather never waits for its own loads.
+            double ra[KM_GROWS], rb[KM_GROWS], wa[KM_GROWS], wb[KM_GROWS];
+            int l_idx = 0;
+            double l_w = 0.0;
+            const int gw = wv - 1;          // gather wave index; wave 0 only runs the chain
+            auto fetch_list = [&](int q) {
+                if (wv == 0) return;
+                const int r = q * KM_ROWS + gw * KM_GROWS + (lane & (KM_GROWS - 1));
+                const int rc = r < cnt ? r : (cnt > 0 ? cnt - 1 : 0);
+                l_idx = cnt > 0 ? ml[rc] : 0;
+                l_w = cnt > 0 ? wl[rc] : 0.0;
             };
-            auto store = [&](const double (&r)[8]) {
+            const int colc = colok ? col : D - 1;
+            auto gather = [&](int q, double (&r)[KM_GROWS], double (&rw)[KM_GROWS]) {
+                if (wv == 0) return;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) chunk[(wv * 8 + e) * 64 + lane] = r[e];
+                for (int e = 0; e < KM_GROWS; ++e) {
+                    const int ie = km_readlane(l_idx, e);
+                    rw[e] = km_readlane(l_w, e);
+                    r[e] = (double)X[(long long)ie * ld + colc];
+                }
+                fetch_list(q + 1);          // entries of the next gather (chunks are gathered in order)
+            };
+            auto store = [&](int q, const double (&r)[KM_GROWS], const double (&rw)[KM_GROWS]) {
+                if (wv == 0) return;
+                const int r0 = q * KM_ROWS + gw * KM_GROWS;
+#pragma unroll
+                for (int e = 0; e < KM_GROWS; ++e) {
+                    const double v = (phase > 0) ? r[e] * rw[e] : r[e];
+                    chunk[(gw * KM_GROWS + e) * 64 + lane] = (colok && r0 + e < cnt) ? v : 0.0;
+                }
             };
             auto chain = [&](int q) {
                 if (wv != 0) return;
                 const int rows = min(KM_ROWS, cnt - q * KM_ROWS);
-                for (int r0 = 0; r0 < rows; r0 += 16) {
-                    double v[16];
+                for (int r0 = 0; r0 < rows; r0 += 8) {
+                    double v[8];
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) v[e] = chunk[(r0 + e) * 64 + lane];
+                    for (int e = 0; e < 8; ++e) v[e] = chunk[(r0 + e) * 64 + lane];
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
+                    for (int e = 0; e < 8; ++e) {
                         if (r0 + e < rows) {
                             if (f32 && phase == 0) accf = accf + (float)v[e];
                             else accd = accd + v[e];
@@ -418,31 +475,34 @@ __global__ __launch_bounds__(KM_THREADS) void k_kmeans(const T *__restrict__ X, 
                 }
             };
             if (nchunk > 0) {
-                gather(0, ra);
-                store(ra);
-                if (nchunk > 1) gather(1, ra);
-                __syncthreads();
+                fetch_list(0);
+                gather(0, ra, wa);
+                store(0, ra, wa);
+                if (nchunk > 1) gather(1, ra, wa);
+                km_lds_barrier();
                 for (int q = 0; q < nchunk; q += 2) {
-                    // LDS = chunk q, ra = chunk q+1
-                    if (q + 2 < nchunk) gather(q + 2, rb);
+                    // LDS = chunk q, set a = chunk q+1
+                    if (q + 2 < nchunk) gather(q + 2, rb, wb);
                     chain(q);
-                    __syncthreads();
+                    km_lds_barrier();
                     if (q + 1 >= nchunk) break;
-                    store(ra);
-                    __syncthreads();
-                    // LDS = chunk q+1, rb = chunk q+2
-                    if (q + 3 < nchunk) gather(q + 3, ra);
+                    store(q + 1, ra, wa);
+                    km_lds_barrier();
+                    // LDS = chunk q+1, set b = chunk q+2
+                    if (q + 3 < nchunk) gather(q + 3, ra, wa);
                     chain(q + 1);
-                    __syncthreads();
+                    km_lds_barrier();
                     if (q + 2 >= nchunk) break;
-                    store(rb);
-                    __syncthreads();
+                    store(q + 2, rb, wb);
+                    km_lds_barrier();
                 }
             }
             if (wv == 0 && colok) sums[(long long)c * D + col] = (f32 && phase == 0) ? (double)accf : accd;
             __syncthreads();
         }
+        KM_T(0)
         grid_sync(&sh->barrier, G, epoch, status);
+        KM_T(1)
 
         // ================= centres = sums / denominator, into LDS (every workgroup)
         bool empty = false;
@@ -462,98 +522,94 @@ __global__ __launch_bounds__(KM_THREADS) void k_kmeans(const T *__restrict__ X, 
         if (phase > 0 && empty) { st = 2; break; }      // (:173-181) after the update
         if (it >= max_iter) { st = 1; break; }
 
+        KM_T(2)
         // ================= assignment sweep (:155-157): one wave per point
         ++it;
         int local_changed = 0;
         const int q8 = lane >> 3, j = lane & 7;
-        T *ls = leafsum + (size_t)wv * nleaf * KM_MAXK;
-        T *sk = stk + (size_t)wv * KM_MAXK * 16;
+        // (clusters c >= k, when k is below the compile-time bound KM, are computed on whatever LDS holds
+        // behind the centres — always inside the allocation — and never looked at: no branches in the loop)
+        // block q of the pairwise tree lives in octet q & 7, round q >> 3; its sum ends in lane
+        // (q & 7) * 8 + (q >> 3); the host-built program then adds lanes pairwise (readlane: uniform lanes)
+        const int rounds = (nleaf + 7) >> 3;
         for (int i = lo + wv; i < hi; i += KM_WAVES) {
             const T *xr = X + (long long)i * ld;
-            for (int lg = 0; lg < nleaf; lg += 8) {
-                const int q = lg + q8;
-                const bool act = q < nleaf;
-                const int s0 = act ? (int)tl_start[q] : 0;
-                const int n = act ? (int)tl_n[q] : 0;
-                const int steps = n >> 3;
-                T acc[KM_MAXK];
+            T val[KM];                      // per lane: the block sum this lane keeps, per cluster
 #pragma unroll
-                for (int c = 0; c < KM_MAXK; ++c) acc[c] = (T)0;
+            for (int c = 0; c < KM; ++c) val[c] = (T)0;
+            for (int r0 = 0; r0 < rounds; r0 += 2) {
+                // two rounds = 16 blocks per pass: all their loads are issued before any arithmetic
+                int s0[2], n[2], steps[2];
+                T xv[2][16];
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    T xv[8];                // eight elements of this lane's accumulator in flight
+                for (int u = 0; u < 2; ++u) {
+                    const int q = (r0 + u) * 8 + q8;
+                    const bool act = q < nleaf;
+                    s0[u] = act ? (int)tl_start[q] : 0;
+                    n[u] = act ? (int)tl_n[q] : 0;
+                    steps[u] = n[u] >> 3;
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        const int tt = h * 8 + t;
-                        xv[t] = xr[(tt < steps) ? s0 + 8 * tt + j : 0];
-                    }
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        const int tt = h * 8 + t;
-                        const int d = (tt < steps) ? s0 + 8 * tt + j : 0;
-#pragma unroll
-                        for (int c = 0; c < KM_MAXK; ++c) {
-                            if (c < k) {
-                                const T df = xv[t] - lds_c[c * D + d];
-                                const T sq = df * df;
-                                const T nv = (tt == 0) ? sq : acc[c] + sq;
-                                acc[c] = (tt < steps) ? nv : acc[c];
-                            }
-                        }
-                    }
+                    for (int t = 0; t < 16; ++t) xv[u][t] = xr[(t < steps[u]) ? s0[u] + 8 * t + j : 0];
                 }
 #pragma unroll
-                for (int c = 0; c < KM_MAXK; ++c) {
-                    if (c < k) {
+                for (int u = 0; u < 2; ++u) {
+                    T acc[KM];
+#pragma unroll
+                    for (int c = 0; c < KM; ++c) acc[c] = (T)0;
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) {
+                        const int d = (t < steps[u]) ? s0[u] + 8 * t + j : 0;
+#pragma unroll
+                        for (int c = 0; c < KM; ++c) {
+                            const T df = xv[u][t] - lds_c[c * D + d];
+                            const T sq = df * df;
+                            const T nv = (t == 0) ? sq : acc[c] + sq;
+                            acc[c] = (t < steps[u]) ? nv : acc[c];
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < KM; ++c) {
                         T r = acc[c];
                         r = r + __shfl_xor(r, 1);
                         r = r + __shfl_xor(r, 2);
                         r = r + __shfl_xor(r, 4);
-                        acc[c] = (steps > 0) ? r : (T)0;
+                        acc[c] = (steps[u] > 0) ? r : (T)0;
                     }
-                }
-                // the n % 8 tail (and a whole block shorter than 8), one by one
-                const int tail0 = steps * 8;
-                for (int e = tail0; e < n; ++e) {
-                    const T x = xr[s0 + e];
+                    // the n % 8 tail (and a whole block shorter than 8), one by one
+                    for (int e = steps[u] * 8; e < n[u]; ++e) {
+                        const T x = xr[s0[u] + e];
 #pragma unroll
-                    for (int c = 0; c < KM_MAXK; ++c) {
-                        if (c < k) {
-                            const T df = x - lds_c[c * D + s0 + e];
+                        for (int c = 0; c < KM; ++c) {
+                            const T df = x - lds_c[c * D + s0[u] + e];
                             acc[c] = acc[c] + df * df;
                         }
                     }
-                }
-                if (act && j == 0) {
+                    const bool keep = j == r0 + u;          // lane (q & 7) * 8 + (q >> 3)
 #pragma unroll
-                    for (int c = 0; c < KM_MAXK; ++c)
-                        if (c < k) ls[q * KM_MAXK + c] = acc[c];
+                    for (int c = 0; c < KM; ++c) val[c] = keep ? acc[c] : val[c];
                 }
             }
-            km_wave_lds_sync();
-            // block sums -> total, lane c = cluster c, numpy's recursion as a stack program
-            T dist = (T)0;
-            if (lane < k) {
-                int sp = 0;
-                for (int o = 0; o < nops; ++o) {
-                    const int op = (int)tl_ops[o];
-                    if (op >= 0) { sk[lane * 16 + sp] = ls[op * KM_MAXK + lane]; sp += 1; }
-                    else {
-                        const T b = sk[lane * 16 + sp - 1], a = sk[lane * 16 + sp - 2];
-                        sk[lane * 16 + sp - 2] = a + b;
-                        sp -= 1;
-                    }
+            // block sums -> total: numpy's recursion as a program of lane additions (left operand's lane
+            // receives the sum); the total ends in the lane of block 0 = lane 0
+            for (int o = 0; o < nops; ++o) {
+                const int la = (int)tl_ops[2 * o], lb = (int)tl_ops[2 * o + 1];
+#pragma unroll
+                for (int c = 0; c < KM; ++c) {
+                    const T sum = km_readlane(val[c], la) + km_readlane(val[c], lb);
+                    val[c] = (lane == la) ? sum : val[c];
                 }
-                dist = sk[lane * 16];
-                dist = f32 ? (T)sqrtf((float)dist) : (T)sqrt((double)dist);
             }
-            km_wave_lds_sync();
             int best = 0;
-            T bd = __shfl(dist, 0);
-            for (int c = 1; c < k; ++c) {
-                const T dc = __shfl(dist, c);
-                // np.argmin: first minimum; a NaN beats everything and the first NaN stays
-                if (!(bd != bd) && ((dc != dc) || dc < bd)) { best = c; bd = dc; }
+            T bd = km_readlane(val[0], 0);
+            bd = f32 ? (T)sqrtf((float)bd) : (T)sqrt((double)bd);
+#pragma unroll
+            for (int c = 1; c < KM; ++c) {
+                if (c < k) {
+                    T dc = km_readlane(val[c], 0);
+                    dc = f32 ? (T)sqrtf((float)dc) : (T)sqrt((double)dc);
+                    // np.argmin: first minimum; a NaN beats everything and the first NaN stays
+                    if (!(bd != bd) && ((dc != dc) || dc < bd)) { best = c; bd = dc; }
+                }
             }
             if (lane == 0) {
                 new_assign[i] = best;
@@ -562,13 +618,20 @@ __global__ __launch_bounds__(KM_THREADS) void k_kmeans(const T *__restrict__ X, 
         }
         if (lane == 0 && local_changed)
             __hip_atomic_fetch_add(&changed[it], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        KM_T(3)
         grid_sync(&sh->barrier, G, epoch, status);
+        KM_T(4)
 
         // ================= convergence test of the sweep (:158-159)
         const int ch = __hip_atomic_load(&changed[it], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (ch == 0) { st = 0; break; }
         for (int i = lo + tid; i < hi; i += KM_THREADS) assign[i] = new_assign[i];
     }
+#ifdef SPA_KM_TIMING
+    if ((g == 0 || g == n_chain) && tid == 0)
+        printf("kmeans cycles (workgroup %d): update %llu (of which member list %llu) | barrier %llu | centres %llu | sweep %llu | "
+               "barrier %llu ; iterations %d, G %u\n", g, kt_[0] + kt_[6], kt_[6], kt_[1], kt_[2], kt_[3], kt_[4], it, G);
+#endif
     if (g == 0 && tid == 0) { info[0] = it; info[1] = st; info[2] = N; info[3] = 0; }
 }
 
@@ -583,14 +646,14 @@ extern "C" int spa_kmeans_weighted(spa_ctx *ctx, const void *X, int32_t x_dtype,
     const size_t lds = (((size_t)k * D * sizeof(double) + 15) & ~(size_t)15) + KM_CHUNK_BYTES;
     KmTree tree;
     memset(&tree, 0, sizeof(tree));
-    if (lds > 150 * 1024 || !km_build_tree(tree, 0, D)) {
+    if (lds > 150 * 1024 || km_build_tree(tree, 0, D) < 0) {
         spa_set_error("k*D = %d*%d centres do not fit LDS next to the chain buffer", k, D);
         return SPA_ERR_ARG;
     }
     hipStream_t s = spa_stream(stream);
     const int nblk = (D + 63) / 64;
     const int n_task = k * nblk + k;
-    int kdiv = 32;               // points per workgroup of the sweep (16 waves: two points per wave)
+    int kdiv = 32;               // points per workgroup of the sweep (8 waves: four points per wave; measured best at N ~ 5 000)
     if (const char *e = getenv("SPA_KM_DIV")) kdiv = atoi(e) > 0 ? atoi(e) : kdiv;               // experiments
     int G = (Ncap + kdiv - 1) / kdiv;
     if (G < n_task) G = n_task;
@@ -615,26 +678,24 @@ extern "C" int spa_kmeans_weighted(spa_ctx *ctx, const void *X, int32_t x_dtype,
     SpaProfScope prof_(ctx, PROF_KMEANS, s);
     double *wlist = (double *)lists;
     int32_t *mlist = (int32_t *)(lists + (size_t)regions * Ncap * 8);
+#define KM_LAUNCH(TT, KK, SLOT)                                                                              \
+    do {                                                                                                         \
+        if (!(ctx->km_attr_done[SLOT / 3] & (1 << (SLOT % 3)))) {                                                \
+            SPA_HIP(hipFuncSetAttribute((const void *)k_kmeans<TT, KK>,                                          \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));                \
+            ctx->km_attr_done[SLOT / 3] |= (1 << (SLOT % 3));                                                    \
+        }                                                                                                        \
+        hipLaunchKernelGGL((k_kmeans<TT, KK>), dim3(G), dim3(KM_THREADS), lds, s, (const TT *)X, (long long)ld, \
+                           D, w, n_ptr, Ncap, k, max_iter, (const long long *)init_other, assign,               \
+                           (int32_t *)(misc + o_na), (double *)(misc + o_sum), (double *)(misc + o_ws),          \
+                           (int *)(misc + o_cn), (int *)(misc + o_pn), mlist, wlist, (int *)(misc + o_ch),       \
+                           (KmShared *)(misc + o_sh), info, ctx->d_status, tree);                                \
+    } while (0)
+    // compile-time cluster bound: registers and unrolled code sized for the common k = 2 / k <= 4 cases
     if (x_dtype == 1) {
-        if (!ctx->km_attr_done[1]) {
-            SPA_HIP(hipFuncSetAttribute((const void *)k_kmeans<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            ctx->km_attr_done[1] = 1;
-        }
-        hipLaunchKernelGGL(k_kmeans<double>, dim3(G), dim3(KM_THREADS), lds, s, (const double *)X,
-                           (long long)ld, D, w, n_ptr, Ncap, k, max_iter, (const long long *)init_other,
-                           assign, (int32_t *)(misc + o_na), (double *)(misc + o_sum), (double *)(misc + o_ws),
-                           (int *)(misc + o_cn), (int *)(misc + o_pn), mlist, wlist, (int *)(misc + o_ch),
-                           (KmShared *)(misc + o_sh), info, ctx->d_status, tree);
+        if (k == 2) KM_LAUNCH(double, 2, 3); else if (k <= 4) KM_LAUNCH(double, 4, 4); else KM_LAUNCH(double, 8, 5);
     } else {
-        if (!ctx->km_attr_done[0]) {
-            SPA_HIP(hipFuncSetAttribute((const void *)k_kmeans<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            ctx->km_attr_done[0] = 1;
-        }
-        hipLaunchKernelGGL(k_kmeans<float>, dim3(G), dim3(KM_THREADS), lds, s, (const float *)X,
-                           (long long)ld, D, w, n_ptr, Ncap, k, max_iter, (const long long *)init_other,
-                           assign, (int32_t *)(misc + o_na), (double *)(misc + o_sum), (double *)(misc + o_ws),
-                           (int *)(misc + o_cn), (int *)(misc + o_pn), mlist, wlist, (int *)(misc + o_ch),
-                           (KmShared *)(misc + o_sh), info, ctx->d_status, tree);
+        if (k == 2) KM_LAUNCH(float, 2, 0); else if (k <= 4) KM_LAUNCH(float, 4, 1); else KM_LAUNCH(float, 8, 2);
     }
     SPA_LAUNCH_CHECK();
     return SPA_OK;
