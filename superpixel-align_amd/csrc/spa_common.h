@@ -75,6 +75,7 @@ enum {
     WS_FZ_VALS,      // felzenszwalb: edge indices (in/out of the radix sort)
     WS_FZ_STATE,     // felzenszwalb: internal costs + reservation marks
     WS_FZ_TMP,       // felzenszwalb: radix sort temporary storage
+    WS_RUNS,         // connectivity: per-row lists of run starts (B,H,W) i32, used from the front of each row
     WS_COUNT
 };
 
@@ -102,6 +103,8 @@ struct spa_ctx {
     // per-context (= per-device) one-time kernel attributes and cached occupancy answers
     int km_attr_done[2];
     int conn_attr_done;
+    int conn_claim_ready;          // the BFS claim words are all-INF (set once per allocation)
+    size_t conn_claim_bytes;
     int upd_wg_per_cu;
 };
 

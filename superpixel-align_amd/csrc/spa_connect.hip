@@ -11,12 +11,19 @@
 //     the BFS visiting order of C (neighbour order +x,-x,+y,-y), that lies outside C in a
 //     component D with seed(D) < seed(C) — whatever label D ended up with — or 0 when there
 //     is none, or when C precedes the first kept component (everything before it is 0).
-//   So: union-find CCL for the components, a prefix sum over raster order for the kept
-//   labels, one wavefront per small component replaying its BFS in the exact queue order
-//   (64 queue entries per step; discoveries inside a step are ordered by an atomicMin on
-//   (queue index, direction) keys), then pointer chasing D -> label.
-//   A component that reaches max_size is cut by the sequential algorithm in BFS order;
-//   that case is detected and reported (SPA_ST_CONN_OVERSIZE).
+//   So: connected components, a prefix sum over raster order for the kept labels, one wavefront
+//   per small component replaying its BFS in the exact queue order, then pointer chasing D -> label.
+//   A component that reaches max_size is cut by the sequential algorithm in BFS order: replayed
+//   per component before the numbering (k_conn_split).
+//
+// Components are found on horizontal RUNS, not pixels: a workgroup per image row finds the runs of
+// equal label (one streaming pass: 4 bytes read, 4 written per pixel), every pixel's parent is the first
+// pixel of its run, and only the run starts (~25 per row on clean images, ~300 on noisy ones, against
+// 2 048 pixels) are nodes of the union-find that links vertically adjacent runs of one label.  Sizes,
+// the raster-order numbering, the classification and the bounding boxes of the small components are
+// run-level passes too (one wave per row); a pixel's component root is parent[parent[pixel]].  The
+// first round's pixel-level passes (k_conn_count / k_conn_number / k_small_bbox) remain for images that
+// contain a component above max_size, whose pieces do not respect run boundaries.
 #include "spa_common.h"
 
 #define INF_KEY 0xFFFFFFFFu
@@ -51,11 +58,25 @@ __device__ __forceinline__ int uf_find(const int *parent, int i)
     return i;
 }
 
+// find with path halving: every visited node is re-pointed at its grandparent (atomicMin: parents only
+// ever move to smaller indices of the same set, whatever other waves do meanwhile)
+__device__ __forceinline__ int uf_find_halve(int *parent, int i)
+{
+    for (;;) {
+        const int p = ld_i32(parent + i);
+        if (p == i) return i;
+        const int g = ld_i32(parent + p);
+        if (g == p) return p;
+        atomicMin(parent + i, g);
+        i = g;
+    }
+}
+
 __device__ __forceinline__ void uf_merge(int *parent, int a, int b)
 {
     for (;;) {
-        a = uf_find(parent, a);
-        b = uf_find(parent, b);
+        a = uf_find_halve(parent, a);
+        b = uf_find_halve(parent, b);
         if (a == b) return;
         if (a > b) { int t = a; a = b; b = t; }
         int old = atomicMin(parent + b, a);
@@ -126,6 +147,172 @@ __global__ __launch_bounds__(256) void k_ccl_flatten(int *__restrict__ parent,
     }
 }
 
+// root of the component of pixel v: parent[v] is the first pixel of v's run (or already a root, for
+// images that went through k_conn_expand / k_conn_split), parent[run start] is the root
+__device__ __forceinline__ int root2(const int *P, int v)
+{
+    return P[P[v]];
+}
+
+// ---------------------------------------------------------------------------------------
+// Run-level connected components.
+// ---------------------------------------------------------------------------------------
+#define RUN_CHUNK 2048          // pixels of a row handled per pass of the row's workgroup (8 per thread)
+
+// one workgroup per (row, image): parent[p] = first pixel of p's run; runs[row][k] = x of the k-th run
+// start; rowcnt[row] = number of runs; size[run start] = 0
+__global__ __launch_bounds__(256) void k_run_rows(const int32_t *__restrict__ lab, int *__restrict__ parent,
+                                                  int *__restrict__ size, int *__restrict__ runs,
+                                                  int *__restrict__ runlab, int *__restrict__ rowcnt, int H, int W)
+{
+    __shared__ int w_last[4], w_cnt[4];
+    __shared__ int carry_start, carry_cnt;
+    const int b = blockIdx.y, y = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const long long npix = (long long)H * W;
+    const int32_t *L = lab + b * npix + (long long)y * W;
+    int *P = parent + b * npix + (long long)y * W;
+    int *S = size + b * npix + (long long)y * W;
+    int *R = runs + b * npix + (long long)y * W;
+    int *RL = runlab + b * npix + (long long)y * W;        // label of the k-th run (compact, like R)
+    const int rowbase = y * W;
+    const bool vec = (W & 3) == 0;
+    if (tid == 0) { carry_start = 0; carry_cnt = 0; }
+    __syncthreads();
+    for (int x0 = 0; x0 < W; x0 += RUN_CHUNK) {
+        const int xb = x0 + tid * 8;
+        int l[8];
+        if (vec && xb + 7 < W) {
+            const int4 a = *(const int4 *)(L + xb), c = *(const int4 *)(L + xb + 4);
+            l[0] = a.x; l[1] = a.y; l[2] = a.z; l[3] = a.w; l[4] = c.x; l[5] = c.y; l[6] = c.z; l[7] = c.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) l[i] = (xb + i < W) ? L[xb + i] : -1;
+        }
+        const int lprev = (xb > 0 && xb < W) ? L[xb - 1] : -2;
+        // run starts inside this thread
+        int last = -1, cnt = 0;
+        bool st[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int x = xb + i;
+            st[i] = x < W && (x == 0 || l[i] != (i == 0 ? lprev : l[i - 1]));
+            if (st[i]) { last = x; ++cnt; }
+        }
+        // exclusive prefix over threads: latest run start to the left, number of starts to the left
+        int pm = last, ps = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int m = __shfl_up(pm, o), c = __shfl_up(ps, o);
+            if (lane >= o) { pm = max(pm, m); ps += c; }
+        }
+        if (lane == 63) { w_last[wv] = pm; w_cnt[wv] = ps; }
+        __syncthreads();
+        int before_start = carry_start, before_cnt = carry_cnt;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < wv) { before_start = max(before_start, w_last[i]); before_cnt += w_cnt[i]; }
+        int ex_start = __shfl_up(pm, 1), ex_cnt = ps - cnt;
+        if (lane == 0) ex_start = -1;
+        int cur = max(before_start, ex_start);          // run start of the pixel left of this thread's first
+        int k = before_cnt + ex_cnt;
+        int out[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int x = xb + i;
+            if (st[i]) {
+                cur = x;
+                RL[k] = l[i];
+                R[k++] = x;
+                S[x] = 0;
+            }
+            out[i] = rowbase + cur;
+        }
+        if (vec && xb + 7 < W) {
+            *(int4 *)(P + xb) = make_int4(out[0], out[1], out[2], out[3]);
+            *(int4 *)(P + xb + 4) = make_int4(out[4], out[5], out[6], out[7]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (xb + i < W) P[xb + i] = out[i];
+        }
+        __syncthreads();
+        if (tid == 255) {
+            carry_start = max(before_start, pm);
+            carry_cnt = before_cnt + ps;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) rowcnt[(long long)b * H + y] = carry_cnt;
+}
+
+// one workgroup per row: link every run to the runs of the same label it touches in the row above.
+// Both rows' run lists (and the labels of the upper row's runs) are staged in LDS: the binary search and
+// the walk over the touching runs cost LDS latency, not L2 latency.
+__global__ __launch_bounds__(256) void k_run_merge(const int *__restrict__ runlab, int *__restrict__ parent,
+                                                   const int *__restrict__ runs, const int *__restrict__ rowcnt,
+                                                   int H, int W)
+{
+    extern __shared__ int lds_m[];                 // Rp [W] | Lp [W] | R [W]
+    const int b = blockIdx.y, y = blockIdx.x + 1;
+    const int tid = threadIdx.x;
+    const long long npix = (long long)H * W;
+    int *P = parent + b * npix;
+    const int *RC = rowcnt + (long long)b * H;
+    const int *R = runs + b * npix + (long long)y * W;
+    const int *RL = runlab + b * npix + (long long)y * W;
+    const int *Rp = R - W, *RLp = RL - W;
+    const int cnt = RC[y], cntp = RC[y - 1];
+    int *sRp = lds_m, *sLp = lds_m + W, *sR = lds_m + 2 * W;
+    for (int k = tid; k < cntp; k += 256) {
+        sRp[k] = Rp[k];
+        sLp[k] = RLp[k];
+    }
+    for (int k = tid; k < cnt; k += 256) sR[k] = R[k];
+    __syncthreads();
+    for (int k = tid; k < cnt; k += 256) {
+        const int xs = sR[k];
+        const int xe = (k + 1 < cnt ? sR[k + 1] : W) - 1;
+        const int l = RL[k];
+        // last run of the row above that starts at or before xs
+        int lo = 0, hi = cntp - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (sRp[mid] <= xs) lo = mid; else hi = mid - 1;
+        }
+        for (int j = lo; j < cntp; ++j) {
+            const int xp = sRp[j];
+            if (xp > xe) break;
+            if (sLp[j] == l) uf_merge(P, (y - 1) * W + xp, y * W + xs);
+        }
+    }
+}
+
+// one wave per row: every run start learns its root; the root collects the run lengths
+__global__ __launch_bounds__(256) void k_run_flatten(int *__restrict__ parent, int *__restrict__ size,
+                                                     const int *__restrict__ runs, const int *__restrict__ rowcnt,
+                                                     int H, int W)
+{
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const long long npix = (long long)H * W;
+    int *P = parent + b * npix;
+    int *S = size + b * npix;
+    const int *RC = rowcnt + (long long)b * H;
+    for (int y = blockIdx.x * 4 + (threadIdx.x >> 6); y < H; y += gridDim.x * 4) {
+        const int *R = runs + b * npix + (long long)y * W;
+        const int cnt = RC[y];
+        for (int k = lane; k < cnt; k += 64) {
+            const int xs = R[k];
+            const int len = (k + 1 < cnt ? R[k + 1] : W) - xs;
+            const int p = y * W + xs;
+            const int r = uf_find_halve(P, p);
+            st_i32(P + p, r);
+            atomicAdd(S + r, len);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // Components larger than max_size.  The reference stops the breadth-first growth of a component
 // at max_size pixels; the pixels it did not reach are found again later by the raster scan and
@@ -149,6 +336,49 @@ __global__ __launch_bounds__(256) void k_conn_find_oversize(const int *__restric
             int k = atomicAdd(&misc[b].n_over, 1);
             over_list[(long long)b * npix + k] = p;
         }
+    }
+}
+
+// run-level twin of k_conn_find_oversize (roots are run starts)
+__global__ __launch_bounds__(256) void k_run_find_oversize(const int *__restrict__ parent,
+                                                           const int *__restrict__ size,
+                                                           const int *__restrict__ runs,
+                                                           const int *__restrict__ rowcnt, int H, int W,
+                                                           int max_size, int *__restrict__ over_list,
+                                                           ConnMisc *__restrict__ misc)
+{
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const long long npix = (long long)H * W;
+    const int *P = parent + b * npix;
+    const int *S = size + b * npix;
+    const int *RC = rowcnt + (long long)b * H;
+    for (int y = blockIdx.x * 4 + (threadIdx.x >> 6); y < H; y += gridDim.x * 4) {
+        const int *R = runs + b * npix + (long long)y * W;
+        const int cnt = RC[y];
+        for (int k = lane; k < cnt; k += 64) {
+            const int p = y * W + R[k];
+            if (P[p] == p && S[p] > max_size) {
+                const int i = atomicAdd(&misc[b].n_over, 1);
+                over_list[b * npix + i] = p;
+            }
+        }
+    }
+}
+
+// images that hold an oversize component leave the run representation: parent[p] = root of p
+__global__ __launch_bounds__(256) void k_conn_expand(int *__restrict__ parent, const ConnMisc *__restrict__ misc,
+                                                     int npix)
+{
+    const int b = blockIdx.y;
+    if (misc[b].n_over == 0) return;
+    int *P = parent + (long long)b * npix;
+    // two passes inside one launch would race (a run start may be rewritten before its pixels read it);
+    // a root is a fixed point (P[root] == root) and P[run start] is already the root, so one gather is exact
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < npix; p += gridDim.x * 256) {
+        const int s = ld_i32(P + p);
+        const int r = ld_i32(P + s);
+        if (r != s) st_i32(P + p, r);
     }
 }
 
@@ -304,6 +534,7 @@ __global__ __launch_bounds__(256) void k_conn_count(const int *__restrict__ pare
 {
     __shared__ int wk[4], wt[4], wf[4];
     const int b = blockIdx.y;
+    if (misc[b].n_over == 0) return;             // run-level path (k_run_count)
     const int *P = parent + (long long)b * npix;
     const int *S = size + (long long)b * npix;
     const int base = blockIdx.x * SCAN_PX + threadIdx.x * 4;
@@ -337,10 +568,11 @@ __global__ __launch_bounds__(256) void k_conn_count(const int *__restrict__ pare
 // pass 2: exclusive scans of the two block-count arrays of one image (single workgroup)
 __global__ __launch_bounds__(256) void k_conn_scan(int *__restrict__ blk, int nblk,
                                                    ConnMisc *__restrict__ misc,
-                                                   int32_t *__restrict__ n_labels)
+                                                   int32_t *__restrict__ n_labels, int run_path)
 {
     __shared__ int part[256];
     const int b = blockIdx.x;
+    if ((misc[b].n_over == 0) != (run_path != 0)) return;
     const int per = (nblk + 255) / 256;
     const int lo = threadIdx.x * per, hi = min(nblk, lo + per);
     for (int which = 0; which < 2; ++which) {
@@ -375,6 +607,7 @@ __global__ __launch_bounds__(256) void k_conn_number(const int *__restrict__ par
 {
     __shared__ int wsk[4], wst[4];
     const int b = blockIdx.y;
+    if (misc[b].n_over == 0) return;             // run-level path (k_run_number)
     const int *P = parent + (long long)b * npix;
     const int *S = size + (long long)b * npix;
     int *F = final_ + (long long)b * npix;
@@ -427,9 +660,11 @@ __global__ __launch_bounds__(256) void k_conn_number(const int *__restrict__ par
 __global__ __launch_bounds__(256) void k_small_bbox(const int *__restrict__ parent,
                                                     const int *__restrict__ size,
                                                     const int *__restrict__ final_, int W, int npix,
-                                                    int min_size, int *__restrict__ sbox)
+                                                    int min_size, int *__restrict__ sbox,
+                                                    const ConnMisc *__restrict__ misc)
 {
     const int b = blockIdx.y;
+    if (misc[b].n_over == 0) return;             // run-level path (k_run_bbox)
     const int lane = threadIdx.x & 63;
     const int *P = parent + (long long)b * npix;
     const int *S = size + (long long)b * npix;
@@ -480,6 +715,129 @@ __global__ __launch_bounds__(256) void k_small_bbox(const int *__restrict__ pare
 }
 
 // ---------------------------------------------------------------------------------------
+// Run-level numbering (images without an oversize component): one wave per row; the roots of a row
+// are met in raster order, rows are ordered by an exclusive scan of their counts (k_conn_scan).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_run_count(const int *__restrict__ parent, const int *__restrict__ size,
+                                                   const int *__restrict__ runs, const int *__restrict__ rowcnt,
+                                                   int H, int W, int min_size, int *__restrict__ blk, int nblk,
+                                                   ConnMisc *__restrict__ misc)
+{
+    const int b = blockIdx.y;
+    if (misc[b].n_over != 0) return;
+    const int lane = threadIdx.x & 63;
+    const long long npix = (long long)H * W;
+    const int *P = parent + b * npix;
+    const int *S = size + b * npix;
+    const int *RC = rowcnt + (long long)b * H;
+    for (int y = blockIdx.x * 4 + (threadIdx.x >> 6); y < H; y += gridDim.x * 4) {
+        const int *R = runs + b * npix + (long long)y * W;
+        const int cnt = RC[y];
+        int ck = 0, ct = 0, fk = 0x7fffffff;
+        for (int k = lane; k < cnt; k += 64) {
+            const int p = y * W + R[k];
+            if (P[p] != p) continue;
+            const int sz = S[p];
+            if (sz >= min_size) { ++ck; fk = min(fk, p); }
+            else if (sz <= LANE_MAX) ++ct;
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            ck += __shfl_xor(ck, o); ct += __shfl_xor(ct, o); fk = min(fk, __shfl_xor(fk, o));
+        }
+        if (lane == 0) {
+            blk[((long long)b * 2 + 0) * nblk + y] = ck;
+            blk[((long long)b * 2 + 1) * nblk + y] = ct;
+            if (fk != 0x7fffffff) atomicMin(&misc[b].first_kept, fk);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_run_number(const int *__restrict__ parent, const int *__restrict__ size,
+                                                    const int *__restrict__ runs, const int *__restrict__ rowcnt,
+                                                    int H, int W, int min_size, const int *__restrict__ blk, int nblk,
+                                                    int *__restrict__ final_, int *__restrict__ tiny_list,
+                                                    int *__restrict__ big_list, int *__restrict__ sbox,
+                                                    ConnMisc *__restrict__ misc)
+{
+    const int b = blockIdx.y;
+    if (misc[b].n_over != 0) return;
+    const int lane = threadIdx.x & 63;
+    const long long npix = (long long)H * W;
+    const int *P = parent + b * npix;
+    const int *S = size + b * npix;
+    int *F = final_ + b * npix;
+    const int *RC = rowcnt + (long long)b * H;
+    for (int y = blockIdx.x * 4 + (threadIdx.x >> 6); y < H; y += gridDim.x * 4) {
+        const int *R = runs + b * npix + (long long)y * W;
+        const int cnt = RC[y];
+        int offk = blk[((long long)b * 2 + 0) * nblk + y];
+        int offt = blk[((long long)b * 2 + 1) * nblk + y];
+        for (int k0 = 0; k0 < cnt; k0 += 64) {
+            const int k = k0 + lane;
+            int cls = 0, p = 0;              // 0 none, 1 kept, 2 tiny, 3 big-small
+            if (k < cnt) {
+                p = y * W + R[k];
+                if (P[p] == p) {
+                    const int sz = S[p];
+                    cls = sz >= min_size ? 1 : (sz <= LANE_MAX ? 2 : 3);
+                }
+            }
+            const unsigned long long mk = __ballot(cls == 1), mt = __ballot(cls == 2);
+            if (cls == 1) F[p] = offk + (int)spa_rank_in_mask(mk);
+            else if (cls == 2) tiny_list[b * npix + offt + (int)spa_rank_in_mask(mt)] = p;
+            else if (cls == 3) {
+                const int slot = atomicAdd(&misc[b].n_big, 1);
+                big_list[b * npix + slot] = p;
+                F[p] = slot;
+                if (slot < SBOX_CAP) {
+                    int *bb = sbox + ((long long)b * SBOX_CAP + slot) * 4;
+                    const int x = p - y * W;
+                    bb[0] = y; bb[1] = y; bb[2] = x; bb[3] = x;
+                }
+            }
+            offk += __popcll(mk);
+            offt += __popcll(mt);
+        }
+    }
+}
+
+// bounding boxes of the big-small components from their runs
+__global__ __launch_bounds__(256) void k_run_bbox(const int *__restrict__ parent, const int *__restrict__ size,
+                                                  const int *__restrict__ final_, const int *__restrict__ runs,
+                                                  const int *__restrict__ rowcnt, int H, int W, int min_size,
+                                                  int *__restrict__ sbox, const ConnMisc *__restrict__ misc)
+{
+    const int b = blockIdx.y;
+    if (misc[b].n_over != 0) return;
+    const int lane = threadIdx.x & 63;
+    const long long npix = (long long)H * W;
+    const int *P = parent + b * npix;
+    const int *S = size + b * npix;
+    const int *F = final_ + b * npix;
+    const int *RC = rowcnt + (long long)b * H;
+    for (int y = blockIdx.x * 4 + (threadIdx.x >> 6); y < H; y += gridDim.x * 4) {
+        const int *R = runs + b * npix + (long long)y * W;
+        const int cnt = RC[y];
+        for (int k = lane; k < cnt; k += 64) {
+            const int xs = R[k];
+            const int xe = (k + 1 < cnt ? R[k + 1] : W) - 1;
+            const int r = P[y * W + xs];
+            const int sz = S[r];
+            if (sz >= min_size || sz <= LANE_MAX) continue;
+            const int slot = F[r];
+            if (slot >= SBOX_CAP) continue;
+            // hundreds of runs share one box: only a run that extends it issues an atomic (a stale read can
+            // only cause a redundant atomic, never a missed one: boxes grow monotonically)
+            int *bb = sbox + ((long long)b * SBOX_CAP + slot) * 4;
+            if (y < ld_i32(bb + 0)) atomicMin(bb + 0, y);
+            if (y > ld_i32(bb + 1)) atomicMax(bb + 1, y);
+            if (xs < ld_i32(bb + 2)) atomicMin(bb + 2, xs);
+            if (xe > ld_i32(bb + 3)) atomicMax(bb + 3, xe);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // BFS replay, lane tier: one THREAD per tiny component (<= LANE_MAX pixels) runs the sequential
 // BFS literally — queue in LDS, "already queued" by searching its own queue — and keeps the
 // last outside neighbour that belongs to a component with a smaller seed.
@@ -503,6 +861,18 @@ __global__ __launch_bounds__(256) void k_conn_bfs_lane(const int *__restrict__ p
         const int r = tiny_list[(long long)b * npix + i];
         if (r < first_kept) { F[r] = -1; continue; }      // before the first kept component: label 0
         const int sz = S[r];
+        {
+            // A component that is ONE horizontal run (most noise specks) below the first image row: the
+            // search visits r, r+1, ..., r+sz-1; the last outside neighbour it looks at is the pixel above
+            // the last one, which lies in the row above r and therefore in a component with a smaller
+            // seed: no queue, one lookup.  (Same row and P[r+sz-1] in the component imply the run itself:
+            // a gap would need a detour longer than the gap, i.e. more than sz pixels.)
+            const int ry = r / W, rx = r - ry * W;
+            if (ry > 0 && rx + sz <= W && root2(P, r + sz - 1) == r) {
+                F[r] = -2 - root2(P, r + sz - 1 - W);
+                continue;
+            }
+        }
         int best = -1;
         int head = 0, tail = 1;
         q[tid] = r;
@@ -516,7 +886,7 @@ __global__ __launch_bounds__(256) void k_conn_bfs_lane(const int *__restrict__ p
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 const bool inb = vx[d] >= 0 && vx[d] < W && vy[d] >= 0 && vy[d] < H;
-                rv[d] = inb ? P[vy[d] * W + vx[d]] : 0x7fffffff;
+                rv[d] = inb ? root2(P, vy[d] * W + vx[d]) : 0x7fffffff;
             }
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
@@ -667,7 +1037,7 @@ __global__ __launch_bounds__(64) void k_conn_bfs_lds(const int *__restrict__ par
                     for (int u = 0; u < 4; ++u) {
                         const int i = i0 + g * 256 + lane * 4 + u;
                         const int yy = y0 + i / bw, xx = x0 + i % bw;
-                        rv[g * 4 + u] = i < area ? P[yy * W + xx] : 0x7fffffff;
+                        rv[g * 4 + u] = i < area ? root2(P, yy * W + xx) : 0x7fffffff;
                     }
                 }
 #pragma unroll
@@ -766,7 +1136,7 @@ __global__ __launch_bounds__(64) void k_conn_bfs_lds(const int *__restrict__ par
             if (best >= 0) {
                 const int loc = (int)(best & 0xFFFFFFFFll);
                 const int gy = y0 + loc / bw, gx = x0 + loc % bw;
-                f = -2 - P[gy * W + gx];
+                f = -2 - root2(P, gy * W + gx);
             }
             F[r] = f;
         }
@@ -829,7 +1199,7 @@ __global__ __launch_bounds__(64) void k_conn_bfs(const int *__restrict__ parent,
                 v[d] = yy * W + xx;
                 cand[d] = false;
                 if (inb) {
-                    int rv = P[v[d]];
+                    int rv = root2(P, v[d]);
                     if (rv == r) {
                         cand[d] = __hip_atomic_load(CL + v[d], __ATOMIC_RELAXED,
                                                     __HIP_MEMORY_SCOPE_AGENT) == INF_KEY;
@@ -867,6 +1237,9 @@ __global__ __launch_bounds__(64) void k_conn_bfs(const int *__restrict__ parent,
             head += cnt;
             tail += total;
         }
+        // the claim words go back to INF: they are all-INF between calls (no per-call memset of the image)
+        for (int i2 = lane; i2 < tail; i2 += 64)
+            __hip_atomic_store(CL + ld_i32(Q + i2), INF_KEY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // wave max of `best`
         for (int o = 32; o > 0; o >>= 1) {
             long long t = __shfl_xor(best, o);
@@ -899,7 +1272,7 @@ __global__ __launch_bounds__(256) void k_conn_relabel(const int *__restrict__ pa
     const int b = blockIdx.y;
     const long long o = (long long)b * npix;
     for (int p = blockIdx.x * 256 + threadIdx.x; p < npix; p += gridDim.x * 256) {
-        int f = final_[o + parent[o + p]];
+        int f = final_[o + root2(parent + o, p)];
         out[o + p] = f < 0 ? 0 : f;
     }
 }
@@ -919,6 +1292,7 @@ extern "C" int spa_enforce_connectivity(spa_ctx *ctx, const int32_t *labels_in, 
 {
     SPA_ARG(ctx && labels_in && labels_out && n_labels && B > 0 && H > 0 && W > 0);
     SPA_ARG((long long)H * W < (1ll << 29));
+    SPA_ARG((size_t)3 * W * 4 <= 150 * 1024);          // two rows of run lists in LDS (k_run_merge)
     hipStream_t s = spa_stream(stream);
     const int npix = H * W;
     const size_t img = (size_t)B * npix * 4;
@@ -927,14 +1301,19 @@ extern "C" int spa_enforce_connectivity(spa_ctx *ctx, const int32_t *labels_in, 
     ConnMisc *misc;
     int rc;
     const int nblk = (npix + SCAN_PX - 1) / SCAN_PX;
+    int *runs, *rowcnt, *blk_run;
     if ((rc = spa_ws_reserve(ctx, WS_PARENT, img, (void **)&parent)) != SPA_OK) return rc;
     if ((rc = spa_ws_reserve(ctx, WS_SIZE, img, (void **)&size)) != SPA_OK) return rc;
     if ((rc = spa_ws_reserve(ctx, WS_FINAL, img, (void **)&final_)) != SPA_OK) return rc;
     if ((rc = spa_ws_reserve(ctx, WS_CLAIM, img, (void **)&claim)) != SPA_OK) return rc;
     if ((rc = spa_ws_reserve(ctx, WS_QUEUE, img, (void **)&queue)) != SPA_OK) return rc;
+    if ((rc = spa_ws_reserve(ctx, WS_RUNS, img, (void **)&runs)) != SPA_OK) return rc;
     if ((rc = spa_ws_reserve(ctx, WS_SMALL, 2 * img, (void **)&tiny)) != SPA_OK) return rc;
     big = tiny + (size_t)B * npix;
-    if ((rc = spa_ws_reserve(ctx, WS_BLK, (size_t)B * 2 * nblk * 4, (void **)&blk)) != SPA_OK) return rc;
+    // per-block counts of the pixel-level scan | per-row counts of the run-level scan | runs per row
+    if ((rc = spa_ws_reserve(ctx, WS_BLK, (size_t)B * (2 * nblk + 3 * (size_t)H) * 4, (void **)&blk)) != SPA_OK) return rc;
+    blk_run = blk + (size_t)B * 2 * nblk;
+    rowcnt = blk_run + (size_t)B * 2 * H;
     if ((rc = spa_ws_reserve(ctx, WS_SBOX, (size_t)B * SBOX_CAP * 16, (void **)&sbox)) != SPA_OK) return rc;
     int *todo0, *todo3;
     if ((rc = spa_ws_reserve(ctx, WS_TODO, 4 * img, (void **)&todo1)) != SPA_OK) return rc;
@@ -945,32 +1324,57 @@ extern "C" int spa_enforce_connectivity(spa_ctx *ctx, const int32_t *labels_in, 
     if ((rc = spa_ws_reserve(ctx, WS_CONNMISC, (size_t)B * sizeof(ConnMisc), (void **)&misc)) != SPA_OK) return rc;
 
     SpaProfScope prof_(ctx, PROF_CONNECT, s);
-    SPA_HIP(hipMemsetAsync(size, 0, img, s));
     hipLaunchKernelGGL(k_conn_init_misc, dim3((B + 63) / 64), dim3(64), 0, s, misc, B, npix);
-    dim3 gp((npix + 255) / 256, B);
-    hipLaunchKernelGGL(k_ccl_init, gp, dim3(256), 0, s, labels_in, parent, W, npix);
-    hipLaunchKernelGGL(k_ccl_merge, gp, dim3(256), 0, s, labels_in, parent, W, npix);
-    hipLaunchKernelGGL(k_ccl_flatten, gp, dim3(256), 0, s, parent, size, npix);
+    // ---- components on runs: rows -> runs, vertical links, roots + sizes (no per-pixel union-find)
+    int gw = (H + 3) / 4;                       // one wave per row, four rows per workgroup
+    if (gw > 1024) gw = 1024;
+    // (the labels of the runs are parked in `final_`, which nothing else uses before the numbering)
+    hipLaunchKernelGGL(k_run_rows, dim3(H, B), dim3(256), 0, s, labels_in, parent, size, runs, final_, rowcnt, H, W);
+    if ((size_t)3 * W * 4 > 48 * 1024 && !(ctx->conn_attr_done & 2)) {
+        SPA_HIP(hipFuncSetAttribute((const void *)k_run_merge, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        ctx->conn_attr_done |= 2;
+    }
+    if (H > 1)
+        hipLaunchKernelGGL(k_run_merge, dim3(H - 1, B), dim3(256), (size_t)3 * W * 4, s, (const int *)final_, parent,
+                           (const int *)runs, (const int *)rowcnt, H, W);
+    hipLaunchKernelGGL(k_run_flatten, dim3(gw, B), dim3(256), 0, s, parent, size, (const int *)runs,
+                       (const int *)rowcnt, H, W);
     {
-        // components above max_size are cut the way the reference cuts them (no-op otherwise)
+        // components above max_size are cut the way the reference cuts them; their images leave the run
+        // representation (k_conn_expand) and take the pixel-level numbering kernels below
         int gf = (npix + 255) / 256;
         if (gf > 1024) gf = 1024;
-        SPA_HIP(hipMemsetAsync(claim, 0xFF, img, s));
-        hipLaunchKernelGGL(k_conn_find_oversize, dim3(gf, B), dim3(256), 0, s, parent, size, npix, max_size,
-                           todo1, misc);
+        if (!ctx->conn_claim_ready || ctx->conn_claim_bytes != ctx->ws_bytes[WS_CLAIM]) {
+            // the claim words are all-INF between calls (every kernel that takes some releases them)
+            SPA_HIP(hipMemsetAsync(claim, 0xFF, ctx->ws_bytes[WS_CLAIM], s));
+            ctx->conn_claim_ready = 1;
+            ctx->conn_claim_bytes = ctx->ws_bytes[WS_CLAIM];
+        }
+        hipLaunchKernelGGL(k_run_find_oversize, dim3(gw, B), dim3(256), 0, s, parent, size, (const int *)runs,
+                           (const int *)rowcnt, H, W, max_size, todo1, misc);
+        hipLaunchKernelGGL(k_conn_expand, dim3(gf, B), dim3(256), 0, s, parent, misc, npix);
         hipLaunchKernelGGL(k_conn_split, dim3(64, B), dim3(64), 0, s, parent, size, (const int *)todo1, misc,
                            claim, queue, H, W, max_size);
         hipLaunchKernelGGL(k_conn_reset_qalloc, dim3((B + 63) / 64), dim3(64), 0, s, misc, B);
     }
-    hipLaunchKernelGGL(k_conn_count, dim3(nblk, B), dim3(256), 0, s, parent, size, npix, min_size,
-                       max_size, blk, nblk, misc, ctx->d_status);
-    hipLaunchKernelGGL(k_conn_scan, dim3(B), dim3(256), 0, s, blk, nblk, misc, n_labels);
-    hipLaunchKernelGGL(k_conn_number, dim3(nblk, B), dim3(256), 0, s, parent, size, npix, W, min_size,
-                       blk, nblk, final_, tiny, big, sbox, misc);
     int gb = (npix + 255) / 256;
     if (gb > 1024) gb = 1024;
+    // ---- numbering: run level (images without an oversize component) ...
+    hipLaunchKernelGGL(k_run_count, dim3(gw, B), dim3(256), 0, s, parent, size, (const int *)runs,
+                       (const int *)rowcnt, H, W, min_size, blk_run, H, misc);
+    hipLaunchKernelGGL(k_conn_scan, dim3(B), dim3(256), 0, s, blk_run, H, misc, n_labels, 1);
+    hipLaunchKernelGGL(k_run_number, dim3(gw, B), dim3(256), 0, s, parent, size, (const int *)runs,
+                       (const int *)rowcnt, H, W, min_size, (const int *)blk_run, H, final_, tiny, big, sbox, misc);
+    hipLaunchKernelGGL(k_run_bbox, dim3(gw, B), dim3(256), 0, s, parent, size, (const int *)final_,
+                       (const int *)runs, (const int *)rowcnt, H, W, min_size, sbox, misc);
+    // ---- ... and pixel level (early exit unless the image was expanded)
+    hipLaunchKernelGGL(k_conn_count, dim3(nblk, B), dim3(256), 0, s, parent, size, npix, min_size,
+                       max_size, blk, nblk, misc, ctx->d_status);
+    hipLaunchKernelGGL(k_conn_scan, dim3(B), dim3(256), 0, s, blk, nblk, misc, n_labels, 0);
+    hipLaunchKernelGGL(k_conn_number, dim3(nblk, B), dim3(256), 0, s, parent, size, npix, W, min_size,
+                       blk, nblk, final_, tiny, big, sbox, misc);
     hipLaunchKernelGGL(k_small_bbox, dim3(gb, B), dim3(256), 0, s, parent, size, final_, W, npix,
-                       min_size, sbox);
+                       min_size, sbox, misc);
     // BFS replay of the small components.  The tiers are independent of each other (a component
     // only reads the roots of its neighbours), so they run concurrently: the lane tier (<= 32 pixels,
     // one thread each) and the rare 80 KB LDS tier on a side stream, the 48 KB LDS tier on another,
@@ -978,9 +1382,9 @@ extern "C" int spa_enforce_connectivity(spa_ctx *ctx, const int32_t *labels_in, 
     // what fits no LDS tier (or overflows a frontier ring) goes to the global-memory wave tier after
     // the join.  Each tier is bound by its slowest replay (a thin 5 000-pixel component is ~1 ms of
     // dependent LDS steps), not by throughput.
-    if (!ctx->conn_attr_done) {        // per context = per device
+    if (!(ctx->conn_attr_done & 1)) {        // per context = per device
         SPA_HIP(hipFuncSetAttribute((const void *)k_conn_bfs_lds, hipFuncAttributeMaxDynamicSharedMemorySize, BFS_LDS_C));
-        ctx->conn_attr_done = 1;
+        ctx->conn_attr_done |= 1;
     }
     hipLaunchKernelGGL(k_conn_classify, dim3(8, B), dim3(256), 0, s, big, sbox, misc, final_, todo0, todo1, todo3, todo2, H, W);
     SPA_HIP(hipEventRecord(ctx->ev_fork, s));

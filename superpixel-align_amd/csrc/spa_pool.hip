@@ -340,6 +340,148 @@ __global__ __launch_bounds__(256) void k_pool_mean(const void *__restrict__ fmap
         store_x(X, x_dtype, (long long)g * ld + C + threadIdx.x, centroid[(long long)g * 2 + threadIdx.x]);
 }
 
+// Step 2, vector form (channels-last rows that are multiples of 16 bytes): 128 threads per superpixel,
+// thread t owns VEC consecutive channels per pass (4 float32 or 8 bfloat16 = one 16-byte load), so a
+// feature pixel is fetched by full-width loads and EIGHT cells are in flight per thread; the products and
+// the running sums keep the order of the scalar kernel (cells in raster order, multiply and add rounded
+// apart), so the descriptors are bit-identical to it and to the oracle.
+#define POOLV_THREADS 128
+template <int DT, int NP>
+__global__ __launch_bounds__(POOLV_THREADS) void k_pool_mean_vec(const void *__restrict__ fmap, int C,
+                                                                 int fh, int fw, long long sb, long long sy,
+                                                                 long long sx, int B, int H, int W, int sampling,
+                                                                 const int32_t *__restrict__ offsets,
+                                                                 const int32_t *__restrict__ bbox,
+                                                                 const int32_t *__restrict__ count,
+                                                                 const CellSlots *__restrict__ cells,
+                                                                 const double *__restrict__ centroid,
+                                                                 int append_pos, void *__restrict__ X,
+                                                                 int x_dtype, long long ld)
+{
+    constexpr int VEC = DT == 0 ? 4 : 8;
+    __shared__ long long l_off[POOL_LIST];
+    __shared__ float l_w[POOL_LIST];
+    __shared__ int wave_cnt[2];
+    const int g = blockIdx.x;
+    if (g >= offsets[B]) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nthr = blockDim.x;                 // 64 or 128: as many threads as one pass over the channels needs
+    const int b = seg_image_p(offsets, B, g);
+    const int s = g - offsets[b];
+    const int n = count[g];
+    const int y0 = bbox[g * 4 + 0], y1 = bbox[g * 4 + 1], x0 = bbox[g * 4 + 2], x1 = bbox[g * 4 + 3];
+    float acc[NP][VEC];
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[p][v] = 0.0f;
+    // channel base of pass p: (p * 128 + tid) * VEC; inactive when beyond C
+    auto accumulate = [&](const uint4 (&q)[NP], float w) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            float f[VEC];
+            if (DT == 0) {
+                f[0] = __uint_as_float(q[p].x); f[1] = __uint_as_float(q[p].y);
+                f[2] = __uint_as_float(q[p].z); f[3] = __uint_as_float(q[p].w);
+            } else {
+                const unsigned u[4] = {q[p].x, q[p].y, q[p].z, q[p].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    f[2 * k] = __uint_as_float(u[k] << 16);            // bfloat16 -> float32, exact
+                    f[2 * k + 1] = __uint_as_float(u[k] & 0xffff0000u);
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) { const float pr = w * f[v]; acc[p][v] = acc[p][v] + pr; }
+        }
+    };
+    if (n > 0) {
+        int u0, u1, v0, v1;
+        if (sampling == 0) {
+            u0 = (int)((long long)y0 * fh / H); u1 = (int)((long long)y1 * fh / H);
+            v0 = (int)((long long)x0 * fw / W); v1 = (int)((long long)x1 * fw / W);
+        } else {
+            const float ry = (H > 1) ? ((float)(fh - 1) / (float)(H - 1)) : 0.0f;
+            const float rx = (W > 1) ? ((float)(fw - 1) / (float)(W - 1)) : 0.0f;
+            u0 = max(0, (int)((float)y0 * ry) - 1); u1 = min(fh - 1, (int)((float)y1 * ry) + 2);
+            v0 = max(0, (int)((float)x0 * rx) - 1); v1 = min(fw - 1, (int)((float)x1 * rx) + 2);
+        }
+        const CellSlots *cb = cells + (long long)b * fh * fw;
+        const long long fb = (long long)b * sb;
+        const int bwc = v1 - v0 + 1;
+        const int ncell = (u1 - u0 + 1) * bwc;
+        const char *base = (const char *)fmap;
+        constexpr int ES = DT == 0 ? 4 : 2;
+        bool act[NP];
+        long long choff[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int c0 = (p * nthr + tid) * VEC;
+            act[p] = c0 < C;
+            choff[p] = (long long)(act[p] ? c0 : 0) * ES;
+        }
+        int len = 0;                               // workgroup-uniform list length
+        for (int c0 = 0; c0 < ncell || len > 0; c0 += nthr) {
+            if (c0 < ncell) {
+                const int ci = c0 + tid;
+                float w = 0.0f;
+                bool found = false;
+                long long fo = 0;
+                if (ci < ncell) {
+                    const int u = u0 + ci / bwc, v = v0 + ci % bwc;
+                    const CellSlots *cs = cb + (long long)u * fw + v;
+                    const int nn = cs->n;
+                    for (int j = 0; j < nn; ++j)
+                        if (cs->lab[j] == s) { w = cs->w[j]; found = true; break; }
+                    fo = (fb + u * sy + v * sx) * ES;
+                }
+                const unsigned long long m = __ballot(found);
+                if (lane == 0) wave_cnt[wv] = __popcll(m);
+                __syncthreads();
+                const int off = len + (wv ? wave_cnt[0] : 0), tot = wave_cnt[0] + (nthr > 64 ? wave_cnt[1] : 0);
+                if (found) { const int pos = off + (int)spa_rank_in_mask(m); l_off[pos] = fo; l_w[pos] = w; }
+                len += tot;
+                __syncthreads();
+            }
+            // consume when the next chunk might not fit, or at the end
+            if (len + nthr > POOL_LIST || c0 + nthr >= ncell) {
+                int j = 0;
+                for (; j + 8 <= len; j += 8) {
+                    uint4 q[8][NP];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+#pragma unroll
+                        for (int p = 0; p < NP; ++p)
+                            q[e][p] = *(const uint4 *)(base + l_off[j + e] + choff[p]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) accumulate(q[e], l_w[j + e]);
+                }
+                for (; j < len; ++j) {
+                    uint4 q[NP];
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) q[p] = *(const uint4 *)(base + l_off[j] + choff[p]);
+                    accumulate(q, l_w[j]);
+                }
+                __syncthreads();
+                len = 0;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < NP; ++p) (void)act[p];
+    }
+    const float tot = (float)n;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int c0 = (p * nthr + tid) * VEC;
+        if (c0 < C) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) store_x(X, x_dtype, (long long)g * ld + c0 + v, (double)(acc[p][v] / tot));
+        }
+    }
+    if (append_pos && tid < 2)
+        store_x(X, x_dtype, (long long)g * ld + C + tid, centroid[(long long)g * 2 + tid]);
+}
+
 extern "C" int spa_pool_mean(spa_ctx *ctx, const void *fmap, const spa_fmap_desc *d,
                              const int32_t *labels, int32_t B, int32_t H, int32_t W,
                              const int32_t *offsets, int32_t Ncap, const int32_t *count,
@@ -366,6 +508,28 @@ extern "C" int spa_pool_mean(spa_ctx *ctx, const void *fmap, const spa_fmap_desc
     hipLaunchKernelGGL(k_cell_weights, dim3((ncell + 255) / 256, B), dim3(256), 0, s, labels, H, W,
                        d->fh, d->fw, sampling, offsets, cells, ctx->d_status); }
     SpaProfScope prof_(ctx, PROF_POOL_MEAN, s);
+    {
+        // vector kernel: every feature pixel's row starts on a 16-byte boundary and holds whole vectors
+        const int es = d->dtype == 0 ? 4 : 2, vec = 16 / es;
+        const bool aligned = ((uintptr_t)fmap % 16 == 0) && (d->stride_x * es) % 16 == 0 &&
+                             (d->stride_y * es) % 16 == 0 && (d->stride_b * es) % 16 == 0 && d->C % vec == 0;
+        const int nthr = d->C <= 64 * vec ? 64 : POOLV_THREADS;
+        const int np = (d->C + nthr * vec - 1) / (nthr * vec);
+        if (aligned && np <= 4) {
+#define POOLV_LAUNCH(DT, NP)                                                                                    \
+            hipLaunchKernelGGL((k_pool_mean_vec<DT, NP>), dim3(Ncap), dim3(nthr), 0, s, fmap, d->C, d->fh,            \
+                               d->fw, (long long)d->stride_b, (long long)d->stride_y, (long long)d->stride_x, B, H,  \
+                               W, sampling, offsets, (const int32_t *)ctx->ws[WS_BBOX], count, cells, centroid,      \
+                               append_pos, X, x_dtype, (long long)ld)
+            if (d->dtype == 0) {
+                if (np == 1) POOLV_LAUNCH(0, 1); else if (np == 2) POOLV_LAUNCH(0, 2); else POOLV_LAUNCH(0, 4);
+            } else {
+                if (np == 1) POOLV_LAUNCH(1, 1); else if (np == 2) POOLV_LAUNCH(1, 2); else POOLV_LAUNCH(1, 4);
+            }
+            SPA_LAUNCH_CHECK();
+            return SPA_OK;
+        }
+    }
     hipLaunchKernelGGL(k_pool_mean, dim3(Ncap), dim3(256), 0, s, fmap, d->dtype, d->C, d->fh, d->fw,
                        (long long)d->stride_b, (long long)d->stride_y, (long long)d->stride_x, B, H,
                        W, sampling, offsets, (const int32_t *)ctx->ws[WS_BBOX], count, cells, centroid,

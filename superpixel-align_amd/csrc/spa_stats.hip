@@ -36,9 +36,10 @@ __global__ __launch_bounds__(256) void k_bbox_count(const int32_t *__restrict__ 
                                                     int npix, const int32_t *__restrict__ offsets,
                                                     int Ncap, int32_t *__restrict__ bbox,
                                                     int32_t *__restrict__ count,
-                                                    uint32_t *__restrict__ status)
+                                                    uint32_t *__restrict__ status, const int *__restrict__ flags)
 {
     const int b = blockIdx.y;
+    if (flags && !flags[b]) return;
     const int off = offsets[b], S = offsets[b + 1] - off;
     const int lane = threadIdx.x & 63;
     for (int p0 = blockIdx.x * 256; p0 < npix; p0 += gridDim.x * 256) {
@@ -86,10 +87,11 @@ __global__ __launch_bounds__(256) void k_bbox_count_lds(const int32_t *__restric
                                                         const int32_t *__restrict__ offsets,
                                                         int Ncap, int32_t *__restrict__ bbox,
                                                         int32_t *__restrict__ count,
-                                                        uint32_t *__restrict__ status)
+                                                        uint32_t *__restrict__ status, const int *__restrict__ flags)
 {
     __shared__ int l_cnt[BBOX_LDS_MAX], l_y0[BBOX_LDS_MAX], l_y1[BBOX_LDS_MAX], l_x0[BBOX_LDS_MAX], l_x1[BBOX_LDS_MAX];
     const int b = blockIdx.y;
+    if (flags && !flags[b]) return;
     const int off = offsets[b], S = offsets[b + 1] - off;
     const int lane = threadIdx.x & 63;
     const int SL = min(S, BBOX_LDS_MAX);          // labels beyond the LDS tables go straight to global
@@ -157,6 +159,149 @@ __device__ __forceinline__ int seg_image(const int32_t *offsets, int B, int g)
     return b;
 }
 
+// ---------------------------------------------------------------------------------------
+// One streaming pass over the label image for everything a superpixel needs: pixel count, bounding
+// box, exact integer coordinate sums (-> centre of mass) and the sum of the Gaussian location prior.
+// A workgroup owns a strip of STRIP_ROWS rows; wave w walks rows w, w+4, ... of the strip 64 pixels at
+// a time.  For every distinct label of a 64-pixel piece the member lanes' contributions are reduced
+// with a fixed xor-butterfly (non-members add 0.0: exact) and added to the WAVE's own LDS table, so
+// every float64 addition happens in an order fixed by the image alone; the four wave tables are then
+// combined in wave order into the strip's row of a global table, and k_stats_final adds the strips in
+// strip order.  The label image is read once (4 bytes per pixel; the first version read it about 3.8
+// times: a count/bbox pass and a pass over every superpixel's bounding box).
+// Labels beyond STATS_LDS_MAX per image take the bounding-box kernel below (k_seg_moments).
+// ---------------------------------------------------------------------------------------
+#define STRIP_ROWS 16
+#define STATS_LDS_MAX 512
+struct StripRec { double pw; unsigned long long sy, sx; int cnt, y0, y1, x0, x1, pad; };
+
+// sum of the indices of the set bits of m
+__device__ __forceinline__ int spa_bit_index_sum(unsigned long long m)
+{
+    return __popcll(m & 0xAAAAAAAAAAAAAAAAull) + 2 * __popcll(m & 0xCCCCCCCCCCCCCCCCull) +
+           4 * __popcll(m & 0xF0F0F0F0F0F0F0F0ull) + 8 * __popcll(m & 0xFF00FF00FF00FF00ull) +
+           16 * __popcll(m & 0xFFFF0000FFFF0000ull) + 32 * __popcll(m & 0xFFFFFFFF00000000ull);
+}
+
+// flags[b] = 1: image b has more than STATS_LDS_MAX labels and takes the two-pass kernels instead
+__global__ __launch_bounds__(256) void k_stats_strip(const int32_t *__restrict__ labels, int H, int W,
+                                                     const int32_t *__restrict__ offsets, int Ncap,
+                                                     double ymean, double xmean, double dy2, double dx2,
+                                                     int want_prior, StripRec *__restrict__ table, int nstrip,
+                                                     int *__restrict__ flags, uint32_t *__restrict__ status)
+{
+    // float64 prior sums: one table per wave (ordered additions); integers: one table, LDS atomics
+    __shared__ double t_pw[4][STATS_LDS_MAX];
+    __shared__ unsigned long long t_sy[STATS_LDS_MAX], t_sx[STATS_LDS_MAX];
+    __shared__ int t_cnt[STATS_LDS_MAX], t_x0[STATS_LDS_MAX], t_x1[STATS_LDS_MAX];
+    __shared__ int t_y0[STATS_LDS_MAX], t_y1[STATS_LDS_MAX];
+    const int b = blockIdx.y, strip = blockIdx.x;
+    const int off = offsets[b], S = offsets[b + 1] - off;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (S > STATS_LDS_MAX) {
+        if (strip == 0 && tid == 0) flags[b] = 1;
+        return;
+    }
+    for (int l = tid; l < S; l += 256) {
+        t_pw[0][l] = 0.0; t_pw[1][l] = 0.0; t_pw[2][l] = 0.0; t_pw[3][l] = 0.0;
+        t_sy[l] = 0; t_sx[l] = 0; t_cnt[l] = 0;
+        t_x0[l] = 0x7fffffff; t_x1[l] = -1; t_y0[l] = 0x7fffffff; t_y1[l] = -1;
+    }
+    __syncthreads();
+    const int32_t *L = labels + (long long)b * H * W;
+    const int r0 = strip * STRIP_ROWS, r1 = min(H, r0 + STRIP_ROWS);
+    for (int y = r0 + wv; y < r1; y += 4) {
+        const double ty = ((double)y - ymean) * ((double)y - ymean) / dy2;
+        // eight 64-pixel pieces of the row are loaded before the first is used: one memory latency per
+        // 512 pixels instead of one per piece
+        for (int xg = 0; xg < W; xg += 512) {
+            int lab8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int x = xg + u * 64 + lane;
+                lab8[u] = (x < W) ? L[(long long)y * W + x] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int xb = xg + u * 64;
+                if (xb >= W) break;
+                const int x = xb + lane;
+                int l = lab8[u];
+                if (x < W && (l < 0 || l >= S || off + l >= Ncap)) { atomicOr(status, SPA_ST_LABEL_RANGE); l = -1; }
+                double e = 0.0;
+                if (want_prior && l >= 0) {
+                    const double tx = ((double)x - xmean) * ((double)x - xmean) / dx2;
+                    e = spa_det_exp(-(ty + tx));
+                }
+                unsigned long long todo = __ballot(l >= 0);
+                while (todo) {
+                    const int leader = __ffsll((long long)todo) - 1;
+                    const int ll = __shfl(l, leader);
+                    const unsigned long long same = __ballot(l == ll);
+                    double v = (l == ll) ? e : 0.0;
+                    if (want_prior) {
+#pragma unroll
+                        for (int o = 1; o < 64; o <<= 1) v = v + __shfl_xor(v, o);
+                    }
+                    if (lane == leader) {
+                        const int n = __popcll(same);
+                        const int last = 63 - __clzll((long long)same);
+                        // lanes are consecutive pixels of one row: sum of x = n * xb + sum of the lane indices
+                        t_pw[wv][ll] = t_pw[wv][ll] + v;
+                        atomicAdd(&t_sy[ll], (unsigned long long)n * (unsigned)y);
+                        atomicAdd(&t_sx[ll], (unsigned long long)n * (unsigned)xb + (unsigned)spa_bit_index_sum(same));
+                        atomicAdd(&t_cnt[ll], n);
+                        atomicMin(&t_x0[ll], xb + leader);
+                        atomicMax(&t_x1[ll], xb + last);
+                        atomicMin(&t_y0[ll], y);
+                        atomicMax(&t_y1[ll], y);
+                    }
+                    todo &= ~same;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int l = tid; l < S; l += 256) {
+        StripRec r;
+        r.pw = ((t_pw[0][l] + t_pw[1][l]) + t_pw[2][l]) + t_pw[3][l];
+        r.sy = t_sy[l]; r.sx = t_sx[l]; r.cnt = t_cnt[l];
+        r.y0 = t_y0[l]; r.y1 = t_y1[l]; r.x0 = t_x0[l]; r.x1 = t_x1[l];
+        r.pad = 0;
+        table[((long long)b * nstrip + strip) * STATS_LDS_MAX + l] = r;
+    }
+}
+
+// strips in order -> count, bounding box, centre of mass, prior of every superpixel with label < smax
+__global__ __launch_bounds__(256) void k_stats_final(const StripRec *__restrict__ table, int nstrip, int smax,
+                                                     const int *__restrict__ flags,
+                                                     const int32_t *__restrict__ offsets, int B, int Ncap,
+                                                     int32_t *__restrict__ bbox, int32_t *__restrict__ count,
+                                                     double *__restrict__ centroid, double *__restrict__ prior)
+{
+    const int b = blockIdx.y;
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    const int off = offsets[b], S = offsets[b + 1] - off;
+    if (flags[b] || l >= S || l >= smax || off + l >= Ncap) return;
+    const int g = off + l;
+    double pw = 0.0;
+    unsigned long long sy = 0, sx = 0;
+    int n = 0, y0 = 0x7fffffff, y1 = -1, x0 = 0x7fffffff, x1 = -1;
+    for (int q = 0; q < nstrip; ++q) {
+        const StripRec r = table[((long long)b * nstrip + q) * smax + l];
+        if (r.cnt == 0) continue;
+        pw = pw + r.pw; sy += r.sy; sx += r.sx; n += r.cnt;
+        y0 = min(y0, r.y0); y1 = max(y1, r.y1); x0 = min(x0, r.x0); x1 = max(x1, r.x1);
+    }
+    count[g] = n;
+    bbox[g * 4 + 0] = y0; bbox[g * 4 + 1] = y1; bbox[g * 4 + 2] = x0; bbox[g * 4 + 3] = x1;
+    if (centroid) {
+        centroid[(long long)g * 2 + 0] = (double)sy / (double)n;
+        centroid[(long long)g * 2 + 1] = (double)sx / (double)n;
+    }
+    if (prior) prior[g] = pw / (double)n;
+}
+
 // segment-major pass over the bounding box: exact integer coordinate sums (-> centre of
 // mass) and the mean of the Gaussian location prior, summed in a fixed order.
 __global__ __launch_bounds__(256) void k_seg_moments(const int32_t *__restrict__ labels, int B,
@@ -166,13 +311,14 @@ __global__ __launch_bounds__(256) void k_seg_moments(const int32_t *__restrict__
                                                      const int32_t *__restrict__ count,
                                                      double ymean, double xmean, double dy2,
                                                      double dx2, double *__restrict__ centroid,
-                                                     double *__restrict__ prior)
+                                                     double *__restrict__ prior, const int *__restrict__ flags)
 {
     __shared__ unsigned long long s_sy[4], s_sx[4];
     __shared__ double s_pw[4];
     const int g = blockIdx.x;
     if (g >= offsets[B]) return;
     const int b = seg_image(offsets, B, g);
+    if (flags && !flags[b]) return;
     const int s = g - offsets[b];
     const int y0 = bbox[g * 4 + 0], y1 = bbox[g * 4 + 1], x0 = bbox[g * 4 + 2], x1 = bbox[g * 4 + 3];
     const int n = count[g];
@@ -225,25 +371,45 @@ extern "C" int spa_segment_stats(spa_ctx *ctx, const int32_t *labels, int32_t B,
     if (rc != SPA_OK) return rc;
     const int npix = H * W;
     SpaProfScope prof_(ctx, PROF_STATS, s);
+    // ymean, xmean = int(h * y_rel_pos), int(w * x_rel_pos); sigma = h * rel_sigma (:116-118)
+    const double ymean = (double)(long long)((double)H * y_rel_pos);
+    const double xmean = (double)(long long)((double)W * x_rel_pos);
+    const double ys = (double)H * y_rel_sigma, xs = (double)W * x_rel_sigma;
+    const double dy2 = (2.0 * ys) * (2.0 * ys), dx2 = (2.0 * xs) * (2.0 * xs);
+    // Images with at most STATS_LDS_MAX superpixels (every SLIC map) take the single streaming pass; an
+    // image with more (a fine felzenszwalb map) raises its flag there and takes the two-pass kernels, which
+    // exit at once for all other images.
+    const int *flags = nullptr;
     hipLaunchKernelGGL(k_bbox_init, dim3((Ncap + 255) / 256), dim3(256), 0, s, bbox, count, Ncap);
+    if (W >= 64) {
+        const int nstrip = (H + STRIP_ROWS - 1) / STRIP_ROWS;
+        char *ws;
+        const size_t fl_bytes = ((size_t)B * 4 + 255) & ~(size_t)255;
+        if ((rc = spa_ws_reserve(ctx, WS_OVERLAP, fl_bytes + (size_t)B * nstrip * STATS_LDS_MAX * sizeof(StripRec),
+                                 (void **)&ws)) != SPA_OK) return rc;
+        int *fl = (int *)ws;
+        StripRec *table = (StripRec *)(ws + fl_bytes);
+        SPA_HIP(hipMemsetAsync(fl, 0, fl_bytes, s));
+        hipLaunchKernelGGL(k_stats_strip, dim3(nstrip, B), dim3(256), 0, s, labels, H, W, offsets, Ncap, ymean,
+                           xmean, dy2, dx2, prior ? 1 : 0, table, nstrip, fl, ctx->d_status);
+        hipLaunchKernelGGL(k_stats_final, dim3((STATS_LDS_MAX + 255) / 256, B), dim3(256), 0, s,
+                           (const StripRec *)table, nstrip, STATS_LDS_MAX, (const int *)fl, offsets, B, Ncap, bbox,
+                           count, centroid, prior);
+        flags = fl;
+    }
     if (W >= 64) {
         const int rows = 16;
         hipLaunchKernelGGL(k_bbox_count_lds, dim3((H + rows - 1) / rows, B), dim3(256), 0, s, labels, W,
-                           H, rows, offsets, Ncap, bbox, count, ctx->d_status);
+                           H, rows, offsets, Ncap, bbox, count, ctx->d_status, flags);
     } else {
         int gx = (npix + 255) / 256;
         if (gx > 1024) gx = 1024;
         hipLaunchKernelGGL(k_bbox_count, dim3(gx, B), dim3(256), 0, s, labels, W, npix, offsets, Ncap,
-                           bbox, count, ctx->d_status);
+                           bbox, count, ctx->d_status, flags);
     }
     if (centroid || prior) {
-        // ymean, xmean = int(h * y_rel_pos), int(w * x_rel_pos); sigma = h * rel_sigma (:116-118)
-        double ymean = (double)(long long)((double)H * y_rel_pos);
-        double xmean = (double)(long long)((double)W * x_rel_pos);
-        double ys = (double)H * y_rel_sigma, xs = (double)W * x_rel_sigma;
-        double dy2 = (2.0 * ys) * (2.0 * ys), dx2 = (2.0 * xs) * (2.0 * xs);
         hipLaunchKernelGGL(k_seg_moments, dim3(Ncap), dim3(256), 0, s, labels, B, H, W, offsets,
-                           bbox, count, ymean, xmean, dy2, dx2, centroid, prior);
+                           bbox, count, ymean, xmean, dy2, dx2, centroid, prior, flags);
     }
     SPA_LAUNCH_CHECK();
     return SPA_OK;
