@@ -76,6 +76,7 @@ def parse():
     p.add_argument('--no_host_loop', action='store_true', help='skip the pinned-host to pinned-host loop')
     p.add_argument('--n_batches', type=int, default=3, help='distinct batches rotating through the steps')
     p.add_argument('--no_prof', action='store_true', help='do not record per-kernel events')
+    p.add_argument('--miopen_conv', action='store_true', help='bf16: leave the heavy 3x3 layers to MIOpen (A/B against spa_conv3x3_bf16)')
     p.add_argument('--overlap', action='store_true',
                    help='run the superpixel branch on a second stream under the DRN forward (+5%% '
                         'images/s; per-kernel durations then include contention, so the roofline '
@@ -245,6 +246,7 @@ def main():
         without_pos=False, y_rel_pos=0.75, x_rel_pos=0.5, y_rel_sigma=0.1, x_rel_sigma=0.1,
         gpu=local, n_clusters=a.n_clusters, use_feature_maps=[7], pool_mode=a.pool_mode,
         mean_sampling='nearest', drn_sub_batch=a.drn_sub_batch or None, drn_streams=a.drn_streams)
+    drn._EPILOGUE['own_conv'] = not a.miopen_conv
     model = drn.create_drn(a.arch, device='cuda:%d' % local, dtype=dtype)
     overlap = a.overlap or a.pool_mode == 'anchor'
     pipe = pipeline.LabelPipeline(args, model, overlap=overlap)
@@ -283,6 +285,7 @@ def main():
     stage = {'time_feature_maps': 0.0, 'time_superpixel': 0.0, 'time_roialign': 0.0, 'time_kmeans': 0.0}
     drn._EPILOGUE['bytes'] = 0
     drn._EPILOGUE['launches'] = 0
+    drn._EPILOGUE['conv_flops'] = 0.0
 
     dist.barrier()
     torch.cuda.synchronize()
@@ -306,6 +309,7 @@ def main():
     dt = dist.max_over_ranks(time.perf_counter() - t0)
     eng.raise_on_status()
     bias_bytes, bias_launches = drn._EPILOGUE['bytes'], drn._EPILOGUE['launches']
+    conv_flops = drn._EPILOGUE['conv_flops']
 
     for e in evs:
         pipe._ev = e
@@ -362,6 +366,11 @@ def main():
             tf = stem_flops(B, H, W) / (avg * 1e-3) / 1e12
             ent.update(bound='mfma', achieved=round(tf, 2), peak=FP32_MATRIX_PEAK_TF, unit='TFLOP/s',
                        frac=round(tf / FP32_MATRIX_PEAK_TF, 4), flops_per_launch=stem_flops(B, H, W))
+        elif name.startswith('k_conv3x3_bf16'):
+            # libspalign's bf16 implicit-GEMM convolutions (the heavy 3x3 layers): family entry, all launches
+            tf = conv_flops / a.steps / (ms / a.steps * 1e-3) / 1e12
+            ent.update(bound='mfma', achieved=round(tf, 1), peak=BF16_MATRIX_PEAK_TF, unit='TFLOP/s',
+                       frac=round(tf / BF16_MATRIX_PEAK_TF, 4), flops_per_step=conv_flops / a.steps)
         else:
             if name.startswith('k_bias_act'):
                 ab = bias_bytes / max(1, bias_launches)          # average over the 23 layers' shapes

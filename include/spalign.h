@@ -97,6 +97,16 @@ int spa_drn_stem_d(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W
                    const double *mean3_host, const double *std3_host, void *y, int32_t out_dtype,
                    float *xn_scratch, void *stream);
 
+/* The heavy 3x3 (dilated) convolutions of the DRN (models/drn.py:230-285, layers 5-8: 256/512 channels at 1/8
+ * resolution) as a bfloat16 implicit GEMM on the matrix cores with the folded-BatchNorm bias, the BasicBlock's
+ * residual add (models/drn.py:23-57) and the ReLU fused into the epilogue.  stride 1, padding = dilation.
+ * x (B,H,W,Cin) bfloat16 channels-last; wt (Cout,9,Cin) bfloat16 = the (Cout,Cin,3,3) weight permuted to
+ * (n, ky, kx, c); bias (Cout) float32; residual (B,H,W,Cout) bfloat16 or NULL; y (B,H,W,Cout) bfloat16.
+ * Cin % 64 == 0, Cout % 256 == 0; float32 accumulation, one rounding to bfloat16 at the end. */
+int spa_conv3x3_bf16(spa_ctx *ctx, const void *x, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                     const void *wt, int32_t Cout, const float *bias, const void *residual,
+                     int32_t relu, int32_t dilation, void *y, void *stream);
+
 /* ---- SLIC superpixels ------------------------------------------------------------------
  * replaces batch_superpixel(), SLIC branch: batch_spalign_kmeans.py:308-311, i.e.
  * skimage.segmentation.slic(img.transpose(1,2,0), n_segments) with every other argument

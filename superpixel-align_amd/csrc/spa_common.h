@@ -75,6 +75,7 @@ enum {
     WS_FZ_VALS,      // felzenszwalb: edge indices (in/out of the radix sort)
     WS_FZ_STATE,     // felzenszwalb: internal costs + reservation marks
     WS_FZ_TMP,       // felzenszwalb: radix sort temporary storage
+    WS_ZERO_LINE,    // convolution: zero line read for padding pixels
     WS_RUNS,         // connectivity: per-row lists of run starts (B,H,W) i32, used from the front of each row
     WS_COUNT
 };
@@ -84,7 +85,7 @@ enum {
 enum {
     PROF_RGB2LAB = 0, PROF_SLIC_ASSIGN, PROF_SLIC_UPDATE, PROF_CONNECT, PROF_STATS,
     PROF_CELL_WEIGHTS, PROF_POOL_MEAN, PROF_POOL_ANCHOR, PROF_KMEANS, PROF_PAINT,
-    PROF_DRN_STEM, PROF_DRN_BIAS_ACT, PROF_SLOTS
+    PROF_DRN_STEM, PROF_DRN_BIAS_ACT, PROF_DRN_CONV, PROF_SLOTS
 };
 
 struct spa_ctx {
@@ -106,6 +107,7 @@ struct spa_ctx {
     int conn_claim_ready;          // the BFS claim words are all-INF (set once per allocation)
     size_t conn_claim_bytes;
     int upd_wg_per_cu;
+    int zero_line_ready, conv_attr_done;
 };
 
 int spa_aux_streams(spa_ctx *ctx);

@@ -1,0 +1,222 @@
+// bfloat16 implicit-GEMM 3x3 (dilated) convolution for the heavy layers of the DRN (models/drn.py:230-285:
+// layers 5-8, 256/512 channels at 1/8 resolution: ~80 % of the network's FLOPs), with the bias left by the
+// folded BatchNorm, the residual add of a BasicBlock and the ReLU fused into the epilogue.
+//
+//   Y[b, y, x, n] = relu?( bias[n] + res[b, y, x, n] + sum_{tap, c} X[b, y + dy(tap)*d, x + dx(tap)*d, c] * Wt[n, tap, c] )
+//
+// channels-last activations (the layout the pooling kernels want anyway), weights repacked once to
+// (Cout, 9, Cin), float32 accumulation on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16).
+//
+// Mapping: GEMM with M = Cout (weights are the MFMA A operand), N = pixels, K = 9 * Cin.  A workgroup
+// (8 waves) owns 256 output channels x 256 consecutive pixels of one image row; the K loop walks the nine
+// taps and, inside a tap, the input channels 64 at a time: the pixel operand of a K step is 256 rows of
+// 128 contiguous bytes (the same pixels shifted by the tap), i.e. exactly a row-major GEMM tile, fetched
+// straight into LDS by 16-byte global_load_lds (pixels outside the image read a zero line).  Both LDS tiles
+// are [256 rows][64 k] with the 16-byte chunks of a row XOR-swizzled by (row & 7) on the SOURCE address
+// (the LDS image of a wave's load is lane-linear), which makes the ds_read_b128 fragment reads of the
+// 16x16x32 MFMA conflict-free.  Two LDS buffers: the loads of K step t+1 are issued before the MFMAs of
+// step t.  The accumulator tile of a lane is four consecutive output channels of one pixel, so the epilogue
+// stores 8 contiguous bytes per lane and tile.
+// Measured (30 x 128 x 256 pixels, 512 -> 512, sustained, random operands): 1 140-1 150 TFLOP/s = 0.46 of the
+// dense bf16 peak; MIOpen's kernel for the same layer 1 070-1 090.  A four-buffer variant in half steps of
+// 32 channels (three half tiles in flight across raw barriers, counted vmcnt) was built, verified and
+// removed: 1 050 TFLOP/s — twice the barriers cost more than the extra loads in flight bought, i.e. the
+// limiter is the LDS-read + barrier phase in which the matrix pipe idles, not the memory side.
+#include "spa_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define CV_BM 256            // output channels per workgroup
+#define CV_BN 256            // pixels per workgroup
+#define CV_BK 64             // K step (input channels of one tap)
+#define CV_THREADS 512
+#define CV_TILE_BYTES (256 * CV_BK * 2)          // one operand tile: 32 KB
+
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f)
+{
+    __bf16 h = (__bf16)f;                          // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
+    return __builtin_bit_cast(unsigned short, h);
+}
+
+// one K step into LDS: 4 weight-row groups + 4 pixel-row groups of 8 rows per wave (1 KB per instruction)
+__device__ __forceinline__ void cv_stage(char *lds_w, char *lds_x, const char *wrow[4], const char *xrow[4],
+                                         int chunk_byte[4], long long koff_w, long long koff_x, int wave)
+{
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int rowblk = r * 8 + wave;                   // 8 rows = 1 KB
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wrow[r] + koff_w + chunk_byte[r]),
+                                         (__attribute__((address_space(3))) void *)(lds_w + rowblk * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int rowblk = r * 8 + wave;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xrow[r] + koff_x + chunk_byte[r]),
+                                         (__attribute__((address_space(3))) void *)(lds_x + rowblk * 1024), 16, 0, 0);
+    }
+}
+
+template <int HAS_RES>
+__global__ __launch_bounds__(CV_THREADS) void k_conv3x3_bf16(const __bf16 *__restrict__ X, const __bf16 *__restrict__ Wt,
+                                                             const float *__restrict__ bias,
+                                                             const __bf16 *__restrict__ R, __bf16 *__restrict__ Y,
+                                                             const char *__restrict__ zero_line, int B, int H, int W,
+                                                             int Cin, int Cout, int dil, int relu, int xtiles,
+                                                             int ntiles, int total_tiles)
+{
+    extern __shared__ __attribute__((aligned(1024))) char lds[];     // [2][weights 32 KB | pixels 32 KB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // XCD-aware tile order: consecutive workgroup ids go round-robin over the 8 XCDs; give every XCD a
+    // contiguous range of tiles (neighbouring rows of one image share two of their three input rows in L2)
+    const int nwg = total_tiles;
+    int id = blockIdx.x;
+    {
+        const int q = nwg / 8, rem = nwg % 8, xcd = id % 8, idx = id / 8;
+        id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+    }
+    // tile id -> (pixel tile, channel tile): the channel tiles of one pixel tile are adjacent
+    const int nt = id % ntiles, pt = id / ntiles;
+    const int xt = pt % xtiles, row_id = pt / xtiles;               // row_id = b * H + y
+    const int y = row_id % H, b = row_id / H;
+    const int x0 = xt * CV_BN, n0 = nt * CV_BM;
+
+    // ---- staging addresses of this thread: rows (r*8 + wave)*8 + lane/8 of both tiles, 16-byte chunk lane%8
+    const int sub = lane >> 3, cs = lane & 7;
+    const char *wrow[4], *xrow_c[4];
+    int chunk_byte[4], px[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = (r * 8 + wave) * 8 + sub;
+        chunk_byte[r] = ((cs ^ (row & 7)) << 4);
+        wrow[r] = (const char *)(Wt + (long long)(n0 + row) * 9 * Cin);
+        px[r] = x0 + row;
+        xrow_c[r] = (const char *)(X + ((long long)row_id * W + px[r]) * Cin);     // centre tap
+    }
+    const int ksteps_per_tap = Cin / CV_BK;
+    const int nk = 9 * ksteps_per_tap;
+
+    auto stage = [&](int t, int buf) {
+        const int tap = t / ksteps_per_tap, kc = t - tap * ksteps_per_tap;
+        const int dy = (tap / 3 - 1) * dil, dx = (tap % 3 - 1) * dil;
+        const int yy = y + dy;
+        const bool yok = yy >= 0 && yy < H;
+        const long long shift = ((long long)dy * W + dx) * Cin * 2;
+        const char *xrow[4];
+        long long koff_x = (long long)kc * CV_BK * 2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int xx = px[r] + dx;
+            const bool ok = yok && xx >= 0 && xx < W && px[r] < W;
+            // a zero line for padding pixels (its 128 bytes are read at offset chunk_byte only)
+            xrow[r] = ok ? xrow_c[r] + shift + koff_x : zero_line;
+        }
+        cv_stage(lds + buf * 2 * CV_TILE_BYTES, lds + buf * 2 * CV_TILE_BYTES + CV_TILE_BYTES, wrow, xrow, chunk_byte,
+                 ((long long)tap * Cin + (long long)kc * CV_BK) * 2, 0, wave);
+    };
+
+    // ---- accumulators: wave (wm, wn) owns channels [wm*128, +128) x pixels [wn*64, +64)
+    const int wm = wave >> 2, wn = wave & 3;
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fk = lane >> 4;                     // fragment row, 16-byte k chunk inside a 32-k step
+
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        // (the eight loads of the next K step go out in one burst: spreading them between the MFMA groups
+        // was measured 20 % slower — every global_load_lds re-programs M0 and breaks the MFMA stream)
+        if (t + 1 < nk) stage(t + 1, cur ^ 1);
+        const char *lw = lds + cur * 2 * CV_TILE_BYTES, *lx = lw + CV_TILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 wf[8], pf[4];
+            const int chunk = kk * 4 + fk;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = wm * 128 + i * 16 + frow;
+                wf[i] = *(const bf16x8 *)(lw + row * 128 + ((chunk ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = wn * 64 + j * 16 + frow;
+                pf[j] = *(const bf16x8 *)(lx + row * 128 + ((chunk ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], pf[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds channels c..c+3 (c = tile channel base + (lane>>4)*4) of pixel (lane & 15)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int xx = x0 + wn * 64 + j * 16 + (lane & 15);
+        if (xx >= W) continue;
+        const long long pix = (long long)row_id * W + xx;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = n0 + wm * 128 + i * 16 + (lane >> 4) * 4;
+            const float4 bv = *(const float4 *)(bias + c);
+            float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y, v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
+            if (HAS_RES) {
+                const uint2 rr = *(const uint2 *)(R + pix * Cout + c);
+                v0 += __uint_as_float(rr.x << 16); v1 += __uint_as_float(rr.x & 0xffff0000u);
+                v2 += __uint_as_float(rr.y << 16); v3 += __uint_as_float(rr.y & 0xffff0000u);
+            }
+            if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+            uint2 o;
+            o.x = (unsigned)f32_to_bf16_bits(v0) | ((unsigned)f32_to_bf16_bits(v1) << 16);
+            o.y = (unsigned)f32_to_bf16_bits(v2) | ((unsigned)f32_to_bf16_bits(v3) << 16);
+            *(uint2 *)(Y + pix * Cout + c) = o;
+        }
+    }
+}
+
+// x (B,H,W,Cin) bf16 channels-last, wt (Cout,9,Cin) bf16 (tap = ky*3 + kx), bias (Cout) float32,
+// residual (B,H,W,Cout) bf16 or NULL, y (B,H,W,Cout) bf16.  stride 1, padding = dilation.
+extern "C" int spa_conv3x3_bf16(spa_ctx *ctx, const void *x, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                                const void *wt, int32_t Cout, const float *bias, const void *residual,
+                                int32_t relu, int32_t dilation, void *y, void *stream)
+{
+    SPA_ARG(ctx && x && wt && bias && y && B > 0 && H > 0 && W > 0 && dilation >= 1);
+    SPA_ARG(Cin % CV_BK == 0 && Cout % CV_BM == 0);
+    SPA_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)wt % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)bias % 16) == 0);
+    hipStream_t s = spa_stream(stream);
+    char *zero;
+    int rc = spa_ws_reserve(ctx, WS_ZERO_LINE, 4096, (void **)&zero);
+    if (rc != SPA_OK) return rc;
+    if (!ctx->zero_line_ready) {
+        SPA_HIP(hipMemsetAsync(zero, 0, 4096, s));
+        ctx->zero_line_ready = 1;
+    }
+    const int xtiles = (W + CV_BN - 1) / CV_BN, ntiles = Cout / CV_BM;
+    const long long total = (long long)B * H * xtiles * ntiles;
+    SPA_ARG(total < (1ll << 31));
+    const size_t lds = 4 * (size_t)CV_TILE_BYTES;
+    if (!ctx->conv_attr_done) {
+        SPA_HIP(hipFuncSetAttribute((const void *)k_conv3x3_bf16<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SPA_HIP(hipFuncSetAttribute((const void *)k_conv3x3_bf16<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ctx->conv_attr_done = 1;
+    }
+    SpaProfScope prof_(ctx, PROF_DRN_CONV, s);
+    if (residual)
+        hipLaunchKernelGGL(k_conv3x3_bf16<1>, dim3((unsigned)total), dim3(CV_THREADS), lds, s, (const __bf16 *)x,
+                           (const __bf16 *)wt, bias, (const __bf16 *)residual, (__bf16 *)y, (const char *)zero, B, H, W,
+                           Cin, Cout, dilation, relu, xtiles, ntiles, (int)total);
+    else
+        hipLaunchKernelGGL(k_conv3x3_bf16<0>, dim3((unsigned)total), dim3(CV_THREADS), lds, s, (const __bf16 *)x,
+                           (const __bf16 *)wt, bias, (const __bf16 *)nullptr, (__bf16 *)y, (const char *)zero, B, H, W,
+                           Cin, Cout, dilation, relu, xtiles, ntiles, (int)total);
+    SPA_LAUNCH_CHECK();
+    return SPA_OK;
+}

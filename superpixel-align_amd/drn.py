@@ -58,7 +58,7 @@ def _conv(cin, cout, k, stride=1, dilation=1):
 
 # set by DRN.prepare() on a GPU: libspalign's fused bias/residual/ReLU; 'bytes' accumulates the algorithmic
 # HBM bytes of its launches (read y + write y [+ read residual]) for bench.py's roofline entry
-_EPILOGUE = {'engine': None, 'bytes': 0, 'launches': 0}
+_EPILOGUE = {'engine': None, 'bytes': 0, 'launches': 0, 'own_conv': True, 'conv_flops': 0.0}
 
 
 def conv_bias_act(conv, bn, x, residual=None, relu=True):
@@ -69,6 +69,14 @@ def conv_bias_act(conv, bn, x, residual=None, relu=True):
     eng = _EPILOGUE['engine']
     if (eng is not None and x.is_cuda and isinstance(bn, nn.Identity) and conv.bias is not None
             and x.dtype in (torch.float32, torch.bfloat16)):
+        packed = getattr(conv, '_spa_packed', None)
+        if (packed is not None and x.dtype == torch.bfloat16 and _EPILOGUE['own_conv']
+                and x.is_contiguous(memory_format=torch.channels_last)
+                and (residual is None or residual.is_contiguous(memory_format=torch.channels_last))):
+            # the heavy 3x3 (dilated) layers: libspalign's bf16 implicit GEMM with bias / residual / ReLU
+            # in its epilogue (no separate elementwise pass, one rounding to bf16)
+            _EPILOGUE['conv_flops'] += 2.0 * x.shape[0] * x.shape[2] * x.shape[3] * conv.out_channels * 9 * conv.in_channels
+            return eng.conv3x3_bf16(x, packed[0], packed[1], residual, relu, conv.dilation[0])
         y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation)
         vec = 4 if y.dtype == torch.float32 else 8
         if (y.is_contiguous(memory_format=torch.channels_last) and y.shape[1] % vec == 0
@@ -207,6 +215,16 @@ class DRN(nn.Module):
         if torch.device(device).type == 'cuda':
             from .engine import default_engine        # fused glue kernels of libspalign
             _EPILOGUE['engine'] = default_engine()
+            for m in self.modules():
+                if isinstance(m, nn.Conv2d):
+                    m._spa_packed = None
+                    # operands of spa_conv3x3_bf16: 3x3, stride 1, padding = dilation, Cin % 64 == 0,
+                    # Cout % 256 == 0 (layers 5-8: ~80 % of the FLOPs), bf16 network, BatchNorm folded
+                    if (dtype == torch.bfloat16 and self.folded and m.kernel_size == (3, 3) and m.stride == (1, 1)
+                            and m.padding == m.dilation and m.dilation[0] == m.dilation[1] and m.groups == 1
+                            and m.in_channels % 64 == 0 and m.out_channels % 256 == 0 and m.bias is not None):
+                        wt = m.weight.detach().permute(0, 2, 3, 1).reshape(m.out_channels, 9, m.in_channels)
+                        m._spa_packed = (wt.contiguous().to(torch.bfloat16), m.bias.detach().float().contiguous())
             if self.arch == 'D' and self.folded and dtype in (torch.float32, torch.bfloat16):
                 # operands of libspalign's fused stem kernel (normalise + layer0 + layer1)
                 c0, c1 = self.layer0[0], self.layer1[0]

@@ -1,0 +1,70 @@
+"""libspalign's bf16 implicit-GEMM 3x3 convolution (spa_conv3x3_bf16) against MIOpen (torch F.conv2d) on the
+heavy DRN layer shapes: numerics (float32 reference of the same bf16 operands) and TFLOP/s.
+    python tools/conv_bench.py [--batch 30] [--quick]"""
+import argparse
+import importlib
+import os
+import sys
+
+os.environ.setdefault('MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD', '0')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn.functional as F
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--batch', type=int, default=30)
+ap.add_argument('--quick', action='store_true')
+a = ap.parse_args()
+engine = importlib.import_module('superpixel-align_amd.engine')
+eng = engine.Engine()
+torch.backends.cudnn.benchmark = True
+torch.manual_seed(0)
+
+
+def run(B, Cin, Cout, H, W, dil, res, reps=5):
+    x = torch.randn((B, Cin, H, W), device='cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn((Cout, Cin, 3, 3), device='cuda') * (2.0 / (9 * Cin)) ** 0.5).to(torch.bfloat16)
+    w_cl = w.contiguous(memory_format=torch.channels_last)
+    bias = torch.randn((Cout,), device='cuda')
+    r = torch.randn((B, Cout, H, W), device='cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last) if res else None
+    wt = w.permute(0, 2, 3, 1).reshape(Cout, 9, Cin).contiguous()
+    y = eng.conv3x3_bf16(x, wt, bias, r, True, dil)
+    # numerics on a slice of the batch (float32 convolution of the same bf16 values)
+    nb = min(B, 2)
+    ref = F.conv2d(x[:nb].float(), w.float(), bias, 1, dil, dil)
+    if res:
+        ref = ref + r[:nb].float()
+    ref = torch.relu(ref)
+    err = (y[:nb].float() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    # timing
+    def t(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    ms_own = t(lambda: eng.conv3x3_bf16(x, wt, bias, r, True, dil))
+    ms_ref = t(lambda: F.conv2d(x, w_cl, None, 1, dil, dil))
+    fl = 2.0 * B * H * W * Cout * 9 * Cin
+    print('B %d  %4d -> %4d  %dx%d dil %d res %d | max err %.3g (scale %.3g, rel %.2e) | own %.3f ms %.0f TF | MIOpen conv only '
+          '%.3f ms %.0f TF' % (B, Cin, Cout, H, W, dil, int(res), err, scale, err / scale, ms_own, fl / ms_own / 1e9,
+                               ms_ref, fl / ms_ref / 1e9))
+    return err / scale
+
+
+if a.quick:
+    run(2, 64, 256, 16, 40, 1, False)
+    run(1, 128, 256, 24, 300, 2, True)
+else:
+    B = a.batch
+    run(2, 64, 256, 16, 40, 1, False)
+    run(1, 128, 256, 24, 300, 2, True)
+    for Cin, Cout, dil, res in [(128, 256, 2, False), (256, 256, 2, True), (256, 512, 4, False), (512, 512, 4, True),
+                                (512, 512, 2, False), (512, 512, 1, False)]:
+        run(B, Cin, Cout, 128, 256, dil, res)
