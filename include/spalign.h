@@ -107,6 +107,15 @@ int spa_conv3x3_bf16(spa_ctx *ctx, const void *x, int32_t B, int32_t H, int32_t 
                      const void *wt, int32_t Cout, const float *bias, const void *residual,
                      int32_t relu, int32_t dilation, void *y, void *stream);
 
+/* ---- input stage ---------------------------------------------------------------------------
+ * replaces the host resize of ResizeImageDataset.get_example (datasets/resize_image_dataset.py:31-34:
+ * chainercv.transforms.resize(image, resize_shape, 3)) as Pillow computes it on an 8-bit image, channel by
+ * channel: PIL.Image.fromarray(ch).resize((w, h), PIL.Image.BICUBIC) — bit exact (integer arithmetic).
+ * src (B,H,W,C) uint8 interleaved (a decoded PNG) -> out (B,C,dst_h,dst_w) float32 planar, values 0..255.
+ * With dst == src size only the layout/dtype change is made. */
+int spa_resize_bicubic_u8(spa_ctx *ctx, const uint8_t *src, int32_t B, int32_t H, int32_t W, int32_t C,
+                          int32_t dst_h, int32_t dst_w, float *out, void *stream);
+
 /* ---- SLIC superpixels ------------------------------------------------------------------
  * replaces batch_superpixel(), SLIC branch: batch_spalign_kmeans.py:308-311, i.e.
  * skimage.segmentation.slic(img.transpose(1,2,0), n_segments) with every other argument

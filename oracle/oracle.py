@@ -478,3 +478,19 @@ def felzenszwalb_u8(img_chw_u8, scale=500.0, sigma=0.9, min_size=20):
     order = np.argsort(costs, kind='stable')
     labels, _ = fz_segment(costs, edges, order, H * W, float(scale) / 255., min_size)
     return labels.reshape(H, W)
+
+
+# --------------------------------------------------------------------------- input stage (8f-2)
+def resize_bicubic_u8(img_chw_u8, shape):
+    """PIL.Image.fromarray(channel).resize((w, h), PIL.Image.BICUBIC) per channel of a uint8 CHW image:
+    what datasets/resize_image_dataset.py:31-34 computes when Pillow does the resize (8-bit path)."""
+    a = np.ascontiguousarray(img_chw_u8, dtype=np.uint8)
+    C, H, W = a.shape
+    h, w = int(shape[0]), int(shape[1])
+    out = np.empty((C, h, w), np.uint8)
+    L = lib()
+    L.orc_resize_bicubic_u8.restype = None
+    L.orc_resize_bicubic_u8.argtypes = [_P, ctypes.c_int, ctypes.c_int, _P, ctypes.c_int, ctypes.c_int]
+    for c in range(C):
+        L.orc_resize_bicubic_u8(a[c].ctypes.data, H, W, out[c].ctypes.data, h, w)
+    return out

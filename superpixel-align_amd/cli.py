@@ -57,6 +57,7 @@ _COMMON_FLAGS = [
     ('--no_figure', dict(action='store_true', default=False)),
     ('--balanced', dict(action='store_true', default=False)),
     ('--io_threads', dict(type=int, default=8)),
+    ('--host_resize', dict(action='store_true', default=False)),      # resize with Pillow on the host threads instead
 ]
 
 
@@ -150,6 +151,26 @@ class ImageList(object):
         if self._shape is not None and tuple(img.shape[1:]) != tuple(self._shape):
             img = resize_bicubic_chw(img, self._shape)
         return img.astype(self._dtype)
+
+    def get_raw(self, i):
+        """The decoded image as it comes out of the PNG decoder: (H, W, 3) uint8, not resized."""
+        src = self._open(self._paths[i]) if self._open else self._paths[i]
+        img = _decode(src)
+        if img.ndim == 2:
+            img = img[:, :, None]
+        return np.ascontiguousarray(img[:, :, :3])
+
+    def batch_device(self, lo, hi, pool, engine):
+        """dataset[lo:hi] as a (B,3,h,w) float32 CUDA tensor: decode on the worker threads, upload the
+        8-bit images (3 bytes per pixel) and resize on the GPU (spa_resize_bicubic_u8: bit exact with the
+        Pillow resize of `get`).  Falls back to `batch` when the images of the batch differ in size."""
+        idx = list(range(len(self))[lo:hi])
+        raw = list(pool.map(self.get_raw, idx)) if pool is not None else [self.get_raw(i) for i in idx]
+        if len({r.shape for r in raw}) != 1 or raw[0].shape[2] != 3:
+            return np.stack([self.get(i) for i in idx])
+        u8 = torch.from_numpy(np.stack(raw)).to(engine.device, non_blocking=True)
+        shape = tuple(self._shape) if self._shape is not None else raw[0].shape[:2]
+        return engine.resize_bicubic_u8(u8, shape)
 
     def batch(self, lo, hi, pool=None):
         """dataset[lo:hi] stacked (python slice semantics, like concat_examples(dataset[i:end_i]));
@@ -351,12 +372,28 @@ def main_labelled(argv=None, get=None, make_pipe=None, originals=False, make_mod
 
     pending = []
     try:
-        nxt = loader.submit(imgs_ds.batch, ranges[0][0], ranges[0][1], workers) if ranges else None
+        # GPU input stage: decode on the worker threads, resize on the device (bit exact with the host resize)
+        # (its own spa_ctx: the loader thread must not share a context with the pipeline's thread)
+        from .engine import Engine
+        eng_in = None if make_model else Engine(ops.engine().device.index)
+        def load(lo, hi):
+            if eng_in is not None and not args.host_resize:
+                with torch.cuda.stream(in_stream):
+                    t = imgs_ds.batch_device(lo, hi, workers, eng_in)
+                    ev = torch.cuda.Event()
+                    ev.record(in_stream)
+                return t, ev
+            return imgs_ds.batch(lo, hi, workers), None
+        in_stream = torch.cuda.Stream(device=eng_in.device) if eng_in is not None else None
+        nxt = loader.submit(load, ranges[0][0], ranges[0][1]) if ranges else None
         for bi, (lo, hi) in enumerate(ranges):
             st_all = time.time()
-            imgs = nxt.result()
+            imgs, ready = nxt.result()
+            if ready is not None:
+                torch.cuda.current_stream().wait_event(ready)
+                imgs.record_stream(torch.cuda.current_stream())
             if bi + 1 < len(ranges):
-                nxt = loader.submit(imgs_ds.batch, ranges[bi + 1][0], ranges[bi + 1][1], workers)
+                nxt = loader.submit(load, ranges[bi + 1][0], ranges[bi + 1][1])
             res = pipe.run(imgs, orig_ds.batch(lo, hi, workers)) if originals else pipe.run(imgs)
             times = pipe.elapsed_times()
             cluster, road = res.masks_to_host()
@@ -436,7 +473,8 @@ def main_labelfree(argv=None):
     io_pool = ThreadPoolExecutor(max_workers=max(1, args.io_threads))
     for lo, hi in spdist.batch_ranges(start, end, args.batchsize):
         lo = max(lo, 0)                     # see main_labelled: a range shorter than one batch
-        res = pipe.run(ds.batch(lo, hi, io_pool))
+        batch = ds.batch(lo, hi, io_pool) if args.host_resize else ds.batch_device(lo, hi, io_pool, ops.engine())   # same thread
+        res = pipe.run(batch)
         _, road = res.masks_to_host()
         for j, i in enumerate(list(range(len(ds)))[lo:hi]):
             rm = road[j]

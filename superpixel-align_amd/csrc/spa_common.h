@@ -76,6 +76,8 @@ enum {
     WS_FZ_STATE,     // felzenszwalb: internal costs + reservation marks
     WS_FZ_TMP,       // felzenszwalb: radix sort temporary storage
     WS_ZERO_LINE,    // convolution: zero line read for padding pixels
+    WS_RESIZE_TAB,   // input stage: bicubic tap tables of the current (input, output) size
+    WS_RESIZE_TMP,   // input stage: horizontally resized images (B,H,w,C) u8
     WS_RUNS,         // connectivity: per-row lists of run starts (B,H,W) i32, used from the front of each row
     WS_COUNT
 };
@@ -108,6 +110,7 @@ struct spa_ctx {
     size_t conn_claim_bytes;
     int upd_wg_per_cu;
     int zero_line_ready, conv_attr_done;
+    int rs_key[4], rs_ks[2];       // bicubic tables held in WS_RESIZE_TAB: (H, W, h, w) and tap counts
 };
 
 int spa_aux_streams(spa_ctx *ctx);

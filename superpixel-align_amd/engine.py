@@ -140,6 +140,16 @@ class Engine(object):
                                          _ptr(residual), 1 if relu else 0, int(dilation), _ptr(y), self._s()))
         return y
 
+    def resize_bicubic_u8(self, src, shape):
+        """Decoded 8-bit images (B,H,W,C) uint8 -> (B,C,h,w) float32, bicubic exactly as Pillow's 8-bit
+        Image.resize(..., BICUBIC) per channel (datasets/resize_image_dataset.py:31-34)."""
+        src = _req(src, torch.uint8, 'src')
+        B, H, W, C = src.shape
+        h, w = int(shape[0]), int(shape[1])
+        out = torch.empty((B, C, h, w), dtype=torch.float32, device=src.device)
+        check(self._lib.spa_resize_bicubic_u8(self._ctx, _ptr(src), B, H, W, C, h, w, _ptr(out), self._s()))
+        return out
+
     # ------------------------------------------------------------------ SLIC
     def rgb2lab(self, rgb, ratio=0.1):
         rgb = _req(rgb, torch.float32, 'rgb')

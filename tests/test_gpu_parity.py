@@ -262,6 +262,27 @@ def test_slic_starved_seeds(eng, orc, name):
     assert eng.last_info & 0x01
 
 
+def test_resize_bicubic_bit_exact(eng, orc):
+    """spa_resize_bicubic_u8 (8f-2) against Pillow's own outputs (fixture), the oracle and the live
+    Pillow on this box, including the 1024x2048 -> 224x224 operating point of every reference launcher."""
+    g = golden('resize_bicubic')
+    for tag in g['cases']:
+        img, ref = g[str(tag) + '_img'], g[str(tag) + '_out']
+        src = dev(np.ascontiguousarray(img.transpose(1, 2, 0))[None])          # (1, H, W, 3) uint8
+        out = eng.resize_bicubic_u8(src, ref.shape[1:])[0].cpu().numpy()
+        assert out.dtype == np.float32 and np.array_equal(out, ref.astype(np.float32)), tag
+    rs = np.random.RandomState(4)
+    big = rs.randint(0, 256, (2, 1024, 2048, 3)).astype(np.uint8)
+    out = eng.resize_bicubic_u8(dev(big), (224, 224)).cpu().numpy()
+    for b in range(2):
+        assert np.array_equal(out[b], orc.resize_bicubic_u8(big[b].transpose(2, 0, 1), (224, 224)).astype(np.float32))
+    from PIL import Image
+    live = np.stack([np.asarray(Image.fromarray(big[0, :, :, c]).resize((224, 224), Image.BICUBIC)) for c in range(3)])
+    assert np.array_equal(out[0], live.astype(np.float32))
+    same = eng.resize_bicubic_u8(dev(big[:1, :64, :96]), (64, 96))[0].cpu().numpy()   # layout / dtype change only
+    assert np.array_equal(same, big[0, :64, :96].transpose(2, 0, 1).astype(np.float32))
+
+
 def test_kmeans_near_ties(eng):
     """Inputs bisected onto the reference's decision boundary (tests/golden/kmeans_tie.npz): the
     kernel's sums must round exactly like numpy's (sequential axis-0 centre sums, pairwise

@@ -187,6 +187,39 @@ def test_cli_drivers_on_synthetic_pngs(mods, orc, synth, tmp_path):
         assert m.shape == (2 * H, 2 * W) and set(np.unique(m)) <= {0, 1}
 
 
+def test_driver_gpu_input_stage_equals_host_resize(mods, synth, tmp_path):
+    """The labelled driver with the GPU input stage (decode on threads, spa_resize_bicubic_u8) writes the
+    same masks and scores as with --host_resize (Pillow on the host threads), images resized 96x192 -> 64x80."""
+    from PIL import Image
+    H, W, n = 96, 192, 4
+    img_fns, lab_fns = [], []
+    for i in range(n):
+        img = synth.synth_image(80 + i, H, W, integer_valued=True).astype(np.uint8)
+        fn = str(tmp_path / ('town_%06d_000019_leftImg8bit.png' % i))
+        Image.fromarray(img.transpose(1, 2, 0)).save(fn)
+        lf = str(tmp_path / ('town_%06d_000019_gtFine_labelIds.png' % i))
+        Image.fromarray(synth.synth_gt_labels(80 + i, H, W)).save(lf)
+        img_fns.append(fn); lab_fns.append(lf)
+    (tmp_path / 'imgs.txt').write_text('\n'.join(img_fns) + '\n')
+    (tmp_path / 'labs.txt').write_text('\n'.join(lab_fns) + '\n')
+    outs = []
+    for extra in ([], ['--host_resize']):
+        out = tmp_path / ('out' + str(len(outs)))
+        argv = ['--superpixel_method', 'slic', '--n_slic_segments', '20', '--n_clusters', '2',
+                '--resize_shape', '64', '80', '--batchsize', '2', '--out_dir', str(out),
+                '--img_file_list', str(tmp_path / 'imgs.txt'), '--label_file_list', str(tmp_path / 'labs.txt'),
+                '--arch', 'drn_d_22', '--pool_mode', 'mean', '--no_figure'] + extra
+        assert mods.cli.main_labelled(argv) == 0
+        outs.append(out)
+    for fn in img_fns:
+        base = os.path.splitext(os.path.basename(fn))[0]
+        for suffix in ('.npy', '_all_cluster.npy'):
+            assert np.array_equal(np.load(outs[0] / (base + suffix)), np.load(outs[1] / (base + suffix))), base
+    a = [json.loads(l) for l in open(outs[0] / 'result.json')]
+    b = [json.loads(l) for l in open(outs[1] / 'result.json')]
+    assert [(x['TP'], x['FP'], x['FN']) for x in a] == [(x['TP'], x['FP'], x['FN']) for x in b]
+
+
 def test_bench_two_ranks_on_one_gpu(tmp_path):
     """bench.py's N > 1 path end to end (sharding, barrier, max-over-ranks timing, record
     all_gather) with two ranks sharing this box's single GPU over gloo."""

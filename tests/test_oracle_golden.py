@@ -216,6 +216,23 @@ def test_confusion_matches_chainercv_formula(orc):
     assert np.array_equal(orc.create_label_mask(lab), [[-1, -1, -1, 1], [0, 0, 1, 0]])
 
 
+def test_resize_oracle_is_pillow_bit_for_bit(orc):
+    """The input stage's bicubic resize (8f-2) against outputs of Pillow 8.4.0 itself and, when Pillow is
+    importable here, against the live library (any version): bit exact, all five size combinations."""
+    g = golden('resize_bicubic')
+    for tag in g['cases']:
+        img, ref = g[str(tag) + '_img'], g[str(tag) + '_out']
+        assert np.array_equal(orc.resize_bicubic_u8(img, ref.shape[1:]), ref), tag
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    rs = np.random.RandomState(3)
+    img = rs.randint(0, 256, (3, 256, 512)).astype(np.uint8)
+    live = np.stack([np.asarray(Image.fromarray(c).resize((224, 224), Image.BICUBIC)) for c in img])
+    assert np.array_equal(orc.resize_bicubic_u8(img, (224, 224)), live)
+
+
 def test_kmeans_near_ties_follow_numpy_rounding(orc):
     """40 inputs that sit on the decision boundary of the reference's kmeans to within the rounding
     noise of its distance sums (pairs that differ in the last bit of one parameter and flip one
