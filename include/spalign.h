@@ -48,6 +48,7 @@ extern "C" {
 #define SPA_ST_POOL_SLOT_OVERFLOW 0x08u  /* > SPA_CELL_SLOTS superpixels touch one feature pixel */
 #define SPA_ST_KMEANS_BARRIER 0x10u      /* grid barrier timed out (should never happen)        */
 #define SPA_ST_LABEL_RANGE 0x20u         /* a label outside [0, S) was met                      */
+#define SPA_ST_RNG_UNDERRUN 0x40u        /* the device random stream ran dry (spa_pyrandom_dev_generate too small) */
 
 #define SPA_CELL_SLOTS 16
 
@@ -207,6 +208,18 @@ typedef struct spa_nprandom spa_nprandom;
 int spa_nprandom_create(uint32_t seed, spa_nprandom **out);
 void spa_nprandom_destroy(spa_nprandom *rng);
 int spa_nprandom_shuffle_host(spa_nprandom *rng, int64_t *a_host, int64_t n);
+
+/* The same selection entirely on the device (no superpixel size ever visits the host): a device-resident
+   CPython generator (seeded like random.seed()), its outputs produced ahead of use into a ring
+   (spa_pyrandom_dev_generate: `want` outputs available; asynchronous, data independent), then for the N =
+   *n_ptr superpixels in order the rejection sampling of every shuffle swap and the first n_anchors places of
+   every shuffled list.  total_pixels >= sum of the sizes.  ranks (Ncap, n_anchors), n_valid (Ncap) int32 out;
+   SPA_ST_RNG_UNDERRUN is latched if the ring runs dry (about 1.4 outputs are used per pixel). */
+int spa_pyrandom_dev_seed(spa_ctx *ctx, uint64_t seed, void *stream);
+int spa_pyrandom_dev_generate(spa_ctx *ctx, int64_t want, void *stream);
+int spa_anchor_ranks_dev(spa_ctx *ctx, const int32_t *count, const int32_t *n_ptr, int32_t Ncap,
+                         int32_t n_anchors, int64_t total_pixels, int32_t *ranks, int32_t *n_valid,
+                         void *stream);
 
 /* Anchor selection, device half: rank -> pixel.  ranks (Ncap, n_anchors) int32,
    n_valid (Ncap) int32 -> anchors (Ncap, n_anchors, 2) int32 (y, x).                      */

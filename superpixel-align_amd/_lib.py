@@ -19,6 +19,7 @@ STATUS_BITS = {
     0x08: 'mean pooling: more than 16 superpixels touch one feature pixel',
     0x10: 'k-means: grid barrier timed out',
     0x20: 'a superpixel label outside [0, n_labels) was met',
+    0x40: 'anchor selection: the device random stream ran dry',
 }
 
 # informational bits: the condition is handled exactly like the reference handles it; never an error
@@ -80,6 +81,9 @@ PROTOTYPES = {
     'spa_nprandom_create': (ctypes.c_int, [ctypes.c_uint32, ctypes.POINTER(c_p)]),
     'spa_nprandom_destroy': (None, [c_p]),
     'spa_nprandom_shuffle_host': (ctypes.c_int, [c_p, c_p, c_i64]),
+    'spa_pyrandom_dev_seed': (ctypes.c_int, [c_p, ctypes.c_uint64, c_p]),
+    'spa_pyrandom_dev_generate': (ctypes.c_int, [c_p, c_i64, c_p]),
+    'spa_anchor_ranks_dev': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_i64, c_p, c_p, c_p]),
     'spa_select_anchor_pixels': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_p, c_i32, c_p, c_p,
                                                 c_i32, c_p, c_p]),
     'spa_pool_anchor': (ctypes.c_int, [c_p, c_p, ctypes.POINTER(FmapDesc), c_i32, c_i32, c_p, c_i32,

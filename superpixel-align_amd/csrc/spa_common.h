@@ -78,6 +78,10 @@ enum {
     WS_ZERO_LINE,    // convolution: zero line read for padding pixels
     WS_RESIZE_TAB,   // input stage: bicubic tap tables of the current (input, output) size
     WS_RESIZE_TMP,   // input stage: horizontally resized images (B,H,w,C) u8
+    WS_RNG_STATE,    // device MT19937 (CPython `random`) state + ring positions
+    WS_RNG_RING,     // ring of generated 32-bit outputs
+    WS_RNG_JBUF,     // accepted swap partners of every shuffle (one int per pixel)
+    WS_RNG_JOFF,     // offsets of the superpixels' swap lists
     WS_RUNS,         // connectivity: per-row lists of run starts (B,H,W) i32, used from the front of each row
     WS_COUNT
 };
@@ -110,6 +114,7 @@ struct spa_ctx {
     size_t conn_claim_bytes;
     int upd_wg_per_cu;
     int zero_line_ready, conv_attr_done;
+    int rng_seeded;
     int rs_key[4], rs_ks[2];       // bicubic tables held in WS_RESIZE_TAB: (H, W, h, w) and tap counts
 };
 

@@ -240,6 +240,24 @@ class Engine(object):
                                           self._s()))
         return count, centroid, prior
 
+    # device-resident CPython `random` stream (random.seed(1111) of the reference's module scope)
+    def pyrandom_seed(self, seed=1111):
+        check(self._lib.spa_pyrandom_dev_seed(self._ctx, int(seed), self._s()))
+
+    def pyrandom_generate(self, want):
+        """Make `want` outputs of the stream available (asynchronous on the current stream)."""
+        check(self._lib.spa_pyrandom_dev_generate(self._ctx, int(want), self._s()))
+
+    def anchor_ranks(self, count, n_ptr, ncap, n_anchors, total_pixels):
+        """random.shuffle(pixel list)[:n_anchors] of every superpixel, on the device:
+        -> ranks (ncap, n_anchors) int32 (raster rank of the chosen pixels), n_valid (ncap) int32."""
+        count = _req(count, torch.int32, 'count')
+        ranks = torch.empty((ncap, n_anchors), dtype=torch.int32, device=count.device)
+        n_valid = torch.zeros((ncap,), dtype=torch.int32, device=count.device)
+        check(self._lib.spa_anchor_ranks_dev(self._ctx, _ptr(count), _ptr(n_ptr), ncap, n_anchors, int(total_pixels),
+                                             _ptr(ranks), _ptr(n_valid), self._s()))
+        return ranks, n_valid
+
     def select_anchor_pixels(self, labels, offsets, ncap, ranks, n_valid):
         labels = _req(labels, torch.int32, 'labels')
         ranks = _req(ranks, torch.int32, 'ranks')

@@ -44,6 +44,12 @@ class LabelPipeline(object):
         self.nprandom = NpRandom(getattr(args, 'seed', 1111))
         self.aux = torch.cuda.Stream(device=self.eng.device) if overlap else None
         self._ev = {}
+        # anchor mode: the CPython `random` stream lives on the device (seeded like the reference's module
+        # scope); its outputs are produced a batch ahead on a low-priority stream (data independent)
+        self.device_rng = bool(getattr(args, 'device_rng', True))
+        self._rng_ready = False
+        self._gen_stream = None
+        self._gen_done = None
 
     # ---------------------------------------------------------------- stages
     def features(self, imgs_dev):
@@ -85,7 +91,29 @@ class LabelPipeline(object):
             labels, off, ncap, (a.y_rel_pos, a.x_rel_pos, a.y_rel_sigma, a.x_rel_sigma),
             want_centroid=True)
         anchors = nvalid = None
-        if self.pool_mode == 'anchor':
+        if self.pool_mode == 'anchor' and self.device_rng:
+            # no superpixel size visits the host: rejection sampling of every shuffle swap and the first
+            # n_anchors places of every shuffled list on the device (spa_anchor_ranks_dev)
+            cur = torch.cuda.current_stream(eng.device)
+            want = min(int(1.7 * B * H * W) + (1 << 21), (1 << 27) - 4096)
+            if not self._rng_ready:
+                eng.pyrandom_seed(getattr(a, 'seed', 1111))
+                eng.pyrandom_generate(want)
+                self._gen_stream = torch.cuda.Stream(device=eng.device, priority=0)
+                self._rng_ready = True
+            elif self._gen_done is not None:
+                cur.wait_event(self._gen_done)
+            ranks, nvalid = eng.anchor_ranks(count, off[B:], ncap, a.n_anchors, B * H * W)
+            anchors = eng.select_anchor_pixels(labels, off, ncap, ranks, nvalid)
+            # top the ring up for the next batch in the background
+            used = torch.cuda.Event()
+            used.record(cur)
+            self._gen_stream.wait_event(used)
+            with torch.cuda.stream(self._gen_stream):
+                eng.pyrandom_generate(want)
+                self._gen_done = torch.cuda.Event()
+                self._gen_done.record(self._gen_stream)
+        elif self.pool_mode == 'anchor':
             n = int(off[-1].item())                      # sizes visit the host for the RNG
             cnt_h = count[:n].cpu().numpy()
             ranks_h, nvalid_h = self.pyrandom.shuffle_select(cnt_h, a.n_anchors)

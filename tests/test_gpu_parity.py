@@ -262,6 +262,41 @@ def test_slic_starved_seeds(eng, orc, name):
     assert eng.last_info & 0x01
 
 
+def test_device_anchor_selection_is_cpython_shuffle(spa, orc):
+    """spa_anchor_ranks_dev (device MT19937 + _randbelow rejection + backward trace of the first places)
+    against CPython's own random.shuffle (tests/golden/rng.npz) and the host emulation, with the generator
+    state carried across calls, a large superpixel (crosses many 1 024-output steps), empty and 1-pixel
+    lists, and more anchors than pixels."""
+    engine = importlib.import_module('superpixel-align_amd.engine')
+    g = golden('rng')
+    for n in (5, 1000, 70000):
+        e = engine.Engine()
+        e.pyrandom_seed(1111)
+        e.pyrandom_generate(400000)
+        for cnt, key in ((n, 'py_%d' % n), (n // 2 + 1, 'py_%d_second' % n)):
+            c = dev(np.array([cnt], np.int32))
+            ranks, nv = e.anchor_ranks(c, dev(np.array([1], np.int32)), 1, 32, cnt)
+            k = min(cnt, 32)
+            assert int(nv[0]) == k and np.array_equal(ranks[0, :k].cpu().numpy(), g[key][:k]), (n, key)
+        e.raise_on_status()
+        e.close()
+    rs = np.random.RandomState(8)
+    counts = np.concatenate([rs.randint(0, 4000, 300), [0, 1, 2, 250000, 7, 1, 0, 33]]).astype(np.int32)
+    e = engine.Engine()
+    e.pyrandom_seed(1111)
+    host = engine.PyRandom(1111)
+    for rep in range(2):                                   # second call continues the stream
+        e.pyrandom_generate(int(1.7 * counts.sum()) + (1 << 20))
+        ranks, nv = e.anchor_ranks(dev(counts), dev(np.array([counts.size], np.int32)), counts.size, 10, int(counts.sum()))
+        hr, hn = host.shuffle_select(counts, 10)
+        assert np.array_equal(nv.cpu().numpy(), hn)
+        got = ranks.cpu().numpy()
+        for s in range(counts.size):
+            assert np.array_equal(got[s, :hn[s]], hr[s, :hn[s]]), (rep, s, counts[s])
+    e.raise_on_status()
+    e.close()
+
+
 def test_resize_bicubic_bit_exact(eng, orc):
     """spa_resize_bicubic_u8 (8f-2) against Pillow's own outputs (fixture), the oracle and the live
     Pillow on this box, including the 1024x2048 -> 224x224 operating point of every reference launcher."""
