@@ -76,6 +76,7 @@ def parse():
     p.add_argument('--no_host_loop', action='store_true', help='skip the pinned-host to pinned-host loop')
     p.add_argument('--n_batches', type=int, default=3, help='distinct batches rotating through the steps')
     p.add_argument('--no_prof', action='store_true', help='do not record per-kernel events')
+    p.add_argument('--device_rng', action='store_true', help='anchor mode: draw the anchors on the device (spa_anchor_ranks_dev)')
     p.add_argument('--miopen_conv', action='store_true', help='bf16: leave the heavy 3x3 layers to MIOpen (A/B against spa_conv3x3_bf16)')
     p.add_argument('--overlap', action='store_true',
                    help='run the superpixel branch on a second stream under the DRN forward (+5%% '
@@ -245,7 +246,8 @@ def main():
         felzenszwalb_scale=300.0, felzenszwalb_sigma=0.8, felzenszwalb_min_size=20,
         without_pos=False, y_rel_pos=0.75, x_rel_pos=0.5, y_rel_sigma=0.1, x_rel_sigma=0.1,
         gpu=local, n_clusters=a.n_clusters, use_feature_maps=[7], pool_mode=a.pool_mode,
-        mean_sampling='nearest', drn_sub_batch=a.drn_sub_batch or None, drn_streams=a.drn_streams)
+        mean_sampling='nearest', drn_sub_batch=a.drn_sub_batch or None, drn_streams=a.drn_streams,
+        device_rng=a.device_rng)
     drn._EPILOGUE['own_conv'] = not a.miopen_conv
     model = drn.create_drn(a.arch, device='cuda:%d' % local, dtype=dtype)
     overlap = a.overlap or a.pool_mode == 'anchor'

@@ -102,6 +102,14 @@ __device__ __forceinline__ int scan_prefix(bool flag, int *scr, int &total)
     return off + (int)spa_rank_in_mask(m);
 }
 
+// workgroup barrier that orders LDS only: the refill load and the swap-list stores stay in flight across it
+__device__ __forceinline__ void scan_lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __global__ __launch_bounds__(SCAN_T) void k_anchor_scan(RngDev *__restrict__ st, const uint32_t *__restrict__ ring,
                                                         const int32_t *__restrict__ count,
                                                         const int32_t *__restrict__ n_ptr, int Ncap, int A,
@@ -146,17 +154,38 @@ __global__ __launch_bounds__(SCAN_T) void k_anchor_scan(RngDev *__restrict__ st,
     }
     if (run_s > jcap) { if (tid == 0) atomicOr(status, SPA_ST_RNG_UNDERRUN); return; }
 
+    // The stream is staged through an LDS ring of 4 096 outputs, refilled 1 024 at a time one step before
+    // it is needed (the global load of the next piece travels under the current step's voting rounds):
+    // invariant before a step: [rpos, rpos + 1024) is in LDS.
+    __shared__ uint32_t lring[4096];
+    __shared__ int vote_cnt[2][16], vote_chg[2][16];
     unsigned long long rpos = st->rpos;
     const unsigned long long wpos = st->wpos;
+    unsigned long long loaded = rpos;
+    for (int c = 0; c < 2; ++c) {
+        const unsigned long long pos = loaded + (unsigned)tid;
+        lring[pos & 4095ull] = pos < wpos ? ring[pos & RNG_MASK] : 0u;
+        loaded += SCAN_T;
+    }
+    __syncthreads();
+    const int lane = tid & 63, wv = tid >> 6;
+    int par = 0;
     for (int s = 0; s < N; ++s) {
         const int n = max(count[s], 0);
         int32_t *J = jbuf + joff[s];
         int i_cur = n - 1;                          // next swap index; the shuffle runs i = n-1 .. 1
         while (i_cur >= 1) {
+            // refill piece (if the ring holds fewer than two steps): issued now, written to LDS after the step
+            const bool refill = loaded - rpos < 2048ull;
+            uint32_t nextraw = 0u;
+            if (refill) {
+                const unsigned long long pos = loaded + (unsigned)tid;
+                nextraw = pos < wpos ? ring[pos & RNG_MASK] : 0u;
+            }
             // candidate t of this step: stream output rpos + t
             const unsigned long long pos = rpos + (unsigned)tid;
             const bool have = pos < wpos;
-            const uint32_t raw = have ? ring[pos & RNG_MASK] : 0u;
+            const uint32_t raw = lring[pos & 4095ull];
             // acceptances before t: fixed point of a = prefix(accept(a)); start from the expected count
             const int k0 = 32 - __clz((unsigned)i_cur + 1u);
             int a = (int)(((unsigned long long)tid * ((unsigned)i_cur + 1u)) >> k0);
@@ -169,35 +198,53 @@ __global__ __launch_bounds__(SCAN_T) void k_anchor_scan(RngDev *__restrict__ st,
                     const uint32_t v = raw >> __clz((unsigned)i_t + 1u);
                     acc = v <= (unsigned)i_t;
                 }
-                const int a_new = scan_prefix(acc, scr, total);
+                // one barrier per round: wave counts and "changed" votes go to alternating LDS rows
+                const unsigned long long m = __ballot(acc);
+                if (lane == 0) vote_cnt[par][wv] = __popcll(m);
+                int off = 0, tot = 0;
+                // the previous round's `a` is compared after the new prefix is known: two-step protocol
+                scan_lds_barrier();
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int c = vote_cnt[par][i];
+                    if (i < wv) off += c;
+                    tot += c;
+                }
+                const int a_new = off + (int)spa_rank_in_mask(m);
                 const bool changed = a_new != a;
                 a = a_new;
-                // (scan_prefix's barriers order the reads of scr; one more vote: did anyone change?)
-                const int any = __syncthreads_or(changed ? 1 : 0);
+                total = tot;
+                const unsigned long long mc = __ballot(changed);
+                if (lane == 0) vote_chg[par][wv] = mc != 0ull;
+                scan_lds_barrier();
+                int any = 0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) any |= vote_chg[par][i];
+                par ^= 1;
                 if (!any) break;
             }
-            // swaps left in this superpixel: i_cur .. 1
+            // swaps left in this superpixel: i_cur .. 1 (an accepted candidate always has a < R)
             const int R = i_cur;
-            const int used_acc = total < R ? total : R;
-            if (acc && a < R) {
+            if (acc) {
                 const int i_t = i_cur - a;
                 J[i_t] = (int32_t)(raw >> __clz((unsigned)i_t + 1u));
             }
             // outputs consumed: all examined ones, or up to and including the R-th acceptance
             if (tid == 0) stop_s = -1;
-            __syncthreads();
+            scan_lds_barrier();
             if (acc && a == R - 1) stop_s = tid;
-            __syncthreads();
+            if (refill) lring[(loaded + (unsigned)tid) & 4095ull] = nextraw;
+            scan_lds_barrier();
+            if (refill) loaded += SCAN_T;
             const unsigned long long avail = wpos > rpos ? wpos - rpos : 0ull;
             const int examined = avail < (unsigned long long)SCAN_T ? (int)avail : SCAN_T;
             const int consumed = stop_s >= 0 ? stop_s + 1 : examined;
             rpos += (unsigned)consumed;
-            i_cur -= used_acc;
+            i_cur -= total;
             if (stop_s < 0 && examined < SCAN_T) {   // ring exhausted before the shuffle finished
                 if (tid == 0) { atomicOr(status, SPA_ST_RNG_UNDERRUN); st->rpos = rpos; }
                 return;
             }
-            __syncthreads();
         }
     }
     if (tid == 0) st->rpos = rpos;

@@ -44,9 +44,12 @@ class LabelPipeline(object):
         self.nprandom = NpRandom(getattr(args, 'seed', 1111))
         self.aux = torch.cuda.Stream(device=self.eng.device) if overlap else None
         self._ev = {}
-        # anchor mode: the CPython `random` stream lives on the device (seeded like the reference's module
-        # scope); its outputs are produced a batch ahead on a low-priority stream (data independent)
-        self.device_rng = bool(getattr(args, 'device_rng', True))
+        # anchor mode, device_rng: the CPython `random` stream lives on the device (seeded like the reference's
+        # module scope), its outputs produced a batch ahead on a side stream, and no superpixel size visits the
+        # host (spa_anchor_ranks_dev).  Off by default: the rejection sampling is one sequential pass over
+        # ~1.4 stream outputs per pixel whatever runs it — 296 ms per 30 full-size images as one workgroup
+        # against 117 ms on a host core hidden under the DRN forward
+        self.device_rng = bool(getattr(args, 'device_rng', False))
         self._rng_ready = False
         self._gen_stream = None
         self._gen_done = None

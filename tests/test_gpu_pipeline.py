@@ -93,9 +93,11 @@ def test_five_ops_drop_in(mods, orc, synth):
     assert fz.dtype == np.int64 and np.array_equal(fz, orc.batch_superpixel(af, scenes))
 
 
-@pytest.mark.parametrize('pool_mode,k', [('mean', 2), ('anchor', 2), ('anchor', 4), ('mean', 3)])
+@pytest.mark.parametrize('pool_mode,k', [('mean', 2), ('anchor', 2), ('anchor', 4), ('mean', 3), ('anchor_dev', 2)])
 def test_fused_pipeline_end_to_end(mods, orc, synth, pool_mode, k):
-    args = _args(pool_mode=pool_mode, n_clusters=k, n_slic_segments=60)
+    device_rng = pool_mode == 'anchor_dev'           # anchors drawn on the device (spa_anchor_ranks_dev)
+    pool_mode = 'anchor' if device_rng else pool_mode
+    args = _args(pool_mode=pool_mode, n_clusters=k, n_slic_segments=60, device_rng=device_rng)
     H, W, B = 160, 320, 3
     imgs = synth.synth_batch([31, 32, 33], H, W)
     model = mods.drn.create_drn('drn_d_22', device='cuda')
