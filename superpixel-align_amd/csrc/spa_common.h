@@ -75,6 +75,7 @@ enum {
     WS_FZ_VALS,      // felzenszwalb: edge indices (in/out of the radix sort)
     WS_FZ_STATE,     // felzenszwalb: internal costs + reservation marks
     WS_FZ_TMP,       // felzenszwalb: radix sort temporary storage
+    WS_STEM_WPACK,   // bf16 stem: weights packed in MFMA fragment order
     WS_ZERO_LINE,    // convolution: zero line read for padding pixels
     WS_RESIZE_TAB,   // input stage: bicubic tap tables of the current (input, output) size
     WS_RESIZE_TMP,   // input stage: horizontally resized images (B,H,w,C) u8

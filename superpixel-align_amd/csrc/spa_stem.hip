@@ -216,6 +216,177 @@ __global__ __launch_bounds__(256) void k_drn_stem_d(const float *__restrict__ xn
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// bfloat16 form of the same fused stem, for the bf16 network (BASELINE config 5): the operands are what
+// the bf16 network defines them to be — the normalised image rounded to bfloat16, bfloat16 weights,
+// float32 accumulation, layer0's output rounded to bfloat16 — on v_mfma_f32_16x16x32_bf16, i.e. 5-6 matrix
+// instructions per 16 pixels instead of 37 + 36 float32 ones (the float32 kernel is bound by the float32
+// matrix rate, 1/16 of this one).  The weights are the MFMA A operand (rows = output channels), the pixels
+// the B operand, so a lane's accumulator is four consecutive channels of one pixel: 8-byte stores.
+//   layer0: k = (ky*3 + c)*8 + kx, kx = 7 is a zero-weight pad: the eight k of a lane are eight consecutive
+//           pixels of one patch row; two copies of the patch (the second shifted by one pixel) keep every
+//           such read 4-byte aligned (ds_read_b32 x 4).  K = 168 padded to 192: 6 instructions.
+//   layer1: k = tap*16 + c: eight consecutive channels of one layer0 pixel = one ds_read_b128 (48-byte pixel
+//           stride in LDS: conflict-free).  K = 144 padded to 160: 5 instructions.
+// ---------------------------------------------------------------------------------------------------
+typedef __bf16 stem_bf8 __attribute__((ext_vector_type(8)));
+#define SB_PW 48                               // patch row pitch in pixels (40 + the kx pad, even)
+#define SB_PLANE (ST_IH * SB_PW)               // pixels per patch plane
+#define SB_L0_PITCH 24                         // bf16 per layer0 pixel in LDS (16 channels + 8: 48 bytes)
+
+__device__ __forceinline__ unsigned short stem_bf16_rn(float f)
+{
+    __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, h);
+}
+
+__global__ __launch_bounds__(256) void k_drn_stem_d_bf16(const unsigned short *__restrict__ xn, int B, int H, int W,   // normalised, bf16, (B,H,W,3)
+                                                         const unsigned short *__restrict__ w0p,   // [6][64] x 8 bf16
+                                                         const float *__restrict__ b0,
+                                                         const unsigned short *__restrict__ w1p,   // [5][64] x 8 bf16
+                                                         const float *__restrict__ b1,
+                                                         unsigned short *__restrict__ yh)
+{
+    // patch copy 0: pixel ix at [c][iy][ix]; copy 1: pixel ix at [c][iy][ix - 1] (so odd ix are 4-byte aligned)
+    __shared__ __attribute__((aligned(16))) unsigned short in_s[2][3 * SB_PLANE + 16];
+    __shared__ __attribute__((aligned(16))) unsigned short l0_s[ST_LP * SB_L0_PITCH + 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int m = lane & 15, g = lane >> 4;
+    const long long npix = (long long)H * W;
+    const int tiles_x = (W + ST_TW - 1) / ST_TW, tiles_y = (H + ST_TH - 1) / ST_TH;
+    const int n_tiles = tiles_x * tiles_y * B;
+
+    // A operands (weights) of this lane, packed on the host in fragment order: [step][lane] x 8 bf16
+    stem_bf8 wa0[6], wa1[5];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) wa0[s] = *(const stem_bf8 *)(w0p + ((size_t)s * 64 + lane) * 8);
+#pragma unroll
+    for (int s = 0; s < 5; ++s) wa1[s] = *(const stem_bf8 *)(w1p + ((size_t)s * 64 + lane) * 8);
+    // bias of the four channels this lane accumulates (rows 4g .. 4g+3)
+    const float4 bias0 = *(const float4 *)(b0 + 4 * g), bias1 = *(const float4 *)(b1 + 4 * g);
+    // layer0: patch offset (in pixels) of k group 4s + g: (ky, c) = divmod(group, 3); groups >= 21 are padding
+    int goff[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const int grp = 4 * s + g;
+        const int ky = grp / 3, c = grp - ky * 3;
+        goff[s] = grp < 21 ? c * SB_PLANE + ky * SB_PW : 0;
+    }
+
+    constexpr int NE = 3 * ST_IH * ST_IW, NU = (NE + 255) / 256;
+    unsigned short raw[NU];
+    auto patch_load = [&](int tile) {
+        const int b = tile / (tiles_x * tiles_y), tr = tile - b * (tiles_x * tiles_y);
+        const int ty0 = (tr / tiles_x) * ST_TH, tx0 = (tr % tiles_x) * ST_TW;
+        // the normalised image, already rounded to bfloat16 (spa_drn_normalise: the exact arithmetic of
+        // DRN.batch_predict, then the bf16 network's rounding of its input), channels-last: 6 bytes per pixel
+        const unsigned short *src = xn + (long long)b * npix * 3;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            int e = tid + u * 256;                       // e = (iy * ST_IW + ix) * 3 + c
+            if (e > NE - 1) e = NE - 1;
+            const int pix = e / 3, c = e - pix * 3;
+            const int iy = pix / ST_IW, ix = pix - iy * ST_IW;
+            const int gy = ty0 - 4 + iy, gx = tx0 - 4 + ix;
+            const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+            raw[u] = src[((long long)cy * W + cx) * 3 + c];
+        }
+    };
+    // the pad columns (ix >= 40) of both copies are read by the kx = 7 lanes: keep them zero
+    for (int i = tid; i < 3 * SB_PLANE + 16; i += 256) { in_s[0][i] = 0; in_s[1][i] = 0; }
+    if ((int)blockIdx.x < n_tiles) patch_load(blockIdx.x);
+    __syncthreads();
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int b = tile / (tiles_x * tiles_y), tr = tile - b * (tiles_x * tiles_y);
+        const int ty0 = (tr / tiles_x) * ST_TH, tx0 = (tr % tiles_x) * ST_TW;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int e = tid + u * 256;
+            const int pix = e / 3, c = e - pix * 3;
+            const int iy = pix / ST_IW, ix = pix - iy * ST_IW;
+            const int gy = ty0 - 4 + iy, gx = tx0 - 4 + ix;
+            const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            if (e < NE) {
+                const unsigned short v = in ? raw[u] : (unsigned short)0;
+                in_s[0][c * SB_PLANE + iy * SB_PW + ix] = v;
+                if (ix >= 1) in_s[1][c * SB_PLANE + iy * SB_PW + ix - 1] = v;
+            }
+        }
+        stem_lds_barrier();
+
+        // ---- layer0 on the 18 x 34 region: 39 tiles of 16 pixels, pixel = B-operand column (lane & 15)
+        for (int t = wv; t < (ST_LP + 15) / 16; t += 4) {
+            int p = t * 16 + m;
+            if (p > ST_LP - 1) p = ST_LP - 1;
+            const int py = p / ST_LW, px = p - py * ST_LW;
+            // eight consecutive patch pixels from x = px: from copy (px & 1) at an even index
+            const unsigned short *base = in_s[px & 1] + py * SB_PW + (px & ~1);
+            stem_f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+                const uint32_t *q = (const uint32_t *)(base + goff[s]);
+                union { uint32_t u[4]; stem_bf8 v; } f;
+                f.u[0] = q[0]; f.u[1] = q[1]; f.u[2] = q[2]; f.u[3] = q[3];
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa0[s], f.v, acc, 0, 0, 0);
+            }
+            // D[row = 4g + j = channel][col = m = pixel]
+            const int q0 = t * 16 + m;
+            if (q0 < ST_LP) {
+                const int gy = ty0 - 1 + py, gx = tx0 - 1 + px;
+                const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                const float v0 = in ? fmaxf(acc[0] + bias0.x, 0.0f) : 0.0f, v1 = in ? fmaxf(acc[1] + bias0.y, 0.0f) : 0.0f;
+                const float v2 = in ? fmaxf(acc[2] + bias0.z, 0.0f) : 0.0f, v3 = in ? fmaxf(acc[3] + bias0.w, 0.0f) : 0.0f;
+                uint2 o;
+                o.x = (unsigned)stem_bf16_rn(v0) | ((unsigned)stem_bf16_rn(v1) << 16);
+                o.y = (unsigned)stem_bf16_rn(v2) | ((unsigned)stem_bf16_rn(v3) << 16);
+                *(uint2 *)(l0_s + q0 * SB_L0_PITCH + 4 * g) = o;
+            }
+        }
+        stem_lds_barrier();
+        if (tile + (int)gridDim.x < n_tiles) patch_load(tile + (int)gridDim.x);     // next tile's input travels under layer1
+
+        // ---- layer1 on the 16 x 32 tile: 32 tiles of 16 pixels (row t >> 1, columns (t & 1) * 16 ..)
+        for (int t = wv; t < 32; t += 4) {
+            const int row = t >> 1, col = (t & 1) * 16 + m;
+            stem_f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int s = 0; s < 5; ++s) {
+                int tap = 2 * s + (g >> 1);
+                if (tap > 8) tap = 8;                        // padding tap: zero weights, any valid address
+                const int ky = tap / 3, kx = tap - ky * 3;
+                const stem_bf8 f = *(const stem_bf8 *)(l0_s + ((row + ky) * ST_LW + col + kx) * SB_L0_PITCH + 8 * (g & 1));
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa1[s], f, acc, 0, 0, 0);
+            }
+            const int gy = ty0 + row, gx = tx0 + col;
+            if (gy < H && gx < W) {
+                uint2 o;
+                o.x = (unsigned)stem_bf16_rn(fmaxf(acc[0] + bias1.x, 0.0f)) | ((unsigned)stem_bf16_rn(fmaxf(acc[1] + bias1.y, 0.0f)) << 16);
+                o.y = (unsigned)stem_bf16_rn(fmaxf(acc[2] + bias1.z, 0.0f)) | ((unsigned)stem_bf16_rn(fmaxf(acc[3] + bias1.w, 0.0f)) << 16);
+                *(uint2 *)(yh + ((((long long)b * H + gy) * W + gx) * 16 + 4 * g)) = o;
+            }
+        }
+        stem_lds_barrier();         // the next tile overwrites both LDS tiles
+    }
+}
+
+// weights -> MFMA A fragments: [step][lane] x 8 bf16; lane = (channel n = lane & 15, k group g = lane >> 4)
+__global__ void k_stem_pack_bf16(const float *__restrict__ w0, const float *__restrict__ w1, unsigned short *__restrict__ wp)
+{
+    const int s = blockIdx.x, lane = threadIdx.x;
+    const int n = lane & 15, g = lane >> 4;
+    unsigned short *o = wp + ((size_t)s * 64 + lane) * 8;
+    if (s < 6) {                                   // layer0: k = (ky*3 + c)*8 + kx
+        const int grp = 4 * s + g, ky = grp / 3, c = grp - ky * 3;
+        for (int j = 0; j < 8; ++j)
+            o[j] = (grp < 21 && j < 7) ? stem_bf16_rn(w0[n * 147 + c * 49 + ky * 7 + j]) : (unsigned short)0;
+    } else {                                       // layer1: k = tap*16 + c
+        const int s1 = s - 6, tap = 2 * s1 + (g >> 1), c0 = 8 * (g & 1);
+        for (int j = 0; j < 8; ++j)
+            o[j] = tap <= 8 ? stem_bf16_rn(w1[n * 144 + tap * 16 + c0 + j]) : (unsigned short)0;
+    }
+}
+
 extern "C" int spa_drn_stem_d(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W,
                               const float *w0, const float *b0, const float *w1, const float *b1,
                               const double *mean3_host, const double *std3_host, void *y, int32_t out_dtype,
@@ -225,19 +396,35 @@ extern "C" int spa_drn_stem_d(spa_ctx *ctx, const float *x, int32_t B, int32_t H
     SPA_ARG(out_dtype == 0 || out_dtype == 1);
     // exact input normalisation (models/drn.py:319-321) into a channels-last workspace, then the stem
     SpaProfScope prof_(ctx, PROF_DRN_STEM, spa_stream(stream));
-    float *xn = xn_scratch;          // caller-owned scratch lets several calls run on different streams
     int rc = SPA_OK;
-    if (!xn) rc = spa_ws_reserve(ctx, WS_STEM_IN, (size_t)B * H * W * 3 * sizeof(float), (void **)&xn);
-    if (rc != SPA_OK) return rc;
-    rc = spa_drn_normalise(ctx, x, B, H, W, xn, 0, mean3_host, std3_host, stream);
-    if (rc != SPA_OK) return rc;
     const long long n_tiles = (long long)((W + ST_TW - 1) / ST_TW) * ((H + ST_TH - 1) / ST_TH) * B;
     SPA_ARG(n_tiles < (1ll << 31));
     SPA_ARG((long long)H * W * 12 < (1ll << 32));            // 32-bit byte offsets inside one image
     long long grid = 3ll * ctx->n_cu;                      // 3 resident workgroups per CU (LDS)
     if (grid > n_tiles) grid = n_tiles;
+    if (out_dtype == 1) {
+        // bf16 network: bf16 operands on the bf16 matrix cores (the weights are packed into fragment order
+        // first); the normalised image is written once as bfloat16 (6 bytes per pixel)
+        unsigned short *wp;
+        if ((rc = spa_ws_reserve(ctx, WS_STEM_WPACK, (size_t)11 * 64 * 8 * 2, (void **)&wp)) != SPA_OK) return rc;
+        hipLaunchKernelGGL(k_stem_pack_bf16, dim3(11), dim3(64), 0, spa_stream(stream), w0, w1, wp);
+        unsigned short *xb = (unsigned short *)xn_scratch;
+        if (!xb && (rc = spa_ws_reserve(ctx, WS_STEM_IN, (size_t)B * H * W * 3 * sizeof(float), (void **)&xb)) != SPA_OK) return rc;
+        if ((rc = spa_drn_normalise(ctx, x, B, H, W, xb, 1, mean3_host, std3_host, stream)) != SPA_OK) return rc;
+        hipLaunchKernelGGL(k_drn_stem_d_bf16, dim3((unsigned)grid), dim3(256), 0, spa_stream(stream), (const unsigned short *)xb, B,
+                           H, W, (const unsigned short *)wp, b0, (const unsigned short *)(wp + 6 * 64 * 8), b1,
+                           (unsigned short *)y);
+        SPA_LAUNCH_CHECK();
+        return SPA_OK;
+    }
+    float *xn = xn_scratch;          // caller-owned scratch lets several calls run on different streams
+    if (!xn) rc = spa_ws_reserve(ctx, WS_STEM_IN, (size_t)B * H * W * 3 * sizeof(float), (void **)&xn);
+    if (rc != SPA_OK) return rc;
+    rc = spa_drn_normalise(ctx, x, B, H, W, xn, 0, mean3_host, std3_host, stream);
+    if (rc != SPA_OK) return rc;
     hipLaunchKernelGGL(k_drn_stem_d, dim3((unsigned)grid), dim3(256), 0, spa_stream(stream), (const float *)xn, B, H, W,
                        w0, b0, w1, b1, y, (int)out_dtype);
     SPA_LAUNCH_CHECK();
     return SPA_OK;
 }
+
