@@ -76,6 +76,8 @@ def parse():
     p.add_argument('--no_host_loop', action='store_true', help='skip the pinned-host to pinned-host loop')
     p.add_argument('--n_batches', type=int, default=3, help='distinct batches rotating through the steps')
     p.add_argument('--no_prof', action='store_true', help='do not record per-kernel events')
+    p.add_argument('--integer_images', action='store_true',
+                   help='integer-valued synthetic images (what decoded 8-bit PNGs are): k_rgb2lab takes its 256-entry sRGB table path')
     p.add_argument('--device_rng', action='store_true', help='anchor mode: draw the anchors on the device (spa_anchor_ranks_dev)')
     p.add_argument('--miopen_conv', action='store_true', help='bf16: leave the heavy 3x3 layers to MIOpen (A/B against spa_conv3x3_bf16)')
     p.add_argument('--overlap', action='store_true',
@@ -128,12 +130,12 @@ def stem_flops(B, H, W):
     return 2.0 * (147 + 144) * 16 * H * W * B
 
 
-def make_batch(synth, B, H, W, scene=False, seed0=0, out=None):
+def make_batch(synth, B, H, W, scene=False, seed0=0, out=None, integer=False):
     """B synthetic images from 4 generated ones (rolled copies are new images for SLIC/DRN).
     scene=True: piecewise-constant scenes (what graph-based felzenszwalb needs to find regions).
     seed0: first generator seed (different batches use different seeds); out: array to fill."""
     gen = synth.synth_scene if scene else synth.synth_image
-    base = [gen(seed0 + s, H, W) for s in range(min(4, B))]
+    base = [gen(seed0 + s, H, W, integer_valued=True) if integer else gen(seed0 + s, H, W) for s in range(min(4, B))]
     imgs = np.empty((B, 3, H, W), np.float32) if out is None else out
     gts = np.empty((B, H, W), np.int32)
     gt0 = [synth.synth_gt_labels(seed0 + s, H, W) for s in range(min(4, B))]
@@ -261,7 +263,7 @@ def main():
     for nb in range(NB):
         pin = torch.empty((B, 3, H, W), dtype=torch.float32).pin_memory()
         _, g = make_batch(spa.synth, B, H, W, scene=(a.superpixel_method == 'felzenszwalb'),
-                          seed0=1000 * rank + 4 * nb, out=pin.numpy())
+                          seed0=1000 * rank + 4 * nb, out=pin.numpy(), integer=a.integer_images)
         host.append(pin)
         gts.append(torch.from_numpy(g).cuda())
     dev = [h.cuda() for h in host]
