@@ -40,6 +40,7 @@ struct ConnMisc {
     int n_a;           // big-small components of the 16 KB LDS tier
     int n_c;           // ... of the 80 KB LDS tier (rare: boxes above 40 K pixels)
     int pad_[2];
+    int nb[3][8];      // LDS tiers: components per size class (2^(c+5) .. 2^(c+6) pixels), replayed largest first
 };
 
 __device__ __forceinline__ int ld_i32(const int *p)
@@ -147,37 +148,34 @@ __global__ __launch_bounds__(256) void k_ccl_flatten(int *__restrict__ parent,
     }
 }
 
-// root of the component of pixel v: parent[v] is the first pixel of v's run (or already a root, for
-// images that went through k_conn_expand / k_conn_split), parent[run start] is the root
-__device__ __forceinline__ int root2(const int *P, int v)
-{
-    return P[P[v]];
-}
-
 // ---------------------------------------------------------------------------------------
-// Run-level connected components.
+// Run-level connected components.  Everything a run needs lives in COMPACT tables at the front of its image
+// row (run id = y * W + k for the k-th run of row y): start x, label, union-find parent (a run id), size
+// (at root runs).  Run ids are ordered like the first pixels of the runs, so the smallest run id of a
+// component is the run of its seed pixel, and comparing run ids compares seeds.  The per-pixel arrays are
+// touched only by the streaming passes: k_run_rows reads the labels, k_run_expand writes parent[pixel] =
+// seed pixel of the pixel's component for every pixel (the representation the BFS replays, the oversize
+// split and the relabel pass work on).
 // ---------------------------------------------------------------------------------------
 #define RUN_CHUNK 2048          // pixels of a row handled per pass of the row's workgroup (8 per thread)
 
-// one workgroup per (row, image): parent[p] = first pixel of p's run; runs[row][k] = x of the k-th run
-// start; rowcnt[row] = number of runs; size[run start] = 0
-__global__ __launch_bounds__(256) void k_run_rows(const int32_t *__restrict__ lab, int *__restrict__ parent,
-                                                  int *__restrict__ size, int *__restrict__ runs,
-                                                  int *__restrict__ runlab, int *__restrict__ rowcnt, int H, int W)
+// one workgroup per (row, image): runs[rid] = start x, runlab[rid] = label, up[rid] = rid, rsz[rid] = 0,
+// rowcnt[row] = number of runs
+__global__ __launch_bounds__(256) void k_run_rows(const int32_t *__restrict__ lab, int *__restrict__ runs,
+                                                  int *__restrict__ runlab, int *__restrict__ up,
+                                                  int *__restrict__ rsz, int *__restrict__ rowcnt, int H, int W)
 {
-    __shared__ int w_last[4], w_cnt[4];
-    __shared__ int carry_start, carry_cnt;
+    __shared__ int w_cnt[4];
+    __shared__ int carry_cnt;
     const int b = blockIdx.y, y = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const long long npix = (long long)H * W;
-    const int32_t *L = lab + b * npix + (long long)y * W;
-    int *P = parent + b * npix + (long long)y * W;
-    int *S = size + b * npix + (long long)y * W;
-    int *R = runs + b * npix + (long long)y * W;
-    int *RL = runlab + b * npix + (long long)y * W;        // label of the k-th run (compact, like R)
-    const int rowbase = y * W;
+    const long long rowoff = b * npix + (long long)y * W;
+    const int32_t *L = lab + rowoff;
+    int *R = runs + rowoff, *RL = runlab + rowoff, *UP = up + rowoff, *SZ = rsz + rowoff;
+    const int ridbase = y * W;
     const bool vec = (W & 3) == 0;
-    if (tid == 0) { carry_start = 0; carry_cnt = 0; }
+    if (tid == 0) carry_cnt = 0;
     __syncthreads();
     for (int x0 = 0; x0 < W; x0 += RUN_CHUNK) {
         const int xb = x0 + tid * 8;
@@ -190,66 +188,47 @@ __global__ __launch_bounds__(256) void k_run_rows(const int32_t *__restrict__ la
             for (int i = 0; i < 8; ++i) l[i] = (xb + i < W) ? L[xb + i] : -1;
         }
         const int lprev = (xb > 0 && xb < W) ? L[xb - 1] : -2;
-        // run starts inside this thread
-        int last = -1, cnt = 0;
+        int cnt = 0;
         bool st[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int x = xb + i;
             st[i] = x < W && (x == 0 || l[i] != (i == 0 ? lprev : l[i - 1]));
-            if (st[i]) { last = x; ++cnt; }
+            cnt += st[i] ? 1 : 0;
         }
-        // exclusive prefix over threads: latest run start to the left, number of starts to the left
-        int pm = last, ps = cnt;
+        int ps = cnt;                                     // inclusive prefix of the run-start counts
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            const int m = __shfl_up(pm, o), c = __shfl_up(ps, o);
-            if (lane >= o) { pm = max(pm, m); ps += c; }
+            const int c = __shfl_up(ps, o);
+            if (lane >= o) ps += c;
         }
-        if (lane == 63) { w_last[wv] = pm; w_cnt[wv] = ps; }
+        if (lane == 63) w_cnt[wv] = ps;
         __syncthreads();
-        int before_start = carry_start, before_cnt = carry_cnt;
+        int before = carry_cnt;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (i < wv) { before_start = max(before_start, w_last[i]); before_cnt += w_cnt[i]; }
-        int ex_start = __shfl_up(pm, 1), ex_cnt = ps - cnt;
-        if (lane == 0) ex_start = -1;
-        int cur = max(before_start, ex_start);          // run start of the pixel left of this thread's first
-        int k = before_cnt + ex_cnt;
-        int out[8];
+            if (i < wv) before += w_cnt[i];
+        int k = before + ps - cnt;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int x = xb + i;
             if (st[i]) {
-                cur = x;
+                R[k] = xb + i;
                 RL[k] = l[i];
-                R[k++] = x;
-                S[x] = 0;
+                UP[k] = ridbase + k;
+                SZ[k] = 0;
+                ++k;
             }
-            out[i] = rowbase + cur;
-        }
-        if (vec && xb + 7 < W) {
-            *(int4 *)(P + xb) = make_int4(out[0], out[1], out[2], out[3]);
-            *(int4 *)(P + xb + 4) = make_int4(out[4], out[5], out[6], out[7]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (xb + i < W) P[xb + i] = out[i];
         }
         __syncthreads();
-        if (tid == 255) {
-            carry_start = max(before_start, pm);
-            carry_cnt = before_cnt + ps;
-        }
+        if (tid == 255) carry_cnt = before + ps;
         __syncthreads();
     }
     if (tid == 0) rowcnt[(long long)b * H + y] = carry_cnt;
 }
 
 // one workgroup per row: link every run to the runs of the same label it touches in the row above.
-// Both rows' run lists (and the labels of the upper row's runs) are staged in LDS: the binary search and
-// the walk over the touching runs cost LDS latency, not L2 latency.
-__global__ __launch_bounds__(256) void k_run_merge(const int *__restrict__ runlab, int *__restrict__ parent,
+// Both rows' run lists (and the labels of the upper row's runs) are staged in LDS.
+__global__ __launch_bounds__(256) void k_run_merge(const int *__restrict__ runlab, int *__restrict__ up,
                                                    const int *__restrict__ runs, const int *__restrict__ rowcnt,
                                                    int H, int W)
 {
@@ -257,7 +236,7 @@ __global__ __launch_bounds__(256) void k_run_merge(const int *__restrict__ runla
     const int b = blockIdx.y, y = blockIdx.x + 1;
     const int tid = threadIdx.x;
     const long long npix = (long long)H * W;
-    int *P = parent + b * npix;
+    int *UP = up + b * npix;
     const int *RC = rowcnt + (long long)b * H;
     const int *R = runs + b * npix + (long long)y * W;
     const int *RL = runlab + b * npix + (long long)y * W;
@@ -281,34 +260,89 @@ __global__ __launch_bounds__(256) void k_run_merge(const int *__restrict__ runla
             if (sRp[mid] <= xs) lo = mid; else hi = mid - 1;
         }
         for (int j = lo; j < cntp; ++j) {
-            const int xp = sRp[j];
-            if (xp > xe) break;
-            if (sLp[j] == l) uf_merge(P, (y - 1) * W + xp, y * W + xs);
+            if (sRp[j] > xe) break;
+            if (sLp[j] == l) uf_merge(UP, (y - 1) * W + j, y * W + k);
         }
     }
 }
 
-// one wave per row: every run start learns its root; the root collects the run lengths
-__global__ __launch_bounds__(256) void k_run_flatten(int *__restrict__ parent, int *__restrict__ size,
+// one wave per row: every run learns its root run; the root collects the run lengths
+__global__ __launch_bounds__(256) void k_run_flatten(int *__restrict__ up, int *__restrict__ rsz,
                                                      const int *__restrict__ runs, const int *__restrict__ rowcnt,
                                                      int H, int W)
 {
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const long long npix = (long long)H * W;
-    int *P = parent + b * npix;
-    int *S = size + b * npix;
+    int *UP = up + b * npix;
+    int *SZ = rsz + b * npix;
     const int *RC = rowcnt + (long long)b * H;
     for (int y = blockIdx.x * 4 + (threadIdx.x >> 6); y < H; y += gridDim.x * 4) {
         const int *R = runs + b * npix + (long long)y * W;
         const int cnt = RC[y];
         for (int k = lane; k < cnt; k += 64) {
-            const int xs = R[k];
-            const int len = (k + 1 < cnt ? R[k + 1] : W) - xs;
-            const int p = y * W + xs;
-            const int r = uf_find_halve(P, p);
-            st_i32(P + p, r);
-            atomicAdd(S + r, len);
+            const int len = (k + 1 < cnt ? R[k + 1] : W) - R[k];
+            const int rid = y * W + k;
+            const int r = uf_find_halve(UP, rid);
+            st_i32(UP + rid, r);
+            atomicAdd(SZ + r, len);
+        }
+    }
+}
+
+// one workgroup per (row, image): parent[pixel] = seed pixel of the pixel's component, for every pixel of the
+// row (streaming write); size[seed pixel] = size of the component (written by the root run)
+__global__ __launch_bounds__(256) void k_run_expand(const int *__restrict__ up, const int *__restrict__ rsz,
+                                                    const int *__restrict__ runs, const int *__restrict__ rowcnt,
+                                                    int *__restrict__ parent, int *__restrict__ size, int H, int W)
+{
+    extern __shared__ int lds_e[];                 // start x [W] | seed pixel [W]
+    const int b = blockIdx.y, y = blockIdx.x;
+    const int tid = threadIdx.x;
+    const long long npix = (long long)H * W;
+    const int *UP = up + b * npix, *SZ = rsz + b * npix, *RA = runs + b * npix;
+    const int *R = RA + (long long)y * W;
+    int *P = parent + b * npix + (long long)y * W;
+    int *S = size + b * npix;
+    const int cnt = rowcnt[(long long)b * H + y];
+    int *sx = lds_e, *sp = lds_e + W;
+    for (int k = tid; k < cnt; k += 256) {
+        const int rid = y * W + k;
+        const int r = UP[rid];                                  // root run id = ry * W + rk
+        const int ry = r / W;
+        const int seed = ry * W + RA[r];                         // its first pixel
+        sx[k] = R[k];
+        sp[k] = seed;
+        if (r == rid) S[seed] = SZ[rid];
+    }
+    __syncthreads();
+    const bool vec = (W & 3) == 0;
+    for (int x0 = 0; x0 < W; x0 += RUN_CHUNK) {
+        const int xb = x0 + tid * 8;
+        if (xb >= W) continue;
+        // run of pixel xb: last start <= xb
+        int lo = 0, hi = cnt - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (sx[mid] <= xb) lo = mid; else hi = mid - 1;
+        }
+        int k = lo;
+        int nxt = (k + 1 < cnt) ? sx[k + 1] : W;
+        int cur = sp[k];
+        int out[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int x = xb + i;
+            if (x >= nxt && x < W) { ++k; cur = sp[k]; nxt = (k + 1 < cnt) ? sx[k + 1] : W; }
+            out[i] = cur;
+        }
+        if (vec && xb + 7 < W) {
+            *(int4 *)(P + xb) = make_int4(out[0], out[1], out[2], out[3]);
+            *(int4 *)(P + xb + 4) = make_int4(out[4], out[5], out[6], out[7]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (xb + i < W) P[xb + i] = out[i];
         }
     }
 }
@@ -339,9 +373,8 @@ __global__ __launch_bounds__(256) void k_conn_find_oversize(const int *__restric
     }
 }
 
-// run-level twin of k_conn_find_oversize (roots are run starts)
-__global__ __launch_bounds__(256) void k_run_find_oversize(const int *__restrict__ parent,
-                                                           const int *__restrict__ size,
+// run-level twin of k_conn_find_oversize: root runs above max_size -> their seed pixels
+__global__ __launch_bounds__(256) void k_run_find_oversize(const int *__restrict__ up, const int *__restrict__ rsz,
                                                            const int *__restrict__ runs,
                                                            const int *__restrict__ rowcnt, int H, int W,
                                                            int max_size, int *__restrict__ over_list,
@@ -350,35 +383,18 @@ __global__ __launch_bounds__(256) void k_run_find_oversize(const int *__restrict
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const long long npix = (long long)H * W;
-    const int *P = parent + b * npix;
-    const int *S = size + b * npix;
+    const int *UP = up + b * npix, *SZ = rsz + b * npix;
     const int *RC = rowcnt + (long long)b * H;
     for (int y = blockIdx.x * 4 + (threadIdx.x >> 6); y < H; y += gridDim.x * 4) {
         const int *R = runs + b * npix + (long long)y * W;
         const int cnt = RC[y];
         for (int k = lane; k < cnt; k += 64) {
-            const int p = y * W + R[k];
-            if (P[p] == p && S[p] > max_size) {
+            const int rid = y * W + k;
+            if (UP[rid] == rid && SZ[rid] > max_size) {
                 const int i = atomicAdd(&misc[b].n_over, 1);
-                over_list[b * npix + i] = p;
+                over_list[b * npix + i] = y * W + R[k];
             }
         }
-    }
-}
-
-// images that hold an oversize component leave the run representation: parent[p] = root of p
-__global__ __launch_bounds__(256) void k_conn_expand(int *__restrict__ parent, const ConnMisc *__restrict__ misc,
-                                                     int npix)
-{
-    const int b = blockIdx.y;
-    if (misc[b].n_over == 0) return;
-    int *P = parent + (long long)b * npix;
-    // two passes inside one launch would race (a run start may be rewritten before its pixels read it);
-    // a root is a fixed point (P[root] == root) and P[run start] is already the root, so one gather is exact
-    for (int p = blockIdx.x * 256 + threadIdx.x; p < npix; p += gridDim.x * 256) {
-        const int s = ld_i32(P + p);
-        const int r = ld_i32(P + s);
-        if (r != s) st_i32(P + p, r);
     }
 }
 
@@ -509,6 +525,7 @@ __global__ void k_conn_reset_qalloc(ConnMisc *misc, int B)
 // A noisy image has ~10^5 tiny components (single boundary pixels), so nothing on their path
 // may cost one atomic on a shared word per component.
 // ---------------------------------------------------------------------------------------
+#define TINY_DONE 0x40000000     // tiny-list entry whose `adjacent` is already in final_ (H*W < 2^29)
 #define SCAN_PX 1024
 #define SBOX_CAP 65536      // big-small components with an index below this get a bounding box
 #define LANE_MAX 16
@@ -718,7 +735,7 @@ __global__ __launch_bounds__(256) void k_small_bbox(const int *__restrict__ pare
 // Run-level numbering (images without an oversize component): one wave per row; the roots of a row
 // are met in raster order, rows are ordered by an exclusive scan of their counts (k_conn_scan).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_run_count(const int *__restrict__ parent, const int *__restrict__ size,
+__global__ __launch_bounds__(256) void k_run_count(const int *__restrict__ up, const int *__restrict__ rsz,
                                                    const int *__restrict__ runs, const int *__restrict__ rowcnt,
                                                    int H, int W, int min_size, int *__restrict__ blk, int nblk,
                                                    ConnMisc *__restrict__ misc)
@@ -727,18 +744,17 @@ __global__ __launch_bounds__(256) void k_run_count(const int *__restrict__ paren
     if (misc[b].n_over != 0) return;
     const int lane = threadIdx.x & 63;
     const long long npix = (long long)H * W;
-    const int *P = parent + b * npix;
-    const int *S = size + b * npix;
+    const int *UP = up + b * npix, *SZ = rsz + b * npix;
     const int *RC = rowcnt + (long long)b * H;
     for (int y = blockIdx.x * 4 + (threadIdx.x >> 6); y < H; y += gridDim.x * 4) {
         const int *R = runs + b * npix + (long long)y * W;
         const int cnt = RC[y];
         int ck = 0, ct = 0, fk = 0x7fffffff;
         for (int k = lane; k < cnt; k += 64) {
-            const int p = y * W + R[k];
-            if (P[p] != p) continue;
-            const int sz = S[p];
-            if (sz >= min_size) { ++ck; fk = min(fk, p); }
+            const int rid = y * W + k;
+            if (UP[rid] != rid) continue;
+            const int sz = SZ[rid];
+            if (sz >= min_size) { ++ck; fk = min(fk, y * W + R[k]); }
             else if (sz <= LANE_MAX) ++ct;
         }
         for (int o = 32; o > 0; o >>= 1) {
@@ -752,20 +768,24 @@ __global__ __launch_bounds__(256) void k_run_count(const int *__restrict__ paren
     }
 }
 
-__global__ __launch_bounds__(256) void k_run_number(const int *__restrict__ parent, const int *__restrict__ size,
+// roots in raster order: kept -> label, tiny -> list, big-small -> slot (also kept per run id for k_run_bbox)
+__global__ __launch_bounds__(256) void k_run_number(const int *__restrict__ up, const int *__restrict__ rsz,
                                                     const int *__restrict__ runs, const int *__restrict__ rowcnt,
                                                     int H, int W, int min_size, const int *__restrict__ blk, int nblk,
                                                     int *__restrict__ final_, int *__restrict__ tiny_list,
                                                     int *__restrict__ big_list, int *__restrict__ sbox,
+                                                    int *__restrict__ rslot, const int *__restrict__ parent,
                                                     ConnMisc *__restrict__ misc)
 {
     const int b = blockIdx.y;
     if (misc[b].n_over != 0) return;
     const int lane = threadIdx.x & 63;
     const long long npix = (long long)H * W;
+    const int *UP = up + b * npix, *SZ = rsz + b * npix;
     const int *P = parent + b * npix;
-    const int *S = size + b * npix;
+    const int first_kept = misc[b].first_kept;
     int *F = final_ + b * npix;
+    int *RS = rslot + b * npix;
     const int *RC = rowcnt + (long long)b * H;
     for (int y = blockIdx.x * 4 + (threadIdx.x >> 6); y < H; y += gridDim.x * 4) {
         const int *R = runs + b * npix + (long long)y * W;
@@ -774,21 +794,35 @@ __global__ __launch_bounds__(256) void k_run_number(const int *__restrict__ pare
         int offt = blk[((long long)b * 2 + 1) * nblk + y];
         for (int k0 = 0; k0 < cnt; k0 += 64) {
             const int k = k0 + lane;
-            int cls = 0, p = 0;              // 0 none, 1 kept, 2 tiny, 3 big-small
+            int cls = 0, p = 0, rid = 0;     // 0 none, 1 kept, 2 tiny, 3 big-small
             if (k < cnt) {
-                p = y * W + R[k];
-                if (P[p] == p) {
-                    const int sz = S[p];
+                rid = y * W + k;
+                if (UP[rid] == rid) {
+                    p = y * W + R[k];
+                    const int sz = SZ[rid];
                     cls = sz >= min_size ? 1 : (sz <= LANE_MAX ? 2 : 3);
                 }
             }
             const unsigned long long mk = __ballot(cls == 1), mt = __ballot(cls == 2);
             if (cls == 1) F[p] = offk + (int)spa_rank_in_mask(mk);
-            else if (cls == 2) tiny_list[b * npix + offt + (int)spa_rank_in_mask(mt)] = p;
-            else if (cls == 3) {
+            else if (cls == 2) {
+                // A tiny component that is ONE run (most noise specks) below the first image row: the search
+                // visits p, p+1, ..., p+sz-1 and the last outside neighbour it looks at is the pixel above the
+                // last one, which lies in the row above the seed and therefore in a component with a smaller
+                // seed: its `adjacent` is known here, without a replay (flag in the list entry).
+                const int sz = SZ[rid];
+                const int len = (k + 1 < cnt ? R[k + 1] : W) - R[k];
+                int entry = p;
+                if (sz == len && y > 0) {
+                    F[p] = p < first_kept ? -1 : -2 - P[p + sz - 1 - W];
+                    entry |= TINY_DONE;
+                }
+                tiny_list[b * npix + offt + (int)spa_rank_in_mask(mt)] = entry;
+            } else if (cls == 3) {
                 const int slot = atomicAdd(&misc[b].n_big, 1);
                 big_list[b * npix + slot] = p;
                 F[p] = slot;
+                RS[rid] = slot;
                 if (slot < SBOX_CAP) {
                     int *bb = sbox + ((long long)b * SBOX_CAP + slot) * 4;
                     const int x = p - y * W;
@@ -802,8 +836,8 @@ __global__ __launch_bounds__(256) void k_run_number(const int *__restrict__ pare
 }
 
 // bounding boxes of the big-small components from their runs
-__global__ __launch_bounds__(256) void k_run_bbox(const int *__restrict__ parent, const int *__restrict__ size,
-                                                  const int *__restrict__ final_, const int *__restrict__ runs,
+__global__ __launch_bounds__(256) void k_run_bbox(const int *__restrict__ up, const int *__restrict__ rsz,
+                                                  const int *__restrict__ rslot, const int *__restrict__ runs,
                                                   const int *__restrict__ rowcnt, int H, int W, int min_size,
                                                   int *__restrict__ sbox, const ConnMisc *__restrict__ misc)
 {
@@ -811,21 +845,19 @@ __global__ __launch_bounds__(256) void k_run_bbox(const int *__restrict__ parent
     if (misc[b].n_over != 0) return;
     const int lane = threadIdx.x & 63;
     const long long npix = (long long)H * W;
-    const int *P = parent + b * npix;
-    const int *S = size + b * npix;
-    const int *F = final_ + b * npix;
+    const int *UP = up + b * npix, *SZ = rsz + b * npix, *RS = rslot + b * npix;
     const int *RC = rowcnt + (long long)b * H;
     for (int y = blockIdx.x * 4 + (threadIdx.x >> 6); y < H; y += gridDim.x * 4) {
         const int *R = runs + b * npix + (long long)y * W;
         const int cnt = RC[y];
         for (int k = lane; k < cnt; k += 64) {
+            const int r = UP[y * W + k];
+            const int sz = SZ[r];
+            if (sz >= min_size || sz <= LANE_MAX) continue;
+            const int slot = RS[r];
+            if (slot >= SBOX_CAP) continue;
             const int xs = R[k];
             const int xe = (k + 1 < cnt ? R[k + 1] : W) - 1;
-            const int r = P[y * W + xs];
-            const int sz = S[r];
-            if (sz >= min_size || sz <= LANE_MAX) continue;
-            const int slot = F[r];
-            if (slot >= SBOX_CAP) continue;
             // hundreds of runs share one box: only a run that extends it issues an atomic (a stale read can
             // only cause a redundant atomic, never a missed one: boxes grow monotonically)
             int *bb = sbox + ((long long)b * SBOX_CAP + slot) * 4;
@@ -859,20 +891,9 @@ __global__ __launch_bounds__(256) void k_conn_bfs_lane(const int *__restrict__ p
     const int first_kept = misc[b].first_kept;
     for (int i = blockIdx.x * 256 + tid; i < n; i += gridDim.x * 256) {
         const int r = tiny_list[(long long)b * npix + i];
+        if (r & TINY_DONE) continue;                       // single-run component: settled by k_run_number
         if (r < first_kept) { F[r] = -1; continue; }      // before the first kept component: label 0
         const int sz = S[r];
-        {
-            // A component that is ONE horizontal run (most noise specks) below the first image row: the
-            // search visits r, r+1, ..., r+sz-1; the last outside neighbour it looks at is the pixel above
-            // the last one, which lies in the row above r and therefore in a component with a smaller
-            // seed: no queue, one lookup.  (Same row and P[r+sz-1] in the component imply the run itself:
-            // a gap would need a detour longer than the gap, i.e. more than sz pixels.)
-            const int ry = r / W, rx = r - ry * W;
-            if (ry > 0 && rx + sz <= W && root2(P, r + sz - 1) == r) {
-                F[r] = -2 - root2(P, r + sz - 1 - W);
-                continue;
-            }
-        }
         int best = -1;
         int head = 0, tail = 1;
         q[tid] = r;
@@ -886,7 +907,7 @@ __global__ __launch_bounds__(256) void k_conn_bfs_lane(const int *__restrict__ p
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 const bool inb = vx[d] >= 0 && vx[d] < W && vy[d] >= 0 && vy[d] < H;
-                rv[d] = inb ? root2(P, vy[d] * W + vx[d]) : 0x7fffffff;
+                rv[d] = inb ? P[vy[d] * W + vx[d]] : 0x7fffffff;
             }
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
@@ -909,25 +930,26 @@ __global__ __launch_bounds__(256) void k_conn_bfs_lane(const int *__restrict__ p
 
 // ---------------------------------------------------------------------------------------
 // BFS replay of one small component, LDS tiers: one wavefront per component.  The component's
-// bounding box (+1 pixel margin) is staged in LDS as one BYTE per pixel
+// bounding box (+1 pixel margin) is staged in LDS as one 16-bit code per pixel
 //     BC_OTHER    not a candidate for `adjacent` (a component with a larger seed)
 //     BC_EARLIER  pixel of a component with a smaller seed (a candidate for `adjacent`)
 //     BC_MEMBER   pixel of this component, not yet discovered
-//     BC_DONE     pixel of this component, discovered
-//     BC_CUR + l  pixel of this component that lane l is expanding in this step
-// and the queue is a ring of 16-bit box-local indices (only the current and the next BFS level
-// are alive), so a component costs (box area + ring) bytes of LDS and 10 of the typical
-// 1-2 thousand pixel components replay concurrently per CU; every step of a replay is a handful
-// of LDS round trips.  A pixel reached from several pixels of the same step goes to the smallest
-// (queue index, direction) key, as in the sequential BFS: each claimant looks at the pixel's
-// other neighbours for step-mates with a smaller key (no atomics).  Components whose box or
-// frontier does not fit are appended to `todo` for the next tier.
+//     q < BC_MEMBER  pixel of this component, discovered: its position q in the queue
+// and the queue is a ring of 16-bit box-local indices (only the current and the next BFS level are alive).
+// A step expands 64 queue entries and costs TWO dependent LDS round trips: the queue read, then ONE batch
+// of reads — the four neighbours' codes and, for each neighbour, the codes of its three other neighbours.
+// A pixel reached from several pixels of the same step goes to the smallest (queue index, direction) key,
+// as in the sequential BFS: a claimant sees from the queue positions stored in those codes whether a
+// step-mate with a smaller key reaches the same pixel (positions head .. head+63 are this step's) — no
+// atomics, no marking pass.  Components whose box or frontier does not fit go to `todo` (next tier).
+// The replay is a chain of dependent steps (a thin 5 000-pixel component has ~2 000 of them), so the pass
+// lasts as long as its longest replay: fewer round trips per step is what shortens it.
 // ---------------------------------------------------------------------------------------
-#define BC_OTHER 0
-#define BC_EARLIER 1
-#define BC_MEMBER 2
-#define BC_DONE 3
-#define BC_CUR 64
+#define BC_OTHER 0xFFFFu
+#define BC_EARLIER 0xFFFEu
+#define BC_MEMBER 0xFFFDu
+#define BC_MAXAREA 65532
+#define BC_MARGIN 2
 
 // tier of every big-small component, from its bounding box alone (the tiers then run concurrently
 // on separate streams): 16 KB LDS, 80 KB LDS, or global memory
@@ -935,9 +957,10 @@ __global__ __launch_bounds__(256) void k_conn_bfs_lane(const int *__restrict__ p
 #define BFS_RING_A 1024
 #define BFS_LDS_B (48 * 1024)
 #define BFS_RING_B 4096
-#define BFS_LDS_C (80 * 1024)
+#define BFS_LDS_C (136 * 1024)
 
 __global__ __launch_bounds__(256) void k_conn_classify(const int *__restrict__ big_list,
+                                                       const int *__restrict__ size,
                                                        const int *__restrict__ sbox,
                                                        ConnMisc *__restrict__ misc, int *__restrict__ final_,
                                                        int *__restrict__ list_a, int *__restrict__ list_b,
@@ -954,19 +977,24 @@ __global__ __launch_bounds__(256) void k_conn_classify(const int *__restrict__ b
         int tier = 3;
         if (slot < SBOX_CAP) {
             const int *bb = sbox + ((long long)b * SBOX_CAP + slot) * 4;
-            const int y0 = max(bb[0] - 1, 0), y1 = min(bb[1] + 1, H - 1);
-            const int x0 = max(bb[2] - 1, 0), x1 = min(bb[3] + 1, W - 1);
-            const long long area = (long long)(x1 - x0 + 1) * (y1 - y0 + 1);
+            const long long area = (long long)(bb[3] - bb[2] + 1 + 2 * BC_MARGIN) * (bb[1] - bb[0] + 1 + 2 * BC_MARGIN);
             const long long area4 = (area + 3) & ~3ll;
-            if (area <= 65535) {
-                if (area4 + BFS_RING_A * 2 <= BFS_LDS_A) tier = 0;
-                else if (area4 + BFS_RING_B * 2 <= BFS_LDS_B) tier = 1;
-                else if (area4 + BFS_RING_B * 2 <= BFS_LDS_C) tier = 2;
+            if (area <= BC_MAXAREA) {
+                if (area4 * 2 + BFS_RING_A * 2 <= BFS_LDS_A) tier = 0;
+                else if (area4 * 2 + BFS_RING_B * 2 <= BFS_LDS_B) tier = 1;
+                else if (area4 * 2 + BFS_RING_B * 2 <= BFS_LDS_C) tier = 2;
             }
         }
-        if (tier == 0) list_a[b * npix + atomicAdd(&misc[b].n_a, 1)] = slot;
-        else if (tier == 1) list_b[b * npix + atomicAdd(&misc[b].n_todo1, 1)] = slot;
-        else if (tier == 2) list_c[b * npix + atomicAdd(&misc[b].n_c, 1)] = slot;
+        // a replay is a chain of dependent steps whose length grows with the component: the longest ones must
+        // start first, or the pass ends with a few workgroups finishing a 5 000-pixel component alone.
+        // Lists per size class (an eighth of the list region each), consumed from the largest class down.
+        const int sz = size[b * npix + r];
+        int cls = 26 - __clz(sz);                      // sz 17..63 -> 0 (and below), 64..127 -> 1, ...
+        cls = cls < 0 ? 0 : (cls > 7 ? 7 : cls);
+        const long long sub = npix / 8 * cls;
+        if (tier == 0) { atomicAdd(&misc[b].n_a, 1); list_a[b * npix + sub + atomicAdd(&misc[b].nb[0][cls], 1)] = slot; }
+        else if (tier == 1) { atomicAdd(&misc[b].n_todo1, 1); list_b[b * npix + sub + atomicAdd(&misc[b].nb[1][cls], 1)] = slot; }
+        else if (tier == 2) { atomicAdd(&misc[b].n_c, 1); list_c[b * npix + sub + atomicAdd(&misc[b].nb[2][cls], 1)] = slot; }
         else list_g[b * npix + atomicAdd(&misc[b].n_todo2, 1)] = slot;
     }
 }
@@ -997,129 +1025,156 @@ __global__ __launch_bounds__(64) void k_conn_bfs_lds(const int *__restrict__ par
     const int n_items = tier == 0 ? misc[b].n_a : (tier == 1 ? misc[b].n_todo1 : misc[b].n_c);
     int *todo_count = &misc[b].n_todo2;          // what fits no LDS tier after all goes to the global tier
     const int first_kept = misc[b].first_kept;
-    const unsigned long long below = (1ull << lane) - 1ull;
     const int rmask = ring - 1;
     // the replays of the larger tiers are the critical path of the pass (few, long, serial): let their
     // instructions issue ahead of the many short waves that share the SIMD
     if (tier > 0) __builtin_amdgcn_s_setprio(3);
 
     for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
-        const int slot = list ? list[(long long)b * npix + it] : it;
+        // item `it` in largest-class-first order
+        int slot = it;
+        if (list) {
+            int rest = it, cls = 7;
+            for (; cls > 0; --cls) {
+                const int c = misc[b].nb[tier][cls];
+                if (rest < c) break;
+                rest -= c;
+            }
+            slot = list[(long long)b * npix + (long long)(npix / 8) * cls + rest];
+        }
         const int r = BL[slot];
         if (r < first_kept) {           // before the first kept component everything is label 0
             if (lane == 0) F[r] = -1;
             continue;
         }
         bool fits = slot < SBOX_CAP;
-        int y0 = 0, y1 = 0, x0 = 0, x1 = 0, bw = 0, bh = 0, area = 0, area4 = 0;
+        int y0 = 0, x0 = 0, bw = 0, bh = 0, area = 0, area4 = 0;
         if (fits) {
+            // the staged box: the bounding box with a BC_MARGIN-pixel margin on every side, image or not
             const int *bb = sbox + ((long long)b * SBOX_CAP + slot) * 4;
-            y0 = max(bb[0] - 1, 0); y1 = min(bb[1] + 1, H - 1);
-            x0 = max(bb[2] - 1, 0); x1 = min(bb[3] + 1, W - 1);
-            bw = x1 - x0 + 1; bh = y1 - y0 + 1;
+            y0 = bb[0] - BC_MARGIN; x0 = bb[2] - BC_MARGIN;
+            bw = bb[3] - bb[2] + 1 + 2 * BC_MARGIN; bh = bb[1] - bb[0] + 1 + 2 * BC_MARGIN;
             area = bw * bh;
             area4 = (area + 3) & ~3;
-            fits = area <= 65535 && area4 + ring * 2 <= lds_bytes;
+            fits = area <= BC_MAXAREA && area4 * 2 + ring * 2 <= lds_bytes;
         }
         bool overflow = false;
-        long long best = -1;            // (key << 32) | box-local index of the outside neighbour
+        int bk = -1, bv = 0;            // the latest (queue index * 4 + direction) that met an earlier component, and where
+#ifdef SPA_CONN_TIMING
+        const unsigned long long t0_ = wall_clock64(), c0_ = __builtin_readcyclecounter();
+        unsigned long long t1_ = t0_, c1_ = c0_, itmax_ = 0;
+        int steps_ = 0;
+#endif
         if (fits) {
-            unsigned char *code = (unsigned char *)lds_u32;
-            unsigned short *Q = (unsigned short *)(code + area4);
+            unsigned short *code = (unsigned short *)lds_u32;
+            unsigned short *Q = code + area4;
             conn_wave_sync();
-            // stage the box: 16 pixels per lane and step (16 independent loads in flight per
-            // lane), four packed 32-bit LDS stores
+            // stage the box: 16 pixels per lane and pass (16 independent loads in flight per lane), four packed
+            // 8-byte LDS stores.  Box coordinates and the global offset advance by additions only.
+            const int qy = 1024 / bw, qx = 1024 - qy * bw;
+            int px[4], py[4], po[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int i = g * 256 + lane * 4;
+                py[g] = i / bw; px[g] = i - py[g] * bw;
+                po[g] = (y0 + py[g]) * W + x0 + px[g];
+            }
+            const int wrap = W - bw, adv = qy * W + qx;
             for (int i0 = 0; i0 < area4; i0 += 1024) {
+#ifdef SPA_CONN_TIMING
+                { const unsigned long long n_ = wall_clock64(); if (i0 > 0 && n_ - c1_ > itmax_) itmax_ = n_ - c1_; c1_ = n_; }
+#endif
                 int rv[16];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const int i = i0 + g * 256 + lane * 4 + u;
-                        const int yy = y0 + i / bw, xx = x0 + i % bw;
-                        rv[g * 4 + u] = i < area ? root2(P, yy * W + xx) : 0x7fffffff;
+                        int xx = px[g] + u, yy = py[g], o = po[g] + u;
+                        if (xx >= bw) { xx -= bw; ++yy; o += wrap; }         // bw >= 5 > u
+                        const bool in = yy < bh && (unsigned)(y0 + yy) < (unsigned)H && (unsigned)(x0 + xx) < (unsigned)W;
+                        const int q = P[(unsigned)(in ? o : r)];            // unconditional: no divergent branch per load
+                        rv[g * 4 + u] = in ? q : 0x7fffffff;
                     }
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    uint32_t packed = 0u;
+                    uint32_t c[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int q = rv[g * 4 + u];
-                        const uint32_t c = q == r ? BC_MEMBER : (q < r ? BC_EARLIER : BC_OTHER);
-                        packed |= c << (8 * u);
+                        c[u] = q == r ? BC_MEMBER : (q < r ? BC_EARLIER : BC_OTHER);
                     }
-                    if (i0 + g * 256 + lane * 4 < area4) lds_u32[((i0 + g * 256) >> 2) + lane] = packed;
+                    if (i0 + g * 256 + lane * 4 < area4)
+                        ((uint2 *)lds_u32)[((i0 + g * 256) >> 2) + lane] = make_uint2(c[0] | (c[1] << 16), c[2] | (c[3] << 16));
+                    px[g] += qx; py[g] += qy; po[g] += adv;
+                    if (px[g] >= bw) { px[g] -= bw; ++py[g]; po[g] += wrap; }
                 }
             }
             const int ry = r / W, rx = r - ry * W;
             const int rloc = (ry - y0) * bw + (rx - x0);
             conn_wave_sync();
-            if (lane == 0) { Q[0] = (unsigned short)rloc; code[rloc] = BC_DONE; }
+            if (lane == 0) { Q[0] = (unsigned short)rloc; code[rloc] = 0; }
             conn_wave_sync();
             int head = 0, tail = 1;
-            const int ddx[4] = {1, -1, 0, 0};
-            const int ddy[4] = {0, 0, 1, -1};
+#ifdef SPA_CONN_TIMING
+            t1_ = wall_clock64();
+            c1_ = __builtin_readcyclecounter();
+#endif
+            // One step = 64 queue entries.  Thanks to the margin no neighbour needs a bounds test: the twelve codes
+            // around u (its 4 neighbours v and the 8 other pixels w that touch a v) are read in one batch.
+            // v goes to the claimant with the smallest (queue index, direction) key; another claimant w of v is in
+            // this step iff its code is a queue position in [head, head + cnt), and then it is expanded by lane
+            // code - head, so "w beats me" is simply (unsigned)(code(w) - head) < lane.
             while (head < tail) {
+#ifdef SPA_CONN_TIMING
+                ++steps_;
+#endif
                 const int cnt = min(64, tail - head);
                 const bool act = lane < cnt;
                 const int uidx = head + lane;
-                const int u = act ? (int)Q[uidx & rmask] : 0;
-                if (act) code[u] = (unsigned char)(BC_CUR + lane);
-                conn_wave_sync();
-                const int uy = u / bw, ux = u - uy * bw;
-                bool win[4];
-                int v[4];
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    const int xx = ux + ddx[d], yy = uy + ddy[d];
-                    const bool inb = act && xx >= 0 && xx < bw && yy >= 0 && yy < bh;
-                    v[d] = yy * bw + xx;
-                    win[d] = false;
-                    if (inb) {
-                        const int c = code[v[d]];
-                        if (c == BC_MEMBER) {
-                            // the other pixels that may reach v in this step: v - dd[d2], direction d2
-                            bool lose = false;
-#pragma unroll
-                            for (int d2 = 0; d2 < 4; ++d2) {
-                                if (d2 == d) continue;
-                                const int wx = xx - ddx[d2], wy = yy - ddy[d2];
-                                if (wx >= 0 && wx < bw && wy >= 0 && wy < bh) {
-                                    const int cw = code[wy * bw + wx];
-                                    if (cw >= BC_CUR && (cw - BC_CUR) * 4 + d2 < lane * 4 + d) lose = true;
-                                }
-                            }
-                            win[d] = !lose;
-                        } else if (c == BC_EARLIER) {
-                            const long long key = ((long long)(uidx * 4 + d) << 32) | (unsigned)v[d];
-                            if (key > best) best = key;
-                        }
-                    }
-                }
-                conn_wave_sync();           // every read of this step is done before the winners mark
-                int mywins = 0, before = 0, total = 0;
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    const unsigned long long m = __ballot(win[d]);
-                    before += __popcll(m & below);
-                    total += __popcll(m);
-                }
+                const int u = act ? (int)Q[uidx & rmask] : rloc;            // round trip 1
+                const unsigned short *c = code + u;
+                // directions in the order of the reference's BFS: (+1,0) (-1,0) (0,+1) (0,-1)
+                const unsigned cE = c[1], cW = c[-1], cS = c[bw], cN = c[-bw];     // round trip 2
+                const unsigned cEE = c[2], cWW = c[-2], cSS = c[2 * bw], cNN = c[-2 * bw];
+                const unsigned cSE = c[bw + 1], cSW = c[bw - 1], cNE = c[1 - bw], cNW = c[-1 - bw];
+                const unsigned uh = (unsigned)head, ul = (unsigned)lane;
+                const bool kEE = cEE - uh < ul, kWW = cWW - uh < ul, kSS = cSS - uh < ul, kNN = cNN - uh < ul;
+                const bool kSE = cSE - uh < ul, kSW = cSW - uh < ul, kNE = cNE - uh < ul, kNW = cNW - uh < ul;
+                const bool wE = act && cE == BC_MEMBER && !(kEE || kNE || kSE);
+                const bool wW = act && cW == BC_MEMBER && !(kWW || kNW || kSW);
+                const bool wS = act && cS == BC_MEMBER && !(kSW || kSE || kSS);
+                const bool wN = act && cN == BC_MEMBER && !(kNW || kNE || kNN);
+                const int k4 = uidx * 4;
+                if (act && cE == BC_EARLIER) { bk = k4; bv = u + 1; }
+                if (act && cW == BC_EARLIER) { bk = k4 + 1; bv = u - 1; }
+                if (act && cS == BC_EARLIER) { bk = k4 + 2; bv = u + bw; }
+                if (act && cN == BC_EARLIER) { bk = k4 + 3; bv = u - bw; }
+                const unsigned long long mE = __ballot(wE), mW = __ballot(wW), mS = __ballot(wS), mN = __ballot(wN);
+                unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned)(mE >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mE, 0u));
+                before = __builtin_amdgcn_mbcnt_hi((unsigned)(mW >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mW, before));
+                before = __builtin_amdgcn_mbcnt_hi((unsigned)(mS >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mS, before));
+                before = __builtin_amdgcn_mbcnt_hi((unsigned)(mN >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mN, before));
+                const int total = __popcll(mE) + __popcll(mW) + __popcll(mS) + __popcll(mN);
                 if (tail + total - (head + cnt) > ring) { overflow = true; break; }
-                const int pos = tail + before;
-#pragma unroll
-                for (int d = 0; d < 4; ++d)
-                    if (win[d]) {
-                        Q[(pos + mywins) & rmask] = (unsigned short)v[d];
-                        code[v[d]] = BC_DONE;
-                        ++mywins;
-                    }
-                if (act) code[u] = BC_DONE;
+                int pos = tail + (int)before;
+                if (wE) { Q[pos & rmask] = (unsigned short)(u + 1); code[u + 1] = (unsigned short)pos; ++pos; }
+                if (wW) { Q[pos & rmask] = (unsigned short)(u - 1); code[u - 1] = (unsigned short)pos; ++pos; }
+                if (wS) { Q[pos & rmask] = (unsigned short)(u + bw); code[u + bw] = (unsigned short)pos; ++pos; }
+                if (wN) { Q[pos & rmask] = (unsigned short)(u - bw); code[u - bw] = (unsigned short)pos; }
                 conn_wave_sync();
                 head += cnt;
                 tail += total;
             }
         }
+#ifdef SPA_CONN_TIMING
+        {
+            const unsigned long long t2_ = wall_clock64(), c2_ = __builtin_readcyclecounter();
+            if (lane == 0 && b == 0 && t2_ - t0_ > 20000)    // > 200 us at 100 MHz
+                printf("bfs tier %d item %d: size %d box %dx%d  steps %d  stage %.1f us (slowest 1024-pixel piece %.1f us)  replay %.1f us = %llu cycles  fits %d overflow %d\n", tier, it,
+                       size[(long long)b * npix + r], bw, bh, steps_, (t1_ - t0_) * 0.01, itmax_ * 0.01, (t2_ - t1_) * 0.01, c2_ - c1_, (int)fits, (int)overflow);
+        }
+#endif
         if (!fits || overflow) {
             if (lane == 0) {
                 const int k = atomicAdd(todo_count, 1);
@@ -1127,6 +1182,7 @@ __global__ __launch_bounds__(64) void k_conn_bfs_lds(const int *__restrict__ par
             }
             continue;
         }
+        long long best = bk < 0 ? -1ll : (((long long)bk << 32) | (unsigned)bv);
         for (int o = 32; o > 0; o >>= 1) {
             long long t = __shfl_xor(best, o);
             if (t > best) best = t;
@@ -1136,7 +1192,7 @@ __global__ __launch_bounds__(64) void k_conn_bfs_lds(const int *__restrict__ par
             if (best >= 0) {
                 const int loc = (int)(best & 0xFFFFFFFFll);
                 const int gy = y0 + loc / bw, gx = x0 + loc % bw;
-                f = -2 - root2(P, gy * W + gx);
+                f = -2 - P[gy * W + gx];
             }
             F[r] = f;
         }
@@ -1199,7 +1255,7 @@ __global__ __launch_bounds__(64) void k_conn_bfs(const int *__restrict__ parent,
                 v[d] = yy * W + xx;
                 cand[d] = false;
                 if (inb) {
-                    int rv = root2(P, v[d]);
+                    int rv = P[v[d]];
                     if (rv == r) {
                         cand[d] = __hip_atomic_load(CL + v[d], __ATOMIC_RELAXED,
                                                     __HIP_MEMORY_SCOPE_AGENT) == INF_KEY;
@@ -1258,7 +1314,7 @@ __global__ __launch_bounds__(256) void k_conn_resolve(const int *__restrict__ li
     const int n = which == 0 ? misc[b].n_small : misc[b].n_big;
     int *F = final_ + (long long)b * npix;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const int r = list[(long long)b * npix + i];
+        const int r = list[(long long)b * npix + i] & ~TINY_DONE;
         int f = ld_i32(F + r);
         while (f < -1) f = ld_i32(F + (-2 - f));   // pointer to a component with a smaller seed
         st_i32(F + r, f == -1 ? 0 : f);
@@ -1272,7 +1328,7 @@ __global__ __launch_bounds__(256) void k_conn_relabel(const int *__restrict__ pa
     const int b = blockIdx.y;
     const long long o = (long long)b * npix;
     for (int p = blockIdx.x * 256 + threadIdx.x; p < npix; p += gridDim.x * 256) {
-        int f = final_[o + root2(parent + o, p)];
+        int f = final_[o + parent[o + p]];
         out[o + p] = f < 0 ? 0 : f;
     }
 }
@@ -1283,6 +1339,8 @@ __global__ void k_conn_init_misc(ConnMisc *misc, int B, int npix)
     if (b < B) {
         misc[b].n_small = 0; misc[b].first_kept = npix; misc[b].qalloc = 0; misc[b].n_kept = 0;
         misc[b].n_todo1 = 0; misc[b].n_todo2 = 0; misc[b].n_big = 0; misc[b].n_over = 0; misc[b].n_a = 0; misc[b].n_c = 0;
+        for (int t = 0; t < 3; ++t)
+            for (int c = 0; c < 8; ++c) misc[b].nb[t][c] = 0;
     }
 }
 
@@ -1292,7 +1350,7 @@ extern "C" int spa_enforce_connectivity(spa_ctx *ctx, const int32_t *labels_in, 
 {
     SPA_ARG(ctx && labels_in && labels_out && n_labels && B > 0 && H > 0 && W > 0);
     SPA_ARG((long long)H * W < (1ll << 29));
-    SPA_ARG((size_t)3 * W * 4 <= 150 * 1024);          // two rows of run lists in LDS (k_run_merge)
+    SPA_ARG((size_t)3 * W * 4 <= 150 * 1024);          // two rows of run tables in LDS (k_run_merge, k_run_expand)
     hipStream_t s = spa_stream(stream);
     const int npix = H * W;
     const size_t img = (size_t)B * npix * 4;
@@ -1301,13 +1359,17 @@ extern "C" int spa_enforce_connectivity(spa_ctx *ctx, const int32_t *labels_in, 
     ConnMisc *misc;
     int rc;
     const int nblk = (npix + SCAN_PX - 1) / SCAN_PX;
-    int *runs, *rowcnt, *blk_run;
+    int *runs, *rowcnt, *blk_run, *rup, *rsz, *rslot;
     if ((rc = spa_ws_reserve(ctx, WS_PARENT, img, (void **)&parent)) != SPA_OK) return rc;
     if ((rc = spa_ws_reserve(ctx, WS_SIZE, img, (void **)&size)) != SPA_OK) return rc;
     if ((rc = spa_ws_reserve(ctx, WS_FINAL, img, (void **)&final_)) != SPA_OK) return rc;
     if ((rc = spa_ws_reserve(ctx, WS_CLAIM, img, (void **)&claim)) != SPA_OK) return rc;
     if ((rc = spa_ws_reserve(ctx, WS_QUEUE, img, (void **)&queue)) != SPA_OK) return rc;
-    if ((rc = spa_ws_reserve(ctx, WS_RUNS, img, (void **)&runs)) != SPA_OK) return rc;
+    // compact run tables (front of every row): start x | union-find parent | size | box slot
+    if ((rc = spa_ws_reserve(ctx, WS_RUNS, 4 * img, (void **)&runs)) != SPA_OK) return rc;
+    rup = runs + (size_t)B * npix;
+    rsz = rup + (size_t)B * npix;
+    rslot = rsz + (size_t)B * npix;
     if ((rc = spa_ws_reserve(ctx, WS_SMALL, 2 * img, (void **)&tiny)) != SPA_OK) return rc;
     big = tiny + (size_t)B * npix;
     // per-block counts of the pixel-level scan | per-row counts of the run-level scan | runs per row
@@ -1325,34 +1387,35 @@ extern "C" int spa_enforce_connectivity(spa_ctx *ctx, const int32_t *labels_in, 
 
     SpaProfScope prof_(ctx, PROF_CONNECT, s);
     hipLaunchKernelGGL(k_conn_init_misc, dim3((B + 63) / 64), dim3(64), 0, s, misc, B, npix);
-    // ---- components on runs: rows -> runs, vertical links, roots + sizes (no per-pixel union-find)
+    // ---- components on runs: rows -> run tables, vertical links, roots + sizes, then one streaming write of
+    // parent[pixel] = seed pixel (no per-pixel union-find, no per-pixel atomics)
     int gw = (H + 3) / 4;                       // one wave per row, four rows per workgroup
     if (gw > 1024) gw = 1024;
     // (the labels of the runs are parked in `final_`, which nothing else uses before the numbering)
-    hipLaunchKernelGGL(k_run_rows, dim3(H, B), dim3(256), 0, s, labels_in, parent, size, runs, final_, rowcnt, H, W);
+    hipLaunchKernelGGL(k_run_rows, dim3(H, B), dim3(256), 0, s, labels_in, runs, final_, rup, rsz, rowcnt, H, W);
     if ((size_t)3 * W * 4 > 48 * 1024 && !(ctx->conn_attr_done & 2)) {
         SPA_HIP(hipFuncSetAttribute((const void *)k_run_merge, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        SPA_HIP(hipFuncSetAttribute((const void *)k_run_expand, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         ctx->conn_attr_done |= 2;
     }
     if (H > 1)
-        hipLaunchKernelGGL(k_run_merge, dim3(H - 1, B), dim3(256), (size_t)3 * W * 4, s, (const int *)final_, parent,
+        hipLaunchKernelGGL(k_run_merge, dim3(H - 1, B), dim3(256), (size_t)3 * W * 4, s, (const int *)final_, rup,
                            (const int *)runs, (const int *)rowcnt, H, W);
-    hipLaunchKernelGGL(k_run_flatten, dim3(gw, B), dim3(256), 0, s, parent, size, (const int *)runs,
+    hipLaunchKernelGGL(k_run_flatten, dim3(gw, B), dim3(256), 0, s, rup, rsz, (const int *)runs,
                        (const int *)rowcnt, H, W);
+    hipLaunchKernelGGL(k_run_expand, dim3(H, B), dim3(256), (size_t)2 * W * 4, s, (const int *)rup, (const int *)rsz,
+                       (const int *)runs, (const int *)rowcnt, parent, size, H, W);
     {
-        // components above max_size are cut the way the reference cuts them; their images leave the run
-        // representation (k_conn_expand) and take the pixel-level numbering kernels below
-        int gf = (npix + 255) / 256;
-        if (gf > 1024) gf = 1024;
+        // components above max_size are cut the way the reference cuts them (k_conn_split works on
+        // parent[pixel] = seed); their images then take the pixel-level numbering kernels below
         if (!ctx->conn_claim_ready || ctx->conn_claim_bytes != ctx->ws_bytes[WS_CLAIM]) {
             // the claim words are all-INF between calls (every kernel that takes some releases them)
             SPA_HIP(hipMemsetAsync(claim, 0xFF, ctx->ws_bytes[WS_CLAIM], s));
             ctx->conn_claim_ready = 1;
             ctx->conn_claim_bytes = ctx->ws_bytes[WS_CLAIM];
         }
-        hipLaunchKernelGGL(k_run_find_oversize, dim3(gw, B), dim3(256), 0, s, parent, size, (const int *)runs,
-                           (const int *)rowcnt, H, W, max_size, todo1, misc);
-        hipLaunchKernelGGL(k_conn_expand, dim3(gf, B), dim3(256), 0, s, parent, misc, npix);
+        hipLaunchKernelGGL(k_run_find_oversize, dim3(gw, B), dim3(256), 0, s, (const int *)rup, (const int *)rsz,
+                           (const int *)runs, (const int *)rowcnt, H, W, max_size, todo1, misc);
         hipLaunchKernelGGL(k_conn_split, dim3(64, B), dim3(64), 0, s, parent, size, (const int *)todo1, misc,
                            claim, queue, H, W, max_size);
         hipLaunchKernelGGL(k_conn_reset_qalloc, dim3((B + 63) / 64), dim3(64), 0, s, misc, B);
@@ -1360,13 +1423,14 @@ extern "C" int spa_enforce_connectivity(spa_ctx *ctx, const int32_t *labels_in, 
     int gb = (npix + 255) / 256;
     if (gb > 1024) gb = 1024;
     // ---- numbering: run level (images without an oversize component) ...
-    hipLaunchKernelGGL(k_run_count, dim3(gw, B), dim3(256), 0, s, parent, size, (const int *)runs,
-                       (const int *)rowcnt, H, W, min_size, blk_run, H, misc);
+    hipLaunchKernelGGL(k_run_count, dim3(gw, B), dim3(256), 0, s, (const int *)rup, (const int *)rsz,
+                       (const int *)runs, (const int *)rowcnt, H, W, min_size, blk_run, H, misc);
     hipLaunchKernelGGL(k_conn_scan, dim3(B), dim3(256), 0, s, blk_run, H, misc, n_labels, 1);
-    hipLaunchKernelGGL(k_run_number, dim3(gw, B), dim3(256), 0, s, parent, size, (const int *)runs,
-                       (const int *)rowcnt, H, W, min_size, (const int *)blk_run, H, final_, tiny, big, sbox, misc);
-    hipLaunchKernelGGL(k_run_bbox, dim3(gw, B), dim3(256), 0, s, parent, size, (const int *)final_,
-                       (const int *)runs, (const int *)rowcnt, H, W, min_size, sbox, misc);
+    hipLaunchKernelGGL(k_run_number, dim3(gw, B), dim3(256), 0, s, (const int *)rup, (const int *)rsz,
+                       (const int *)runs, (const int *)rowcnt, H, W, min_size, (const int *)blk_run, H, final_, tiny,
+                       big, sbox, rslot, (const int *)parent, misc);
+    hipLaunchKernelGGL(k_run_bbox, dim3(gw, B), dim3(256), 0, s, (const int *)rup, (const int *)rsz,
+                       (const int *)rslot, (const int *)runs, (const int *)rowcnt, H, W, min_size, sbox, misc);
     // ---- ... and pixel level (early exit unless the image was expanded)
     hipLaunchKernelGGL(k_conn_count, dim3(nblk, B), dim3(256), 0, s, parent, size, npix, min_size,
                        max_size, blk, nblk, misc, ctx->d_status);
@@ -1386,7 +1450,7 @@ extern "C" int spa_enforce_connectivity(spa_ctx *ctx, const int32_t *labels_in, 
         SPA_HIP(hipFuncSetAttribute((const void *)k_conn_bfs_lds, hipFuncAttributeMaxDynamicSharedMemorySize, BFS_LDS_C));
         ctx->conn_attr_done |= 1;
     }
-    hipLaunchKernelGGL(k_conn_classify, dim3(8, B), dim3(256), 0, s, big, sbox, misc, final_, todo0, todo1, todo3, todo2, H, W);
+    hipLaunchKernelGGL(k_conn_classify, dim3(8, B), dim3(256), 0, s, big, (const int *)size, sbox, misc, final_, todo0, todo1, todo3, todo2, H, W);
     SPA_HIP(hipEventRecord(ctx->ev_fork, s));
     SPA_HIP(hipStreamWaitEvent(ctx->aux[0], ctx->ev_fork, 0));
     SPA_HIP(hipStreamWaitEvent(ctx->aux[1], ctx->ev_fork, 0));
