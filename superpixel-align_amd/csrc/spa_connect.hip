@@ -226,14 +226,203 @@ __global__ __launch_bounds__(256) void k_run_rows(const int32_t *__restrict__ la
     if (tid == 0) rowcnt[(long long)b * H + y] = carry_cnt;
 }
 
-// one workgroup per row: link every run to the runs of the same label it touches in the row above.
-// Both rows' run lists (and the labels of the upper row's runs) are staged in LDS.
-__global__ __launch_bounds__(256) void k_run_merge(const int *__restrict__ runlab, int *__restrict__ up,
+// ---- vertical links, two levels.  A strip of STRIP_ROWS rows holds a few thousand runs: its union-find lives
+// in LDS (k_run_strip), where a hop costs an LDS access instead of an L2 round trip and the sizes and boxes
+// of the strip-local components are summed with LDS atomics.  Only the row pairs that straddle two strips
+// (one in STRIP_ROWS) are linked through global memory (k_run_border), on a forest that is already flat
+// inside every strip, and only the strip-local roots carry size/box contributions to their final root
+// (k_run_flatten).  Tables per run id, valid at root runs: rsz = pixels, ry1 / rx0 / rx1 = bounding box
+// (its first row is the root run's own row: the root is the component's first run in raster order).
+#define STRIP_ROWS 8
+#define STRIP_CAP 4096          // runs per strip held in LDS; a busier strip links its rows through global memory
+
+__device__ __forceinline__ int lds_uf_find(int *lp, int i)
+{
+    for (;;) {
+        const int p = lp[i];
+        if (p == i) return i;
+        const int g = lp[p];
+        if (g == p) return p;
+        atomicMin(lp + i, g);
+        i = g;
+    }
+}
+
+__device__ __forceinline__ void lds_uf_merge(int *lp, int a, int b)
+{
+    for (;;) {
+        a = lds_uf_find(lp, a);
+        b = lds_uf_find(lp, b);
+        if (a == b) return;
+        if (a > b) { int t = a; a = b; b = t; }
+        const int old = atomicMin(lp + b, a);
+        if (old == b) return;
+        b = old;
+    }
+}
+
+// link run k of row y (xs..xe, label l) to the runs of the same label it touches in the row above (global tables)
+__device__ __forceinline__ void run_link_up_global(int *UP, const int *Rp, const int *RLp, int cntp, int y, int k,
+                                                   int xs, int xe, int l, int W)
+{
+    int lo = 0, hi = cntp - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (Rp[mid] <= xs) lo = mid; else hi = mid - 1;
+    }
+    for (int j = lo; j < cntp; ++j) {
+        if (Rp[j] > xe) break;
+        if (RLp[j] == l) uf_merge(UP, (y - 1) * W + j, y * W + k);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_run_strip(const int *__restrict__ runlab, int *__restrict__ up,
+                                                   int *__restrict__ rsz, int *__restrict__ ry1,
+                                                   int *__restrict__ rx0, int *__restrict__ rx1,
                                                    const int *__restrict__ runs, const int *__restrict__ rowcnt,
                                                    int H, int W)
 {
+    __shared__ int lp[STRIP_CAP];      // local parent
+    __shared__ int la[STRIP_CAP];      // links: label          sums: pixels of the local component
+    __shared__ int lb[STRIP_CAP];      // links: start x        sums: row << 28 | x0 << 14 | x1, kept current with a CAS
+    __shared__ int off_s[STRIP_ROWS + 1];
+    const int b = blockIdx.y, ys = blockIdx.x * STRIP_ROWS;
+    const int nrows = min(STRIP_ROWS, H - ys);
+    const int tid = threadIdx.x;
+    const long long npix = (long long)H * W;
+    const int *RC = rowcnt + (long long)b * H + ys;
+    int off[STRIP_ROWS + 1];           // statically indexed copy (row_of); off_s for the dynamic look-ups
+    off[0] = 0;
+#pragma unroll
+    for (int j = 0; j < STRIP_ROWS; ++j) off[j + 1] = off[j] + (j < nrows ? RC[j] : 0);
+    if (tid <= STRIP_ROWS) {
+        int v = 0;
+#pragma unroll
+        for (int j = 0; j <= STRIP_ROWS; ++j) v = (j == tid) ? off[j] : v;
+        off_s[tid] = v;
+    }
+    const int total = off[STRIP_ROWS];
+    auto row_of = [&](int i) {
+        int j = 0;
+#pragma unroll
+        for (int t = 1; t < STRIP_ROWS; ++t) j += (i >= off[t]) ? 1 : 0;
+        return j;
+    };
+    int *UP = up + b * npix;
+    const long long base = b * npix + (long long)ys * W;
+    const int *R0 = runs + base, *RL0 = runlab + base;
+    int *SZ = rsz + base, *Y1 = ry1 + base, *X0 = rx0 + base, *X1 = rx1 + base;
+    __syncthreads();
+
+    if (total > STRIP_CAP) {
+        // every run stays its own local component; the rows are linked through global memory
+        for (int j = 0; j < nrows; ++j) {
+            const int cnt = off_s[j + 1] - off_s[j];
+            const int cntp = j > 0 ? off_s[j] - off_s[j - 1] : 0;
+            const int *R = R0 + (long long)j * W, *RL = RL0 + (long long)j * W;
+            for (int k = tid; k < cnt; k += 256) {
+                const int xs = R[k];
+                const int xe = (k + 1 < cnt ? R[k + 1] : W) - 1;
+                SZ[j * W + k] = xe - xs + 1;
+                Y1[j * W + k] = ys + j; X0[j * W + k] = xs; X1[j * W + k] = xe;
+                if (j > 0) run_link_up_global(UP, R - W, RL - W, cntp, ys + j, k, xs, xe, RL[k], W);
+            }
+        }
+        return;
+    }
+    // ---- stage the strip's runs
+    for (int i = tid; i < total; i += 256) {
+        const int j = row_of(i);
+        const int k = i - off_s[j];
+        lp[i] = i;
+        la[i] = RL0[(long long)j * W + k];
+        lb[i] = R0[(long long)j * W + k];
+    }
+    __syncthreads();
+    // ---- links between the rows of the strip
+    for (int i = off[1] + tid; i < total; i += 256) {
+        const int j = row_of(i);
+        const int o0 = off_s[j - 1], o1 = off_s[j], o2 = off_s[j + 1];
+        const int xs = lb[i];
+        const int xe = (i + 1 < o2 ? lb[i + 1] : W) - 1;
+        const int l = la[i];
+        int lo = o0, hi = o1 - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (lb[mid] <= xs) lo = mid; else hi = mid - 1;
+        }
+        for (int q = lo; q < o1; ++q) {
+            if (lb[q] > xe) break;
+            if (la[q] == l) lds_uf_merge(lp, q, i);
+        }
+    }
+    __syncthreads();
+    // ---- flatten; every thread keeps its runs' extents in registers while la / lb change their meaning
+    constexpr int PER = STRIP_CAP / 256;
+    int rt[PER], xs_[PER], xe_[PER];
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        const int i = tid + t * 256;
+        rt[t] = -1; xs_[t] = 0; xe_[t] = 0;
+        if (i < total) {
+            const int j = row_of(i);
+            rt[t] = lds_uf_find(lp, i);
+            xs_[t] = lb[i];
+            xe_[t] = (i + 1 < off_s[j + 1] ? lb[i + 1] : W) - 1;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        const int i = tid + t * 256;
+        if (i < total) { la[i] = 0; lb[i] = 0x3FFF << 14; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        const int i = tid + t * 256;
+        if (i >= total) continue;
+        const unsigned j = (unsigned)row_of(i);
+        const int r = rt[t];
+        atomicAdd(la + r, xe_[t] - xs_[t] + 1);
+        unsigned old = (unsigned)lb[r];
+        for (;;) {
+            const unsigned x0 = min((old >> 14) & 0x3FFFu, (unsigned)xs_[t]), x1 = max(old & 0x3FFFu, (unsigned)xe_[t]);
+            const unsigned want = (max(old >> 28, j) << 28) | (x0 << 14) | x1;
+            if (want == old) break;
+            const unsigned seen = atomicCAS((unsigned *)lb + r, old, want);
+            if (seen == old) break;
+            old = seen;
+        }
+    }
+    __syncthreads();
+    // ---- out: every run points at its local root; the local roots carry the sums
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        const int i = tid + t * 256;
+        if (i >= total) continue;
+        const int j = row_of(i);
+        const int r = rt[t];
+        const int jr = row_of(r);
+        const int o = j * W + (i - off_s[j]);
+        UP[(long long)ys * W + o] = (ys + jr) * W + (r - off_s[jr]);
+        if (r == i) {
+            const unsigned bx = (unsigned)lb[i];
+            SZ[o] = la[i];
+            Y1[o] = ys + (int)(bx >> 28);
+            X0[o] = (int)((bx >> 14) & 0x3FFFu);
+            X1[o] = (int)(bx & 0x3FFFu);
+        }
+    }
+}
+
+// the row pairs between two strips: one workgroup per pair, both rows' run lists staged in LDS
+__global__ __launch_bounds__(256) void k_run_border(const int *__restrict__ runlab, int *__restrict__ up,
+                                                    const int *__restrict__ runs, const int *__restrict__ rowcnt,
+                                                    int H, int W)
+{
     extern __shared__ int lds_m[];                 // Rp [W] | Lp [W] | R [W]
-    const int b = blockIdx.y, y = blockIdx.x + 1;
+    const int b = blockIdx.y, y = (blockIdx.x + 1) * STRIP_ROWS;
     const int tid = threadIdx.x;
     const long long npix = (long long)H * W;
     int *UP = up + b * npix;
@@ -252,40 +441,37 @@ __global__ __launch_bounds__(256) void k_run_merge(const int *__restrict__ runla
     for (int k = tid; k < cnt; k += 256) {
         const int xs = sR[k];
         const int xe = (k + 1 < cnt ? sR[k + 1] : W) - 1;
-        const int l = RL[k];
-        // last run of the row above that starts at or before xs
-        int lo = 0, hi = cntp - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (sRp[mid] <= xs) lo = mid; else hi = mid - 1;
-        }
-        for (int j = lo; j < cntp; ++j) {
-            if (sRp[j] > xe) break;
-            if (sLp[j] == l) uf_merge(UP, (y - 1) * W + j, y * W + k);
-        }
+        run_link_up_global(UP, sRp, sLp, cntp, y, k, xs, xe, RL[k], W);
     }
 }
 
-// one wave per row: every run learns its root run; the root collects the run lengths
+// one wave per row: every run learns its root run; the strip-local roots hand their sums to the root
 __global__ __launch_bounds__(256) void k_run_flatten(int *__restrict__ up, int *__restrict__ rsz,
-                                                     const int *__restrict__ runs, const int *__restrict__ rowcnt,
+                                                     int *__restrict__ ry1, int *__restrict__ rx0,
+                                                     int *__restrict__ rx1, const int *__restrict__ rowcnt,
                                                      int H, int W)
 {
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const long long npix = (long long)H * W;
     int *UP = up + b * npix;
-    int *SZ = rsz + b * npix;
+    int *SZ = rsz + b * npix, *Y1 = ry1 + b * npix, *X0 = rx0 + b * npix, *X1 = rx1 + b * npix;
     const int *RC = rowcnt + (long long)b * H;
     for (int y = blockIdx.x * 4 + (threadIdx.x >> 6); y < H; y += gridDim.x * 4) {
-        const int *R = runs + b * npix + (long long)y * W;
         const int cnt = RC[y];
         for (int k = lane; k < cnt; k += 64) {
-            const int len = (k + 1 < cnt ? R[k + 1] : W) - R[k];
             const int rid = y * W + k;
+            const int p = ld_i32(UP + rid);
+            const int mine = SZ[rid];             // > 0: a strip-local root (nobody adds to it unless it is THE root)
+            if (p == rid) continue;               // a root (of its strip and of the forest)
             const int r = uf_find_halve(UP, rid);
             st_i32(UP + rid, r);
-            atomicAdd(SZ + r, len);
+            if (mine > 0) {
+                atomicAdd(SZ + r, mine);
+                atomicMax(Y1 + r, Y1[rid]);
+                atomicMin(X0 + r, X0[rid]);
+                atomicMax(X1 + r, X1[rid]);
+            }
         }
     }
 }
@@ -768,13 +954,14 @@ __global__ __launch_bounds__(256) void k_run_count(const int *__restrict__ up, c
     }
 }
 
-// roots in raster order: kept -> label, tiny -> list, big-small -> slot (also kept per run id for k_run_bbox)
+// roots in raster order: kept -> label, tiny -> list, big-small -> slot and bounding box
 __global__ __launch_bounds__(256) void k_run_number(const int *__restrict__ up, const int *__restrict__ rsz,
                                                     const int *__restrict__ runs, const int *__restrict__ rowcnt,
                                                     int H, int W, int min_size, const int *__restrict__ blk, int nblk,
                                                     int *__restrict__ final_, int *__restrict__ tiny_list,
                                                     int *__restrict__ big_list, int *__restrict__ sbox,
-                                                    int *__restrict__ rslot, const int *__restrict__ parent,
+                                                    const int *__restrict__ ry1, const int *__restrict__ rx0,
+                                                    const int *__restrict__ rx1, const int *__restrict__ parent,
                                                     ConnMisc *__restrict__ misc)
 {
     const int b = blockIdx.y;
@@ -785,7 +972,6 @@ __global__ __launch_bounds__(256) void k_run_number(const int *__restrict__ up, 
     const int *P = parent + b * npix;
     const int first_kept = misc[b].first_kept;
     int *F = final_ + b * npix;
-    int *RS = rslot + b * npix;
     const int *RC = rowcnt + (long long)b * H;
     for (int y = blockIdx.x * 4 + (threadIdx.x >> 6); y < H; y += gridDim.x * 4) {
         const int *R = runs + b * npix + (long long)y * W;
@@ -822,49 +1008,14 @@ __global__ __launch_bounds__(256) void k_run_number(const int *__restrict__ up, 
                 const int slot = atomicAdd(&misc[b].n_big, 1);
                 big_list[b * npix + slot] = p;
                 F[p] = slot;
-                RS[rid] = slot;
                 if (slot < SBOX_CAP) {
+                    // the root run is the component's first run in raster order: its row is the box's first row
                     int *bb = sbox + ((long long)b * SBOX_CAP + slot) * 4;
-                    const int x = p - y * W;
-                    bb[0] = y; bb[1] = y; bb[2] = x; bb[3] = x;
+                    bb[0] = y; bb[1] = ry1[b * npix + rid]; bb[2] = rx0[b * npix + rid]; bb[3] = rx1[b * npix + rid];
                 }
             }
             offk += __popcll(mk);
             offt += __popcll(mt);
-        }
-    }
-}
-
-// bounding boxes of the big-small components from their runs
-__global__ __launch_bounds__(256) void k_run_bbox(const int *__restrict__ up, const int *__restrict__ rsz,
-                                                  const int *__restrict__ rslot, const int *__restrict__ runs,
-                                                  const int *__restrict__ rowcnt, int H, int W, int min_size,
-                                                  int *__restrict__ sbox, const ConnMisc *__restrict__ misc)
-{
-    const int b = blockIdx.y;
-    if (misc[b].n_over != 0) return;
-    const int lane = threadIdx.x & 63;
-    const long long npix = (long long)H * W;
-    const int *UP = up + b * npix, *SZ = rsz + b * npix, *RS = rslot + b * npix;
-    const int *RC = rowcnt + (long long)b * H;
-    for (int y = blockIdx.x * 4 + (threadIdx.x >> 6); y < H; y += gridDim.x * 4) {
-        const int *R = runs + b * npix + (long long)y * W;
-        const int cnt = RC[y];
-        for (int k = lane; k < cnt; k += 64) {
-            const int r = UP[y * W + k];
-            const int sz = SZ[r];
-            if (sz >= min_size || sz <= LANE_MAX) continue;
-            const int slot = RS[r];
-            if (slot >= SBOX_CAP) continue;
-            const int xs = R[k];
-            const int xe = (k + 1 < cnt ? R[k + 1] : W) - 1;
-            // hundreds of runs share one box: only a run that extends it issues an atomic (a stale read can
-            // only cause a redundant atomic, never a missed one: boxes grow monotonically)
-            int *bb = sbox + ((long long)b * SBOX_CAP + slot) * 4;
-            if (y < ld_i32(bb + 0)) atomicMin(bb + 0, y);
-            if (y > ld_i32(bb + 1)) atomicMax(bb + 1, y);
-            if (xs < ld_i32(bb + 2)) atomicMin(bb + 2, xs);
-            if (xe > ld_i32(bb + 3)) atomicMax(bb + 3, xe);
         }
     }
 }
@@ -874,6 +1025,7 @@ __global__ __launch_bounds__(256) void k_run_bbox(const int *__restrict__ up, co
 // BFS literally — queue in LDS, "already queued" by searching its own queue — and keeps the
 // last outside neighbour that belongs to a component with a smaller seed.
 // ---------------------------------------------------------------------------------------
+#define LANE_CHUNK 1024
 __global__ __launch_bounds__(256) void k_conn_bfs_lane(const int *__restrict__ parent,
                                                        const int *__restrict__ size,
                                                        const int *__restrict__ tiny_list,
@@ -881,6 +1033,8 @@ __global__ __launch_bounds__(256) void k_conn_bfs_lane(const int *__restrict__ p
                                                        int *__restrict__ final_, int H, int W)
 {
     __shared__ int q[LANE_MAX * 256];
+    __shared__ int cl[LANE_CHUNK];
+    __shared__ int ccount;
     const int b = blockIdx.y;
     const int npix = H * W;
     const int tid = threadIdx.x;
@@ -889,10 +1043,24 @@ __global__ __launch_bounds__(256) void k_conn_bfs_lane(const int *__restrict__ p
     int *F = final_ + (long long)b * npix;
     const int n = misc[b].n_small;
     const int first_kept = misc[b].first_kept;
-    for (int i = blockIdx.x * 256 + tid; i < n; i += gridDim.x * 256) {
-        const int r = tiny_list[(long long)b * npix + i];
-        if (r & TINY_DONE) continue;                       // single-run component: settled by k_run_number
-        if (r < first_kept) { F[r] = -1; continue; }      // before the first kept component: label 0
+    for (int base = blockIdx.x * LANE_CHUNK; base < n; base += gridDim.x * LANE_CHUNK) {
+      // four in five list entries are single-run components k_run_number has settled: compact the rest first,
+      // or every wave would run its replay loop for a dozen live lanes
+      if (tid == 0) ccount = 0;
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < LANE_CHUNK / 256; ++j) {
+          const int i = base + j * 256 + tid;
+          if (i >= n) continue;
+          const int r = tiny_list[(long long)b * npix + i];
+          if (r & TINY_DONE) continue;
+          if (r < first_kept) { F[r] = -1; continue; }   // before the first kept component: label 0
+          cl[atomicAdd(&ccount, 1)] = r;
+      }
+      __syncthreads();
+      const int nc = ccount;
+      for (int i = tid; i < nc; i += 256) {
+        const int r = cl[i];
         const int sz = S[r];
         int best = -1;
         int head = 0, tail = 1;
@@ -925,39 +1093,46 @@ __global__ __launch_bounds__(256) void k_conn_bfs_lane(const int *__restrict__ p
             ++head;
         }
         F[r] = best < 0 ? -1 : -2 - best;
+      }
+      __syncthreads();
     }
 }
 
 // ---------------------------------------------------------------------------------------
-// BFS replay of one small component, LDS tiers: one wavefront per component.  The component's
-// bounding box (+1 pixel margin) is staged in LDS as one 16-bit code per pixel
-//     BC_OTHER    not a candidate for `adjacent` (a component with a larger seed)
+// BFS replay of one small component, LDS tiers: one wavefront per component.  The component's bounding box
+// with a BC_MARGIN-pixel margin on every side (image or not) is staged in LDS as one byte per pixel
+//     BC_OTHER    not a candidate for `adjacent` (a component with a larger seed, or outside the image)
 //     BC_EARLIER  pixel of a component with a smaller seed (a candidate for `adjacent`)
 //     BC_MEMBER   pixel of this component, not yet discovered
-//     q < BC_MEMBER  pixel of this component, discovered: its position q in the queue
+//     BC_FOUND    pixel of this component, in the queue or already expanded
+//     BC_CUR + l  pixel of this component that lane l expands in the current step
 // and the queue is a ring of 16-bit box-local indices (only the current and the next BFS level are alive).
-// A step expands 64 queue entries and costs TWO dependent LDS round trips: the queue read, then ONE batch
-// of reads — the four neighbours' codes and, for each neighbour, the codes of its three other neighbours.
-// A pixel reached from several pixels of the same step goes to the smallest (queue index, direction) key,
-// as in the sequential BFS: a claimant sees from the queue positions stored in those codes whether a
-// step-mate with a smaller key reaches the same pixel (positions head .. head+63 are this step's) — no
-// atomics, no marking pass.  Components whose box or frontier does not fit go to `todo` (next tier).
-// The replay is a chain of dependent steps (a thin 5 000-pixel component has ~2 000 of them), so the pass
-// lasts as long as its longest replay: fewer round trips per step is what shortens it.
+// A step expands 64 queue entries: queue read, mark the own pixel BC_CUR + lane, ONE batch of twelve byte
+// reads (the 4 neighbours v and the 8 other pixels w that touch a v — thanks to the margin none needs a
+// bounds test and none needs the pixel's row/column), ballots, queue/code writes.  A pixel reached from
+// several pixels of the same step goes to the smallest (queue index, direction) key, as in the sequential
+// BFS: another claimant w of v is a step-mate iff its code is BC_CUR + l, and it wins iff l < lane — no
+// atomics.  The replay is a chain of dependent steps, and one wave issues an instruction every ~5 cycles:
+// the step is ~200 instructions, ~1 100 cycles (it was 3 800 with per-neighbour bounds tests and divisions).
+// LDS bytes x time is what the tiers compete for, hence bytes, not 16-bit codes, per pixel.
+// Components whose box or frontier does not fit go to `todo` (next tier).
 // ---------------------------------------------------------------------------------------
-#define BC_OTHER 0xFFFFu
-#define BC_EARLIER 0xFFFEu
-#define BC_MEMBER 0xFFFDu
-#define BC_MAXAREA 65532
+#define BC_OTHER 0u
+#define BC_EARLIER 1u
+#define BC_MEMBER 2u
+#define BC_FOUND 3u
+#define BC_CUR 64u
+#define BC_MAXAREA 65535
 #define BC_MARGIN 2
 
 // tier of every big-small component, from its bounding box alone (the tiers then run concurrently
 // on separate streams): 16 KB LDS, 80 KB LDS, or global memory
 #define BFS_LDS_A (16 * 1024)
 #define BFS_RING_A 1024
-#define BFS_LDS_B (48 * 1024)
-#define BFS_RING_B 4096
-#define BFS_LDS_C (136 * 1024)
+#define BFS_LDS_B (53 * 512)          // six per CU
+#define BFS_RING_B 2048
+#define BFS_LDS_C (80 * 1024)
+#define BFS_RING_C 4096
 
 __global__ __launch_bounds__(256) void k_conn_classify(const int *__restrict__ big_list,
                                                        const int *__restrict__ size,
@@ -980,9 +1155,9 @@ __global__ __launch_bounds__(256) void k_conn_classify(const int *__restrict__ b
             const long long area = (long long)(bb[3] - bb[2] + 1 + 2 * BC_MARGIN) * (bb[1] - bb[0] + 1 + 2 * BC_MARGIN);
             const long long area4 = (area + 3) & ~3ll;
             if (area <= BC_MAXAREA) {
-                if (area4 * 2 + BFS_RING_A * 2 <= BFS_LDS_A) tier = 0;
-                else if (area4 * 2 + BFS_RING_B * 2 <= BFS_LDS_B) tier = 1;
-                else if (area4 * 2 + BFS_RING_B * 2 <= BFS_LDS_C) tier = 2;
+                if (area4 + BFS_RING_A * 2 <= BFS_LDS_A) tier = 0;
+                else if (area4 + BFS_RING_B * 2 <= BFS_LDS_B) tier = 1;
+                else if (area4 + BFS_RING_C * 2 <= BFS_LDS_C) tier = 2;
             }
         }
         // a replay is a chain of dependent steps whose length grows with the component: the longest ones must
@@ -1056,7 +1231,7 @@ __global__ __launch_bounds__(64) void k_conn_bfs_lds(const int *__restrict__ par
             bw = bb[3] - bb[2] + 1 + 2 * BC_MARGIN; bh = bb[1] - bb[0] + 1 + 2 * BC_MARGIN;
             area = bw * bh;
             area4 = (area + 3) & ~3;
-            fits = area <= BC_MAXAREA && area4 * 2 + ring * 2 <= lds_bytes;
+            fits = area <= BC_MAXAREA && area4 + ring * 2 <= lds_bytes;
         }
         bool overflow = false;
         int bk = -1, bv = 0;            // the latest (queue index * 4 + direction) that met an earlier component, and where
@@ -1066,8 +1241,8 @@ __global__ __launch_bounds__(64) void k_conn_bfs_lds(const int *__restrict__ par
         int steps_ = 0;
 #endif
         if (fits) {
-            unsigned short *code = (unsigned short *)lds_u32;
-            unsigned short *Q = code + area4;
+            unsigned char *code = (unsigned char *)lds_u32;
+            unsigned short *Q = (unsigned short *)(code + area4);
             conn_wave_sync();
             // stage the box: 16 pixels per lane and pass (16 independent loads in flight per lane), four packed
             // 8-byte LDS stores.  Box coordinates and the global offset advance by additions only.
@@ -1105,7 +1280,7 @@ __global__ __launch_bounds__(64) void k_conn_bfs_lds(const int *__restrict__ par
                         c[u] = q == r ? BC_MEMBER : (q < r ? BC_EARLIER : BC_OTHER);
                     }
                     if (i0 + g * 256 + lane * 4 < area4)
-                        ((uint2 *)lds_u32)[((i0 + g * 256) >> 2) + lane] = make_uint2(c[0] | (c[1] << 16), c[2] | (c[3] << 16));
+                        lds_u32[((i0 + g * 256) >> 2) + lane] = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);
                     px[g] += qx; py[g] += qy; po[g] += adv;
                     if (px[g] >= bw) { px[g] -= bw; ++py[g]; po[g] += wrap; }
                 }
@@ -1113,18 +1288,13 @@ __global__ __launch_bounds__(64) void k_conn_bfs_lds(const int *__restrict__ par
             const int ry = r / W, rx = r - ry * W;
             const int rloc = (ry - y0) * bw + (rx - x0);
             conn_wave_sync();
-            if (lane == 0) { Q[0] = (unsigned short)rloc; code[rloc] = 0; }
+            if (lane == 0) { Q[0] = (unsigned short)rloc; code[rloc] = BC_FOUND; }
             conn_wave_sync();
             int head = 0, tail = 1;
 #ifdef SPA_CONN_TIMING
             t1_ = wall_clock64();
             c1_ = __builtin_readcyclecounter();
 #endif
-            // One step = 64 queue entries.  Thanks to the margin no neighbour needs a bounds test: the twelve codes
-            // around u (its 4 neighbours v and the 8 other pixels w that touch a v) are read in one batch.
-            // v goes to the claimant with the smallest (queue index, direction) key; another claimant w of v is in
-            // this step iff its code is a queue position in [head, head + cnt), and then it is expanded by lane
-            // code - head, so "w beats me" is simply (unsigned)(code(w) - head) < lane.
             while (head < tail) {
 #ifdef SPA_CONN_TIMING
                 ++steps_;
@@ -1132,13 +1302,15 @@ __global__ __launch_bounds__(64) void k_conn_bfs_lds(const int *__restrict__ par
                 const int cnt = min(64, tail - head);
                 const bool act = lane < cnt;
                 const int uidx = head + lane;
-                const int u = act ? (int)Q[uidx & rmask] : rloc;            // round trip 1
-                const unsigned short *c = code + u;
+                const int u = act ? (int)Q[uidx & rmask] : rloc;
+                unsigned char *c = code + u;
+                if (act) c[0] = (unsigned char)(BC_CUR + lane);
+                conn_wave_sync();
                 // directions in the order of the reference's BFS: (+1,0) (-1,0) (0,+1) (0,-1)
                 const unsigned cE = c[1], cW = c[-1], cS = c[bw], cN = c[-bw];     // round trip 2
                 const unsigned cEE = c[2], cWW = c[-2], cSS = c[2 * bw], cNN = c[-2 * bw];
                 const unsigned cSE = c[bw + 1], cSW = c[bw - 1], cNE = c[1 - bw], cNW = c[-1 - bw];
-                const unsigned uh = (unsigned)head, ul = (unsigned)lane;
+                const unsigned uh = BC_CUR, ul = (unsigned)lane;             // "w is expanded in this step by an earlier lane"
                 const bool kEE = cEE - uh < ul, kWW = cWW - uh < ul, kSS = cSS - uh < ul, kNN = cNN - uh < ul;
                 const bool kSE = cSE - uh < ul, kSW = cSW - uh < ul, kNE = cNE - uh < ul, kNW = cNW - uh < ul;
                 const bool wE = act && cE == BC_MEMBER && !(kEE || kNE || kSE);
@@ -1158,10 +1330,11 @@ __global__ __launch_bounds__(64) void k_conn_bfs_lds(const int *__restrict__ par
                 const int total = __popcll(mE) + __popcll(mW) + __popcll(mS) + __popcll(mN);
                 if (tail + total - (head + cnt) > ring) { overflow = true; break; }
                 int pos = tail + (int)before;
-                if (wE) { Q[pos & rmask] = (unsigned short)(u + 1); code[u + 1] = (unsigned short)pos; ++pos; }
-                if (wW) { Q[pos & rmask] = (unsigned short)(u - 1); code[u - 1] = (unsigned short)pos; ++pos; }
-                if (wS) { Q[pos & rmask] = (unsigned short)(u + bw); code[u + bw] = (unsigned short)pos; ++pos; }
-                if (wN) { Q[pos & rmask] = (unsigned short)(u - bw); code[u - bw] = (unsigned short)pos; }
+                if (wE) { Q[pos & rmask] = (unsigned short)(u + 1); c[1] = BC_FOUND; ++pos; }
+                if (wW) { Q[pos & rmask] = (unsigned short)(u - 1); c[-1] = BC_FOUND; ++pos; }
+                if (wS) { Q[pos & rmask] = (unsigned short)(u + bw); c[bw] = BC_FOUND; ++pos; }
+                if (wN) { Q[pos & rmask] = (unsigned short)(u - bw); c[-bw] = BC_FOUND; }
+                if (act) c[0] = BC_FOUND;
                 conn_wave_sync();
                 head += cnt;
                 tail += total;
@@ -1350,7 +1523,7 @@ extern "C" int spa_enforce_connectivity(spa_ctx *ctx, const int32_t *labels_in, 
 {
     SPA_ARG(ctx && labels_in && labels_out && n_labels && B > 0 && H > 0 && W > 0);
     SPA_ARG((long long)H * W < (1ll << 29));
-    SPA_ARG((size_t)3 * W * 4 <= 150 * 1024);          // two rows of run tables in LDS (k_run_merge, k_run_expand)
+    SPA_ARG((size_t)3 * W * 4 <= 150 * 1024);          // two rows of run tables in LDS (k_run_border, k_run_expand)
     hipStream_t s = spa_stream(stream);
     const int npix = H * W;
     const size_t img = (size_t)B * npix * 4;
@@ -1359,17 +1532,19 @@ extern "C" int spa_enforce_connectivity(spa_ctx *ctx, const int32_t *labels_in, 
     ConnMisc *misc;
     int rc;
     const int nblk = (npix + SCAN_PX - 1) / SCAN_PX;
-    int *runs, *rowcnt, *blk_run, *rup, *rsz, *rslot;
+    int *runs, *rowcnt, *blk_run, *rup, *rsz, *ry1, *rx0, *rx1;
     if ((rc = spa_ws_reserve(ctx, WS_PARENT, img, (void **)&parent)) != SPA_OK) return rc;
     if ((rc = spa_ws_reserve(ctx, WS_SIZE, img, (void **)&size)) != SPA_OK) return rc;
     if ((rc = spa_ws_reserve(ctx, WS_FINAL, img, (void **)&final_)) != SPA_OK) return rc;
     if ((rc = spa_ws_reserve(ctx, WS_CLAIM, img, (void **)&claim)) != SPA_OK) return rc;
     if ((rc = spa_ws_reserve(ctx, WS_QUEUE, img, (void **)&queue)) != SPA_OK) return rc;
-    // compact run tables (front of every row): start x | union-find parent | size | box slot
-    if ((rc = spa_ws_reserve(ctx, WS_RUNS, 4 * img, (void **)&runs)) != SPA_OK) return rc;
+    // compact run tables (front of every row): start x | union-find parent | size | box: last row, first x, last x
+    if ((rc = spa_ws_reserve(ctx, WS_RUNS, 6 * img, (void **)&runs)) != SPA_OK) return rc;
     rup = runs + (size_t)B * npix;
     rsz = rup + (size_t)B * npix;
-    rslot = rsz + (size_t)B * npix;
+    ry1 = rsz + (size_t)B * npix;
+    rx0 = ry1 + (size_t)B * npix;
+    rx1 = rx0 + (size_t)B * npix;
     if ((rc = spa_ws_reserve(ctx, WS_SMALL, 2 * img, (void **)&tiny)) != SPA_OK) return rc;
     big = tiny + (size_t)B * npix;
     // per-block counts of the pixel-level scan | per-row counts of the run-level scan | runs per row
@@ -1394,15 +1569,17 @@ extern "C" int spa_enforce_connectivity(spa_ctx *ctx, const int32_t *labels_in, 
     // (the labels of the runs are parked in `final_`, which nothing else uses before the numbering)
     hipLaunchKernelGGL(k_run_rows, dim3(H, B), dim3(256), 0, s, labels_in, runs, final_, rup, rsz, rowcnt, H, W);
     if ((size_t)3 * W * 4 > 48 * 1024 && !(ctx->conn_attr_done & 2)) {
-        SPA_HIP(hipFuncSetAttribute((const void *)k_run_merge, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        SPA_HIP(hipFuncSetAttribute((const void *)k_run_border, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         SPA_HIP(hipFuncSetAttribute((const void *)k_run_expand, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         ctx->conn_attr_done |= 2;
     }
-    if (H > 1)
-        hipLaunchKernelGGL(k_run_merge, dim3(H - 1, B), dim3(256), (size_t)3 * W * 4, s, (const int *)final_, rup,
+    const int n_strips = (H + STRIP_ROWS - 1) / STRIP_ROWS;
+    hipLaunchKernelGGL(k_run_strip, dim3(n_strips, B), dim3(256), 0, s, (const int *)final_, rup, rsz, ry1, rx0, rx1,
+                       (const int *)runs, (const int *)rowcnt, H, W);
+    if (n_strips > 1)
+        hipLaunchKernelGGL(k_run_border, dim3(n_strips - 1, B), dim3(256), (size_t)3 * W * 4, s, (const int *)final_, rup,
                            (const int *)runs, (const int *)rowcnt, H, W);
-    hipLaunchKernelGGL(k_run_flatten, dim3(gw, B), dim3(256), 0, s, rup, rsz, (const int *)runs,
-                       (const int *)rowcnt, H, W);
+    hipLaunchKernelGGL(k_run_flatten, dim3(gw, B), dim3(256), 0, s, rup, rsz, ry1, rx0, rx1, (const int *)rowcnt, H, W);
     hipLaunchKernelGGL(k_run_expand, dim3(H, B), dim3(256), (size_t)2 * W * 4, s, (const int *)rup, (const int *)rsz,
                        (const int *)runs, (const int *)rowcnt, parent, size, H, W);
     {
@@ -1428,9 +1605,7 @@ extern "C" int spa_enforce_connectivity(spa_ctx *ctx, const int32_t *labels_in, 
     hipLaunchKernelGGL(k_conn_scan, dim3(B), dim3(256), 0, s, blk_run, H, misc, n_labels, 1);
     hipLaunchKernelGGL(k_run_number, dim3(gw, B), dim3(256), 0, s, (const int *)rup, (const int *)rsz,
                        (const int *)runs, (const int *)rowcnt, H, W, min_size, (const int *)blk_run, H, final_, tiny,
-                       big, sbox, rslot, (const int *)parent, misc);
-    hipLaunchKernelGGL(k_run_bbox, dim3(gw, B), dim3(256), 0, s, (const int *)rup, (const int *)rsz,
-                       (const int *)rslot, (const int *)runs, (const int *)rowcnt, H, W, min_size, sbox, misc);
+                       big, sbox, (const int *)ry1, (const int *)rx0, (const int *)rx1, (const int *)parent, misc);
     // ---- ... and pixel level (early exit unless the image was expanded)
     hipLaunchKernelGGL(k_conn_count, dim3(nblk, B), dim3(256), 0, s, parent, size, npix, min_size,
                        max_size, blk, nblk, misc, ctx->d_status);
@@ -1439,13 +1614,13 @@ extern "C" int spa_enforce_connectivity(spa_ctx *ctx, const int32_t *labels_in, 
                        blk, nblk, final_, tiny, big, sbox, misc);
     hipLaunchKernelGGL(k_small_bbox, dim3(gb, B), dim3(256), 0, s, parent, size, final_, W, npix,
                        min_size, sbox, misc);
-    // BFS replay of the small components.  The tiers are independent of each other (a component
-    // only reads the roots of its neighbours), so they run concurrently: the lane tier (<= 32 pixels,
-    // one thread each) and the rare 80 KB LDS tier on a side stream, the 48 KB LDS tier on another,
-    // the 16 KB LDS tier here;
-    // what fits no LDS tier (or overflows a frontier ring) goes to the global-memory wave tier after
-    // the join.  Each tier is bound by its slowest replay (a thin 5 000-pixel component is ~1 ms of
-    // dependent LDS steps), not by throughput.
+    // BFS replay of the small components.  The tiers are independent of each other (a component only reads
+    // the roots of its neighbours), so they run concurrently: the lane tier (<= 16 pixels, one thread each)
+    // and the rare 80 KB LDS tier on a side stream, the six-per-CU LDS tier on another, the 16 KB LDS tier
+    // here; what fits no LDS tier (or overflows a frontier ring) goes to the global-memory wave tier after the
+    // join.  Measured alone each tier lasts about as long as its longest replay (~230 us: 370 steps of
+    // ~1 100 cycles); together they are bound by LDS bytes x time and VALU issue (one replaying wave keeps
+    // most of a SIMD's issue slots), ~1.1 ms for the bench images, whatever the stream assignment.
     if (!(ctx->conn_attr_done & 1)) {        // per context = per device
         SPA_HIP(hipFuncSetAttribute((const void *)k_conn_bfs_lds, hipFuncAttributeMaxDynamicSharedMemorySize, BFS_LDS_C));
         ctx->conn_attr_done |= 1;
@@ -1459,7 +1634,7 @@ extern "C" int spa_enforce_connectivity(spa_ctx *ctx, const int32_t *labels_in, 
     hipLaunchKernelGGL(k_conn_bfs_lane, dim3(gb, B), dim3(256), 0, ctx->aux[0], parent, size, tiny, misc,
                        final_, H, W);
     hipLaunchKernelGGL(k_conn_bfs_lds, dim3(64, B), dim3(64), BFS_LDS_C, ctx->aux[0], parent, size, big, sbox,
-                       (const int *)todo3, todo2, misc, 2, final_, H, W, BFS_LDS_C, BFS_RING_B);
+                       (const int *)todo3, todo2, misc, 2, final_, H, W, BFS_LDS_C, BFS_RING_C);
     hipLaunchKernelGGL(k_conn_bfs_lds, dim3(1024, B), dim3(64), BFS_LDS_A, s, parent, size, big, sbox,
                        (const int *)todo0, todo2, misc, 0, final_, H, W, BFS_LDS_A, BFS_RING_A);
     SPA_HIP(hipEventRecord(ctx->ev_join[0], ctx->aux[0]));
