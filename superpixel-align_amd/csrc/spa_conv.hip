@@ -22,6 +22,17 @@
 // 32 channels (three half tiles in flight across raw barriers, counted vmcnt) was built, verified and
 // removed: 1 050 TFLOP/s — twice the barriers cost more than the extra loads in flight bought, i.e. the
 // limiter is the LDS-read + barrier phase in which the matrix pipe idles, not the memory side.
+// Round 2, same conclusion from the other side (tools/conv_bench.py, 512 -> 512, this kernel 1 064-1 091):
+//   * four waves of 128 x 128 (256 accumulator registers, one wave per SIMD, a third less LDS traffic per FLOP)
+//     with two fragment register sets and the step's barrier between its two half steps, so that no MFMA waits
+//     for an LDS round trip: 985-1 041 TFLOP/s; the same pipeline with eight waves spills (224 registers of
+//     accumulators + fragments): 910-925;
+//   * that four-wave loop with the global loads compiled out (timing only): 1 220-1 300 TFLOP/s without the
+//     pixel-tile loads, 1 115 without the weight loads — the LDS-read + MFMA loop on random operands tops out
+//     near 0.5 of the nominal peak (the chip lowers its clock under dense bf16 MFMA on random data:
+//     MI355X_MICROARCH.md, DVFS give-back), so this kernel is at ~0.85-0.9 of what the loop can deliver.
+//     What would remain is the pixel-tile traffic: one row segment with halo per (dy, k step) serving the three
+//     dx taps (a third less L2 -> LDS traffic).
 #include "spa_common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

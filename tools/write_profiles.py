@@ -12,7 +12,7 @@ import sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 go = os.path.join(root, 'gpurun_out')
 prof = os.path.join(root, 'profiles')
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r1_final'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r2_final'
 
 # ---- 1. kernel stats of the default bench
 stats = glob.glob(os.path.join(go, 'final_stats', '**', '*kernel_stats.csv'), recursive=True)[0]
@@ -65,8 +65,13 @@ px = 1024 * 2048
 alg = {'k_rgb2lab': 24 * px, 'k_slic_assign': 16 * px, 'k_slic_update': 16 * px, 'k_paint': 6 * px,
        'k_pool_mean': 512 * 128 * 256 * 4 + px * 4, 'k_cell_weights': 4 * px + 128 * 256 * 16,
        'k_conn_relabel': 12 * px, 'k_ccl_merge': 8 * px}
-wide = {'k_rgb2lab', 'k_slic_assign', 'k_paint', 'k_pool_mean', 'k_conn_relabel', 'k_cell_weights',
-        'k_ccl_init', 'k_ccl_flatten', 'k_bbox_count_lds', 'k_seg_moments'}      # 16 B/lane streaming reads
+wide = {'k_rgb2lab', 'k_slic_assign', 'k_paint', 'k_pool_mean', 'k_pool_mean_vec<0, 1>', 'k_conn_relabel',
+        'k_cell_weights', 'k_run_rows', 'k_bbox_count_lds', 'k_seg_moments'}      # 16 B/lane streaming reads
+families = {'connectivity(all)': ('k_run_', 'k_conn_', 'k_small_bbox'),
+            'segment_stats(all)': ('k_stats_', 'k_bbox_', 'k_seg_moments', 'k_offsets')}
+alias = {'k_pool_mean_vec<0, 1>': 'k_pool_mean', 'k_slic_update<4>': 'k_slic_update', 'k_kmeans<double, 2>': 'k_kmeans'}
+alg['connectivity(all)'] = 8 * px
+alg['segment_stats(all)'] = 4 * px
 lines = ['# HBM traffic per launch from PMC counters (%s), batch 8, 1024x2048, MI355X' % tag,
          'command (one pass per counter, as MI355X_MICROARCH.md prescribes):',
          '  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 tools/prof_stages.py --batch 8 --reps 2',
@@ -88,6 +93,21 @@ for k in sorted(fe):
     lines.append('%-22s %8d %11.1f%s %12.1f %12.1f %8s' % (name[:22], fe[k][0], f_mb, '*' if name in wide else ' ',
                                                           w_mb, tot, ('%.2fx' % (tot * 1e6 / (a * B))) if a else '-'))
     traffic[name] = tot * 1e6 / B
+    if name in alias:
+        traffic[alias[name]] = traffic[name]
+passes = fe.get('k_rgb2lab', (1, 0))[0]
+lines.append('')
+lines.append('families (all launches of one pass summed; %d passes profiled):' % passes)
+for fam, prefixes in families.items():
+    tot = 0.0
+    for k in fe:
+        name = k.replace('void ', '')
+        if name.startswith(prefixes):
+            f_mb = fe[k][1] * fe[k][0] * 1024 / 1e6 * (2 if name in wide else 1)
+            w_mb = wr.get(k, (0, 0.0))[1] * wr.get(k, (0, 0.0))[0] * 1024 / 1e6
+            tot += (f_mb + w_mb) / passes
+    lines.append('%-22s %8s %12s %12s %12.1f %8s' % (fam, '-', '', '', tot, '%.2fx' % (tot * 1e6 / (alg[fam] * B))))
+    traffic[fam] = tot * 1e6 / B
 lines.append('```')
 open(os.path.join(prof, tag + '_pmc_hbm_traffic_b8.md'), 'w').write('\n'.join(lines) + '\n')
 json.dump({'note': 'HBM bytes per launch PER IMAGE (1024x2048) from the PMC passes of ' + tag +
