@@ -1,6 +1,5 @@
-for V in NOW NOX "NOW -DCV_EXP_NOX"; do
-  (cd superpixel-align_amd/csrc && touch spa_conv.hip && make EXTRA="-DCV_EXP_$V" > /dev/null 2>&1)
-  echo "== variant $V" >> gpurun_out/r2_cv2.log
-  python3 tools/conv_bench.py 2>&1 | grep "B 30   512" >> gpurun_out/r2_cv2.log
-done
-cat gpurun_out/r2_cv2.log
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_baselines.py -q -m gpu -x -k "kmeans or baseline or direct or anchor_pipeline" 2>&1 | tail -3 > gpurun_out/r2_km.log
+python3 tools/km_bench.py 4600 514 2 2>&1 | grep "DIV  32" >> gpurun_out/r2_km.log
+python3 tools/km_bench.py 12000 514 2 2>&1 | grep "DIV  32" >> gpurun_out/r2_km.log
+python3 tools/km_bench.py 12000 514 4 2>&1 | grep "DIV  32" >> gpurun_out/r2_km.log
+cat gpurun_out/r2_km.log

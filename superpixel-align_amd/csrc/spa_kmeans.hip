@@ -286,7 +286,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_kmeans(const T *__restrict__ X, 
     // [0, k*D*8): centres (T) | then KM_CHUNK_BYTES shared by the chain buffer and the sweep scratch
     T *lds_c = (T *)lds_raw;
     unsigned char *scratch = lds_raw + (((size_t)k * D * sizeof(double) + 15) & ~(size_t)15);
-    double *chunk = (double *)scratch;                           // [KM_ROWS][64]
+    double *chunk = (double *)scratch;                           // [2][KM_ROWS][64]: two chain chunks
     __shared__ int scr[KM_WAVES + 4];
     __shared__ short tl_start[KM_MAXLEAF], tl_n[KM_MAXLEAF], tl_ops[2 * KM_MAXLEAF];
     __shared__ unsigned hist[256];
@@ -455,45 +455,55 @@ __global__ __launch_bounds__(KM_THREADS) void k_kmeans(const T *__restrict__ X, 
 #pragma unroll
                 for (int e = 0; e < KM_GROWS; ++e) {
                     const double v = (phase > 0) ? r[e] * rw[e] : r[e];
-                    chunk[(gw * KM_GROWS + e) * 64 + lane] = (colok && r0 + e < cnt) ? v : 0.0;
+                    chunk[((q & 1) * KM_ROWS + gw * KM_GROWS + e) * 64 + lane] = (colok && r0 + e < cnt) ? v : 0.0;
                 }
             };
             auto chain = [&](int q) {
                 if (wv != 0) return;
-                const int rows = min(KM_ROWS, cnt - q * KM_ROWS);
-                for (int r0 = 0; r0 < rows; r0 += 8) {
-                    double v[8];
+#ifdef SPA_KM_TIMING
+                const unsigned long long c0_ = __builtin_readcyclecounter();
+#endif
+                // all KM_ROWS rows, unconditionally: the rows past the member count hold +0.0 (store), and x + 0.0 = x
+                // (the running sum is never -0.0: it starts at +0.0).  Straight-line code: the LDS reads of the
+                // later rows are in flight while the dependent additions of the earlier rows issue.
+                const double *src = chunk + (q & 1) * KM_ROWS * 64 + lane;
+                double v[KM_ROWS];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = chunk[(r0 + e) * 64 + lane];
+                for (int e = 0; e < KM_ROWS; ++e) v[e] = src[e * 64];
+                if (f32 && phase == 0) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        if (r0 + e < rows) {
-                            if (f32 && phase == 0) accf = accf + (float)v[e];
-                            else accd = accd + v[e];
-                        }
-                    }
+                    for (int e = 0; e < KM_ROWS; ++e) accf = accf + (float)v[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < KM_ROWS; ++e) accd = accd + v[e];
                 }
+#ifdef SPA_KM_TIMING
+                kt_[7] += __builtin_readcyclecounter() - c0_;
+#endif
             };
+            // Two LDS chunk buffers: while wave 0 adds chunk q (56 dependent additions per column), the gather
+            // waves form the products of chunk q + 1 and write them to the other buffer, then issue the loads of
+            // chunk q + 3 into the register set they just emptied: one barrier per chunk, and the chain never
+            // waits for a store (it did, with one buffer: chain, barrier, store, barrier).  A third register set
+            // (three chunks of loads in flight) was measured: no gain, and it spills.
             if (nchunk > 0) {
                 fetch_list(0);
                 gather(0, ra, wa);
+                if (nchunk > 1) gather(1, rb, wb);
                 store(0, ra, wa);
-                if (nchunk > 1) gather(1, ra, wa);
+                if (nchunk > 2) gather(2, ra, wa);
                 km_lds_barrier();
                 for (int q = 0; q < nchunk; q += 2) {
-                    // LDS = chunk q, set a = chunk q+1
-                    if (q + 2 < nchunk) gather(q + 2, rb, wb);
+                    // buffer 0 = chunk q; set b = chunk q + 1, set a = chunk q + 2
+                    if (q + 1 < nchunk) store(q + 1, rb, wb);
+                    if (q + 3 < nchunk) gather(q + 3, rb, wb);
                     chain(q);
                     km_lds_barrier();
                     if (q + 1 >= nchunk) break;
-                    store(q + 1, ra, wa);
-                    km_lds_barrier();
-                    // LDS = chunk q+1, set b = chunk q+2
-                    if (q + 3 < nchunk) gather(q + 3, ra, wa);
+                    // buffer 1 = chunk q + 1; set a = chunk q + 2, set b = chunk q + 3
+                    if (q + 2 < nchunk) store(q + 2, ra, wa);
+                    if (q + 4 < nchunk) gather(q + 4, ra, wa);
                     chain(q + 1);
-                    km_lds_barrier();
-                    if (q + 2 >= nchunk) break;
-                    store(q + 2, rb, wb);
                     km_lds_barrier();
                 }
             }
@@ -630,7 +640,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_kmeans(const T *__restrict__ X, 
 #ifdef SPA_KM_TIMING
     if ((g == 0 || g == n_chain) && tid == 0)
         printf("kmeans cycles (workgroup %d): update %llu (of which member list %llu) | barrier %llu | centres %llu | sweep %llu | "
-               "barrier %llu ; iterations %d, G %u\n", g, kt_[0] + kt_[6], kt_[6], kt_[1], kt_[2], kt_[3], kt_[4], it, G);
+               "barrier %llu ; chain adds alone %llu ; iterations %d, G %u\n", g, kt_[0] + kt_[6], kt_[6], kt_[1], kt_[2], kt_[3], kt_[4], kt_[7], it, G);
 #endif
     if (g == 0 && tid == 0) { info[0] = it; info[1] = st; info[2] = N; info[3] = 0; }
 }
