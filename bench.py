@@ -93,6 +93,14 @@ LIMITERS = {
     'k_slic_assign': 'VALU issue: ~20 candidate centres per pixel x ~17 separately rounded float32 operations '
                      '(SQ_INSTS_VALU x 4 cycles / SIMD = the whole launch time)',
     'k_slic_update': 'serial float32 chains (6-cycle dependent add x pixels of the largest segment) + VALU issue',
+    'connectivity(all)': 'latency and issue, not bytes: run tables + strip-local union-find ~1.1 ms, then the BFS replays '
+                         '(exact scan-order semantics): a replay is a chain of ~1 100-cycle steps, one wave each; the tiers '
+                         'compete for LDS bytes x time and VALU issue (~1.1 ms), relabel 0.17 ms',
+    'k_kmeans': 'latency: numpy-ordered float64 sums (one serial chain per cluster and column, ~10 cycles per member row) and '
+                'two grid barriers per Lloyd iteration',
+    'k_rgb2lab': 'DP VALU: binary64 exp/log emulation of the float32 power and cube root (bit-defined transcendental)',
+    'k_conv3x3_bf16(all)': 'LDS-read + MFMA loop on random operands tops out at 1 220-1 300 TFLOP/s with the global loads '
+                           'compiled out (clock give-back under dense bf16 MFMA); pixel-tile loads cost the rest',
 }
 
 
@@ -425,8 +433,12 @@ def main():
         'host_to_host': h2h,
         'drn': {'bound': 'mfma', 'achieved': round(drn_tf, 2), 'peak': peak_tf, 'unit': 'TFLOP/s',
                 'frac': round(drn_tf / peak_tf, 4), 'ms_per_step': round(drn_ms, 3),
-                'note': 'the big convolutions are PyTorch-ROCm (MIOpen); libspalign adds the fused float32-MFMA stem of '
-                        'DRN-D (normalise + layer0 + layer1, k_drn_stem_d) and the bias/residual/ReLU epilogues'},
+                'note': ('bf16: the 256/512-channel dilated 3x3 layers (~80 % of the FLOPs) are libspalign\'s bf16 '
+                         'implicit-GEMM convolution with the bias/residual/ReLU epilogue fused (k_conv3x3_bf16, see '
+                         '`kernels`), the stem is its bf16-MFMA kernel; the light layers are PyTorch-ROCm (MIOpen)'
+                         if conv_flops > 0 else
+                         'the big convolutions are PyTorch-ROCm (MIOpen); libspalign adds the fused float32-MFMA stem '
+                         'of DRN-D (normalise + layer0 + layer1, k_drn_stem_d) and the bias/residual/ReLU epilogues')},
         'stage_ms_per_step': dict({k: round(v / a.steps, 3) for k, v in stage.items()},
                                   streams='two: superpixel branch overlaps the DRN forward' if overlap
                                   else 'one'),

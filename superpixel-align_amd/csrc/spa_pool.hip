@@ -362,10 +362,9 @@ __global__ __launch_bounds__(POOLV_THREADS) void k_pool_mean_vec(const void *__r
     __shared__ long long l_off[POOL_LIST];
     __shared__ float l_w[POOL_LIST];
     __shared__ int wave_cnt[2];
-    // Workgroups go to the XCDs round robin; segments g and g + 1 are neighbours in the image and share feature
-    // cells along their border: contiguous ranges of segments per XCD (whole images) let the second reader of a
-    // cell hit that XCD's L2 instead of fetching the line again.  gridDim.x is a multiple of 8.
-    const int g = (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    // (contiguous segment ranges per XCD — whole images per L2 — were measured: same FETCH_SIZE, 0.61 -> 0.84 ms;
+    // the round-robin order spreads every image over all XCDs and memory channels)
+    const int g = blockIdx.x;
     if (g >= offsets[B]) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nthr = blockDim.x;                 // 64 or 128: as many threads as one pass over the channels needs
@@ -520,7 +519,7 @@ extern "C" int spa_pool_mean(spa_ctx *ctx, const void *fmap, const spa_fmap_desc
         const int np = (d->C + nthr * vec - 1) / (nthr * vec);
         if (aligned && np <= 4) {
 #define POOLV_LAUNCH(DT, NP)                                                                                    \
-            hipLaunchKernelGGL((k_pool_mean_vec<DT, NP>), dim3((Ncap + 7) & ~7), dim3(nthr), 0, s, fmap, d->C, d->fh,            \
+            hipLaunchKernelGGL((k_pool_mean_vec<DT, NP>), dim3(Ncap), dim3(nthr), 0, s, fmap, d->C, d->fh,            \
                                d->fw, (long long)d->stride_b, (long long)d->stride_y, (long long)d->stride_x, B, H,  \
                                W, sampling, offsets, (const int32_t *)ctx->ws[WS_BBOX], count, cells, centroid,      \
                                append_pos, X, x_dtype, (long long)ld)

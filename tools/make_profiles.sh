@@ -1,9 +1,11 @@
 #!/bin/bash
 # Refresh the judged profiles (run on the GPU box from the repo root):
-#   1. rocprofv3 --kernel-trace --stats of the default bench  -> gpurun_out/final_stats/
-#   2. the default bench line itself                           -> gpurun_out/final_bench_line.json
+#   1. the default bench line                                   -> gpurun_out/final_bench_line.json
+#   2. rocprofv3 --kernel-trace --stats of the default bench    -> gpurun_out/final_stats/
 #   3. HBM traffic PMC passes (FETCH_SIZE, WRITE_SIZE; separate passes) over tools/prof_stages.py
-cd /tmp && export TMPDIR=/tmp
+#   4. the other operating points (one JSON line each)          -> gpurun_out/final_variant_*.json
+# then, in the build container:  python tools/write_profiles.py r2_final
+export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/final_stats gpurun_out/final_pmc_*
 python3 bench.py > gpurun_out/final_bench_line.json 2> gpurun_out/final_bench.err
@@ -13,3 +15,15 @@ for P in FETCH_SIZE WRITE_SIZE; do
 done
 python3 tools/pmc_summary.py gpurun_out/final_pmc_FETCH_SIZE > gpurun_out/final_pmc_fetch.txt
 python3 tools/pmc_summary.py gpurun_out/final_pmc_WRITE_SIZE > gpurun_out/final_pmc_write.txt
+rm -rf gpurun_out/final_pmc_FETCH_SIZE gpurun_out/final_pmc_WRITE_SIZE          # raw counter dumps: tens of MB
+v() { name=$1; shift; python3 bench.py --no_cpu_baseline "$@" 2> gpurun_out/final_variant_$name.err | tail -1 > gpurun_out/final_variant_$name.json; }
+v bf16 --dtype bf16
+v cfg5 --dtype bf16 --n_slic_segments 400
+v cfg5_overlap --dtype bf16 --n_slic_segments 400 --overlap
+v overlap --overlap
+v anchor --pool_mode anchor
+v anchor_bf16 --pool_mode anchor --dtype bf16
+v anchor_bf16_device_rng --pool_mode anchor --dtype bf16 --device_rng
+v integer_images --integer_images
+v reference_operating_point --superpixel_method felzenszwalb --height 224 --width 224 --arch drn_c_26 --pool_mode anchor --n_clusters 4
+ls -la gpurun_out | tail -20

@@ -83,9 +83,9 @@ lines = ['# HBM traffic per launch from PMC counters (%s), batch 8, 1024x2048, M
          '```', '%-22s %8s %12s %12s %12s %8s' % ('kernel', 'launches', 'FETCH MB', 'WRITE MB', 'HBM MB', 'vs alg')]
 traffic = {}
 for k in sorted(fe):
-    if not k.startswith('k_') and 'k_kmeans' not in k:
-        continue
     name = k.replace('void ', '')
+    if not name.startswith('k_'):
+        continue
     f_mb = fe[k][1] * 1024 / 1e6 * (2 if name in wide else 1)
     w_mb = wr.get(k, (0, 0.0))[1] * 1024 / 1e6
     tot = f_mb + w_mb
