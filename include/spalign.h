@@ -154,6 +154,17 @@ int spa_enforce_connectivity(spa_ctx *ctx, const int32_t *labels_in, int32_t B, 
                              int32_t W, int32_t min_size, int32_t max_size,
                              int32_t *labels_out, int32_t *n_labels, void *stream);
 
+/* ---- the float64 instantiation: superpixel_overlaps.py:301-304 calls slic(uint8 image, n_segments), and
+ * scikit-image then runs rgb2lab and _slic_cython in float64 (slic_superpixels.py: dtype = image.dtype).
+ * rgb (B,3,H,W) float32 holding the uint8 values 0..255 (anything else latches SPA_ST_LABEL_RANGE).      */
+int spa_rgb2lab_u8_f64(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t W, double ratio,
+                       double *lab, void *stream);            /* lab (B,3,H,W) float64 planar, x ratio */
+int spa_slic_core_f64(spa_ctx *ctx, const double *lab, int32_t B, int32_t H, int32_t W,
+                      int32_t n_segments, int32_t max_iter, int32_t *labels, double *centres,
+                      void *stream);                          /* centres (B, n_centroids, 6) float64 or NULL */
+int spa_slic_u8(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t W, int32_t n_segments,
+                double compactness, int32_t max_iter, int32_t *labels, int32_t *n_labels, void *stream);
+
 /* whole slic() call: rgb -> labels (B,H,W) int32 contiguous ids 0..n_labels[b]-1.         */
 int spa_slic(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t W,
              int32_t n_segments, float compactness, int32_t max_iter,

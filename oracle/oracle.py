@@ -48,6 +48,12 @@ def lib():
         L.orc_rgb2lab_scaled.argtypes = [_P, _i64, _i64, ctypes.c_float, _P]
         L.orc_slic.restype = _i64
         L.orc_slic.argtypes = [_P, _i64, _i64, _i64, _dbl, _i64, _P]
+        L.orc_slic_core_f64.restype = _i64
+        L.orc_slic_core_f64.argtypes = [_P, _i64, _i64, _i64, _i64, _P, _P, _i64]
+        L.orc_rgb2lab_u8_f64.restype = None
+        L.orc_rgb2lab_u8_f64.argtypes = [_P, _i64, _i64, _dbl, _P]
+        L.orc_slic_u8.restype = _i64
+        L.orc_slic_u8.argtypes = [_P, _i64, _i64, _i64, _dbl, _i64, _P]
         L.orc_segment_stats.restype = None
         L.orc_segment_stats.argtypes = [_P, _i64, _i64, _i64, _P, _P, _P]
         L.orc_create_prior.restype = None
@@ -134,6 +140,40 @@ def slic(img_chw, n_segments, compactness=10.0, max_iter=10):
     n = lib().orc_slic(img.ctypes.data, H, W, n_segments, compactness, max_iter, out.ctypes.data)
     if n < 0:
         raise RuntimeError('orc_slic failed: %d' % n)
+    return out
+
+
+def rgb2lab_u8_f64(img_chw_u8, compactness=10.0):
+    """rgb2lab(img_as_float(uint8 image)) * (1/compactness) in float64, as slic() computes it for the uint8
+    input of superpixel_overlaps.py:303; (3,H,W) u8 -> (H,W,3) f64."""
+    img = _c(img_chw_u8, np.uint8)
+    _, H, W = img.shape
+    out = np.empty((H, W, 3), np.float64)
+    lib().orc_rgb2lab_u8_f64(img.ctypes.data, H, W, 1.0 / compactness, out.ctypes.data)
+    return out
+
+
+def slic_core_f64(lab_hwc, n_segments, max_iter=10):
+    """_slic_cython[double] on a given (already scaled) float64 Lab image -> (labels (H,W), centres (n,6))."""
+    lab = _c(lab_hwc, np.float64)
+    H, W, _ = lab.shape
+    labels = np.empty((H, W), np.int64)
+    cen = np.zeros((max(8, 4 * n_segments + 64), 6), np.float64)
+    n = lib().orc_slic_core_f64(lab.ctypes.data, H, W, n_segments, max_iter,
+                                labels.ctypes.data, cen.ctypes.data, cen.shape[0])
+    if n <= 0:
+        raise RuntimeError('orc_slic_core_f64 failed: %d' % n)
+    return labels, cen[:n].copy()
+
+
+def slic_u8(img_chw_u8, n_segments, compactness=10.0, max_iter=10):
+    """slic(img.transpose(1,2,0), n_segments) on a uint8 image as superpixel_overlaps.py:303 calls it."""
+    img = _c(img_chw_u8, np.uint8)
+    _, H, W = img.shape
+    out = np.empty((H, W), np.int64)
+    n = lib().orc_slic_u8(img.ctypes.data, H, W, n_segments, compactness, max_iter, out.ctypes.data)
+    if n < 0:
+        raise RuntimeError('orc_slic_u8 failed: %d' % n)
     return out
 
 

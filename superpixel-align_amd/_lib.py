@@ -70,6 +70,9 @@ PROTOTYPES = {
                                                 c_p, c_p]),
     'spa_slic': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, c_p, c_p, c_p]),
     'spa_felzenszwalb': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_f64, c_f64, c_i32, c_p, c_p, c_p]),
+    'spa_rgb2lab_u8_f64': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_f64, c_p, c_p]),
+    'spa_slic_core_f64': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_p]),
+    'spa_slic_u8': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_f64, c_i32, c_p, c_p, c_p]),
     'spa_felzenszwalb_u8': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_f64, c_f64, c_i32, c_p, c_p, c_p]),
     'spa_overlap_refine': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i64, c_i32, c_f64, c_p, c_p]),
     'spa_segment_offsets':(ctypes.c_int, [c_p, c_p, c_i32, c_p, c_p]),

@@ -109,9 +109,8 @@ class SuperpixelOverlaps(DirectClustering):
         if a.superpixel_method == 'felzenszwalb':
             return eng.felzenszwalb(rgb, a.felzenszwalb_scale, a.felzenszwalb_sigma, a.felzenszwalb_min_size,
                                     uint8_image=True)
-        # skimage runs its float64 SLIC core on a uint8 image; libspalign's SLIC is the float32 core
-        raise ValueError('superpixel_overlaps with --superpixel_method slic needs the float64 SLIC core '
-                         '(uint8 input): not built; use felzenszwalb (the script default)')
+        # scikit-image runs its float64 SLIC core on a uint8 image (superpixel_overlaps.py:301-304)
+        return eng.slic_u8(rgb, a.n_slic_segments)
 
     def refine(self, road, labels, n_labels):
         """road (n,h,w) u8 at map size, labels (n,H,W): nearest-neighbour resize of the mask to the

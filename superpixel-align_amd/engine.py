@@ -193,6 +193,38 @@ class Engine(object):
                                  _ptr(labels), _ptr(n_labels), self._s()))
         return labels, n_labels
 
+    def slic_u8(self, rgb, n_segments, compactness=10.0, max_iter=10):
+        """slic(uint8 image, n_segments) as superpixel_overlaps.py:303 calls it: scikit-image's float64 core.
+        rgb (B,3,H,W) f32 holding the uint8 values -> labels (B,H,W) i32, n_labels (B)."""
+        rgb = _req(rgb, torch.float32, 'rgb')
+        B, C, H, W = rgb.shape
+        assert C == 3
+        labels = torch.empty((B, H, W), dtype=torch.int32, device=rgb.device)
+        n_labels = torch.empty((B,), dtype=torch.int32, device=rgb.device)
+        check(self._lib.spa_slic_u8(self._ctx, _ptr(rgb), B, H, W, n_segments, float(compactness), max_iter,
+                                    _ptr(labels), _ptr(n_labels), self._s()))
+        return labels, n_labels
+
+    def rgb2lab_u8_f64(self, rgb, compactness=10.0):
+        """rgb2lab(img_as_float(uint8 image)) * (1/compactness), float64 planar (B,3,H,W)."""
+        rgb = _req(rgb, torch.float32, 'rgb')
+        B, C, H, W = rgb.shape
+        lab = torch.empty((B, 3, H, W), dtype=torch.float64, device=rgb.device)
+        check(self._lib.spa_rgb2lab_u8_f64(self._ctx, _ptr(rgb), B, H, W, 1.0 / float(compactness), _ptr(lab), self._s()))
+        return lab
+
+    def slic_core_f64(self, lab, n_segments, max_iter=10, want_centres=False):
+        """_slic_cython[double] on a scaled float64 Lab image (B,3,H,W) -> labels (B,H,W) i32 [, centres (B,nC,6)]."""
+        lab = _req(lab, torch.float64, 'lab')
+        B, C, H, W = lab.shape
+        labels = torch.empty((B, H, W), dtype=torch.int32, device=lab.device)
+        cen = None
+        if want_centres:
+            cen = torch.empty((B, _lib.make_plan(H, W, n_segments).n_centroids, 6), dtype=torch.float64, device=lab.device)
+        check(self._lib.spa_slic_core_f64(self._ctx, _ptr(lab), B, H, W, n_segments, max_iter, _ptr(labels),
+                                          _ptr(cen), self._s()))
+        return (labels, cen) if want_centres else labels
+
     def felzenszwalb(self, rgb, scale=300.0, sigma=0.8, min_size=20, uint8_image=False):
         """felzenszwalb(img/255, scale, sigma, min_size) for a batch -> labels (B,H,W) i32, n_labels (B).
         uint8_image: the reference passed a uint8 image, so /255. happens in float64

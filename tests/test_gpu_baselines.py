@@ -22,10 +22,12 @@ def eng():
     e.close()
 
 
-def _args(k, thr=0.01):
-    return types.SimpleNamespace(n_clusters=k, y_rel_pos=0.75, x_rel_pos=0.5, y_rel_sigma=0.1, x_rel_sigma=0.1,
-                                 use_feature_maps=[7], superpixel_method='felzenszwalb', felzenszwalb_scale=500.0,
-                                 felzenszwalb_sigma=0.9, felzenszwalb_min_size=20, overlap_threshold=thr)
+def _args(k, thr=0.01, **kw):
+    a = types.SimpleNamespace(n_clusters=k, y_rel_pos=0.75, x_rel_pos=0.5, y_rel_sigma=0.1, x_rel_sigma=0.1,
+                              use_feature_maps=[7], superpixel_method='felzenszwalb', felzenszwalb_scale=500.0,
+                              felzenszwalb_sigma=0.9, felzenszwalb_min_size=20, overlap_threshold=thr)
+    a.__dict__.update(kw)
+    return a
 
 
 def _fmap(g):
@@ -102,6 +104,21 @@ def test_superpixel_overlaps_pipeline(eng, orc):
     for i in range(len(refined)):
         osp = orc.felzenszwalb_u8(g['imgs'][i], 500.0, 0.9, 20)
         assert np.array_equal(refined[i], orc.overlap_refine(oroad[i], osp, 0.05))
+
+
+def test_superpixel_overlaps_with_slic_matches_reference_outputs(eng, orc):
+    """--superpixel_method slic of superpixel_overlaps.py (:301-304): the uint8 image goes through scikit-image's
+    float64 SLIC.  Superpixels and refined masks of the reference's own run (fixture) are reproduced exactly."""
+    g = golden('baseline_so_slic_k2')
+    so = baselines.SuperpixelOverlaps(_args(int(g['k']), float(g['thr']), superpixel_method='slic', n_slic_segments=20),
+                                      model=None, eng=eng, nprandom=engine_mod.NpRandom(1111))
+    labels, n_labels = so.superpixels(g['imgs'])
+    eng.raise_on_status()
+    assert np.array_equal(labels.cpu().numpy().astype(np.int64), g['superpixels'])
+    cl, _ = so.cluster(_fmap(g))
+    assert np.array_equal(cl.cpu().numpy().astype(np.int64), g['cluster'])
+    refined = so.refine((cl == 0).to(torch.uint8), labels, n_labels).cpu().numpy()
+    assert np.array_equal(refined, g['refined'])
 
 
 def test_baseline_drivers_on_synthetic_pngs(orc, synth, tmp_path):

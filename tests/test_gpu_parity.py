@@ -6,12 +6,14 @@ Bar: bit exact for every integer output (labels, counts, assignments, masks, con
 for the float32 stages whose arithmetic order is pinned (Lab image, SLIC centroids, anchor
 and mean pooling); 1e-12 relative for the float64 prior (different summation order).
 """
+import glob
 import importlib
+import os
 
 import numpy as np
 import pytest
 
-from conftest import golden, kmeans_tie_cases
+from conftest import GOLDEN, golden, kmeans_tie_cases
 
 pytestmark = pytest.mark.gpu
 
@@ -260,6 +262,44 @@ def test_slic_starved_seeds(eng, orc, name):
     assert int(n_labels[0]) == int(g['post'].max()) + 1
     eng.raise_on_status()
     assert eng.last_info & 0x01
+
+
+SLIC64 = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 'slic64_*.npz')))
+
+
+@pytest.mark.parametrize('name', SLIC64)
+def test_slic_float64_on_uint8_images(eng, orc, name):
+    """superpixel_overlaps.py:303: slic(uint8 image, n) = scikit-image's float64 core.  Lab bit-equal to the
+    restatement, core labels and float64 centres bit-equal to the compiled core's (fixtures), and the whole call
+    identical to the untouched scikit-image call."""
+    g = golden(name)
+    seed, H, W, n, nC, mn, mx = (int(v) for v in g['meta'])
+    rgb = dev(g['img'].astype(np.float32)[None])
+    lab = eng.rgb2lab_u8_f64(rgb)
+    assert np.array_equal(lab[0].cpu().numpy().transpose(1, 2, 0), orc.rgb2lab_u8_f64(g['img']))
+    labels, cen = eng.slic_core_f64(lab, n, want_centres=True)
+    assert np.array_equal(labels[0].cpu().numpy(), g['pre'].astype(np.int32))
+    assert np.array_equal(cen[0].cpu().numpy(), g['centres'], equal_nan=True)
+    full, n_labels = eng.slic_u8(rgb, n)
+    assert np.array_equal(full[0].cpu().numpy(), g['e2e_skimage'].astype(np.int32))
+    assert int(n_labels[0]) == int(g['e2e_skimage'].max()) + 1
+    eng.raise_on_status()
+
+
+def test_slic_float64_batch_vs_oracle(eng, orc):
+    """a batch of larger uint8 images against the restatement (which is identical to scikit-image on the fixtures)"""
+    rs = np.random.RandomState(7)
+    B, H, W, n = 3, 192, 416, 150
+    imgs = np.zeros((B, 3, H, W), np.uint8)
+    for b in range(B):
+        low = rs.randint(0, 256, (3, H // 16 + 1, W // 16 + 1)).repeat(16, 1).repeat(16, 2)[:, :H, :W]
+        imgs[b] = np.clip(low + rs.normal(0, 9, (3, H, W)), 0, 255).astype(np.uint8)
+    full, n_labels = eng.slic_u8(dev(imgs.astype(np.float32)), n)
+    for b in range(B):
+        ref = orc.slic_u8(imgs[b], n)
+        assert np.array_equal(full[b].cpu().numpy(), ref.astype(np.int32))
+        assert int(n_labels[b]) == int(ref.max()) + 1
+    eng.raise_on_status()
 
 
 def test_device_anchor_selection_is_cpython_shuffle(spa, orc):

@@ -94,6 +94,34 @@ def test_slic_starved_seeds_follow_skimage(orc, name):
     assert np.array_equal(post, g['post'].astype(np.int64))
 
 
+SLIC64_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 'slic64_*.npz')))
+
+
+@pytest.mark.parametrize('name', SLIC64_CASES)
+def test_slic_float64_on_uint8_images(orc, name):
+    """superpixel_overlaps.py:303: slic(uint8 image, n) runs scikit-image's float64 core.  Core and
+    connectivity bit exact given the Lab image; Lab within 1e-12 of scikit-image's (its float64 power / cbrt
+    are not reproducible bit for bit); the untouched call is identical on every fixture."""
+    g = golden(name)
+    seed, H, W, n, nC, mn, mx = (int(v) for v in g['meta'])
+    lab = orc.rgb2lab_u8_f64(g['img'])
+    assert np.abs(lab - g['lab_skimage']).max() < 1e-12
+    pre, centres = orc.slic_core_f64(lab, n)
+    assert centres.shape[0] == nC
+    assert np.array_equal(pre, g['pre'].astype(np.int64))
+    assert np.array_equal(centres, g['centres'], equal_nan=True)      # NaN rows: seeds that lost all pixels
+    post, _ = orc.enforce_connectivity(pre, mn, mx)
+    assert np.array_equal(post, g['post'].astype(np.int64))
+    assert np.array_equal(orc.slic_u8(g['img'], n), g['e2e_skimage'].astype(np.int64))
+
+
+def test_slic_uint8_matches_the_reference_baseline_run(orc):
+    """superpixels of the reference's own superpixel_overlaps.batch_superpixel(slic) on uint8 images"""
+    g = golden('baseline_so_slic_k2')
+    for img, sp in zip(g['imgs'], g['superpixels']):
+        assert np.array_equal(orc.slic_u8(img, 20), sp)
+
+
 def test_lab_within_tolerance_of_skimage(orc, synth):
     g = golden('slic_s0_64x128_n20')
     lab = orc.rgb2lab_scaled(synth.synth_image(0, 64, 128))

@@ -39,9 +39,12 @@ B = a.batch
 small = torch.from_numpy(np.stack([spa.synth.synth_image(i, 224, 224) for i in range(B)])).cuda()
 orig = torch.from_numpy(np.stack([np.clip(spa.synth.synth_image(i, a.orig[0], a.orig[1]), 0, 255).astype(np.uint8)
                                   for i in range(B)])).cuda()
-for name, cls in (('direct_clustering', baselines.DirectClustering), ('superpixel_overlaps', baselines.SuperpixelOverlaps)):
+for name, cls in (('direct_clustering', baselines.DirectClustering), ('superpixel_overlaps', baselines.SuperpixelOverlaps),
+                  ('superpixel_overlaps_slic', baselines.SuperpixelOverlaps)):
+    if name == 'superpixel_overlaps_slic':
+        args = types.SimpleNamespace(**dict(args.__dict__, superpixel_method='slic', n_slic_segments=100))
     pipe = cls(args, model, eng, engine.NpRandom(1111))
-    run = (lambda: pipe.run(small, orig)) if name == 'superpixel_overlaps' else (lambda: pipe.run(small))
+    run = (lambda: pipe.run(small, orig)) if name.startswith('superpixel_overlaps') else (lambda: pipe.run(small))
     stages = {}
     for i in range(a.warmup + a.steps):
         if i == a.warmup:
@@ -58,8 +61,9 @@ for name, cls in (('direct_clustering', baselines.DirectClustering), ('superpixe
                       'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 2),
                       'config': {'workload': '%s: drn_c_26 fp32 on 224x224, weighted k-means (k=4) over %d feature '
                                              'pixels x 514 dims%s' % (name, B * 28 * 28,
-                                                                      ', felzenszwalb(500,0.9,20) of the %dx%d uint8 originals + overlap refinement'
-                                                                      % tuple(a.orig) if name == 'superpixel_overlaps' else ''),
+                                                                      ', %s of the %dx%d uint8 originals + overlap refinement'
+                                                                      % (('float64 slic(n=100)' if name.endswith('slic') else 'felzenszwalb(500,0.9,20)',) + tuple(a.orig))
+                                                                      if name.startswith('superpixel_overlaps') else ''),
                                  'images_per_step': B},
                       'stage_ms_per_step': {k2: round(v / a.steps * 1e3, 2) for k2, v in stages.items()},
                       'kmeans_iterations': int(info[0]), 'data': 'synthetic', 'dtype': 'f32'}), flush=True)
