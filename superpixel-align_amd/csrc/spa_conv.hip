@@ -43,29 +43,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CV_BK 64             // K step (input channels of one tap)
 #define CV_THREADS 512
 #define CV_TILE_BYTES (256 * CV_BK * 2)          // one operand tile: 32 KB
+#define CV_HALO 4                                // pixels either side of the 256-pixel segment: dilation <= 4
+#define CV_XSEG_BYTES ((256 + 2 * CV_HALO) * CV_BK * 2)   // 33 row blocks of 8 pixels
 
 __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f)
 {
     __bf16 h = (__bf16)f;                          // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
     return __builtin_bit_cast(unsigned short, h);
-}
-
-// one K step into LDS: 4 weight-row groups + 4 pixel-row groups of 8 rows per wave (1 KB per instruction)
-__device__ __forceinline__ void cv_stage(char *lds_w, char *lds_x, const char *wrow[4], const char *xrow[4],
-                                         int chunk_byte[4], long long koff_w, long long koff_x, int wave)
-{
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int rowblk = r * 8 + wave;                   // 8 rows = 1 KB
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wrow[r] + koff_w + chunk_byte[r]),
-                                         (__attribute__((address_space(3))) void *)(lds_w + rowblk * 1024), 16, 0, 0);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int rowblk = r * 8 + wave;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xrow[r] + koff_x + chunk_byte[r]),
-                                         (__attribute__((address_space(3))) void *)(lds_x + rowblk * 1024), 16, 0, 0);
-    }
 }
 
 template <int HAS_RES>
@@ -76,7 +60,7 @@ __global__ __launch_bounds__(CV_THREADS) void k_conv3x3_bf16(const __bf16 *__res
                                                              int Cin, int Cout, int dil, int relu, int xtiles,
                                                              int ntiles, int total_tiles)
 {
-    extern __shared__ __attribute__((aligned(1024))) char lds[];     // [2][weights 32 KB | pixels 32 KB]
+    extern __shared__ __attribute__((aligned(1024))) char lds[];     // [2] weight tiles 32 KB | [2] pixel segments 33 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-aware tile order: consecutive workgroup ids go round-robin over the 8 XCDs; give every XCD a
     // contiguous range of tiles (neighbouring rows of one image share two of their three input rows in L2)
@@ -89,41 +73,52 @@ __global__ __launch_bounds__(CV_THREADS) void k_conv3x3_bf16(const __bf16 *__res
     // tile id -> (pixel tile, channel tile): the channel tiles of one pixel tile are adjacent
     const int nt = id % ntiles, pt = id / ntiles;
     const int xt = pt % xtiles, row_id = pt / xtiles;               // row_id = b * H + y
-    const int y = row_id % H, b = row_id / H;
+    const int y = row_id % H;
     const int x0 = xt * CV_BN, n0 = nt * CV_BM;
 
-    // ---- staging addresses of this thread: rows (r*8 + wave)*8 + lane/8 of both tiles, 16-byte chunk lane%8
+    // K order: (dy, 64-channel step, dx).  The three dx taps of one (dy, k step) read the SAME input pixels
+    // shifted by the dilation: one row segment of 256 + 2*CV_HALO pixels is staged per (dy, k step) — a third
+    // of it with each of the previous group's three K steps — and the taps read it at a row offset.  A K step
+    // thus moves 32 KB of weights + 11 KB of pixels instead of 32 + 32.
+    char *wbuf = lds, *xbuf = lds + 2 * CV_TILE_BYTES;
     const int sub = lane >> 3, cs = lane & 7;
-    const char *wrow[4], *xrow_c[4];
-    int chunk_byte[4], px[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = (r * 8 + wave) * 8 + sub;
-        chunk_byte[r] = ((cs ^ (row & 7)) << 4);
-        wrow[r] = (const char *)(Wt + (long long)(n0 + row) * 9 * Cin);
-        px[r] = x0 + row;
-        xrow_c[r] = (const char *)(X + ((long long)row_id * W + px[r]) * Cin);     // centre tap
-    }
-    const int ksteps_per_tap = Cin / CV_BK;
-    const int nk = 9 * ksteps_per_tap;
+    const int chunk_byte = (cs ^ sub) << 4;        // staged row = block * 8 + sub: (row & 7) = sub for every block
+    const char *wbase = (const char *)(Wt + (long long)n0 * 9 * Cin);
+    const char *xbase = (const char *)(X + (long long)row_id * W * Cin);      // input row y, pixel 0
+    const int ks = Cin / CV_BK;
+    const int nk = 9 * ks, ngroups = 3 * ks;
 
-    auto stage = [&](int t, int buf) {
-        const int tap = t / ksteps_per_tap, kc = t - tap * ksteps_per_tap;
-        const int dy = (tap / 3 - 1) * dil, dx = (tap % 3 - 1) * dil;
-        const int yy = y + dy;
-        const bool yok = yy >= 0 && yy < H;
-        const long long shift = ((long long)dy * W + dx) * Cin * 2;
-        const char *xrow[4];
-        long long koff_x = (long long)kc * CV_BK * 2;
+    auto stage_w = [&](int t, int buf) {
+        const int g = t / 3, dxi = t - g * 3;
+        const int dyi = g / ks, kc = g - dyi * ks;
+        const char *wk = wbase + ((long long)(dyi * 3 + dxi) * Cin + (long long)kc * CV_BK) * 2 + chunk_byte;
+        char *dst = wbuf + buf * CV_TILE_BYTES;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int xx = px[r] + dx;
-            const bool ok = yok && xx >= 0 && xx < W && px[r] < W;
-            // a zero line for padding pixels (its 128 bytes are read at offset chunk_byte only)
-            xrow[r] = ok ? xrow_c[r] + shift + koff_x : zero_line;
+            const int blk = r * 8 + wave;                       // 8 rows = 1 KB per instruction
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wk + (long long)(blk * 8 + sub) * 9 * Cin * 2),
+                                             (__attribute__((address_space(3))) void *)(dst + blk * 1024), 16, 0, 0);
         }
-        cv_stage(lds + buf * 2 * CV_TILE_BYTES, lds + buf * 2 * CV_TILE_BYTES + CV_TILE_BYTES, wrow, xrow, chunk_byte,
-                 ((long long)tap * Cin + (long long)kc * CV_BK) * 2, 0, wave);
+    };
+    // one third (11 of 33 row blocks) of the pixel segment of group g
+    auto stage_x = [&](int g, int third) {
+        const int dyi = g / ks, kc = g - dyi * ks;
+        const int yy = y + (dyi - 1) * dil;
+        const bool yok = yy >= 0 && yy < H;
+        const char *xk = xbase + ((long long)(dyi - 1) * dil * W) * Cin * 2 + (long long)kc * CV_BK * 2 + chunk_byte;
+        char *dst = xbuf + (g & 1) * CV_XSEG_BYTES;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int i = r * 8 + wave;
+            if (i >= 11) break;
+            const int blk = third * 11 + i;
+            const int px = x0 - CV_HALO + blk * 8 + sub;
+            const bool ok = yok && px >= 0 && px < W;
+            // a zero line for padding pixels (its 128 bytes are read at the chunk offset only)
+            const char *src = ok ? xk + (long long)px * Cin * 2 : zero_line + chunk_byte;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(dst + blk * 1024), 16, 0, 0);
+        }
     };
 
     // ---- accumulators: wave (wm, wn) owns channels [wm*128, +128) x pixels [wn*64, +64)
@@ -135,15 +130,19 @@ __global__ __launch_bounds__(CV_THREADS) void k_conv3x3_bf16(const __bf16 *__res
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int frow = lane & 15, fk = lane >> 4;                     // fragment row, 16-byte k chunk inside a 32-k step
 
-    stage(0, 0);
+    stage_w(0, 0);
+    stage_x(0, 0); stage_x(0, 1); stage_x(0, 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int t = 0; t < nk; ++t) {
         const int cur = t & 1;
-        // (the eight loads of the next K step go out in one burst: spreading them between the MFMA groups
-        // was measured 20 % slower — every global_load_lds re-programs M0 and breaks the MFMA stream)
-        if (t + 1 < nk) stage(t + 1, cur ^ 1);
-        const char *lw = lds + cur * 2 * CV_TILE_BYTES, *lx = lw + CV_TILE_BYTES;
+        const int g = t / 3, dxi = t - g * 3;
+        // (the loads of the next K step go out in one burst: spreading them between the MFMA groups was
+        // measured 20 % slower — every global_load_lds re-programs M0 and breaks the MFMA stream)
+        if (t + 1 < nk) stage_w(t + 1, cur ^ 1);
+        if (g + 1 < ngroups) stage_x(g + 1, dxi);
+        const char *lw = wbuf + cur * CV_TILE_BYTES, *lx = xbuf + (g & 1) * CV_XSEG_BYTES;
+        const int xshift = CV_HALO + (dxi - 1) * dil + wn * 64 + frow;      // segment row of fragment 0
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 wf[8], pf[4];
@@ -155,7 +154,7 @@ __global__ __launch_bounds__(CV_THREADS) void k_conv3x3_bf16(const __bf16 *__res
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int row = wn * 64 + j * 16 + frow;
+                const int row = xshift + j * 16;
                 pf[j] = *(const bf16x8 *)(lx + row * 128 + ((chunk ^ (row & 7)) << 4));
             }
 #pragma unroll
@@ -200,7 +199,7 @@ extern "C" int spa_conv3x3_bf16(spa_ctx *ctx, const void *x, int32_t B, int32_t 
                                 int32_t relu, int32_t dilation, void *y, void *stream)
 {
     SPA_ARG(ctx && x && wt && bias && y && B > 0 && H > 0 && W > 0 && dilation >= 1);
-    SPA_ARG(Cin % CV_BK == 0 && Cout % CV_BM == 0);
+    SPA_ARG(Cin % CV_BK == 0 && Cout % CV_BM == 0 && dilation <= CV_HALO);
     SPA_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)wt % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)bias % 16) == 0);
     hipStream_t s = spa_stream(stream);
     char *zero;
@@ -213,7 +212,7 @@ extern "C" int spa_conv3x3_bf16(spa_ctx *ctx, const void *x, int32_t B, int32_t 
     const int xtiles = (W + CV_BN - 1) / CV_BN, ntiles = Cout / CV_BM;
     const long long total = (long long)B * H * xtiles * ntiles;
     SPA_ARG(total < (1ll << 31));
-    const size_t lds = 4 * (size_t)CV_TILE_BYTES;
+    const size_t lds = 2 * (size_t)CV_TILE_BYTES + 2 * (size_t)CV_XSEG_BYTES;
     if (!ctx->conv_attr_done) {
         SPA_HIP(hipFuncSetAttribute((const void *)k_conv3x3_bf16<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         SPA_HIP(hipFuncSetAttribute((const void *)k_conv3x3_bf16<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
