@@ -8,31 +8,32 @@
 // (Cout, 9, Cin), float32 accumulation on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16).
 //
 // Mapping: GEMM with M = Cout (weights are the MFMA A operand), N = pixels, K = 9 * Cin.  A workgroup
-// (8 waves) owns 256 output channels x 256 consecutive pixels of one image row; the K loop walks the nine
-// taps and, inside a tap, the input channels 64 at a time: the pixel operand of a K step is 256 rows of
-// 128 contiguous bytes (the same pixels shifted by the tap), i.e. exactly a row-major GEMM tile, fetched
-// straight into LDS by 16-byte global_load_lds (pixels outside the image read a zero line).  Both LDS tiles
-// are [256 rows][64 k] with the 16-byte chunks of a row XOR-swizzled by (row & 7) on the SOURCE address
-// (the LDS image of a wave's load is lane-linear), which makes the ds_read_b128 fragment reads of the
-// 16x16x32 MFMA conflict-free.  Two LDS buffers: the loads of K step t+1 are issued before the MFMAs of
-// step t.  The accumulator tile of a lane is four consecutive output channels of one pixel, so the epilogue
-// stores 8 contiguous bytes per lane and tile.
-// Measured (30 x 128 x 256 pixels, 512 -> 512, sustained, random operands): 1 140-1 150 TFLOP/s = 0.46 of the
-// dense bf16 peak; MIOpen's kernel for the same layer 1 070-1 090.  A four-buffer variant in half steps of
-// 32 channels (three half tiles in flight across raw barriers, counted vmcnt) was built, verified and
-// removed: 1 050 TFLOP/s — twice the barriers cost more than the extra loads in flight bought, i.e. the
-// limiter is the LDS-read + barrier phase in which the matrix pipe idles, not the memory side.
-// Round 2, same conclusion from the other side (tools/conv_bench.py, 512 -> 512, this kernel 1 064-1 091):
+// (8 waves) owns 256 output channels x 256 consecutive pixels of one image row.  The K loop runs in the order
+// (dy, 64 input channels, dx): the three dx taps of one (dy, channel step) read the SAME input pixels shifted by
+// the dilation, so ONE row segment of 256 + 2*4 pixels x 64 channels is staged per (dy, channel step) — a third
+// of it with each of the previous group's three K steps — and the taps read it at a row offset; the weight tile
+// [256 channels][64 k] is staged per K step.  Everything goes global -> LDS by 16-byte global_load_lds (pixels
+// outside the image read a zero line); LDS rows are 128 bytes with the 16-byte chunks XOR-swizzled by (row & 7)
+// on the SOURCE address (the LDS image of a wave's load is lane-linear), which keeps the ds_read_b128 fragment
+// reads of the 16x16x32 MFMA conflict-free at any row offset.  Two buffers of each: the loads of K step t+1 are
+// issued before the MFMAs of step t.  The accumulator tile of a lane is four consecutive output channels of one
+// pixel, so the epilogue stores 8 contiguous bytes per lane and tile.
+//
+// Measured (tools/conv_bench.py: 30 x 128 x 256 pixels, random operands; MIOpen's kernel alone 1 044-1 090):
+//   512 -> 512: 1 126-1 163 TFLOP/s (0.45-0.47 of the nominal dense bf16 peak), 256 -> 512: 1 050, 256 -> 256: 919.
+// What was tried around it, each built, verified and measured on the 512 -> 512 layer:
+//   * one pixel tile per tap (9 x 32 KB instead of 3 x 33 KB per channel step; round 1): 1 064-1 091;
+//   * four LDS buffers in half steps of 32 channels (three half tiles in flight, counted vmcnt): 1 050 — twice
+//     the barriers cost more than the extra loads in flight bought;
+//   * loads interleaved between the MFMA groups: 926 (every global_load_lds re-programs M0);
 //   * four waves of 128 x 128 (256 accumulator registers, one wave per SIMD, a third less LDS traffic per FLOP)
 //     with two fragment register sets and the step's barrier between its two half steps, so that no MFMA waits
-//     for an LDS round trip: 985-1 041 TFLOP/s; the same pipeline with eight waves spills (224 registers of
-//     accumulators + fragments): 910-925;
-//   * that four-wave loop with the global loads compiled out (timing only): 1 220-1 300 TFLOP/s without the
-//     pixel-tile loads, 1 115 without the weight loads — the LDS-read + MFMA loop on random operands tops out
-//     near 0.5 of the nominal peak (the chip lowers its clock under dense bf16 MFMA on random data:
-//     MI355X_MICROARCH.md, DVFS give-back), so this kernel is at ~0.85-0.9 of what the loop can deliver.
-//     What would remain is the pixel-tile traffic: one row segment with halo per (dy, k step) serving the three
-//     dx taps (a third less L2 -> LDS traffic).
+//     for an LDS round trip: 985-1 041, with the row-segment staging 1 016-1 087; the same pipeline with eight
+//     waves spills (224 registers of accumulators + fragments): 910-925;
+//   * that four-wave loop with the global loads compiled out (timing only): 1 220-1 300 without the pixel loads,
+//     1 115 without the weight loads — an LDS-read + MFMA loop on random operands tops out near 0.5 of the nominal
+//     peak (the chip lowers its clock under dense bf16 MFMA on random data: MI355X_MICROARCH.md, DVFS give-back),
+//     so the kernel is at ~0.9 of what its loop can deliver.
 #include "spa_common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
