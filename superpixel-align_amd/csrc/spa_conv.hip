@@ -39,7 +39,9 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define CV_BM 256            // output channels per workgroup
+// output channels per workgroup: template parameter BM = 256 (2 x 4 waves of 128 x 64), 128 (2 x 4 waves of
+// 64 x 64) or 64 (1 x 8 waves of 64 x 32) — the narrow tiles serve the 64/128-channel layers, which are bound by
+// their activations' HBM traffic, not by the matrix pipe
 #define CV_BN 256            // pixels per workgroup
 #define CV_BK 64             // K step (input channels of one tap)
 #define CV_THREADS 512
@@ -53,7 +55,7 @@ __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f)
     return __builtin_bit_cast(unsigned short, h);
 }
 
-template <int HAS_RES>
+template <int HAS_RES, int BM>
 __global__ __launch_bounds__(CV_THREADS) void k_conv3x3_bf16(const __bf16 *__restrict__ X, const __bf16 *__restrict__ Wt,
                                                              const float *__restrict__ bias,
                                                              const __bf16 *__restrict__ R, __bf16 *__restrict__ Y,
@@ -75,7 +77,11 @@ __global__ __launch_bounds__(CV_THREADS) void k_conv3x3_bf16(const __bf16 *__res
     const int nt = id % ntiles, pt = id / ntiles;
     const int xt = pt % xtiles, row_id = pt / xtiles;               // row_id = b * H + y
     const int y = row_id % H;
-    const int x0 = xt * CV_BN, n0 = nt * CV_BM;
+    const int x0 = xt * CV_BN, n0 = nt * BM;
+    constexpr int WN = BM == 64 ? 8 : 4;                 // waves along the pixels
+    constexpr int MI = BM == 256 ? 8 : 4;                // 16-channel MFMA tiles per wave
+    constexpr int NJ = 256 / WN / 16;                    // 16-pixel MFMA tiles per wave
+    constexpr int WROWS = MI * 16;                       // channels per wave
 
     // K order: (dy, 64-channel step, dx).  The three dx taps of one (dy, k step) read the SAME input pixels
     // shifted by the dilation: one row segment of 256 + 2*CV_HALO pixels is staged per (dy, k step) — a third
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(CV_THREADS) void k_conv3x3_bf16(const __bf16 *__res
         const char *wk = wbase + ((long long)(dyi * 3 + dxi) * Cin + (long long)kc * CV_BK) * 2 + chunk_byte;
         char *dst = wbuf + buf * CV_TILE_BYTES;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < BM / 64; ++r) {
             const int blk = r * 8 + wave;                       // 8 rows = 1 KB per instruction
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wk + (long long)(blk * 8 + sub) * 9 * Cin * 2),
                                              (__attribute__((address_space(3))) void *)(dst + blk * 1024), 16, 0, 0);
@@ -122,13 +128,13 @@ __global__ __launch_bounds__(CV_THREADS) void k_conv3x3_bf16(const __bf16 *__res
         }
     };
 
-    // ---- accumulators: wave (wm, wn) owns channels [wm*128, +128) x pixels [wn*64, +64)
-    const int wm = wave >> 2, wn = wave & 3;
-    f32x4 acc[8][4];
+    // ---- accumulators: wave (wm, wn) owns channels [wm*WROWS, +WROWS) x pixels [wn*NJ*16, +NJ*16)
+    const int wm = wave / WN, wn = wave % WN;
+    f32x4 acc[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int frow = lane & 15, fk = lane >> 4;                     // fragment row, 16-byte k chunk inside a 32-k step
 
     stage_w(0, 0);
@@ -143,25 +149,25 @@ __global__ __launch_bounds__(CV_THREADS) void k_conv3x3_bf16(const __bf16 *__res
         if (t + 1 < nk) stage_w(t + 1, cur ^ 1);
         if (g + 1 < ngroups) stage_x(g + 1, dxi);
         const char *lw = wbuf + cur * CV_TILE_BYTES, *lx = xbuf + (g & 1) * CV_XSEG_BYTES;
-        const int xshift = CV_HALO + (dxi - 1) * dil + wn * 64 + frow;      // segment row of fragment 0
+        const int xshift = CV_HALO + (dxi - 1) * dil + wn * (NJ * 16) + frow;      // segment row of fragment 0
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 wf[8], pf[4];
+            bf16x8 wf[MI], pf[NJ];
             const int chunk = kk * 4 + fk;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int row = wm * 128 + i * 16 + frow;
+            for (int i = 0; i < MI; ++i) {
+                const int row = wm * WROWS + i * 16 + frow;
                 wf[i] = *(const bf16x8 *)(lw + row * 128 + ((chunk ^ (row & 7)) << 4));
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const int row = xshift + j * 16;
                 pf[j] = *(const bf16x8 *)(lx + row * 128 + ((chunk ^ (row & 7)) << 4));
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], pf[j], acc[i][j], 0, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -170,13 +176,13 @@ __global__ __launch_bounds__(CV_THREADS) void k_conv3x3_bf16(const __bf16 *__res
 
     // ---- epilogue: lane holds channels c..c+3 (c = tile channel base + (lane>>4)*4) of pixel (lane & 15)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int xx = x0 + wn * 64 + j * 16 + (lane & 15);
+    for (int j = 0; j < NJ; ++j) {
+        const int xx = x0 + wn * (NJ * 16) + j * 16 + (lane & 15);
         if (xx >= W) continue;
         const long long pix = (long long)row_id * W + xx;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int c = n0 + wm * 128 + i * 16 + (lane >> 4) * 4;
+        for (int i = 0; i < MI; ++i) {
+            const int c = n0 + wm * WROWS + i * 16 + (lane >> 4) * 4;
             const float4 bv = *(const float4 *)(bias + c);
             float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y, v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
             if (HAS_RES) {
@@ -200,7 +206,7 @@ extern "C" int spa_conv3x3_bf16(spa_ctx *ctx, const void *x, int32_t B, int32_t 
                                 int32_t relu, int32_t dilation, void *y, void *stream)
 {
     SPA_ARG(ctx && x && wt && bias && y && B > 0 && H > 0 && W > 0 && dilation >= 1);
-    SPA_ARG(Cin % CV_BK == 0 && Cout % CV_BM == 0 && dilation <= CV_HALO);
+    SPA_ARG(Cin % CV_BK == 0 && Cout % 64 == 0 && dilation <= CV_HALO);
     SPA_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)wt % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)bias % 16) == 0);
     hipStream_t s = spa_stream(stream);
     char *zero;
@@ -210,24 +216,28 @@ extern "C" int spa_conv3x3_bf16(spa_ctx *ctx, const void *x, int32_t B, int32_t 
         SPA_HIP(hipMemsetAsync(zero, 0, 4096, s));
         ctx->zero_line_ready = 1;
     }
-    const int xtiles = (W + CV_BN - 1) / CV_BN, ntiles = Cout / CV_BM;
+    const int bm = Cout % 256 == 0 ? 256 : (Cout % 128 == 0 ? 128 : 64);
+    const int xtiles = (W + CV_BN - 1) / CV_BN, ntiles = Cout / bm;
     const long long total = (long long)B * H * xtiles * ntiles;
     SPA_ARG(total < (1ll << 31));
     const size_t lds = 2 * (size_t)CV_TILE_BYTES + 2 * (size_t)CV_XSEG_BYTES;
     if (!ctx->conv_attr_done) {
-        SPA_HIP(hipFuncSetAttribute((const void *)k_conv3x3_bf16<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        SPA_HIP(hipFuncSetAttribute((const void *)k_conv3x3_bf16<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#define CV_ATTR(R, M) SPA_HIP(hipFuncSetAttribute((const void *)k_conv3x3_bf16<R, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
+        CV_ATTR(0, 256); CV_ATTR(1, 256); CV_ATTR(0, 128); CV_ATTR(1, 128); CV_ATTR(0, 64); CV_ATTR(1, 64);
+#undef CV_ATTR
         ctx->conv_attr_done = 1;
     }
     SpaProfScope prof_(ctx, PROF_DRN_CONV, s);
-    if (residual)
-        hipLaunchKernelGGL(k_conv3x3_bf16<1>, dim3((unsigned)total), dim3(CV_THREADS), lds, s, (const __bf16 *)x,
-                           (const __bf16 *)wt, bias, (const __bf16 *)residual, (__bf16 *)y, (const char *)zero, B, H, W,
-                           Cin, Cout, dilation, relu, xtiles, ntiles, (int)total);
-    else
-        hipLaunchKernelGGL(k_conv3x3_bf16<0>, dim3((unsigned)total), dim3(CV_THREADS), lds, s, (const __bf16 *)x,
-                           (const __bf16 *)wt, bias, (const __bf16 *)nullptr, (__bf16 *)y, (const char *)zero, B, H, W,
-                           Cin, Cout, dilation, relu, xtiles, ntiles, (int)total);
+#define CV_LAUNCH(R, M)                                                                                                  \
+    hipLaunchKernelGGL((k_conv3x3_bf16<R, M>), dim3((unsigned)total), dim3(CV_THREADS), lds, s, (const __bf16 *)x,       \
+                       (const __bf16 *)wt, bias, (const __bf16 *)residual, (__bf16 *)y, (const char *)zero, B, H, W,    \
+                       Cin, Cout, dilation, relu, xtiles, ntiles, (int)total)
+    if (residual) {
+        if (bm == 256) CV_LAUNCH(1, 256); else if (bm == 128) CV_LAUNCH(1, 128); else CV_LAUNCH(1, 64);
+    } else {
+        if (bm == 256) CV_LAUNCH(0, 256); else if (bm == 128) CV_LAUNCH(0, 128); else CV_LAUNCH(0, 64);
+    }
+#undef CV_LAUNCH
     SPA_LAUNCH_CHECK();
     return SPA_OK;
 }

@@ -219,10 +219,11 @@ class DRN(nn.Module):
                 if isinstance(m, nn.Conv2d):
                     m._spa_packed = None
                     # operands of spa_conv3x3_bf16: 3x3, stride 1, padding = dilation, Cin % 64 == 0,
-                    # Cout % 256 == 0 (layers 5-8: ~80 % of the FLOPs), bf16 network, BatchNorm folded
+                    # Cout % 64 == 0 (layers 3-8 of the DRN: all 3x3 stride-1 layers from 64 channels up), bf16 network,
+                    # BatchNorm folded
                     if (dtype == torch.bfloat16 and self.folded and m.kernel_size == (3, 3) and m.stride == (1, 1)
                             and m.padding == m.dilation and m.dilation[0] == m.dilation[1] <= 4 and m.groups == 1
-                            and m.in_channels % 64 == 0 and m.out_channels % 256 == 0 and m.bias is not None):
+                            and m.in_channels % 64 == 0 and m.out_channels % 64 == 0 and m.bias is not None):
                         wt = m.weight.detach().permute(0, 2, 3, 1).reshape(m.out_channels, 9, m.in_channels)
                         m._spa_packed = (wt.contiguous().to(torch.bfloat16), m.bias.detach().float().contiguous())
             if self.arch == 'D' and self.folded and dtype in (torch.float32, torch.bfloat16):

@@ -68,3 +68,8 @@ else:
     for Cin, Cout, dil, res in [(128, 256, 2, False), (256, 256, 2, True), (256, 512, 4, False), (512, 512, 4, True),
                                 (512, 512, 2, False), (512, 512, 1, False)]:
         run(B, Cin, Cout, 128, 256, dil, res)
+    # the narrow channel tiles (64 / 128 output channels): HBM-bound layers
+    run(2, 64, 64, 20, 300, 1, True)
+    run(2, 128, 128, 9, 70, 1, False)
+    run(B, 64, 64, 256, 512, 1, True)
+    run(B, 128, 128, 128, 256, 1, True)
