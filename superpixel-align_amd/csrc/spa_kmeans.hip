@@ -162,52 +162,80 @@ __device__ __forceinline__ int km_wg_rank(bool flag, int *scr, int &total)
     return off + (int)spa_rank_in_mask(m);
 }
 
-// numpy's pairwise sum of wl[0..n) (float64) by ONE wave: lanes 0..7 are the eight accumulators of the
-// current block; the recursion is emulated with an explicit (wave-uniform) stack.
-__device__ double km_pairwise_wave(const double *wl, int n, int *fs, double *fv)
+// numpy's pairwise sum of wl[0..n) (float64) by ONE wave: lanes 0..7 (every octet redundantly) are the eight
+// accumulators of the current block; the recursion is emulated with an explicit wave-uniform stack that lives in
+// four VGPRs — lane t holds pending call t (v_readlane / lane select: no LDS round trip, no synchronisation per
+// step).  A block's up to 16 values per accumulator are all fetched before the first of the dependent additions.
+__device__ __forceinline__ double km_rl(double v, int l)
 {
-    // fs: 3 * 40 ints of LDS (start, length, stage of the pending calls), fv: 40 doubles (left sums)
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// (v_writelane has no builtin here: a compare + select does the same for a wave-uniform slot)
+#define KM_WRLANE(vec_, slot_, val_) vec_ = (lane == (slot_)) ? (val_) : vec_
+
+__device__ double km_pairwise_wave(const double *wl, int n, int *, double *)
+{
     const int lane = threadIdx.x & 63, j = lane & 7;
-    int *fn = fs + 40, *fst = fs + 80;
+    int st_s = 0, st_n = 0, st_st = 0;      // per lane t: start, length, stage of pending call t
+    double st_v = 0.0;                      // ... and its left sum
+    KM_WRLANE(st_n, 0, n);
     int sp = 1;
-    if (lane == 0) { fs[0] = 0; fn[0] = n; fst[0] = 0; }
-    km_wave_lds_sync();
     double ret = 0.0;
     while (sp > 0) {
-        const int t = sp - 1;
-        if (fst[t] == 0) {
-            const int s0 = fs[t], nn = fn[t];
+        const int t = __builtin_amdgcn_readfirstlane(sp - 1);
+        const int stage = __builtin_amdgcn_readlane(st_st, t);
+        const int s0 = __builtin_amdgcn_readlane(st_s, t), nn = __builtin_amdgcn_readlane(st_n, t);
+        if (stage == 0) {
             if (nn <= 128) {
+                const int n8 = nn - (nn % 8);
+                double v[16], tl[7];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = (8 * i < n8) ? wl[s0 + 8 * i + j] : 0.0;
+#pragma unroll
+                for (int i = 0; i < 7; ++i) tl[i] = (n8 + i < nn) ? wl[s0 + n8 + i] : 0.0;
                 double res = 0.0;
-                int i = 0;
                 if (nn >= 8) {
-                    double r = wl[s0 + j];
-                    for (i = 8; i < nn - (nn % 8); i += 8) r = r + wl[s0 + i + j];
+                    double r = v[0];
+#pragma unroll
+                    for (int i = 1; i < 16; ++i)
+                        if (8 * i < n8) r = r + v[i];
                     r = r + __shfl_xor(r, 1);
                     r = r + __shfl_xor(r, 2);
                     r = r + __shfl_xor(r, 4);
                     res = r;
                 }
-                for (; i < nn; ++i) res = res + wl[s0 + i];
+#pragma unroll
+                for (int i = 0; i < 7; ++i)
+                    if (n8 + i < nn) res = res + tl[i];
                 ret = res;
                 sp -= 1;
             } else {
                 int n2 = nn / 2;
                 n2 -= n2 % 8;
-                if (lane == 0) { fst[t] = 1; fs[sp] = s0; fn[sp] = n2; fst[sp] = 0; }
+                const int u = __builtin_amdgcn_readfirstlane(sp);
+                KM_WRLANE(st_st, t, 1);
+                KM_WRLANE(st_s, u, s0);
+                KM_WRLANE(st_n, u, n2);
+                KM_WRLANE(st_st, u, 0);
                 sp += 1;
             }
-        } else if (fst[t] == 1) {
-            const int s0 = fs[t], nn = fn[t];
+        } else if (stage == 1) {
             int n2 = nn / 2;
             n2 -= n2 % 8;
-            if (lane == 0) { fv[t] = ret; fst[t] = 2; fs[sp] = s0 + n2; fn[sp] = nn - n2; fst[sp] = 0; }
+            const int u = __builtin_amdgcn_readfirstlane(sp);
+            KM_WRLANE(st_v, t, ret);
+            KM_WRLANE(st_st, t, 2);
+            KM_WRLANE(st_s, u, s0 + n2);
+            KM_WRLANE(st_n, u, nn - n2);
+            KM_WRLANE(st_st, u, 0);
             sp += 1;
         } else {
-            ret = fv[t] + ret;
+            ret = km_rl(st_v, t) + ret;
             sp -= 1;
         }
-        km_wave_lds_sync();
     }
     return ret;
 }
