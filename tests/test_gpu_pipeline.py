@@ -307,3 +307,39 @@ def test_fused_stem_in_bf16_mode(mods):
         e_plain = float((plain[i] - ref[i]).abs().max()) / scale
         e_fused = float((fused[i].float() - ref[i]).abs().max()) / scale
         assert e_fused <= max(1.25 * e_plain, 2e-2), (i, e_fused, e_plain)
+
+
+@pytest.mark.parametrize('case', [
+    # B, Cin, Cout, H, W, dilation, residual, relu       (channel tiles of 256 / 128 / 64; ragged pixel tiles;
+    (2, 64, 256, 9, 300, 1, False, True),              #  dilations 1 / 2 / 4 at the image borders)
+    (1, 128, 512, 20, 256, 4, True, True),
+    (2, 256, 256, 7, 70, 2, True, False),
+    (1, 64, 128, 11, 513, 1, True, True),
+    (2, 128, 128, 6, 40, 2, False, True),
+    (1, 64, 64, 13, 260, 1, True, True),
+    (1, 192, 64, 5, 33, 4, False, False),
+])
+def test_conv3x3_bf16_against_float32_convolution(mods, case):
+    """spa_conv3x3_bf16 (bf16 MFMA implicit GEMM, float32 accumulation, bias / residual / ReLU fused) against
+    torch's float32 convolution of the SAME bf16 operands: the only difference allowed is the float32
+    accumulation order and the final rounding to bf16 (tolerance: one bf16 ulp of the largest output, 2^-8)."""
+    B, Cin, Cout, H, W, dil, res, relu = case
+    eng = mods.engine.default_engine()
+    g = torch.Generator(device='cuda').manual_seed(Cin * 7 + Cout + H)
+    x = torch.randn((B, Cin, H, W), device='cuda', generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn((Cout, Cin, 3, 3), device='cuda', generator=g) * (2.0 / (9 * Cin)) ** 0.5).to(torch.bfloat16)
+    bias = torch.randn((Cout,), device='cuda', generator=g)
+    r = None
+    if res:
+        r = torch.randn((B, Cout, H, W), device='cuda', generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    wt = w.permute(0, 2, 3, 1).reshape(Cout, 9, Cin).contiguous()
+    y = eng.conv3x3_bf16(x, wt, bias, r, relu, dil)
+    assert y.dtype == torch.bfloat16 and y.shape == (B, Cout, H, W)
+    ref = torch.nn.functional.conv2d(x.float(), w.float(), bias, 1, dil, dil)
+    if res:
+        ref = ref + r.float()
+    if relu:
+        ref = torch.relu(ref)
+    scale = float(ref.abs().max())
+    assert float((y.float() - ref).abs().max()) <= scale * 2.0 ** -8
+    eng.raise_on_status()
