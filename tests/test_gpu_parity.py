@@ -134,6 +134,32 @@ def test_connectivity_random_cuts(eng, orc):
         assert np.array_equal(out[0].cpu().numpy().astype(np.int64), ref), (trial, mn, mx)
 
 
+@pytest.mark.parametrize('case', [
+    # H, W, labels, noise, min_size, max_size
+    (24, 2048, 4, 1.0, 6, 100000),        # every pixel a random label: > 4 096 runs per strip of 8 rows -> the
+    (40, 1536, 3, 0.8, 12, 100000),       #   strips link their rows through global memory
+    (96, 640, 6, 0.35, 40, 100000),       # strips in LDS, many multi-row specks (lane tier) and mid-size boxes
+    (300, 700, 5, 0.05, 3000, 100000),    # large small-components: the 26.5 KB / 80 KB LDS tiers
+    (64, 4000, 3, 0.5, 25, 2000),         # wide rows + oversize cuts
+])
+def test_connectivity_run_tables_and_tiers(eng, orc, case):
+    """Label maps built to reach every branch of the run-level pass: strips whose run count exceeds the LDS
+    table, the lane tier, each LDS replay tier and the oversize (pixel-level) path — all against the restatement
+    of scikit-image's scan-order rule."""
+    H, W, nl, noise, mn, mx = case
+    rs = np.random.RandomState(H * 7 + W)
+    base = (np.arange(H)[:, None] // 29) * 5 + (np.arange(W)[None, :] // 131)
+    seg = np.where(rs.uniform(size=(H, W)) < noise, rs.randint(0, nl, size=(H, W)), base).astype(np.int64)
+    ref, n_ref = orc.enforce_connectivity(seg, mn, mx)
+    out, n_labels = eng.enforce_connectivity(dev(np.stack([seg, seg[::-1].copy()]), torch.int32), mn, mx)
+    eng.raise_on_status(ignore=0x04)
+    assert np.array_equal(out[0].cpu().numpy().astype(np.int64), ref)
+    assert int(n_labels[0]) == max(n_ref, 1)
+    ref2, n_ref2 = orc.enforce_connectivity(seg[::-1].copy(), mn, mx)
+    assert np.array_equal(out[1].cpu().numpy().astype(np.int64), ref2)
+    assert int(n_labels[1]) == max(n_ref2, 1)
+
+
 def test_slic_full_1024x2048_golden(eng, orc, synth):
     """BASELINE size: whole spa_slic call against the skimage-pinned fixture."""
     g = golden('slic_s0_1024x2048_n200')
