@@ -401,8 +401,8 @@ __global__ __launch_bounds__(256) void k_slic_assign(const float *__restrict__ l
 //     segment's pixel stream.  Each lane then writes the packed (row, x) of its mask's set bits
 //     to that place of an LDS index buffer — as many leading entries as fit the buffer;
 //   * the stream is consumed in rounds of UPD_ROUND pixels: lane i reads index i, loads L, a, b
-//     of that pixel (every lane of every load is a wanted pixel; three statically named register
-//     sets keep two rounds of loads in flight, the schedule is straight-line so that the
+//     of that pixel (every lane of every load is a wanted pixel; five statically named register
+//     sets keep four rounds of loads in flight, the schedule is straight-line so that the
 //     compiler's vmcnt waits stay exact) and writes y, x, L, a, b to the wave's staging rows;
 //   * lanes 0..4 then walk the staging rows: four 16-byte LDS reads per 16 dependent adds, the
 //     reads of the next 16 pixels in flight meanwhile.
@@ -741,16 +741,26 @@ void k_slic_update(const float *__restrict__ lab, uint32_t *__restrict__ cen, in
         // straight-line schedule, no branch around the loads of an issue(): the compiler's vmcnt
         // accounting stays exact (waits leave the younger loads in flight) only when the number
         // of loads between an issue and its use is the same on every path.
-        UpdRound r0, r1, r2;
+        // Five register sets, four rounds (24 loads per lane) in flight.  (With two in flight the launch was 3 %
+        // slower: the phase is not load-latency bound.  PMC per launch: 2.0 VALU wave-instructions per pixel — 1.0
+        // of them the chain adds — = 54 % of the SIMDs' issue time; waves: 39 % issuing, 26 % issue-stalled,
+        // 35 % waiting.  What remains is the instruction count, i.e. several segments' chains per wave.)
+        UpdRound r0, r1, r2, r3, r4;
         issue(r0);
         issue(r1);
+        issue(r2);
+        issue(r3);
         do {
-            issue(r2);
+            issue(r4);
             consume(r0);
             issue(r0);
             consume(r1);
             issue(r1);
             consume(r2);
+            issue(r2);
+            consume(r3);
+            issue(r3);
+            consume(r4);
         } while (inflight > 0 || lr < nr || e0 < npieces);
         UPD_T(4)
     }
