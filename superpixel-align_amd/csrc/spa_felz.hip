@@ -605,7 +605,12 @@ static int fz_run(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t 
     if ((rc = spa_ws_reserve(ctx, WS_CONNMISC, 64 * sizeof(FzImg) + 64 * sizeof(int), (void **)&st)) != SPA_OK) return rc;
     size_t tmp_bytes = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys0, keys1, vals0, vals1, (int)g.nE, 0, 64, s);
-    if ((rc = spa_ws_reserve(ctx, WS_FZ_TMP, tmp_bytes, &tmp)) != SPA_OK) return rc;
+    tmp_bytes = (tmp_bytes + 255) & ~(size_t)255;
+    // small images: a sort of a few hundred thousand keys is ~8 short launches, so a batch of sorts is launch
+    // bound on one stream — they are dealt to three streams (own scratch each)
+    const bool par_sort = B > 2 && g.nE <= (1ll << 21);
+    if ((rc = spa_ws_reserve(ctx, WS_FZ_TMP, tmp_bytes * (par_sort ? 3 : 1), &tmp)) != SPA_OK) return rc;
+    if (par_sort && (rc = spa_aux_streams(ctx)) != SPA_OK) return rc;
 
     int gx = (int)((npix + 255) / 256);
     if (gx > 1024) gx = 1024;
@@ -614,10 +619,23 @@ static int fz_run(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t 
     int ge = (int)((g.nE + 255) / 256);
     if (ge > 2048) ge = 2048;
     hipLaunchKernelGGL(k_fz_costs, dim3(ge, B), dim3(256), 0, s, (const double *)sm1, g, keys0, vals0);
+    if (par_sort) {
+        SPA_HIP(hipEventRecord(ctx->ev_fork, s));
+        SPA_HIP(hipStreamWaitEvent(ctx->aux[0], ctx->ev_fork, 0));
+        SPA_HIP(hipStreamWaitEvent(ctx->aux[1], ctx->ev_fork, 0));
+    }
     for (int b = 0; b < B; ++b) {
-        SPA_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys0 + (size_t)b * g.nE, keys1 + (size_t)b * g.nE,
+        hipStream_t sb = par_sort ? (b % 3 == 0 ? s : ctx->aux[b % 3 - 1]) : s;
+        void *tb = (char *)tmp + (par_sort ? (size_t)(b % 3) * tmp_bytes : 0);
+        SPA_HIP(hipcub::DeviceRadixSort::SortPairs(tb, tmp_bytes, keys0 + (size_t)b * g.nE, keys1 + (size_t)b * g.nE,
                                                    vals0 + (size_t)b * g.nE, vals1 + (size_t)b * g.nE, (int)g.nE,
-                                                   0, 64, s));
+                                                   0, 64, sb));
+    }
+    if (par_sort) {
+        SPA_HIP(hipEventRecord(ctx->ev_join[0], ctx->aux[0]));
+        SPA_HIP(hipEventRecord(ctx->ev_join[1], ctx->aux[1]));
+        SPA_HIP(hipStreamWaitEvent(s, ctx->ev_join[0], 0));
+        SPA_HIP(hipStreamWaitEvent(s, ctx->ev_join[1], 0));
     }
     hipLaunchKernelGGL(k_fz_init, dim3(1024), dim3(256), 0, s, parent, size, cint, mark, (long long)B * npix, st, B);
     int *zcount = (int *)((char *)st + 64 * sizeof(FzImg));
