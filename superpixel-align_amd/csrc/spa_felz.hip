@@ -324,6 +324,7 @@ __global__ __launch_bounds__(256) void k_fz_zero_sizes(const int *__restrict__ z
 
 // One greedy pass (mode 0: merge test of the paper; mode 1: min_size clean-up) over the sorted
 // edges of every image; grid = (G, B), workgroups (., b) form the group of image b.
+template <bool LDSP>
 __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass(const unsigned long long *__restrict__ keys,
                                                         const unsigned *__restrict__ vals, FzGeom g,
                                                         int *__restrict__ parent, int *__restrict__ size,
@@ -350,6 +351,20 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass(const unsigned long long
     unsigned round = round0;
     unsigned slot = 0;
     int win = 0;
+    // LDSP (images of <= 65 535 pixels, one workgroup per image): the parent array — the only pointer-chased
+    // state, two to three dependent round trips per endpoint and round — lives in LDS as 16-bit indices
+    // (0xFFFF = root) for the duration of the pass.
+    extern __shared__ unsigned short lpar[];
+    auto getp = [&](int i) -> int {
+        if (LDSP) { const unsigned v = lpar[i]; return v == 0xFFFFu ? -1 : (int)v; }
+        return P[i];
+    };
+    auto setp = [&](int i, int v) { if (LDSP) lpar[i] = (unsigned short)v; else P[i] = v; };
+    auto find = [&](int i) { int p; while ((p = getp(i)) >= 0) i = p; return i; };
+    if (LDSP) {
+        for (int p = (int)tg; p < (int)npix; p += FZ_THREADS) { const int q = P[p]; lpar[p] = q < 0 ? (unsigned short)0xFFFFu : (unsigned short)q; }
+        __syncthreads();
+    }
 
     for (long long lo = zcount[b]; lo < g.nE; lo += T * FZ_EPT) {   // zero-cost edges: done up front
         if (tg == 0) me->pad[2] += 1;                           // diagnostics: windows
@@ -357,10 +372,10 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass(const unsigned long long
         // done every `flatten_every` windows (about once per npix/4 edges)
         if ((win++ % flatten_every) == 0) {
             for (long long p = tg; p < npix; p += T) {
-                int q = P[p];
+                int q = getp((int)p);
                 if (q >= 0) {
-                    int r = fz_find(P, q);
-                    if (r != q) P[p] = r;
+                    int r = find(q);
+                    if (r != q) setp((int)p, r);
                 }
             }
         }
@@ -389,8 +404,8 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass(const unsigned long long
             for (int u = 0; u < FZ_EPT; ++u) {
                 want[u] = false; resv[u] = false;
                 if (!pend[u]) continue;
-                ra[u] = fz_find(P, ea[u]);
-                rb[u] = fz_find(P, eb[u]);
+                ra[u] = find(ea[u]);
+                rb[u] = find(eb[u]);
                 if (ra[u] == rb[u]) { pend[u] = false; continue; }      // same component for ever
                 if (mode == 0) {
                     const float t0 = (float)(CI[ra[u]] + scale / (double)S[ra[u]]);
@@ -445,7 +460,7 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass(const unsigned long long
                 if (want[u]) {
                     const int lo_r = min(ra[u], rb[u]), hi_r = max(ra[u], rb[u]);
                     const int ns = S[ra[u]] + S[rb[u]];
-                    P[hi_r] = lo_r;
+                    setp(hi_r, lo_r);
                     S[lo_r] = ns;
                     if (mode == 0) CI[lo_r] = cost[u];
                 }
@@ -453,6 +468,10 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass(const unsigned long long
             }
             if (fz_group_sum(me, slot, left, tg == 0, G, epoch, status) == 0) break;
         }
+    }
+    if (LDSP) {
+        __syncthreads();
+        for (int p = (int)tg; p < (int)npix; p += FZ_THREADS) { const unsigned v = lpar[p]; P[p] = v == 0xFFFFu ? -1 : (int)v; }
     }
 }
 
@@ -659,11 +678,23 @@ static int fz_run(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t 
     const int flatten_every = fe < 1 ? 1 : (int)fe;
     // scale = float(scale) / 255.
     const double k = scale / 255.0;
-    hipLaunchKernelGGL(k_fz_pass, dim3(G, B), dim3(FZ_THREADS), 0, s, (const unsigned long long *)keys1,
-                       (const unsigned *)vals1, g, parent, size, cint, mark, st, k, min_size, 0, 0u, (const int *)zcount, flatten_every, ctx->d_status);
-    hipLaunchKernelGGL(k_fz_pass, dim3(G, B), dim3(FZ_THREADS), 0, s, (const unsigned long long *)keys1,
-                       (const unsigned *)vals1, g, parent, size, cint, mark, st, k, min_size, 1, 0x40000000u,
-                       (const int *)zcount, flatten_every, ctx->d_status);
+    const bool ldsp = G == 1 && npix <= 65535;
+    const size_t lds_par = ldsp ? (size_t)npix * 2 : 0;
+    if (ldsp && !ctx->fz_attr_done) {
+        SPA_HIP(hipFuncSetAttribute((const void *)k_fz_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        ctx->fz_attr_done = 1;
+    }
+    for (int mode = 0; mode < 2; ++mode) {
+        const unsigned r0 = mode ? 0x40000000u : 0u;
+        if (ldsp)
+            hipLaunchKernelGGL(k_fz_pass<true>, dim3(G, B), dim3(FZ_THREADS), lds_par, s, (const unsigned long long *)keys1,
+                               (const unsigned *)vals1, g, parent, size, cint, mark, st, k, min_size, mode, r0,
+                               (const int *)zcount, flatten_every, ctx->d_status);
+        else
+            hipLaunchKernelGGL(k_fz_pass<false>, dim3(G, B), dim3(FZ_THREADS), 0, s, (const unsigned long long *)keys1,
+                               (const unsigned *)vals1, g, parent, size, cint, mark, st, k, min_size, mode, r0,
+                               (const int *)zcount, flatten_every, ctx->d_status);
+    }
     hipLaunchKernelGGL(k_fz_count_roots, dim3(nblk, B), dim3(256), 0, s, parent, (int)npix, blk, nblk);
     hipLaunchKernelGGL(k_fz_scan, dim3(B), dim3(256), 0, s, blk, nblk, n_labels);
     hipLaunchKernelGGL(k_fz_number, dim3(nblk, B), dim3(256), 0, s, parent, (int)npix, blk, nblk, rank);
