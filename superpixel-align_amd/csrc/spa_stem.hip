@@ -89,18 +89,28 @@ __global__ __launch_bounds__(256) void k_drn_stem_d(const float *__restrict__ xn
     // wait for the one before it.
     constexpr int NE = 3 * ST_IH * ST_IW, NU = (NE + 255) / 256;
     float raw[NU];
+    // patch element e = tid + u * 256 = (iy * ST_IW + ix) * 3 + c of this thread: the same for every tile, so its
+    // decomposition (two divisions) and its LDS offset are computed once
+    int eiy[NU], eix[NU], elds[NU];          // eix: ix * 4 + c; elds: c * ST_IPLANE + pix, or -1 past the end
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        int e = tid + u * 256;
+        const bool ok = e < NE;
+        if (!ok) e = NE - 1;
+        const int pix = e / 3, c = e - pix * 3;
+        eiy[u] = pix / ST_IW;
+        eix[u] = (pix - eiy[u] * ST_IW) * 4 + c;
+        elds[u] = ok ? c * ST_IPLANE + pix : -1;
+    }
     auto patch_load = [&](int tile) {
         const int b = tile / (tiles_x * tiles_y), tr = tile - b * (tiles_x * tiles_y);
         const int ty0 = (tr / tiles_x) * ST_TH, tx0 = (tr % tiles_x) * ST_TW;
         const float *src = xn + (long long)b * npix * 3;
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
-            const int e = tid + u * 256;                 // e = (iy * ST_IW + ix) * 3 + c
-            const int pix = e / 3, c = e - pix * 3;
-            const int iy = pix / ST_IW, ix = pix - iy * ST_IW;
-            const int gy = ty0 - 4 + iy, gx = tx0 - 4 + ix;
+            const int gy = ty0 - 4 + eiy[u], gx = tx0 - 4 + (eix[u] >> 2);
             const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
-            const unsigned off = ((unsigned)cy * (unsigned)W + (unsigned)cx) * 12u + (unsigned)c * 4u;
+            const unsigned off = ((unsigned)cy * (unsigned)W + (unsigned)cx) * 12u + (unsigned)(eix[u] & 3) * 4u;
             raw[u] = *(const float *)((const char *)src + off);
         }
     };
@@ -113,12 +123,9 @@ __global__ __launch_bounds__(256) void k_drn_stem_d(const float *__restrict__ xn
     {
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
-            const int e = tid + u * 256;
-            const int pix = e / 3, c = e - pix * 3;
-            const int iy = pix / ST_IW, ix = pix - iy * ST_IW;
-            const int gy = ty0 - 4 + iy, gx = tx0 - 4 + ix;
-            const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-            if (e < NE) in_s[c * ST_IPLANE + pix] = in ? raw[u] : 0.0f;
+            const int gy = ty0 - 4 + eiy[u], gx = tx0 - 4 + (eix[u] >> 2);
+            const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            if (elds[u] >= 0) in_s[elds[u]] = in ? raw[u] : 0.0f;
         }
     }
     stem_lds_barrier();
@@ -230,8 +237,15 @@ __global__ __launch_bounds__(256) void k_drn_stem_d(const float *__restrict__ xn
 //           stride in LDS: conflict-free).  K = 144 padded to 160: 5 instructions.
 // ---------------------------------------------------------------------------------------------------
 typedef __bf16 stem_bf8 __attribute__((ext_vector_type(8)));
-#define SB_PW 48                               // patch row pitch in pixels (40 + the kx pad, even)
-#define SB_PLANE (ST_IH * SB_PW)               // pixels per patch plane
+// LDS bank mapping of layer0's fragment reads (one ds_read_b32 of a wave: 16 pixels x 4 k groups): the word
+// offsets of a k group are c * plane + ky * row pitch, of the odd pixels' patch copy + copy stride.  With plane
+// and copy strides that are multiples of 32 words the three channel planes (and both copies) fell on the same
+// banks: 5.7 lanes per bank on average (PMC: SQ_LDS_BANK_CONFLICT = 4 x SQ_ACTIVE_INST_LDS).  Row pitch 25,
+// plane stride 1 and copy stride 16 words (mod 32) — found by enumerating the strides — give 3.1 (2.0 is the
+// floor: 64 lanes x 4 bytes over 32 banks).
+#define SB_PW 50                               // patch row pitch in pixels (40 + the kx pad, even): 25 words
+#define SB_PLANE (ST_IH * SB_PW + 18)          // pixels per patch plane: 609 words = 1 (mod 32)
+#define SB_COPY (3 * SB_PLANE + 26)            // pixels per patch copy: 1 840 words = 16 (mod 32)
 #define SB_L0_PITCH 24                         // bf16 per layer0 pixel in LDS (16 channels + 8: 48 bytes)
 
 __device__ __forceinline__ unsigned short stem_bf16_rn(float f)
@@ -248,7 +262,7 @@ __global__ __launch_bounds__(256) void k_drn_stem_d_bf16(const unsigned short *_
                                                          unsigned short *__restrict__ yh)
 {
     // patch copy 0: pixel ix at [c][iy][ix]; copy 1: pixel ix at [c][iy][ix - 1] (so odd ix are 4-byte aligned)
-    __shared__ __attribute__((aligned(16))) unsigned short in_s[2][3 * SB_PLANE + 16];
+    __shared__ __attribute__((aligned(16))) unsigned short in_s[2][SB_COPY];
     __shared__ __attribute__((aligned(16))) unsigned short l0_s[ST_LP * SB_L0_PITCH + 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int m = lane & 15, g = lane >> 4;
@@ -273,8 +287,32 @@ __global__ __launch_bounds__(256) void k_drn_stem_d_bf16(const unsigned short *_
         goff[s] = grp < 21 ? c * SB_PLANE + ky * SB_PW : 0;
     }
 
+    // layer1: offset of k group (step s, g): tap = 2s + g/2 (tap 9 is the zero-weight pad: any valid address),
+    // channels 8 * (g & 1)
+    int l1off[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        int tap = 2 * s + (g >> 1);
+        if (tap > 8) tap = 8;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        l1off[s] = (ky * ST_LW + kx) * SB_L0_PITCH + 8 * (g & 1);
+    }
     constexpr int NE = 3 * ST_IH * ST_IW, NU = (NE + 255) / 256;
     unsigned short raw[NU];
+    // patch element e = tid + u * 256 = (iy * ST_IW + ix) * 3 + c of this thread: the same for every tile, so its
+    // decomposition (two divisions) and its LDS offset are computed once (PMC: the staging was 7 of the kernel's
+    // 12 vector instructions per MFMA)
+    int eiy[NU], eix[NU], elds[NU];          // elds: c * SB_PLANE + iy * SB_PW + ix, or -1 past the end
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        int e = tid + u * 256;
+        const bool ok = e < NE;
+        if (!ok) e = NE - 1;
+        const int pix = e / 3, c = e - pix * 3;
+        eiy[u] = pix / ST_IW; eix[u] = pix - eiy[u] * ST_IW;
+        elds[u] = ok ? c * SB_PLANE + eiy[u] * SB_PW + eix[u] : -1;
+        eix[u] = eix[u] * 4 + c;             // packed: ix and the channel
+    }
     auto patch_load = [&](int tile) {
         const int b = tile / (tiles_x * tiles_y), tr = tile - b * (tiles_x * tiles_y);
         const int ty0 = (tr / tiles_x) * ST_TH, tx0 = (tr % tiles_x) * ST_TW;
@@ -283,17 +321,13 @@ __global__ __launch_bounds__(256) void k_drn_stem_d_bf16(const unsigned short *_
         const unsigned short *src = xn + (long long)b * npix * 3;
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
-            int e = tid + u * 256;                       // e = (iy * ST_IW + ix) * 3 + c
-            if (e > NE - 1) e = NE - 1;
-            const int pix = e / 3, c = e - pix * 3;
-            const int iy = pix / ST_IW, ix = pix - iy * ST_IW;
-            const int gy = ty0 - 4 + iy, gx = tx0 - 4 + ix;
+            const int gy = ty0 - 4 + eiy[u], gx = tx0 - 4 + (eix[u] >> 2);
             const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
-            raw[u] = src[((long long)cy * W + cx) * 3 + c];
+            raw[u] = src[(unsigned)((cy * W + cx) * 3 + (eix[u] & 3))];
         }
     };
     // the pad columns (ix >= 40) of both copies are read by the kx = 7 lanes: keep them zero
-    for (int i = tid; i < 3 * SB_PLANE + 16; i += 256) { in_s[0][i] = 0; in_s[1][i] = 0; }
+    for (int i = tid; i < SB_COPY; i += 256) { in_s[0][i] = 0; in_s[1][i] = 0; }
     if ((int)blockIdx.x < n_tiles) patch_load(blockIdx.x);
     __syncthreads();
 
@@ -302,15 +336,13 @@ __global__ __launch_bounds__(256) void k_drn_stem_d_bf16(const unsigned short *_
         const int ty0 = (tr / tiles_x) * ST_TH, tx0 = (tr % tiles_x) * ST_TW;
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
-            const int e = tid + u * 256;
-            const int pix = e / 3, c = e - pix * 3;
-            const int iy = pix / ST_IW, ix = pix - iy * ST_IW;
-            const int gy = ty0 - 4 + iy, gx = tx0 - 4 + ix;
-            const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-            if (e < NE) {
+            const int ix = eix[u] >> 2;
+            const int gy = ty0 - 4 + eiy[u], gx = tx0 - 4 + ix;
+            const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            if (elds[u] >= 0) {
                 const unsigned short v = in ? raw[u] : (unsigned short)0;
-                in_s[0][c * SB_PLANE + iy * SB_PW + ix] = v;
-                if (ix >= 1) in_s[1][c * SB_PLANE + iy * SB_PW + ix - 1] = v;
+                in_s[0][elds[u]] = v;
+                if (ix >= 1) in_s[1][elds[u] - 1] = v;
             }
         }
         stem_lds_barrier();
@@ -350,12 +382,10 @@ __global__ __launch_bounds__(256) void k_drn_stem_d_bf16(const unsigned short *_
         for (int t = wv; t < 32; t += 4) {
             const int row = t >> 1, col = (t & 1) * 16 + m;
             stem_f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+            const unsigned short *lb = l0_s + (row * ST_LW + col) * SB_L0_PITCH;
 #pragma unroll
             for (int s = 0; s < 5; ++s) {
-                int tap = 2 * s + (g >> 1);
-                if (tap > 8) tap = 8;                        // padding tap: zero weights, any valid address
-                const int ky = tap / 3, kx = tap - ky * 3;
-                const stem_bf8 f = *(const stem_bf8 *)(l0_s + ((row + ky) * ST_LW + col + kx) * SB_L0_PITCH + 8 * (g & 1));
+                const stem_bf8 f = *(const stem_bf8 *)(lb + l1off[s]);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa1[s], f, acc, 0, 0, 0);
             }
             const int gy = ty0 + row, gx = tx0 + col;
