@@ -164,7 +164,7 @@ __device__ __forceinline__ int seg_image(const int32_t *offsets, int B, int g)
 // box, exact integer coordinate sums (-> centre of mass) and the sum of the Gaussian location prior.
 // A workgroup owns a strip of STRIP_ROWS rows; wave w walks rows w, w+4, ... of the strip 64 pixels at
 // a time.  For every distinct label of a 64-pixel piece the member lanes' contributions are reduced
-// with a fixed xor-butterfly (non-members add 0.0: exact) and added to the WAVE's own LDS table, so
+// in a fixed order (DPP scan steps; non-members add 0.0: exact) and added to the WAVE's own LDS table, so
 // every float64 addition happens in an order fixed by the image alone; the four wave tables are then
 // combined in wave order into the strip's row of a global table, and k_stats_final adds the strips in
 // strip order.  The label image is read once (4 bytes per pixel; the first version read it about 3.8
@@ -181,6 +181,31 @@ __device__ __forceinline__ int spa_bit_index_sum(unsigned long long m)
     return __popcll(m & 0xAAAAAAAAAAAAAAAAull) + 2 * __popcll(m & 0xCCCCCCCCCCCCCCCCull) +
            4 * __popcll(m & 0xF0F0F0F0F0F0F0F0ull) + 8 * __popcll(m & 0xFF00FF00FF00FF00ull) +
            16 * __popcll(m & 0xFFFF0000FFFF0000ull) + 32 * __popcll(m & 0xFFFFFFFF00000000ull);
+}
+
+// sum of v over the 64 lanes, in a fixed order, with DPP moves (no LDS round trips: a float64 __shfl_xor is two
+// ds_bpermute, and six of them per distinct label and piece were most of this kernel's time).  Inclusive scan
+// steps row_shr 1, 2, 4, 8, then row_bcast 15 and 31: lane 63 ends with the total; lanes without a source add 0.0.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ double stats_dpp_add(double v)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, ROWS, 0xF, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, ROWS, 0xF, false);
+    return v + __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double stats_wave_sum(double v)
+{
+    v = stats_dpp_add<0x111, 0xF>(v);
+    v = stats_dpp_add<0x112, 0xF>(v);
+    v = stats_dpp_add<0x114, 0xF>(v);
+    v = stats_dpp_add<0x118, 0xF>(v);
+    v = stats_dpp_add<0x142, 0xA>(v);
+    v = stats_dpp_add<0x143, 0xC>(v);
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), 63);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
 // flags[b] = 1: image b has more than STATS_LDS_MAX labels and takes the two-pass kernels instead
@@ -239,10 +264,7 @@ __global__ __launch_bounds__(256) void k_stats_strip(const int32_t *__restrict__
                     const int ll = __shfl(l, leader);
                     const unsigned long long same = __ballot(l == ll);
                     double v = (l == ll) ? e : 0.0;
-                    if (want_prior) {
-#pragma unroll
-                        for (int o = 1; o < 64; o <<= 1) v = v + __shfl_xor(v, o);
-                    }
+                    if (want_prior) v = stats_wave_sum(v);
                     if (lane == leader) {
                         const int n = __popcll(same);
                         const int last = 63 - __clzll((long long)same);
