@@ -162,6 +162,27 @@ __device__ __forceinline__ int km_wg_rank(bool flag, int *scr, int &total)
     return off + (int)spa_rank_in_mask(m);
 }
 
+// value of lane (lane ^ X) inside every octet, X = 1, 2, 4, by DPP moves (a __shfl_xor is a ds_bpermute per
+// 32 bits: an LDS round trip on the per-point path of the sweep)
+template <int X>
+__device__ __forceinline__ int km_xor_i32(int v)
+{
+    if (X == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);           // quad_perm [1,0,3,2]
+    if (X == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);           // quad_perm [2,3,0,1]
+    const int up = __builtin_amdgcn_update_dpp(0, v, 0x104, 0xF, 0xF, false);              // row_shl:4: lane i <- i + 4
+    const int dn = __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);              // row_shr:4: lane i <- i - 4
+    return (threadIdx.x & 4) ? dn : up;
+}
+template <int X>
+__device__ __forceinline__ double km_xor(double v)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)km_xor_i32<X>((int)(unsigned)u), hi = (unsigned)km_xor_i32<X>((int)(unsigned)(u >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <int X>
+__device__ __forceinline__ float km_xor(float v) { return __int_as_float(km_xor_i32<X>(__float_as_int(v))); }
+
 // numpy's pairwise sum of wl[0..n) (float64) by ONE wave: lanes 0..7 (every octet redundantly) are the eight
 // accumulators of the current block; the recursion is emulated with an explicit wave-uniform stack that lives in
 // four VGPRs — lane t holds pending call t (v_readlane / lane select: no LDS round trip, no synchronisation per
@@ -202,9 +223,9 @@ __device__ double km_pairwise_wave(const double *wl, int n, int *, double *)
 #pragma unroll
                     for (int i = 1; i < 16; ++i)
                         if (8 * i < n8) r = r + v[i];
-                    r = r + __shfl_xor(r, 1);
-                    r = r + __shfl_xor(r, 2);
-                    r = r + __shfl_xor(r, 4);
+                    r = r + km_xor<1>(r);
+                    r = r + km_xor<2>(r);
+                    r = r + km_xor<4>(r);
                     res = r;
                 }
 #pragma unroll
@@ -608,9 +629,9 @@ __global__ __launch_bounds__(KM_THREADS) void k_kmeans(const T *__restrict__ X, 
 #pragma unroll
                     for (int c = 0; c < KM; ++c) {
                         T r = acc[c];
-                        r = r + __shfl_xor(r, 1);
-                        r = r + __shfl_xor(r, 2);
-                        r = r + __shfl_xor(r, 4);
+                        r = r + km_xor<1>(r);
+                        r = r + km_xor<2>(r);
+                        r = r + km_xor<4>(r);
                         acc[c] = (steps[u] > 0) ? r : (T)0;
                     }
                     // the n % 8 tail (and a whole block shorter than 8), one by one
