@@ -104,14 +104,19 @@ LIMITERS = {
 }
 
 
-def pmc_traffic(kernel, B, H, W):
-    """HBM bytes per launch measured with the PMC counters (committed summary), or None."""
+def pmc_traffic(kernel, B, H, W, algorithmic_bytes=None):
+    """HBM bytes per launch measured with the PMC counters (committed summary), or None.  Kernels whose launches
+    differ in size (the DRN epilogue) are recorded as a ratio to their algorithmic bytes."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic.json')
     if (H, W) != (1024, 2048) or not os.path.exists(path):
         return None
     with open(path) as f:
-        per_image = json.load(f)['bytes_per_image_per_launch'].get(kernel)
-    return None if per_image is None else int(per_image * B)
+        d = json.load(f)
+    per_image = d['bytes_per_image_per_launch'].get(kernel)
+    if per_image is not None:
+        return int(per_image * B)
+    ratio = d.get('ratio_to_algorithmic_bytes', {}).get(kernel)
+    return int(ratio * algorithmic_bytes) if ratio is not None and algorithmic_bytes else None
 
 
 def algorithmic_bytes(kernel, B, H, W, C, fh, fw, n_seg, feat_bytes):
@@ -392,7 +397,7 @@ def main():
             gbs = ab / (avg * 1e-3) / 1e9 if ab else None
             ent.update(bound='hbm' if ab else 'latency', achieved=round(gbs, 1) if gbs else None, peak=HBM_PEAK_GBS,
                        unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4) if gbs else None,
-                       algorithmic_bytes_per_launch=int(ab), traffic=pmc_traffic(name, B, H, W))
+                       algorithmic_bytes_per_launch=int(ab), traffic=pmc_traffic(name, B, H, W, ab))
         ent['achieved_GBs'] = ent['achieved'] if ent.get('unit') == 'GB/s' else None
         if name in LIMITERS:
             ent['limiter'] = LIMITERS[name]

@@ -25,6 +25,8 @@ ap.add_argument('--n', type=int, default=200)
 ap.add_argument('--channels', type=int, default=512)
 ap.add_argument('--reps', type=int, default=3)
 ap.add_argument('--pool_mode', default='mean')
+ap.add_argument('--bias_act', action='store_true', help='also run the DRN epilogue kernel (k_bias_act) on the shapes of '
+                'the heavy layers, for the PMC traffic passes')
 a = ap.parse_args()
 
 spa = importlib.import_module('superpixel-align_amd')
@@ -50,3 +52,14 @@ print('last run: superpixel %.3f ms  describe %.3f ms  kmeans+paint %.3f ms' %
       (t['time_superpixel'] * 1e3, t['time_roialign'] * 1e3, t['time_kmeans'] * 1e3))
 for name, (ms, n) in pipe.eng.prof_read().items():
     print('%-22s launches/run %5.1f  avg %9.1f us  per run %9.3f ms' % (name, n / a.reps, ms / n * 1e3, ms / a.reps))
+
+if a.bias_act:
+    # the 512- and 256-channel layers of DRN-D-22 at 1/8 resolution, with and without the residual operand
+    for C, res in ((512, True), (512, False), (256, True)):
+        y = torch.randn((a.batch, C, a.height // 8, a.width // 8), device='cuda').contiguous(memory_format=torch.channels_last)
+        r = torch.randn_like(y) if res else None
+        bias = torch.randn((C,), device='cuda')
+        for _ in range(a.reps):
+            pipe.eng.bias_act_(y, bias, r, True)
+    torch.cuda.synchronize()
+    print('bias_act: 512 ch + residual, 512 ch, 256 ch + residual at %dx%d, %d launches each' % (a.height // 8, a.width // 8, a.reps))

@@ -95,6 +95,19 @@ for k in sorted(fe):
     traffic[name] = tot * 1e6 / B
     if name in alias:
         traffic[alias[name]] = traffic[name]
+# the DRN epilogue kernel on the heavy layers' shapes (prof_stages.py --bias_act): bytes per launch vary with the
+# layer, so its entry is the RATIO of HBM bytes to algorithmic bytes (8 B per element, 12 with a residual)
+ratio = {}
+if 'k_bias_act_f32' in fe:
+    n_l, f_kb = fe['k_bias_act_f32']
+    w_kb = wr.get('k_bias_act_f32', (0, 0.0))[1]
+    hbm = (f_kb * 2 + w_kb) * 1024                      # 16-byte loads: FETCH_SIZE x 2
+    el = lambda C: B * C * (1024 // 8) * (2048 // 8) * 4  # bytes of one float32 activation
+    alg_mean = (3 * el(512) + 2 * el(512) + 3 * el(256)) / 3.0
+    ratio['k_bias_act(all)'] = hbm / alg_mean
+    lines.append('')
+    lines.append('k_bias_act_f32 on the 512 ch + residual / 512 ch / 256 ch + residual layer shapes: %.1f MB per launch on average = %.2fx the algorithmic bytes'
+                 % (hbm / 1e6, ratio['k_bias_act(all)']))
 passes = fe.get('k_rgb2lab', (1, 0))[0]
 lines.append('')
 lines.append('families (all launches of one pass summed; %d passes profiled):' % passes)
@@ -112,5 +125,6 @@ lines.append('```')
 open(os.path.join(prof, tag + '_pmc_hbm_traffic_b8.md'), 'w').write('\n'.join(lines) + '\n')
 json.dump({'note': 'HBM bytes per launch PER IMAGE (1024x2048) from the PMC passes of ' + tag +
                    '_pmc_hbm_traffic_b8.md; bench.py reports roofline.traffic = this x images per launch',
-           'bytes_per_image_per_launch': traffic}, open(os.path.join(prof, 'pmc_traffic.json'), 'w'), indent=1)
+           'bytes_per_image_per_launch': traffic, 'ratio_to_algorithmic_bytes': ratio},
+          open(os.path.join(prof, 'pmc_traffic.json'), 'w'), indent=1)
 print('\n'.join(lines[-40:]))
