@@ -96,6 +96,8 @@ LIMITERS = {
     'connectivity(all)': 'latency and issue, not bytes: run tables + strip-local union-find ~1.1 ms, then the BFS replays '
                          '(exact scan-order semantics): a replay is a chain of ~1 100-cycle steps, one wave each; the tiers '
                          'compete for LDS bytes x time and VALU issue (~1.1 ms), relabel 0.17 ms',
+    'k_bias_act(all)': 'HBM bandwidth: one in-place pass over each convolution output (PMC traffic = 1.00x the algorithmic bytes); '
+                       '~5 TB/s of the ~6.3 TB/s a streaming kernel reaches on this part, small layers pay the launch ramp',
     'k_kmeans': 'latency: numpy-ordered float64 sums (one serial chain per cluster and column, ~10 cycles per member row) and '
                 'two grid barriers per Lloyd iteration',
     'k_rgb2lab': 'DP VALU: binary64 exp/log emulation of the float32 power and cube root (bit-defined transcendental)',
