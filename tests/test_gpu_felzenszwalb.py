@@ -60,6 +60,19 @@ def test_felzenszwalb_edge_shapes(eng, orc, synth, H, W, scale, sigma, min_size)
     assert np.array_equal(labels[0].cpu().numpy().astype(np.int64), ref)
 
 
+@pytest.mark.parametrize('H,W', [(255, 257), (256, 256), (257, 256)])
+def test_felzenszwalb_lds_parent_boundary(eng, orc, synth, H, W):
+    """65 535 pixels is the last size whose parent array lives in LDS (16-bit indices, 0xFFFF = root); 65 536
+    and above run on the global array.  Batches of three, so the sorts also take the three-stream path."""
+    imgs = np.stack([synth.synth_scene(300 + i, H, W, n_rect=40) for i in range(3)])
+    labels, n_labels = eng.felzenszwalb(torch.from_numpy(imgs).cuda(), 120.0, 0.8, 20)
+    eng.raise_on_status()
+    for b in range(3):
+        ref = orc.felzenszwalb(imgs[b], 120.0, 0.8, 20)
+        assert np.array_equal(labels[b].cpu().numpy().astype(np.int64), ref), (H, W, b)
+        assert int(n_labels[b]) == ref.max() + 1
+
+
 def test_felzenszwalb_full_size(eng, orc, synth):
     """1024x2048 (8.4 M edges): the reservation scheme at scale."""
     img = synth.synth_scene(77, 1024, 2048, n_rect=120)
