@@ -1,18 +1,14 @@
 /*
  * ORACLE — TEST INFRASTRUCTURE ONLY (see slic_oracle.c header).
  *
- * Deterministic x^2.4 and cbrt(x) for float32 arguments.
- *
- * The reference evaluates these through numpy float32 ufuncs
- * (skimage/color/colorconv.py:659 np.power(.., 2.4); :959 np.cbrt), whose
- * implementation — glibc powf/cbrtf or Intel SVML, depending on the CPU the
- * interpreter runs on — is not reproducible bit for bit.  The restatement
- * therefore fixes ONE definition: evaluate exp(p * log(x)) in binary64 with
- * only +, -, *, / (each IEEE-754 correctly rounded, no fused multiply-add) and
- * round once to binary32.  The binary64 result carries < 1e-14 relative error,
- * so the binary32 result equals the correctly rounded one except with
- * probability ~1e-7 per call, and — the point — the same source gives the same
- * bits under gcc on any x86-64 host and under hipcc on gfx950.
+ * Deterministic binary64 exp and log from +, -, *, / only (each IEEE-754
+ * correctly rounded, no fused multiply-add): < 1e-14 relative error and the
+ * same bits under gcc on any x86-64 host and under hipcc on gfx950.  Used where
+ * the reference's value is only pinned to a tolerance anyway: the prior's
+ * exp (pool_oracle.c), the Gaussian weights of felzenszwalb (fz_oracle.c) and
+ * the float64 Lab of the uint8 SLIC (slic_oracle.c, x^2.4 and cbrt as
+ * exp(p * log x)).  The float32 Lab of the hot path does NOT use these: it
+ * follows the C library bit for bit (glibc_flt32.h).
  */
 #ifndef ORC_DETMATH_H
 #define ORC_DETMATH_H
@@ -77,14 +73,4 @@ static inline double det_exp(double t)
     return p * sc;
 }
 
-/* x > 0 (callers guarantee x > 0.04045 resp. x > 0.008856) */
-static inline float det_powf_2p4(float x)
-{
-    return (float)det_exp(2.4 * det_log_pos((double)x));
-}
-
-static inline float det_cbrtf(float x)
-{
-    return (float)det_exp(det_log_pos((double)x) / 3.0);
-}
 #endif

@@ -23,6 +23,8 @@ import warnings
 sys.dont_write_bytecode = True
 warnings.filterwarnings('ignore')
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import refconfig  # noqa: E402  (the reference configuration: before numpy)
 import numpy as np  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -135,8 +137,12 @@ def gen_slic(ref):
              (4, 224, 224, 100), (5, 100, 37, 12), (0, 512, 1024, 200), (0, 1024, 2048, 200)]
     for (seed, H, W, n) in cases:
         img = synth.synth_image(seed, H, W)                      # CHW f32 0..255
-        lab = orc.rgb2lab_scaled(img)                             # deterministic Lab * 0.1
-        image = np.ascontiguousarray(lab[None], dtype=np.float32)
+        hwc = np.ascontiguousarray(img.transpose(1, 2, 0))
+        # the Lab image exactly as slic() forms it (slic_superpixels.py:257, :307): float32 rgb2lab, * ratio
+        image = np.ascontiguousarray(rgb2lab(hwc)[None] * (1.0 / 10.0), dtype=np.float32)
+        lab = orc.rgb2lab_scaled(img)                             # the restatement: must be the same bits
+        assert image.dtype == np.float32 and np.array_equal(image[0].view(np.uint32), lab.view(np.uint32)), \
+            'oracle Lab is not bit identical to skimage.color.rgb2lab under the reference configuration'
         cent, steps = _get_grid_centroids(image, n)
         nC = cent.shape[0]
         segs = np.ascontiguousarray(np.concatenate([cent, np.zeros((nC, 3))], axis=-1), dtype=np.float32)
@@ -146,13 +152,13 @@ def gen_slic(ref):
         post = _enforce_label_connectivity_cython(pre, mn, mx, start_label=0)
         # end-to-end call exactly as batch_spalign_kmeans.py:311 makes it
         e2e = ref.batch_superpixel(args_ns(n_slic_segments=n), img[None])[0]
+        assert np.array_equal(e2e, post[0]), 'private cores and the public slic() call disagree'
         extra = {}
         if H * W <= 64 * 128:
-            hwc = np.ascontiguousarray(img.transpose(1, 2, 0))
-            extra['skimage_lab_scaled'] = np.ascontiguousarray(rgb2lab(hwc) * 0.1, dtype=np.float32)
+            extra['skimage_lab_scaled'] = image[0]
         save('slic_s%d_%dx%d_n%d' % (seed, H, W, n),
              meta=np.array([seed, H, W, n, nC, mn, mx], np.int64),
-             lab_sha256=np.array(sha(lab)), pre=pre[0].astype(np.int16), post=post[0].astype(np.int16),
+             skimage_lab_sha256=np.array(sha(image[0])), pre=pre[0].astype(np.int16), post=post[0].astype(np.int16),
              centres=segs, e2e_skimage=e2e.astype(np.int16), **extra)
 
     # connectivity stress: random blobs with many small fragments and an oversize component
@@ -253,13 +259,19 @@ def gen_rng():
 
 if __name__ == '__main__':
     os.makedirs(GOLD, exist_ok=True)
+    CONFIG = refconfig.check()
+    with open('/proc/cpuinfo') as fp:
+        HOST = [l.split(':', 1)[1].strip() for l in fp if l.startswith('model name')][0]
     ref = import_reference()
     gen_rng()
     gen_slic(ref)
     gen_pipeline(ref)
     import skimage, scipy
     with open(os.path.join(GOLD, 'PROVENANCE.txt'), 'w') as fp:
-        fp.write('generated by oracle/gen_golden.py\n'
+        fp.write('generated by oracle/gen_golden.py (and the other oracle/gen_golden_*.py, same interpreter)\n'
                  'python %s\nnumpy %s\nscipy %s\nscikit-image %s\n'
                  'reference: /root/reference/batch_spalign_kmeans.py (imported with stub modules)\n'
-                 % (sys.version.split()[0], np.__version__, scipy.__version__, skimage.__version__))
+                 'reference configuration (oracle/refconfig.py): %s\n'
+                 'host: %s\n'
+                 % (sys.version.split()[0], np.__version__, scipy.__version__, skimage.__version__,
+                    CONFIG, HOST))

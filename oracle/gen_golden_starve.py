@@ -18,6 +18,8 @@ import warnings
 sys.dont_write_bytecode = True
 warnings.filterwarnings('ignore')
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import refconfig  # noqa: E402  (the reference configuration: before numpy)
 import numpy as np  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))

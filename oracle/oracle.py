@@ -27,7 +27,8 @@ def build(force=False):
     """Compile liborc.so with gcc (a few seconds). Building the checker is not using it."""
     so = os.path.join(_HERE, 'liborc.so')
     srcs = [os.path.join(_HERE, f) for f in
-            ('slic_oracle.c', 'pool_oracle.c', 'kmeans_oracle.c', 'fz_oracle.c', 'detmath.h', 'Makefile')]
+            ('slic_oracle.c', 'pool_oracle.c', 'kmeans_oracle.c', 'fz_oracle.c', 'resize_oracle.c', 'detmath.h',
+             'glibc_flt32.h', 'Makefile')]
     if force or not os.path.exists(so) or \
             any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(['make', '-s', '-C', _HERE, 'liborc.so'])
@@ -48,6 +49,10 @@ def lib():
         L.orc_rgb2lab_scaled.argtypes = [_P, _i64, _i64, ctypes.c_float, _P]
         L.orc_slic.restype = _i64
         L.orc_slic.argtypes = [_P, _i64, _i64, _i64, _dbl, _i64, _P]
+        L.orc_glibc_powf_vec.restype = None
+        L.orc_glibc_powf_vec.argtypes = [_P, ctypes.c_float, _i64, _P]
+        L.orc_glibc_cbrtf_vec.restype = None
+        L.orc_glibc_cbrtf_vec.argtypes = [_P, _i64, _P]
         L.orc_slic_core_f64.restype = _i64
         L.orc_slic_core_f64.argtypes = [_P, _i64, _i64, _i64, _i64, _P, _P, _i64]
         L.orc_rgb2lab_u8_f64.restype = None
@@ -102,6 +107,22 @@ def rgb2lab_scaled(img_chw, compactness=10.0):
     _, H, W = img.shape
     out = np.empty((H, W, 3), np.float32)
     lib().orc_rgb2lab_scaled(img.ctypes.data, H, W, np.float32(1.0 / compactness), out.ctypes.data)
+    return out
+
+
+def glibc_powf(x, y):
+    """glibc 2.35 powf(x, y) restated (glibc_flt32.h), elementwise on a float32 array."""
+    x = _c(x, np.float32)
+    out = np.empty_like(x)
+    lib().orc_glibc_powf_vec(x.ctypes.data, np.float32(y), x.size, out.ctypes.data)
+    return out
+
+
+def glibc_cbrtf(x):
+    """glibc 2.35 cbrtf(x) restated (glibc_flt32.h), elementwise on a float32 array."""
+    x = _c(x, np.float32)
+    out = np.empty_like(x)
+    lib().orc_glibc_cbrtf_vec(x.ctypes.data, x.size, out.ctypes.data)
     return out
 
 

@@ -17,23 +17,25 @@
 //    the five running sums (y, x, L, a, b) through the ring.  The chains of different segments
 //    are independent, so the GPU runs thousands of them concurrently (B * n_centroids waves).
 #include "spa_common.h"
+#include "spa_glibcf.h"
 
 // ------------------------------------------------------------------------------------
 // rgb -> scaled Lab (skimage/color/colorconv.py:657-661, :950-969), float32 steps in the
-// reference's order; x^2.4 and cbrt through the deterministic binary64 routines.
+// reference's order; np.power(float32, 2.4) = powf(x, 2.4f) and np.cbrt = cbrtf as the C library of the
+// reference configuration evaluates them (spa_glibcf.h): the Lab image is scikit-image's bit for bit.
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ float lab_f(float s)
+__device__ __forceinline__ float lab_f(float s, const spa_glibcf_tables *__restrict__ T)
 {
-    if (s > (float)0.008856) return (float)spa_det_exp(spa_det_log_pos((double)s) / 3.0);
+    if (s > (float)0.008856) return spa_glibc_cbrtf(s, T);
     return (float)7.787 * s + (float)(16.0 / 116.0);
 }
 
 // sRGB companding of one channel value, exactly as the reference evaluates it
-__device__ __forceinline__ float srgb_linear(float a)
+__device__ __forceinline__ float srgb_linear(float a, const spa_glibcf_tables *__restrict__ T)
 {
     if (a > (float)0.04045) {
         float u = (a + (float)0.055) / (float)1.055;
-        return (float)spa_det_exp(2.4 * spa_det_log_pos((double)u));
+        return spa_glibc_powf_2p4(u, T);
     }
     return a / (float)12.92;
 }
@@ -43,7 +45,7 @@ __device__ __forceinline__ float srgb_linear(float a)
 // evaluation it replaces and halves the transcendental work for such images
 __global__ void k_srgb_lut(float *__restrict__ lut)
 {
-    lut[threadIdx.x] = srgb_linear((float)threadIdx.x);
+    lut[threadIdx.x] = srgb_linear((float)threadIdx.x, &spa_glibcf_global);
 }
 
 // does the image look like a decoded 8-bit one?  (a sample of the first image; the table path
@@ -62,7 +64,8 @@ __global__ void k_srgb_probe(const float *__restrict__ rgb, long long n, float *
 
 template <bool TABLE>
 __device__ __forceinline__ void rgb2lab_px(float r, float g, float b, float ratio,
-                                           const float *__restrict__ lut, float &L, float &A, float &Bc)
+                                           const float *__restrict__ lut, const spa_glibcf_tables *__restrict__ T,
+                                           float &L, float &A, float &Bc)
 {
     float v[3] = {r, g, b};
 #pragma unroll
@@ -70,9 +73,9 @@ __device__ __forceinline__ void rgb2lab_px(float r, float g, float b, float rati
         const float a = v[c];
         if (TABLE) {
             const int ai = (int)a;
-            v[c] = (a >= 0.0f && a <= 255.0f && (float)ai == a) ? lut[ai] : srgb_linear(a);
+            v[c] = (a >= 0.0f && a <= 255.0f && (float)ai == a) ? lut[ai] : srgb_linear(a, T);
         } else {
-            v[c] = srgb_linear(a);
+            v[c] = srgb_linear(a, T);
         }
     }
     float X = (float)0.412453 * v[0];
@@ -84,9 +87,9 @@ __device__ __forceinline__ void rgb2lab_px(float r, float g, float b, float rati
     float Z = (float)0.019334 * v[0];
     Z = Z + (float)0.119193 * v[1];
     Z = Z + (float)0.950227 * v[2];
-    float fx = lab_f(X / (float)0.95047);
-    float fy = lab_f(Y / (float)1.0);
-    float fz = lab_f(Z / (float)1.08883);
+    float fx = lab_f(X / (float)0.95047, T);
+    float fy = lab_f(Y / (float)1.0, T);
+    float fz = lab_f(Z / (float)1.08883, T);
     L = ((float)116.0 * fy - (float)16.0) * ratio;
     A = ((float)500.0 * (fx - fy)) * ratio;
     Bc = ((float)200.0 * (fy - fz)) * ratio;
@@ -95,7 +98,8 @@ __device__ __forceinline__ void rgb2lab_px(float r, float g, float b, float rati
 template <bool TABLE>
 __device__ __forceinline__ void rgb2lab_sweep(const float *__restrict__ src, float *__restrict__ dst,
                                               long long npix, float ratio, int vec4,
-                                              const float *__restrict__ lut)
+                                              const float *__restrict__ lut,
+                                              const spa_glibcf_tables *__restrict__ T)
 {
     long long stride = (long long)gridDim.x * blockDim.x;
     if (vec4) {
@@ -105,10 +109,10 @@ __device__ __forceinline__ void rgb2lab_sweep(const float *__restrict__ src, flo
             float4 g = ((const float4 *)(src + npix))[i];
             float4 bl = ((const float4 *)(src + 2 * npix))[i];
             float4 L, A, Bc;
-            rgb2lab_px<TABLE>(r.x, g.x, bl.x, ratio, lut, L.x, A.x, Bc.x);
-            rgb2lab_px<TABLE>(r.y, g.y, bl.y, ratio, lut, L.y, A.y, Bc.y);
-            rgb2lab_px<TABLE>(r.z, g.z, bl.z, ratio, lut, L.z, A.z, Bc.z);
-            rgb2lab_px<TABLE>(r.w, g.w, bl.w, ratio, lut, L.w, A.w, Bc.w);
+            rgb2lab_px<TABLE>(r.x, g.x, bl.x, ratio, lut, T, L.x, A.x, Bc.x);
+            rgb2lab_px<TABLE>(r.y, g.y, bl.y, ratio, lut, T, L.y, A.y, Bc.y);
+            rgb2lab_px<TABLE>(r.z, g.z, bl.z, ratio, lut, T, L.z, A.z, Bc.z);
+            rgb2lab_px<TABLE>(r.w, g.w, bl.w, ratio, lut, T, L.w, A.w, Bc.w);
             ((float4 *)dst)[i] = L;
             ((float4 *)(dst + npix))[i] = A;
             ((float4 *)(dst + 2 * npix))[i] = Bc;
@@ -116,7 +120,7 @@ __device__ __forceinline__ void rgb2lab_sweep(const float *__restrict__ src, flo
     } else {
         for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += stride) {
             float L, A, Bc;
-            rgb2lab_px<TABLE>(src[i], src[npix + i], src[2 * npix + i], ratio, lut, L, A, Bc);
+            rgb2lab_px<TABLE>(src[i], src[npix + i], src[2 * npix + i], ratio, lut, T, L, A, Bc);
             dst[i] = L;
             dst[npix + i] = A;
             dst[2 * npix + i] = Bc;
@@ -131,8 +135,11 @@ __global__ __launch_bounds__(256) void k_rgb2lab(const float *__restrict__ rgb,
     const int b = blockIdx.y;
     const float *src = rgb + (long long)b * 3 * npix;
     float *dst = lab + (long long)b * 3 * npix;
-    if (((const int *)lut)[256]) rgb2lab_sweep<true>(src, dst, npix, ratio, vec4, lut);     // wave-uniform
-    else rgb2lab_sweep<false>(src, dst, npix, ratio, vec4, lut);
+    __shared__ spa_glibcf_tables tabs;
+    spa_glibcf_stage(&tabs);
+    __syncthreads();
+    if (((const int *)lut)[256]) rgb2lab_sweep<true>(src, dst, npix, ratio, vec4, lut, &tabs);     // wave-uniform
+    else rgb2lab_sweep<false>(src, dst, npix, ratio, vec4, lut, &tabs);
 }
 
 extern "C" int spa_rgb2lab(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t W,

@@ -160,14 +160,27 @@ def test_connectivity_run_tables_and_tiers(eng, orc, case):
     assert int(n_labels[1]) == max(n_ref2, 1)
 
 
-def test_slic_full_1024x2048_golden(eng, orc, synth):
-    """BASELINE size: whole spa_slic call against the skimage-pinned fixture."""
-    g = golden('slic_s0_1024x2048_n200')
-    img = synth.synth_image(0, 1024, 2048)
-    labels, n_labels = eng.slic(dev(img[None]), 200)
+E2E_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 'slic_s[0-9]_*.npz')))
+
+
+@pytest.mark.parametrize('name', E2E_CASES)
+def test_slic_from_rgb_is_the_untouched_skimage_call(eng, name):
+    """Whole spa_slic call from RGB (BASELINE size 1024x2048 included) against `e2e_skimage`: the label map the
+    reference's own batch_superpixel (batch_spalign_kmeans.py:308-311 -> skimage.segmentation.slic, untouched)
+    returned for the same image under the reference configuration of tests/golden/PROVENANCE.txt.  0 pixels
+    differ; the Lab image is scikit-image's bit for bit (sha256 of the float32 words)."""
+    import hashlib
+    import importlib
+    synth = importlib.import_module('superpixel-align_amd.synth')
+    g = golden(name)
+    seed, H, W, n = (int(v) for v in g['meta'][:4])
+    img = synth.synth_image(seed, H, W)
+    lab = eng.rgb2lab(dev(img[None]), 0.1)[0].permute(1, 2, 0).contiguous().cpu().numpy()
+    assert hashlib.sha256(lab.tobytes()).hexdigest() == str(g['skimage_lab_sha256'])
+    labels, n_labels = eng.slic(dev(img[None]), n)
     eng.raise_on_status()
-    assert np.array_equal(labels[0].cpu().numpy(), g['post'].astype(np.int32))
-    assert int(n_labels[0]) == int(g['post'].max()) + 1
+    assert np.array_equal(labels[0].cpu().numpy(), g['e2e_skimage'].astype(np.int32))
+    assert int(n_labels[0]) == int(g['e2e_skimage'].max()) + 1
 
 
 def test_slic_full_batch_vs_oracle(eng, orc, synth):
@@ -218,7 +231,10 @@ def test_anchor_pipeline_against_reference_golden(eng, orc, synth, tag):
     N = sum(n_per)
     fm = synth.synth_feature_map(seed + 1, C, H // 8, W // 8, batch=B)
     fmap = dev(fm).contiguous(memory_format=torch.channels_last)
-    labels = dev(sps)
+    # the reference's own batch_superpixel output (skimage slic from RGB) is what the GPU computes from RGB
+    labels, n_labels = eng.slic(dev(synth.synth_batch([seed + b for b in range(B)], H, W)), n)
+    eng.raise_on_status()
+    assert np.array_equal(labels.cpu().numpy(), sps) and [int(v) for v in n_labels] == n_per
     off = eng.segment_offsets(dev(np.array(n_per, np.int32)))
     count, centroid, prior = eng.segment_stats(labels, off, N, (0.75, 0.5, 0.1, 0.1))
     np.testing.assert_allclose(prior.cpu().numpy(), g['prior'], rtol=1e-12, atol=0)

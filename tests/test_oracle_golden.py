@@ -39,12 +39,6 @@ def test_rng_streams(orc):
         assert np.array_equal(a[:32], g['np_%d' % n])
 
 
-# pixels (of H*W) that differ from skimage.slic() run from RGB: the reference's float32 pow/cbrt are
-# numpy SVML kernels, up to 9 ulp from the correctly rounded value and machine dependent, whereas
-# the oracle and the HIP kernel evaluate ONE deterministic definition
-E2E_MISMATCH = {'slic_s0_1024x2048_n200': 63, 'slic_s0_512x1024_n200': 7, 'slic_s0_64x128_n20': 0,
-                'slic_s1_128x256_n100': 18, 'slic_s2_256x512_n100': 14, 'slic_s3_96x96_n30': 210,
-                'slic_s4_224x224_n100': 2, 'slic_s5_100x37_n12': 0}
 SLIC_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 'slic_s[0-9]_*.npz')))
 
 
@@ -57,7 +51,8 @@ def test_slic_core_and_connectivity_bit_exact(orc, synth, name):
         pass
     img = synth.synth_image(seed, H, W)
     lab = orc.rgb2lab_scaled(img)
-    assert _sha(lab) == str(g['lab_sha256']), 'deterministic Lab changed: regenerate fixtures'
+    # the Lab image slic() forms (float32 rgb2lab * ratio) under the reference configuration, bit for bit
+    assert _sha(lab) == str(g['skimage_lab_sha256']), 'oracle Lab is not skimage.color.rgb2lab\'s'
     pre, centres = orc.slic_core(lab, n)
     assert centres.shape[0] == nC
     assert np.array_equal(pre, g['pre'].astype(np.int64))          # bit exact vs _slic_cython
@@ -66,13 +61,10 @@ def test_slic_core_and_connectivity_bit_exact(orc, synth, name):
     post, nl = orc.enforce_connectivity(pre, mn, mx)
     assert np.array_equal(post, g['post'].astype(np.int64))        # bit exact vs _enforce_label_connectivity_cython
     assert nl == int(g['post'].max()) + 1
-    # whole call from RGB: label agreement with skimage.slic (Lab stage is floating point and
-    # machine dependent in the reference: numpy float32 pow is up to 9 ulp off on this host)
+    # whole call from RGB: identical to the untouched slic() call of batch_spalign_kmeans.py:311 run through the
+    # reference's own batch_superpixel under the reference configuration (tests/golden/PROVENANCE.txt)
     full = orc.slic(img, n)
-    assert np.array_equal(full, post)
-    # measured per fixture: pixels where the deterministic-Lab result differs from the untouched
-    # skimage.slic() call of batch_spalign_kmeans.py:311 on this host (0 .. 210 pixels)
-    assert int((full != g['e2e_skimage']).sum()) == E2E_MISMATCH[name], name
+    assert np.array_equal(full, g['e2e_skimage'].astype(np.int64)), name
 
 
 STARVE_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 'slic_starve_*.npz')))
@@ -122,12 +114,41 @@ def test_slic_uint8_matches_the_reference_baseline_run(orc):
         assert np.array_equal(orc.slic_u8(img, 20), sp)
 
 
-def test_lab_within_tolerance_of_skimage(orc, synth):
-    g = golden('slic_s0_64x128_n20')
-    lab = orc.rgb2lab_scaled(synth.synth_image(0, 64, 128))
-    ref = g['skimage_lab_scaled']
-    scale = np.abs(ref).max()
-    assert np.abs(lab - ref).max() / scale < 5e-6      # float32 stage: tolerance, not bits
+def test_lab_is_skimage_lab_bit_for_bit(orc, synth):
+    """float32 rgb2lab * ratio of scikit-image 0.18.3 under the reference configuration: same words."""
+    for name, (seed, H, W) in {'slic_s0_64x128_n20': (0, 64, 128), 'slic_s5_100x37_n12': (5, 100, 37)}.items():
+        lab = orc.rgb2lab_scaled(synth.synth_image(seed, H, W))
+        ref = golden(name)['skimage_lab_scaled']
+        assert ref.dtype == np.float32 and np.array_equal(lab.view(np.uint32), ref.view(np.uint32))
+
+
+def test_glibc_restatement_vs_host_libm(orc):
+    """oracle/glibc_flt32.h against the C library of this host: powf(x, 2.4f) and cbrtf(x) on 4 M float32 values
+    of the domain the Lab conversion can reach (the exhaustive run over [1e-3, 1e7], 278 M values, is
+    tools/glibc_exhaustive.c: 0 differences).  Only meaningful where the host runs glibc 2.35."""
+    import ctypes
+    gnu = ctypes.CDLL('libc.so.6').gnu_get_libc_version
+    gnu.restype = ctypes.c_char_p
+    if gnu().decode() != '2.35':
+        pytest.skip('host C library is glibc %s, the restatement follows 2.35' % gnu().decode())
+    cmp_so = os.path.join(os.path.dirname(GOLDEN), '_libm_vec.so')
+    src = os.path.join(os.path.dirname(GOLDEN), 'libm_vec.c')
+    import subprocess
+    subprocess.check_call(['gcc', '-O1', '-shared', '-fPIC', '-o', cmp_so, src, '-lm'])
+    L = ctypes.CDLL(cmp_so)
+    rs = np.random.RandomState(11)
+    # every binade from 2^-7 to 2^20, uniformly in the mantissa, plus the neighbourhoods of the two branch points
+    bits = (rs.randint(120, 148, 4000000).astype(np.uint32) << 23) | rs.randint(0, 1 << 23, 4000000).astype(np.uint32)
+    x = np.concatenate([bits.view(np.float32),
+                        np.nextafter(np.float32(0.0905), np.float32(1), dtype=np.float32) + np.arange(4096, dtype=np.float32) * np.float32(1e-8),
+                        np.float32(0.008856) + np.arange(4096, dtype=np.float32) * np.float32(1e-9),
+                        np.arange(0, 256, dtype=np.float32) / np.float32(1.055) + np.float32(0.055) / np.float32(1.055)])
+    x = np.ascontiguousarray(x[x > 0], np.float32)
+    ref = np.empty_like(x)
+    L.libm_powf_vec(x.ctypes.data_as(ctypes.c_void_p), ctypes.c_float(2.4), ctypes.c_int64(x.size), ref.ctypes.data_as(ctypes.c_void_p))
+    assert np.array_equal(orc.glibc_powf(x, 2.4).view(np.uint32), ref.view(np.uint32))
+    L.libm_cbrtf_vec(x.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(x.size), ref.ctypes.data_as(ctypes.c_void_p))
+    assert np.array_equal(orc.glibc_cbrtf(x).view(np.uint32), ref.view(np.uint32))
 
 
 @pytest.mark.parametrize('name', sorted(os.path.basename(p)[:-4] for p in
@@ -182,6 +203,10 @@ def test_pipeline_ops_against_reference(orc, synth, tag):
     imgs = synth.synth_batch([seed + b for b in range(B)], H, W)
     fmaps = synth.synth_feature_map(seed + 1, C, H // 8, W // 8, batch=B)
     args = _args(n_slic_segments=n)
+
+    # the superpixels the reference's batch_superpixel returned (skimage slic from RGB): identical
+    for b in range(B):
+        assert np.array_equal(orc.slic(imgs[b], n), sps[b])
 
     # prior: float64, numpy exp + pairwise mean vs deterministic exp + sequential mean
     prior = orc.batch_create_prior(args, sps)
