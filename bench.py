@@ -72,7 +72,8 @@ def parse():
                         'that follow run slower by as much (measured), so the default is 1')
     p.add_argument('--no_cpu_baseline', action='store_true')
     p.add_argument('--cpu_sample', type=int, default=1, help='images of the PyTorch-CPU DRN sample')
-    p.add_argument('--cpu_threads', type=int, default=16, help='threads (= images) of the all-cores oracle row')
+    p.add_argument('--cpu_threads', type=int, default=64,
+                   help='threads (= images in flight) of the all-cores oracle row: min(host cores, this)')
     p.add_argument('--no_host_loop', action='store_true', help='skip the pinned-host to pinned-host loop')
     p.add_argument('--n_batches', type=int, default=3, help='distinct batches rotating through the steps')
     p.add_argument('--no_prof', action='store_true', help='do not record per-kernel events')
@@ -240,8 +241,26 @@ def cpu_baseline(a, synth, n_img):
                                         '(scikit-image SLIC, 1.8-3.8 s/image in the build container, is not on this box)'}}
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks ourselves, exactly as
+    the driver would (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`), as a
+    CHILD process — this process has not touched the GPU and never will — forward rank 0's line and exit with the
+    child's code.  (The reference's equivalent is the bash fan-out of utils/create_random300_labels.sh:37-51.)"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(a))
     import torch
     spa = importlib.import_module('superpixel-align_amd')
     dist = importlib.import_module('superpixel-align_amd.dist')
@@ -252,8 +271,7 @@ def main():
     if os.environ.get('SPA_BENCH_SAME_DEVICE') == '1':
         local = 0               # test hook: several ranks on one GPU (with SPA_DIST_BACKEND=gloo)
     if ws != a.gpus:
-        if rank == 0:
-            print('warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE' % (a.gpus, ws), file=sys.stderr)
+        raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks' % (a.gpus, ws))
     torch.cuda.set_device(local)
     torch.backends.cudnn.benchmark = True
     dtype = {'fp32': torch.float32, 'bf16': torch.bfloat16}[a.dtype]

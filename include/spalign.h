@@ -103,7 +103,8 @@ int spa_drn_stem_d(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W
  * residual add (models/drn.py:23-57) and the ReLU fused into the epilogue.  stride 1, padding = dilation.
  * x (B,H,W,Cin) bfloat16 channels-last; wt (Cout,9,Cin) bfloat16 = the (Cout,Cin,3,3) weight permuted to
  * (n, ky, kx, c); bias (Cout) float32; residual (B,H,W,Cout) bfloat16 or NULL; y (B,H,W,Cout) bfloat16.
- * Cin % 64 == 0, Cout % 256 == 0; float32 accumulation, one rounding to bfloat16 at the end. */
+ * Cin % 64 == 0, Cout % 64 == 0 (channel tiles of 256, 128 or 64), every pointer 16-byte aligned; float32
+ * accumulation, one rounding to bfloat16 at the end. */
 int spa_conv3x3_bf16(spa_ctx *ctx, const void *x, int32_t B, int32_t H, int32_t W, int32_t Cin,
                      const void *wt, int32_t Cout, const float *bias, const void *residual,
                      int32_t relu, int32_t dilation, void *y, void *stream);

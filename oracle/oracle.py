@@ -405,17 +405,47 @@ def batch_create_prior(args, superpixels):
                                         args.x_rel_sigma) for sp in superpixels])
 
 
-def batch_weighted_kmeans(args, superpixels, superpixel_features, superpixel_weights,
-                          n_superpixels_per_image, nprandom=None):
-    """:347-358 + :186-207 -> (clustering (B,H,W) uint8, road (B,H,W) bool, info)."""
-    assign, it, status = kmeans(args.n_clusters, superpixel_features, superpixel_weights,
-                                nprandom=nprandom)
+RETRY_DEPTH_LIMIT = 990        # CPython's default recursion limit (1000) minus the frames below weighted_kmeans
+
+
+def weighted_kmeans(superpixels, superpixel_features, superpixel_weights, k, n_superpixels_per_image,
+                    nprandom=None, _depth=0):
+    """weighted_kmeans() :186-207 including its retry: after painting image b, if the image has no cluster-0
+    pixel the function prints and calls ITSELF with the same arguments, result discarded (:201-205), then goes on
+    with image b + 1.  Every call runs kmeans(), i.e. one np.random.shuffle of the initial assignment (:147-149):
+    for k > 2 the retries move the stream later batches draw from; for k = 2 the assignment does not depend on the
+    shuffle, the retry fails the same way and the reference ends in RecursionError — reproduced as such."""
+    if _depth > RETRY_DEPTH_LIMIT:
+        raise RecursionError('maximum recursion depth exceeded (weighted_kmeans retry, batch_spalign_kmeans.py:201-205)')
+    if nprandom is None:
+        nprandom = NpRandom()
+    if k == 2:
+        # kmeans() shuffles an all-ones vector here: no effect on the result, but the stream advances
+        N = np.asarray(superpixel_features).shape[0]
+        w = np.asarray(superpixel_weights, np.float64)
+        ones = np.ones(int((w <= np.sort(w)[N // 2]).sum()), np.int64)
+        nprandom.shuffle(ones)
+    assign, it, status = kmeans(k, superpixel_features, superpixel_weights, nprandom=nprandom)
     cl = np.zeros(np.asarray(superpixels).shape, np.uint8)
     off = 0
     for b, n in enumerate(n_superpixels_per_image):
         cl[b], _ = paint(superpixels[b], assign[off:off + n])
         off += n
+        if (cl[b] == 0).sum() == 0:
+            print('\nSomehow KMeans seems failed. Try again\n')
+            if k == 2:          # deterministic: the retry fails identically, ~990 frames deep the interpreter gives up
+                raise RecursionError('maximum recursion depth exceeded (weighted_kmeans retry, '
+                                     'batch_spalign_kmeans.py:201-205, k = 2 repeats the same failure)')
+            weighted_kmeans(superpixels, superpixel_features, superpixel_weights, k, n_superpixels_per_image,
+                            nprandom, _depth + 1)
     return cl, cl == 0, dict(assign=assign, n_iter=it, status=status)
+
+
+def batch_weighted_kmeans(args, superpixels, superpixel_features, superpixel_weights,
+                          n_superpixels_per_image, nprandom=None):
+    """:347-358 + :186-207 -> (clustering (B,H,W) uint8, road (B,H,W) bool, info)."""
+    return weighted_kmeans(superpixels, superpixel_features, superpixel_weights, args.n_clusters,
+                           n_superpixels_per_image, nprandom)
 
 
 # --------------------------------------------------------------------------- felzenszwalb

@@ -167,7 +167,14 @@ class ImageList(object):
         idx = list(range(len(self))[lo:hi])
         raw = list(pool.map(self.get_raw, idx)) if pool is not None else [self.get_raw(i) for i in idx]
         if len({r.shape for r in raw}) != 1 or raw[0].shape[2] != 3:
-            return np.stack([self.get(i) for i in idx])
+            # images of different sizes (or greyscale, which stays one channel like the reference's dataset):
+            # host path on the frames already decoded — a NumPy batch, the caller uploads it
+            def host(r):
+                img = r.transpose(2, 0, 1)
+                if self._shape is not None and tuple(img.shape[1:]) != tuple(self._shape):
+                    img = resize_bicubic_chw(img, self._shape)
+                return img.astype(self._dtype)
+            return np.stack(list(pool.map(host, raw)) if pool is not None else [host(r) for r in raw])
         u8 = torch.from_numpy(np.stack(raw)).to(engine.device, non_blocking=True)
         shape = tuple(self._shape) if self._shape is not None else raw[0].shape[:2]
         return engine.resize_bicubic_u8(u8, shape)
@@ -357,13 +364,17 @@ def main_labelled(argv=None, get=None, make_pipe=None, originals=False, make_mod
 
     records = []
     own = {}
+    drained = set()
 
     def drain(futs):
         """Collect finished images; a single process appends their result.json lines NOW (the
         reference appends one line per image as it goes, :407-422), so a failure in a later batch
         loses nothing already computed.  Under torchrun rank 0 writes after the gather instead."""
         for f in futs:
+            if f in drained:
+                continue
             i, line, rec = f.result()
+            drained.add(f)
             records.append(rec)
             own[i] = line
             if ws == 1:
@@ -380,6 +391,8 @@ def main_labelled(argv=None, get=None, make_pipe=None, originals=False, make_mod
             if eng_in is not None and not args.host_resize:
                 with torch.cuda.stream(in_stream):
                     t = imgs_ds.batch_device(lo, hi, workers, eng_in)
+                    if not isinstance(t, torch.Tensor):
+                        return t, None                   # mixed-size batch: host arrays, nothing in flight
                     ev = torch.cuda.Event()
                     ev.record(in_stream)
                 return t, ev
@@ -401,8 +414,10 @@ def main_labelled(argv=None, get=None, make_pipe=None, originals=False, make_mod
             n_sp = res.n_labels.cpu().numpy()
             # a re-labelled image (last batch shifted back, :539-542) must overwrite its earlier files:
             # wait for the previous batch's writers before queueing this batch's
-            done, pending = pending, []
-            drain(done)
+            # (`pending` keeps them until they are drained, so that the finally clause still sees the
+            # successful ones if one of them failed)
+            drain(pending)
+            pending = []
             for j, i in enumerate(list(range(len(imgs_ds)))[lo:hi]):
                 pending.append(workers.submit(finish, i, road[j], cluster[j], int(n_sp[j]), info, times, st_all))
     finally:

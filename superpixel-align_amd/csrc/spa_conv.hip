@@ -208,6 +208,7 @@ extern "C" int spa_conv3x3_bf16(spa_ctx *ctx, const void *x, int32_t B, int32_t 
     SPA_ARG(ctx && x && wt && bias && y && B > 0 && H > 0 && W > 0 && dilation >= 1);
     SPA_ARG(Cin % CV_BK == 0 && Cout % 64 == 0 && dilation <= CV_HALO);
     SPA_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)wt % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)bias % 16) == 0);
+    SPA_ARG(((uintptr_t)residual % 16) == 0);
     hipStream_t s = spa_stream(stream);
     char *zero;
     int rc = spa_ws_reserve(ctx, WS_ZERO_LINE, 4096, (void **)&zero);

@@ -358,16 +358,37 @@ class DRN(nn.Module):
         return self
 
     def load_chainer_npz(self, path):
-        """models/drn_c_26.npz written by the reference's convert_pth2ch.py (chainer save_npz)."""
+        """models/drn_c_26.npz written by the reference's convert_pth2ch.py (chainer save_npz).
+
+        Key grammar of chainer.serializers.save_npz: a Chain names its children by attribute ("layer3", "conv1",
+        "downsample"), the reference's Sequential is a ChainList (models/sequential.py:9, :272-290) and numbers
+        ONLY its links, in insertion order — F.relu entries are skipped, so Sequential(conv, bn, relu, conv, bn,
+        relu) saves "0/W", "1/gamma", "2/W", "3/gamma" where torch's nn.Sequential has modules 0, 1, 3, 4.  A link
+        holds W, b (Convolution2D), gamma, beta, avg_mean, avg_var, N (BatchNormalization)."""
         rename = {'W': 'weight', 'b': 'bias', 'gamma': 'weight', 'beta': 'bias',
                   'avg_mean': 'running_mean', 'avg_var': 'running_var'}
         own = self.state_dict()
+
+        def resolve(parts):
+            mod, out = self, []
+            for p in parts:
+                if isinstance(mod, nn.Sequential) and p.isdigit():
+                    links = [i for i, m in enumerate(mod) if any(True for _ in m.parameters())]
+                    if int(p) >= len(links):
+                        raise KeyError('no link %s under %s' % (p, '.'.join(out)))
+                    p = str(links[int(p)])
+                out.append(p)
+                mod = getattr(mod, p) if not p.isdigit() else mod[int(p)]
+            return out
         with np.load(path) as z:
             for key in z.files:
                 parts = key.split('/')
                 if parts[-1] == 'N' or (parts[0] == 'fc' and self.fc is None):
                     continue
-                name = '.'.join(parts[:-1] + [rename[parts[-1]]])
+                try:
+                    name = '.'.join(resolve(parts[:-1]) + [rename[parts[-1]]])
+                except (AttributeError, IndexError, KeyError):
+                    raise KeyError('unexpected entry %s in %s' % (key, path))
                 if name not in own:
                     raise KeyError('unexpected entry %s in %s' % (key, path))
                 own[name].copy_(torch.from_numpy(z[key]).reshape(own[name].shape))

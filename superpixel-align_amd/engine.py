@@ -111,8 +111,9 @@ class Engine(object):
         out = torch.empty((B, 16, H, W), dtype=dtype, device=x.device, memory_format=torch.channels_last)
         mean = (ctypes.c_double * 3)(0.485, 0.456, 0.406)
         std = (ctypes.c_double * 3)(0.229, 0.224, 0.225)
-        # float32 path: normalised copy of the image, per call (stream safe); the bf16 kernel normalises while staging
-        scratch = torch.empty((B, H, W, 3), dtype=torch.float32, device=x.device) if dtype == torch.float32 else None
+        # normalised channels-last copy of the image (float32, or bfloat16 for the bf16 kernel): per call, so calls
+        # on different streams (DRN.batch_predict(streams > 1)) never share the context-wide workspace
+        scratch = torch.empty((B, H, W, 3), dtype=dtype, device=x.device)
         check(self._lib.spa_drn_stem_d(self._ctx, _ptr(x), B, H, W, _ptr(w0), _ptr(b0), _ptr(w1p), _ptr(b1),
                                        mean, std, _ptr(out), 0 if dtype == torch.float32 else 1, _ptr(scratch),
                                        self._s()))

@@ -143,7 +143,12 @@ def batch_create_prior(args, superpixels):
 
 
 def batch_weighted_kmeans(args, superpixels, superpixel_features, superpixel_weights,
-                          n_superpixels_per_image):
+                          n_superpixels_per_image, _depth=0):
+    """:347-358 + weighted_kmeans :186-207, including its retry (:201-205): after image b is painted, an image
+    without a cluster-0 pixel makes the reference print and call itself again with the same arguments, result
+    discarded.  Every call runs kmeans(), i.e. one np.random.shuffle (:147-149): the retries therefore move the
+    stream of later batches (k > 2) and may recurse; for k = 2 the retry repeats the failure and the reference
+    ends in RecursionError — same here."""
     eng = engine()
     labels, _ = _labels_on_device(superpixels)
     B = labels.shape[0]
@@ -152,18 +157,21 @@ def batch_weighted_kmeans(args, superpixels, superpixel_features, superpixel_wei
     w = hw['prior'] if hw and 'prior' in hw else _dev(superpixel_weights, torch.float64)
     off = _dev(np.concatenate([[0], np.cumsum(n_superpixels_per_image)]).astype(np.int32))
     k = args.n_clusters
-    init_other = None
-    if k > 2:
-        wh = np.asarray(superpixel_weights, dtype=np.float64)
-        thr = np.sort(wh)[len(wh) // 2]
-        idx = (np.arange(int((wh <= thr).sum())) % (k - 1) + 1).astype(np.int64)
-        _rng()[1].shuffle(idx)
-        init_other = _dev(idx)
+    wh = np.asarray(superpixel_weights, dtype=np.float64)
+    thr = np.sort(wh)[len(wh) // 2]
+    idx = (np.arange(int((wh <= thr).sum())) % (k - 1) + 1).astype(np.int64)
+    _rng()[1].shuffle(idx)                       # k = 2: all ones, no effect on the result, the stream still moves
+    init_other = _dev(idx) if k > 2 else None
     assign, info = eng.kmeans(X, w, off[B:], k, 1000, init_other)
     cluster, road = eng.paint(labels, assign, off)
     eng.raise_on_status()
     cl = cluster.cpu().numpy()
-    if (cl.reshape(B, -1) == 0).sum(axis=1).min() == 0:
-        # the reference prints this and re-runs k-means with the result discarded (:201-205)
-        print('\nSomehow KMeans seems failed. Try again\n')
+    for b in range(B):
+        if (cl[b] == 0).sum() == 0:
+            print('\nSomehow KMeans seems failed. Try again\n')
+            if k == 2 or _depth >= 990:
+                raise RecursionError('maximum recursion depth exceeded: weighted_kmeans retry, '
+                                     'batch_spalign_kmeans.py:201-205' + (' (k = 2 repeats the same failure)' if k == 2 else ''))
+            batch_weighted_kmeans(args, superpixels, superpixel_features, superpixel_weights,
+                                  n_superpixels_per_image, _depth + 1)
     return cl.astype(np.int64), cl == 0

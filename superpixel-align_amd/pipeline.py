@@ -27,7 +27,30 @@ class BatchResult(object):
 
     def masks_to_host(self):
         """(clustering (B,H,W) uint8, road (B,H,W) uint8) as numpy — one D2H each."""
+        self.check_retry()
         return self.cluster.cpu().numpy(), self.road.cpu().numpy()
+
+    def check_retry(self):
+        """k = 2 only: an image without a cluster-0 pixel sends the reference into its retry (:201-205), which
+        repeats the same deterministic failure until the interpreter raises RecursionError — same outcome here,
+        checked when the results are fetched (the flags are device-side, the batch loop stays asynchronous)."""
+        fail = getattr(self, 'retry_fail', None)
+        if fail is not None and bool(fail.any().item()):
+            print('\nSomehow KMeans seems failed. Try again\n')
+            raise RecursionError(RETRY_MESSAGE + ' (image(s) %s of the batch have no cluster-0 pixel; k = 2 repeats '
+                                 'the same failure)' % fail.nonzero().flatten().tolist())
+
+
+RETRY_MESSAGE = 'maximum recursion depth exceeded: weighted_kmeans retry, batch_spalign_kmeans.py:201-205'
+RETRY_DEPTH_LIMIT = 990        # CPython's default recursion limit minus the frames below weighted_kmeans
+
+
+def images_without_cluster0(assign, off, B):
+    """(B,) bool on the device: image b has no superpixel in cluster 0 (labels are dense, so no pixel either)."""
+    z = torch.cumsum((assign == 0).to(torch.int32), 0)
+    c = torch.cat([z.new_zeros(1), z])
+    o = off[:B + 1].long()
+    return (c[o[1:]] - c[o[:-1]]) == 0
 
 
 class LabelPipeline(object):
@@ -94,6 +117,18 @@ class LabelPipeline(object):
             labels, off, ncap, (a.y_rel_pos, a.x_rel_pos, a.y_rel_sigma, a.x_rel_sigma),
             want_centroid=True)
         anchors = nvalid = None
+        if self.pool_mode == 'anchor' and self.device_rng and int(1.7 * B * H * W) + (1 << 21) > (1 << 27) - 4096:
+            # the shuffles of one batch consume ~1.4-1.5 generator outputs per pixel; the device ring holds 2^27.
+            # A batch beyond ~75 M pixels therefore draws on the host (same stream, bit for bit) — possible only
+            # while the generator state has not moved to the device yet
+            if self._rng_ready:
+                raise ValueError('device_rng: a batch of %d pixels needs more generator outputs than the device ring '
+                                 'holds and the generator state already lives on the device; use smaller batches or '
+                                 'the host generator from the start' % (B * H * W))
+            import warnings
+            warnings.warn('device_rng: batch of %d pixels exceeds the device ring; drawing the anchors on the host'
+                          % (B * H * W))
+            self.device_rng = False
         if self.pool_mode == 'anchor' and self.device_rng:
             # no superpixel size visits the host: rejection sampling of every shuffle swap and the first
             # n_anchors places of every shuffled list on the device (spa_anchor_ranks_dev)
@@ -141,8 +176,13 @@ class LabelPipeline(object):
         return eng.pool_anchor(fmap, imgs_shape[2], seg['off'], seg['ncap'], seg['anchors'],
                                seg['nvalid'], a.n_neighbors, cen, append_pos)
 
-    def cluster(self, labels, off, X, prior):
-        """batch_weighted_kmeans (:347-358) -> assign, info, cluster map, road mask (device)."""
+    def cluster(self, labels, off, X, prior, _depth=0):
+        """batch_weighted_kmeans (:347-358) -> assign, info, cluster map, road mask, retry flags (device).
+
+        The reference's weighted_kmeans re-runs itself, result discarded, for every image that ends without a
+        cluster-0 pixel (:201-205).  k > 2: each run shuffles the initial assignment with numpy's global
+        generator, so the retries (a tree: a retry can fail and recurse) are executed here for their effect on
+        the stream later batches draw from.  k = 2: see BatchResult.check_retry."""
         a, eng = self.args, self.eng
         B = labels.shape[0]
         init_other = None
@@ -157,7 +197,15 @@ class LabelPipeline(object):
             init_other = torch.from_numpy(idx).to(labels.device)
         assign, info = eng.kmeans(X, prior, off[B:], a.n_clusters, 1000, init_other)
         cluster, road = eng.paint(labels, assign, off)
-        return assign, info, cluster, road
+        fail = images_without_cluster0(assign, off, B)
+        if a.n_clusters > 2:
+            for b in fail.cpu().numpy().nonzero()[0]:
+                print('\nSomehow KMeans seems failed. Try again\n')
+                if _depth >= RETRY_DEPTH_LIMIT:
+                    raise RecursionError(RETRY_MESSAGE)
+                self.cluster(labels, off, X, prior, _depth + 1)        # discarded, as in the reference
+            fail = None
+        return assign, info, cluster, road, fail
 
     # ---------------------------------------------------------------- whole batch
     def _tick(self, name):
@@ -202,13 +250,15 @@ class LabelPipeline(object):
         self._tick('joined')
         X = self.pool(imgs_dev.shape, labels, seg, fmap)
         self._tick('describe')
-        assign, info, cluster, road = self.cluster(labels, seg['off'], X, seg['prior'])
+        assign, info, cluster, road, fail = self.cluster(labels, seg['off'], X, seg['prior'])
         self._tick('kmeans')
+        res = BatchResult(labels=labels, n_labels=n_labels, offsets=seg['off'], count=seg['count'],
+                          X=X, prior=seg['prior'], assign=assign, info=info, cluster=cluster,
+                          road=road, fmap=fmap, retry_fail=fail)
         if check_status:
             self.eng.raise_on_status()
-        return BatchResult(labels=labels, n_labels=n_labels, offsets=seg['off'], count=seg['count'],
-                           X=X, prior=seg['prior'], assign=assign, info=info, cluster=cluster,
-                           road=road, fmap=fmap)
+            res.check_retry()
+        return res
 
     def stage_ms(self):
         """Device-event durations of the last run() in ms.  With two streams the superpixel

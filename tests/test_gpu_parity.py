@@ -283,6 +283,46 @@ def test_kmeans_engineered(eng, orc):
     eng.raise_on_status()
 
 
+def test_kmeans_retry_branch_follows_the_reference(eng, capsys):
+    """weighted_kmeans :201-205 on the GPU paths.  The drop-in op (ops.batch_weighted_kmeans) and the fused
+    pipeline (LabelPipeline.cluster) execute the reference's discarded retries, so two consecutive k = 4 batches
+    reproduce the cluster maps recorded from the reference's own weighted_kmeans (oracle/gen_golden_retry.py);
+    k = 2 ends in RecursionError like the reference."""
+    import types
+    ops = importlib.import_module('superpixel-align_amd.ops')
+    pipeline = importlib.import_module('superpixel-align_amd.pipeline')
+    g = golden('kmeans_retry')
+    args = types.SimpleNamespace(n_clusters=4, seed=1111)
+    ops.seed(1111)
+    cl0, road0 = ops.batch_weighted_kmeans(args, g['sps0'].astype(np.int64), g['X0'], g['w0'], [int(v) for v in g['n_per0']])
+    cl1, road1 = ops.batch_weighted_kmeans(args, g['sps1'].astype(np.int64), g['X1'], g['w1'], [int(v) for v in g['n_per1']])
+    assert capsys.readouterr().out.count('Somehow KMeans seems failed') == int(g['n_retry'])
+    assert np.array_equal(cl0, g['cl0']) and np.array_equal(cl1, g['cl1']) and np.array_equal(road0, g['cl0'] == 0)
+    # fused pipeline: same stages on device tensors
+    pipe = pipeline.LabelPipeline(args, model=None, engine=eng, pool_mode='mean', overlap=False)
+    outs = []
+    for t in ('0', '1'):
+        n_per = g['n_per' + t].astype(np.int32)
+        off = dev(np.concatenate([[0], np.cumsum(n_per)]).astype(np.int32))
+        assign, info, cluster, road, fail = pipe.cluster(dev(g['sps' + t].astype(np.int32)), off, dev(g['X' + t]), dev(g['w' + t]))
+        assert fail is None
+        outs.append(cluster.cpu().numpy())
+    assert capsys.readouterr().out.count('Somehow KMeans seems failed') == int(g['n_retry'])
+    assert np.array_equal(outs[0], g['cl0']) and np.array_equal(outs[1], g['cl1'])
+    # k = 2
+    args2 = types.SimpleNamespace(n_clusters=2, seed=1111)
+    with pytest.raises(RecursionError):
+        ops.batch_weighted_kmeans(args2, g['sps2'].astype(np.int64), g['X2'], g['w2'], [int(v) for v in g['n_per2']])
+    pipe2 = pipeline.LabelPipeline(args2, model=None, engine=eng, pool_mode='mean', overlap=False)
+    n_per = g['n_per2'].astype(np.int32)
+    off = dev(np.concatenate([[0], np.cumsum(n_per)]).astype(np.int32))
+    assign, info, cluster, road, fail = pipe2.cluster(dev(g['sps2'].astype(np.int32)), off, dev(g['X2']), dev(g['w2']))
+    assert fail.cpu().tolist() == [False, True]
+    with pytest.raises(RecursionError):
+        pipeline.BatchResult(cluster=cluster, road=road, retry_fail=fail).masks_to_host()
+    eng.raise_on_status()
+
+
 @pytest.mark.parametrize('name', ['slic_starve_s0_24x40_n30', 'slic_starve_s2_40x64_n30',
                                   'slic_starve_s5_32x32_n60', 'slic_starve_s6_40x64_n60'])
 def test_slic_starved_seeds(eng, orc, name):

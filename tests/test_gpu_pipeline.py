@@ -53,6 +53,22 @@ def test_drn_on_gpu_matches_reference_maps(mods):
         assert err < 0.05, err                     # bf16 storage + fp32 accumulation
 
 
+@pytest.mark.parametrize('dtype', ['bf16', 'fp32'])
+def test_drn_streams_two_equals_one(mods, synth, dtype):
+    """DRN.batch_predict(streams=2): both halves run the fused stem concurrently on side streams with ONE context;
+    every call owns its normalised-image scratch, so the maps equal the single-stream forward bit for bit
+    (the bf16 stem used to share the context-wide workspace between the streams)."""
+    td = {'bf16': torch.bfloat16, 'fp32': torch.float32}[dtype]
+    m = mods.drn.create_drn('drn_d_22', device='cuda', dtype=td)
+    x = synth.synth_batch(list(range(40, 48)), 256, 512)
+    for _ in range(3):
+        _, one = m.batch_predict(x, need=[1, 7], streams=1)
+        _, two = m.batch_predict(x, need=[1, 7], streams=2)
+        torch.cuda.synchronize()
+        for i in (1, 7):
+            assert torch.equal(one[i], two[i]), i
+
+
 def test_five_ops_drop_in(mods, orc, synth):
     """The reference call sequence (utils/apply_spalign_kmeans.py:30-57) with host arrays."""
     ops = mods.ops
@@ -222,6 +238,38 @@ def test_driver_gpu_input_stage_equals_host_resize(mods, synth, tmp_path):
     assert [(x['TP'], x['FP'], x['FN']) for x in a] == [(x['TP'], x['FP'], x['FN']) for x in b]
 
 
+def test_driver_mixed_size_batch_takes_the_host_path(mods, synth, tmp_path):
+    """A batch whose source PNGs differ in size (one of them RGBA) cannot be uploaded as one 8-bit tensor: the
+    input stage falls back to the host resize on the frames it already decoded and the driver writes the same
+    masks as with --host_resize (used to raise AttributeError on the NumPy batch)."""
+    from PIL import Image
+    sizes = [(96, 192), (80, 100), (96, 192), (120, 90)]
+    img_fns, lab_fns = [], []
+    for i, (H, W) in enumerate(sizes):
+        img = synth.synth_image(90 + i, H, W, integer_valued=True).astype(np.uint8).transpose(1, 2, 0)
+        if i == 1:
+            img = np.concatenate([img, np.full((H, W, 1), 255, np.uint8)], axis=2)      # RGBA: alpha dropped
+        fn = str(tmp_path / ('mix_%06d_000019_leftImg8bit.png' % i))
+        Image.fromarray(img).save(fn)
+        lf = str(tmp_path / ('mix_%06d_000019_gtFine_labelIds.png' % i))
+        Image.fromarray(synth.synth_gt_labels(90 + i, 64, 80)).save(lf)
+        img_fns.append(fn); lab_fns.append(lf)
+    (tmp_path / 'imgs.txt').write_text('\n'.join(img_fns) + '\n')
+    (tmp_path / 'labs.txt').write_text('\n'.join(lab_fns) + '\n')
+    outs = []
+    for extra in ([], ['--host_resize']):
+        out = tmp_path / ('out' + str(len(outs)))
+        argv = ['--superpixel_method', 'slic', '--n_slic_segments', '20', '--n_clusters', '2',
+                '--resize_shape', '64', '80', '--batchsize', '2', '--out_dir', str(out),
+                '--img_file_list', str(tmp_path / 'imgs.txt'), '--label_file_list', str(tmp_path / 'labs.txt'),
+                '--arch', 'drn_d_22', '--pool_mode', 'mean', '--no_figure'] + extra
+        assert mods.cli.main_labelled(argv) == 0
+        outs.append(out)
+    for fn in img_fns:
+        base = os.path.splitext(os.path.basename(fn))[0]
+        assert np.array_equal(np.load(outs[0] / (base + '.npy')), np.load(outs[1] / (base + '.npy'))), base
+
+
 def test_bench_two_ranks_on_one_gpu(tmp_path):
     """bench.py's N > 1 path end to end (sharding, barrier, max-over-ranks timing, record
     all_gather) with two ranks sharing this box's single GPU over gloo."""
@@ -242,6 +290,25 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert d['roofline']['ms_per_step'] == max(k['ms_per_step'] for k in d['kernels'].values())
     h = d['host_to_host']                                    # SURVEY 8d's region, second timed loop
     assert h['value'] > 0 and h['images_downloaded'] == 2 * 2 * 2
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher environment starts its two ranks itself (torchrun as a child of
+    a process that never touched the GPU) and forwards rank 0's single line with n_gpus = 2."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(SPA_DIST_BACKEND='gloo', SPA_BENCH_SAME_DEVICE='1')
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+           '--batch', '2', '--height', '128', '--width', '256', '--n_slic_segments', '40', '--drn_sub_batch', '2',
+           '--no_host_loop']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['value'] > 0 and d['quality']['records_gathered'] == 4
+    assert 'cpu_baseline' not in d                           # rank 0 at N = 1 only
 
 
 def test_host_stream_matches_device_resident_path(mods, synth):

@@ -76,25 +76,79 @@ def test_drn_state_dict_names_match_upstream_checkpoint_layout():
         assert k in keys
 
 
+def chainer_npz_arrays(model):
+    """The arrays chainer.serializers.save_npz would write for the reference's model of the same architecture,
+    built from Chainer's published naming rules, NOT from the module's own state_dict keys: a Chain names children
+    by attribute; the reference's Sequential is a ChainList (models/sequential.py:9, :272-290) whose add_link
+    numbers links only (activation functions take no number); Convolution2D holds W (+ b), BatchNormalization
+    gamma, beta and the persistents avg_mean, avg_var, N."""
+    import torch.nn as nn
+    out = {}
+
+    def link(prefix, m):
+        if isinstance(m, nn.Conv2d):
+            out[prefix + '/W'] = m.weight.detach().numpy()
+            if m.bias is not None:
+                out[prefix + '/b'] = m.bias.detach().numpy()
+        elif isinstance(m, nn.BatchNorm2d):
+            out[prefix + '/gamma'] = m.weight.detach().numpy()
+            out[prefix + '/beta'] = m.bias.detach().numpy()
+            out[prefix + '/avg_mean'] = m.running_mean.numpy()
+            out[prefix + '/avg_var'] = m.running_var.numpy()
+            out[prefix + '/N'] = np.array(0)
+        elif isinstance(m, nn.Sequential):                      # ChainList: links only, numbered as inserted
+            k = 0
+            for child in m:
+                if any(True for _ in child.parameters()):
+                    link('%s/%d' % (prefix, k), child)
+                    k += 1
+        else:                                                   # Chain (BasicBlock): attribute names
+            for name, child in m.named_children():
+                if any(True for _ in child.parameters()):
+                    link(prefix + '/' + name, child)
+    for name, child in model.named_children():
+        if any(True for _ in child.parameters()):
+            link(name, child)
+    return out
+
+
 def test_chainer_npz_loader(tmp_path):
-    src = drn.DRN('drn_c_26')
+    """load_chainer_npz against keys written the way Chainer names them.  DRN-C-26 / DRN-D-22 plus a DRN-D stem
+    with TWO convolutions per plain layer, where ChainList numbering (0,1,2,3) and nn.Sequential numbering
+    (0,1,3,4) part ways."""
+    import torch.nn as nn
+    for arch in ('drn_c_26', 'drn_d_22'):
+        src = drn.DRN(arch)
+        det_fill(src)
+        arrays = chainer_npz_arrays(src)
+        if arch == 'drn_d_22':
+            assert 'layer0/0/W' in arrays and 'layer0/1/avg_var' in arrays and 'layer3/0/downsample/1/gamma' in arrays
+            assert 'layer8/1/beta' in arrays and not any(k.startswith('layer0/2') for k in arrays)
+        path = str(tmp_path / (arch + '.npz'))
+        np.savez(path, **arrays)
+        dst = drn.DRN(arch).load_chainer_npz(path)
+        for k, v in src.state_dict().items():
+            if not k.endswith('num_batches_tracked'):
+                assert torch.equal(v, dst.state_dict()[k]), k
+    # two convolutions in a plain layer: conv, bn, relu, conv, bn, relu
+    def widen(m):
+        m._cin = 16
+        m.layer1 = m._plain(16, 2, 1, 1, 2e-5)
+        return m
+    src = widen(drn.DRN('drn_d_22'))
     det_fill(src)
-    rename = {'weight': ('W', 'gamma'), 'bias': ('b', 'beta'), 'running_mean': ('avg_mean',) * 2,
-              'running_var': ('avg_var',) * 2}
-    arrays = {}
-    for k, v in src.state_dict().items():
-        if k.endswith('num_batches_tracked'):
-            arrays[k.rsplit('.', 1)[0].replace('.', '/') + '/N'] = np.array(0)
-            continue
-        parts = k.split('.')
-        is_bn = v.ndim == 1
-        arrays['/'.join(parts[:-1] + [rename[parts[-1]][1 if is_bn else 0]])] = v.numpy()
-    path = str(tmp_path / 'drn_c_26.npz')
+    arrays = chainer_npz_arrays(src)
+    assert 'layer1/2/W' in arrays and 'layer1/3/gamma' in arrays and 'layer1/4/W' not in arrays
+    assert 'layer1.3.weight' in src.state_dict() and isinstance(src.layer1[2], nn.ReLU)
+    path = str(tmp_path / 'two.npz')
     np.savez(path, **arrays)
-    dst = drn.DRN('drn_c_26').load_chainer_npz(path)
+    dst = widen(drn.DRN('drn_d_22')).load_chainer_npz(path)
     for k, v in src.state_dict().items():
         if not k.endswith('num_batches_tracked'):
             assert torch.equal(v, dst.state_dict()[k]), k
+    np.savez(path, **dict(arrays, **{'layer1/4/W': arrays['layer1/2/W']}))
+    with pytest.raises(KeyError):
+        widen(drn.DRN('drn_d_22')).load_chainer_npz(path)
 
 
 def test_batch_loop_and_sharding_rules():

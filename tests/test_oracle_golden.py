@@ -342,3 +342,29 @@ def test_superpixel_overlaps_restatement_matches_reference(orc, tag):
     assert np.array_equal(cl, g['cluster'])
     for i in range(len(cl)):
         assert np.array_equal(orc.overlap_refine(road[i], g['superpixels'][i], float(g['thr'])), g['refined'][i])
+
+
+def test_kmeans_retry_branch_follows_the_reference(orc, capsys):
+    """weighted_kmeans :201-205: an image without a cluster-0 pixel triggers a discarded re-run of the whole
+    function, which shuffles again (k > 2) and may recurse.  Two consecutive batches of the reference's own
+    weighted_kmeans (oracle/gen_golden_retry.py): cluster maps of both and every shuffled vector, in call order."""
+    g = golden('kmeans_retry')
+    rec = []
+
+    class Rec(orc.NpRandom):
+        def shuffle(self, a):
+            super().shuffle(a)
+            rec.append(a.copy())
+    rnd = Rec(1111)
+    cl0, road0, _ = orc.weighted_kmeans(g['sps0'].astype(np.int64), g['X0'], g['w0'], 4, [int(v) for v in g['n_per0']], rnd)
+    cl1, road1, _ = orc.weighted_kmeans(g['sps1'].astype(np.int64), g['X1'], g['w1'], 4, [int(v) for v in g['n_per1']], rnd)
+    assert capsys.readouterr().out.count('Somehow KMeans seems failed') == int(g['n_retry']) >= 3
+    assert len(rec) == len(g['shuffled_len'])
+    for r, ref, n in zip(rec, g['shuffled'], g['shuffled_len']):
+        assert np.array_equal(r, ref[:n])
+    assert np.array_equal(cl0, g['cl0']) and np.array_equal(cl1, g['cl1'])
+    assert np.array_equal(road0, g['cl0'] == 0)
+    # k = 2: nothing is random, the retry repeats the failure: the reference ends in RecursionError
+    assert bool(g['k2_recursion_error'])
+    with pytest.raises(RecursionError):
+        orc.weighted_kmeans(g['sps2'].astype(np.int64), g['X2'], g['w2'], 2, [int(v) for v in g['n_per2']], orc.NpRandom(1111))
