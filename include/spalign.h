@@ -63,6 +63,11 @@ int spa_ctx_create(int device, spa_ctx **out);
 void spa_ctx_destroy(spa_ctx *ctx);
 /* copies the latched status bits to *status_host and clears them; synchronises `stream`. */
 int spa_status(spa_ctx *ctx, uint32_t *status_host, void *stream);
+/* asynchronous variant for batch loops that never wait for the batch they have just enqueued: copies the
+   latched bits to *status_pinned (pinned host memory) in stream order, clears nothing, synchronises nothing —
+   the caller reads the word once an event recorded behind the call has completed.  (The reference has no
+   counterpart: its per-image exceptions surface synchronously, batch_spalign_kmeans.py:538-548.) */
+int spa_status_peek_async(spa_ctx *ctx, uint32_t *status_pinned, void *stream);
 
 /* Per-kernel timing for the roofline report (bench.py): when enabled, HIP events are recorded on
    the launch stream around each kernel family; spa_prof_read synchronises the device and

@@ -57,6 +57,7 @@ _COMMON_FLAGS = [
     ('--no_figure', dict(action='store_true', default=False)),
     ('--balanced', dict(action='store_true', default=False)),
     ('--io_threads', dict(type=int, default=8)),
+    ('--strict_retry', dict(action='store_true', default=False)),     # k = 2: die with RecursionError where the reference does
     ('--host_resize', dict(action='store_true', default=False)),      # resize with Pillow on the host threads instead
 ]
 
@@ -133,6 +134,46 @@ def resize_bicubic_chw(img_chw, shape):
     return np.stack(out)
 
 
+class PinnedRing(object):
+    """A few persistent pinned host buffers of one shape, handed out in turn.  The decode workers copy their
+    frames straight into a buffer (parallel memcpy, no np.stack into freshly mapped pages: that alone was 100+ ms
+    per batch of 30 full-size images) and the upload from it is a true asynchronous DMA; a buffer is reused only
+    after the event recorded behind its upload has completed."""
+
+    def __init__(self, depth=3):
+        self._bufs, self._depth = {}, depth
+
+    def take(self, shape, dtype=torch.uint8):
+        key = (tuple(shape), dtype)
+        ring = self._bufs.setdefault(key, {'i': 0, 'slots': []})
+        if len(ring['slots']) < self._depth:
+            ring['slots'].append([torch.empty(shape, dtype=dtype).pin_memory(), None])
+            slot = ring['slots'][-1]
+        else:
+            slot = ring['slots'][ring['i'] % self._depth]
+            ring['i'] += 1
+            if slot[1] is not None:
+                slot[1].synchronize()
+        return slot
+
+    def upload(self, arrays, device, pool=None):
+        """list of equally shaped arrays -> (len, ...) device tensor, enqueued on the current stream."""
+        slot = self.take((len(arrays),) + tuple(arrays[0].shape), torch.from_numpy(arrays[0]).dtype)
+        dst = slot[0].numpy()
+
+        def put(j):
+            dst[j] = arrays[j]
+        if pool is not None:
+            list(pool.map(put, range(len(arrays))))
+        else:
+            for j in range(len(arrays)):
+                put(j)
+        t = slot[0].to(device, non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record(torch.cuda.current_stream(device))
+        return t
+
+
 class ImageList(object):
     """ResizeImageDataset (datasets/resize_image_dataset.py:8-36): path -> CHW array."""
 
@@ -160,7 +201,13 @@ class ImageList(object):
             img = img[:, :, None]
         return np.ascontiguousarray(img[:, :, :3])
 
-    def batch_device(self, lo, hi, pool, engine):
+    def get_gray(self, i):
+        """A single-channel PNG (gtFine labelIds) as it is decoded: (H, W) uint8."""
+        src = self._open(self._paths[i]) if self._open else self._paths[i]
+        img = _decode(src)
+        return np.ascontiguousarray(img if img.ndim == 2 else img[:, :, 0])
+
+    def batch_device(self, lo, hi, pool, engine, ring=None):
         """dataset[lo:hi] as a (B,3,h,w) float32 CUDA tensor: decode on the worker threads, upload the
         8-bit images (3 bytes per pixel) and resize on the GPU (spa_resize_bicubic_u8: bit exact with the
         Pillow resize of `get`).  Falls back to `batch` when the images of the batch differ in size."""
@@ -175,7 +222,11 @@ class ImageList(object):
                     img = resize_bicubic_chw(img, self._shape)
                 return img.astype(self._dtype)
             return np.stack(list(pool.map(host, raw)) if pool is not None else [host(r) for r in raw])
-        u8 = torch.from_numpy(np.stack(raw)).to(engine.device, non_blocking=True)
+        if ring is None:
+            if not hasattr(self, '_ring'):
+                self._ring = PinnedRing()
+            ring = self._ring
+        u8 = ring.upload(raw, engine.device, pool)
         shape = tuple(self._shape) if self._shape is not None else raw[0].shape[:2]
         return engine.resize_bicubic_u8(u8, shape)
 
@@ -237,11 +288,26 @@ def score(road_mask, gt):
                 recall=float(TP / (TP + FN)) if TP + FN > 0 else None, TP=TP, FP=FP, FN=FN)
 
 
+def score_from_counts(TN, FP, FN, TP):
+    """The same scores from the four integer counts (spa_confusion on the device)."""
+    conf = np.array([[TN, FP], [FN, TP]], np.int64)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        iou = np.diag(conf) / (conf.sum(1) + conf.sum(0) - np.diag(conf))
+    return dict(road_iou=float(iou[1]), non_road_iou=float(iou[0]),
+                precision=float(TP / (TP + FP)) if TP + FP > 0 else None,
+                recall=float(TP / (TP + FN)) if TP + FN > 0 else None, TP=TP, FP=FP, FN=FN)
+
+
+def nearest_index(n_dst, n_src):
+    """Source index of every destination index under cv.INTER_NEAREST (see resize_nearest)."""
+    return np.minimum((np.arange(n_dst) * (n_src / n_dst)).astype(np.int64), n_src - 1)
+
+
 def save_npy(args, img_fn, road_mask, clustering_result):
     """:392-396 — <basename>.npy (uint8, 1 = road) and <basename>_all_cluster.npy."""
     out_fn = os.path.splitext(os.path.basename(img_fn))[0]
-    np.save(os.path.join(args.out_dir, out_fn), road_mask.astype(np.uint8))
-    np.save(os.path.join(args.out_dir, out_fn + '_all_cluster'), clustering_result.astype(np.uint8))
+    np.save(os.path.join(args.out_dir, out_fn), road_mask.astype(np.uint8, copy=False))
+    np.save(os.path.join(args.out_dir, out_fn + '_all_cluster'), clustering_result.astype(np.uint8, copy=False))
 
 
 def write_label_zip(out_dir, zip_path):
@@ -338,26 +404,41 @@ def main_labelled(argv=None, get=None, make_pipe=None, originals=False, make_mod
     # worker threads while the GPU labels the current batch.
     from concurrent.futures import ThreadPoolExecutor
     workers = ThreadPoolExecutor(max_workers=max(1, args.io_threads))
-    loader = ThreadPoolExecutor(max_workers=1)
+    loader = ThreadPoolExecutor(max_workers=2)     # two batches ahead in the asynchronous loop, one otherwise
     # a range shorter than one batch that starts at image 0 makes the reference slice dataset[-k:end],
     # which is empty, and crash in concat_examples; here that range is labelled as one smaller batch
     ranges = [(max(lo, 0), hi) for lo, hi in spdist.batch_ranges(start, end, args.batchsize)] if end > start else []
     path = os.path.join(args.out_dir, 'result.json')
 
-    def finish(i, rm, cl, n_sp, info, times, st_all):
+    def finish(i, rm, cl, n_sp, info, times, st_all, conf=None, gt_raw=None):
+        """Everything the reference does per image after the masks exist (:461-483, :388-424).  conf: the
+        image's {TN, FP, FN, TP} already counted on the device against its ground truth, with rm / cl already at
+        the ground truth's size (the asynchronous loop); otherwise decode, resize and count here."""
         img_fn, label_fn = imgs_ds._paths[i], labels_ds._paths[i]
-        gt = create_label_mask(labels_ds.get(i)[0])
-        if rm.shape != gt.shape:                                       # :470-477
-            rm = resize_nearest(rm, gt.shape)
-        if cl.shape != gt.shape:
-            cl = resize_nearest(cl, gt.shape)
-        save_npy(args, img_fn, rm, cl)
-        if not args.no_figure:
-            full = _decode(imgs_ds._open(img_fn) if imgs_ds._open else img_fn)   # :464 reloads the PNG
-            save_figure(args, full, rm, gt, cl, img_fn)
-        sc = score(rm, gt)
+        if conf is not None:
+            if isinstance(st_all, float) and st_all < 0:            # -seconds of device time of the batch
+                st_all = time.time() + st_all
+            save_npy(args, img_fn, rm, cl)
+            gt = None
+            if not args.no_figure:
+                gt = create_label_mask(gt_raw)
+                full = _decode(imgs_ds._open(img_fn) if imgs_ds._open else img_fn)   # :464 reloads the PNG
+                save_figure(args, full, rm, gt, cl, img_fn)
+            sc = score_from_counts(*(int(v) for v in conf))
+            tn = int(conf[0])
+        else:
+            gt = create_label_mask(labels_ds.get(i)[0] if gt_raw is None else gt_raw)
+            if rm.shape != gt.shape:                                       # :470-477
+                rm = resize_nearest(rm, gt.shape)
+            if cl.shape != gt.shape:
+                cl = resize_nearest(cl, gt.shape)
+            save_npy(args, img_fn, rm, cl)
+            if not args.no_figure:
+                full = _decode(imgs_ds._open(img_fn) if imgs_ds._open else img_fn)   # :464 reloads the PNG
+                save_figure(args, full, rm, gt, cl, img_fn)
+            sc = score(rm, gt)
+            tn = int(((gt == 0) & (rm == 0)).sum())
         line = result_line(args, img_fn, label_fn, sc, times, st_all)
-        tn = int(((gt == 0) & (rm == 0)).sum())
         timers = dict(times, elapsed_time=line['elapsed_time'], gpu=args.gpu)
         return i, line, [i, tn, sc['FP'], sc['FN'], sc['TP'], n_sp, int(info[0]), int(info[1])] \
             + spdist.pack_timers(timers)
@@ -382,44 +463,164 @@ def main_labelled(argv=None, get=None, make_pipe=None, originals=False, make_mod
             print('Road IoU:', line['road_iou'], os.path.basename(line['img_fn']))
 
     pending = []
+    keep = []               # pinned buffers the writers of `pending` read from
+    # the asynchronous loop: LabelPipeline on the GPU (the baselines and the stub-model tests keep the simple one)
+    use_async = make_pipe is None and make_model is None
     try:
         # GPU input stage: decode on the worker threads, resize on the device (bit exact with the host resize)
         # (its own spa_ctx: the loader thread must not share a context with the pipeline's thread)
         from .engine import Engine
-        eng_in = None if make_model else Engine(ops.engine().device.index)
+        import threading
+        have_gpu = make_model is None
+        tls = threading.local()         # one spa_ctx + one stream per loader thread (a context's workspaces serve
+        #                                 one caller at a time), pinned rings likewise
+
         def load(lo, hi):
-            if eng_in is not None and not args.host_resize:
-                with torch.cuda.stream(in_stream):
-                    t = imgs_ds.batch_device(lo, hi, workers, eng_in)
-                    if not isinstance(t, torch.Tensor):
-                        return t, None                   # mixed-size batch: host arrays, nothing in flight
-                    ev = torch.cuda.Event()
-                    ev.record(in_stream)
-                return t, ev
-            return imgs_ds.batch(lo, hi, workers), None
-        in_stream = torch.cuda.Stream(device=eng_in.device) if eng_in is not None else None
-        nxt = loader.submit(load, ranges[0][0], ranges[0][1]) if ranges else None
-        for bi, (lo, hi) in enumerate(ranges):
-            st_all = time.time()
-            imgs, ready = nxt.result()
-            if ready is not None:
-                torch.cuda.current_stream().wait_event(ready)
-                imgs.record_stream(torch.cuda.current_stream())
-            if bi + 1 < len(ranges):
-                nxt = loader.submit(load, ranges[bi + 1][0], ranges[bi + 1][1])
-            res = pipe.run(imgs, orig_ds.batch(lo, hi, workers)) if originals else pipe.run(imgs)
-            times = pipe.elapsed_times()
-            cluster, road = res.masks_to_host()
-            info = res.info.cpu().numpy()
-            n_sp = res.n_labels.cpu().numpy()
-            # a re-labelled image (last batch shifted back, :539-542) must overwrite its earlier files:
-            # wait for the previous batch's writers before queueing this batch's
-            # (`pending` keeps them until they are drained, so that the finally clause still sees the
-            # successful ones if one of them failed)
+            idx = list(range(len(imgs_ds)))[lo:hi]
+            if have_gpu and not hasattr(tls, 'eng'):
+                tls.eng = Engine(ops.engine().device.index)
+                tls.stream = torch.cuda.Stream(device=tls.eng.device)
+                tls.ring = PinnedRing()
+                tls.gt_ring = PinnedRing()
+            # ground truth PNGs of the batch decode alongside its images
+            gt_f = [workers.submit(labels_ds.get_gray, i) for i in idx] if use_async else None
+            gts = gt_dev = ev = None
+            if have_gpu and not args.host_resize:
+                with torch.cuda.stream(tls.stream):
+                    t = imgs_ds.batch_device(lo, hi, workers, tls.eng, tls.ring)
+            else:
+                t = imgs_ds.batch(lo, hi, workers)
+            if gt_f is not None:
+                gts = [f.result() for f in gt_f]
+                if len({g.shape for g in gts}) == 1:
+                    with torch.cuda.stream(tls.stream):
+                        gt_dev = tls.gt_ring.upload(gts, tls.eng.device, workers)
+            if have_gpu and (isinstance(t, torch.Tensor) or gt_dev is not None):    # else: host arrays, nothing in flight
+                ev = torch.cuda.Event()
+                ev.record(tls.stream)
+            return t, ev, gts, gt_dev
+
+        def drain_all():
             drain(pending)
-            pending = []
-            for j, i in enumerate(list(range(len(imgs_ds)))[lo:hi]):
-                pending.append(workers.submit(finish, i, road[j], cluster[j], int(n_sp[j]), info, times, st_all))
+            del pending[:]
+            del keep[:]
+
+        depth = 2 if use_async else 1
+        queue = [loader.submit(load, lo, hi) for lo, hi in ranges[:depth]]
+        if use_async:
+            # One batch of deferral: while the GPU labels batch k the host finishes batch k-1 (status, timers from
+            # its device events, writers) and decodes batch k+1 — the main thread never waits for the batch it
+            # has just enqueued.  Scoring runs on the device (create_label_mask, nearest resize to the ground
+            # truth's size, spa_confusion), so a worker only writes the two .npy files and the result line.
+            eng = ops.engine()
+            dev = eng.device
+            d2h = torch.cuda.Stream(device=dev)
+            index_cache = {}
+
+            def to_gt_size(m, shape):
+                if tuple(m.shape[1:]) == tuple(shape):
+                    return m
+                key = (tuple(m.shape[1:]), tuple(shape))
+                if key not in index_cache:
+                    index_cache[key] = (torch.from_numpy(nearest_index(shape[0], m.shape[1])).to(dev),
+                                        torch.from_numpy(nearest_index(shape[1], m.shape[2])).to(dev))
+                ys, xs = index_cache[key]
+                return m.index_select(1, ys).index_select(2, xs)
+
+            def finalize(st):
+                st['done'].synchronize()
+                eng.raise_on_word(st['status_h'])
+                if st['fail_h'] is not None:
+                    st['res'].check_retry(st['fail_h'])
+                times = pipe.elapsed_times(st['events'])
+                t_dev = st['events']['start'].elapsed_time(st['done']) / 1000.0
+                info, n_sp = st['info_h'].numpy(), st['nsp_h'].numpy()
+                conf = st['conf_h'].numpy() if st['conf_h'] is not None else None
+                # a re-labelled image (last batch shifted back, :539-542) must overwrite its earlier files:
+                # the previous batch's writers finish before this batch's are queued
+                drain_all()
+                keep.append(st)
+                for j, i in enumerate(st['idx']):
+                    pending.append(workers.submit(finish, i, st['road_h'][j].numpy(), st['cl_h'][j].numpy(), int(n_sp[j]),
+                                                  info, times, -t_dev if conf is not None else st['st_all'],
+                                                  None if conf is None else conf[j],
+                                                  None if st['gts'] is None else st['gts'][j]))
+
+            prev = None
+            trace = os.environ.get('SPA_DRIVER_TRACE') == '1'      # host-side timeline of the loop, one line per batch
+            for bi, (lo, hi) in enumerate(ranges):
+                st_all = time.time()
+                imgs, ready, gts, gt_dev = queue.pop(0).result()
+                if bi + depth < len(ranges):
+                    queue.append(loader.submit(load, ranges[bi + depth][0], ranges[bi + depth][1]))
+                t_loaded = time.time()
+                main = torch.cuda.current_stream()
+                if ready is not None:
+                    main.wait_event(ready)
+                    for t in (imgs, gt_dev):
+                        if isinstance(t, torch.Tensor):
+                            t.record_stream(main)
+                res = pipe.run(imgs, check_status=False)
+                events = dict(pipe._ev)
+                road_d, cl_d, conf_d = res.road, res.cluster, None
+                if gt_dev is not None:
+                    road_d, cl_d = to_gt_size(res.road, gt_dev.shape[1:]), to_gt_size(res.cluster, gt_dev.shape[1:])
+                    gtm = torch.where(gt_dev <= 6, -1, torch.where(gt_dev == 7, 1, 0)).to(torch.int32)   # :279-296
+                    conf_d = eng.confusion(road_d.contiguous(), gtm)
+                status_h = eng.status_peek_async()
+                computed = torch.cuda.Event()
+                computed.record(main)
+                with torch.cuda.stream(d2h):
+                    d2h.wait_event(computed)
+                    st = dict(idx=list(range(len(imgs_ds)))[lo:hi], res=res, events=events, gts=gts, st_all=st_all,
+                              status_h=status_h,
+                              road_h=torch.empty(road_d.shape, dtype=torch.uint8, pin_memory=True),
+                              cl_h=torch.empty(cl_d.shape, dtype=torch.uint8, pin_memory=True),
+                              info_h=torch.empty(res.info.shape, dtype=res.info.dtype, pin_memory=True),
+                              nsp_h=torch.empty(res.n_labels.shape, dtype=res.n_labels.dtype, pin_memory=True),
+                              conf_h=None if conf_d is None else torch.empty(conf_d.shape, dtype=conf_d.dtype, pin_memory=True),
+                              fail_h=None if res.retry_fail is None else torch.empty(res.retry_fail.shape, dtype=torch.bool, pin_memory=True))
+                    for h, d in ((st['road_h'], road_d), (st['cl_h'], cl_d), (st['info_h'], res.info),
+                                 (st['nsp_h'], res.n_labels), (st['conf_h'], conf_d), (st['fail_h'], res.retry_fail)):
+                        if h is not None:
+                            h.copy_(d, non_blocking=True)
+                            d.record_stream(d2h)
+                    st['done'] = torch.cuda.Event(enable_timing=True)
+                    st['done'].record(d2h)
+                t_enq = time.time()
+                if prev is not None:
+                    finalize(prev)
+                    if trace:
+                        print('trace batch %d: wait_load %.1f ms, enqueue %.1f ms, finalize(prev) %.1f ms, device gap '
+                              'done(prev)->start %.1f ms, device batch(prev) %.1f ms'
+                              % (bi, (t_loaded - st_all) * 1e3, (t_enq - t_loaded) * 1e3, (time.time() - t_enq) * 1e3,
+                                 prev['done'].elapsed_time(events['start']) if False else -1.0,
+                                 prev['events']['start'].elapsed_time(prev['done'])), file=sys.stderr)
+                prev = st
+            if prev is not None:
+                finalize(prev)
+        else:
+            for bi, (lo, hi) in enumerate(ranges):
+                st_all = time.time()
+                imgs, ready, _gts, _gt_dev = queue.pop(0).result()
+                if ready is not None:
+                    torch.cuda.current_stream().wait_event(ready)
+                    if isinstance(imgs, torch.Tensor):
+                        imgs.record_stream(torch.cuda.current_stream())
+                if bi + depth < len(ranges):
+                    queue.append(loader.submit(load, ranges[bi + depth][0], ranges[bi + depth][1]))
+                res = pipe.run(imgs, orig_ds.batch(lo, hi, workers)) if originals else pipe.run(imgs)
+                times = pipe.elapsed_times()
+                cluster, road = res.masks_to_host()
+                info = res.info.cpu().numpy()
+                n_sp = res.n_labels.cpu().numpy()
+                # a re-labelled image (last batch shifted back, :539-542) must overwrite its earlier files:
+                # wait for the previous batch's writers before queueing this batch's
+                # (`pending` keeps them until they are drained, so that the finally clause still sees the
+                # successful ones if one of them failed)
+                drain_all()
+                for j, i in enumerate(list(range(len(imgs_ds)))[lo:hi]):
+                    pending.append(workers.submit(finish, i, road[j], cluster[j], int(n_sp[j]), info, times, st_all))
     finally:
         # whatever was computed before an error (corrupt PNG, device status, OOM) still reaches disk
         ok = [f for f in pending if f.exception() is None]

@@ -89,6 +89,13 @@ extern "C" int spa_status(spa_ctx *ctx, uint32_t *status_host, void *stream)
     return SPA_OK;
 }
 
+extern "C" int spa_status_peek_async(spa_ctx *ctx, uint32_t *status_pinned, void *stream)
+{
+    SPA_ARG(ctx && status_pinned);
+    SPA_HIP(hipMemcpyAsync(status_pinned, ctx->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, spa_stream(stream)));
+    return SPA_OK;
+}
+
 // ---------------------------------------------------------------------------------------
 // skimage.util.regular_grid((1, H, W), n) — host integer/double logic of slic()
 // (skimage/util/_regular_grid.py:61-83; call sites slic_superpixels.py:91 and inside the

@@ -61,6 +61,23 @@ class Engine(object):
         check(self._lib.spa_status(self._ctx, ctypes.byref(v), self._s()))
         return v.value
 
+    def status_peek_async(self, word=None):
+        """Enqueue a copy of the latched status bits into a pinned one-element int32 tensor on the current stream
+        (nothing is cleared or synchronised); check it with `raise_on_word` once the stream got that far."""
+        if word is None:
+            word = torch.zeros(1, dtype=torch.int32).pin_memory()
+        check(self._lib.spa_status_peek_async(self._ctx, ctypes.c_void_p(word.data_ptr()), self._s()))
+        return word
+
+    def raise_on_word(self, word, ignore=_lib.INFO_BITS):
+        st = int(word.item()) & 0xffffffff
+        self.last_info = st & _lib.INFO_BITS
+        st &= ~ignore
+        if st:
+            self.status()                                            # clear the latch, then report
+            msgs = [m for bit, m in _lib.STATUS_BITS.items() if st & bit]
+            raise SpalignError('device status 0x%x: %s' % (st, '; '.join(msgs)))
+
     def raise_on_status(self, ignore=_lib.INFO_BITS):
         """Raise on latched error bits.  Informational bits (a starved SLIC seed, an oversize
         component: both handled as scikit-image handles them) are collected in `self.last_info`."""

@@ -15,6 +15,7 @@ Inputs that came out of a previous op are recognised (by identity) and their dev
 reused, so chaining the five ops uploads nothing twice.  The fused, download-once path is
 pipeline.LabelPipeline.
 """
+import os
 import weakref
 
 import numpy as np
@@ -148,7 +149,8 @@ def batch_weighted_kmeans(args, superpixels, superpixel_features, superpixel_wei
     without a cluster-0 pixel makes the reference print and call itself again with the same arguments, result
     discarded.  Every call runs kmeans(), i.e. one np.random.shuffle (:147-149): the retries therefore move the
     stream of later batches (k > 2) and may recurse; for k = 2 the retry repeats the failure and the reference
-    ends in RecursionError — same here."""
+    ends in RecursionError — same here with args.strict_retry / SPA_STRICT_RETRY=1; by default the message is
+    printed and the batch is kept."""
     eng = engine()
     labels, _ = _labels_on_device(superpixels)
     B = labels.shape[0]
@@ -169,6 +171,8 @@ def batch_weighted_kmeans(args, superpixels, superpixel_features, superpixel_wei
     for b in range(B):
         if (cl[b] == 0).sum() == 0:
             print('\nSomehow KMeans seems failed. Try again\n')
+            if k == 2 and not (getattr(args, 'strict_retry', False) or os.environ.get('SPA_STRICT_RETRY') == '1'):
+                continue        # the reference dies here (RecursionError); default: message printed, batch kept
             if k == 2 or _depth >= 990:
                 raise RecursionError('maximum recursion depth exceeded: weighted_kmeans retry, '
                                      'batch_spalign_kmeans.py:201-205' + (' (k = 2 repeats the same failure)' if k == 2 else ''))

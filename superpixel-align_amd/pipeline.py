@@ -12,6 +12,8 @@ Two HIP streams: the superpixel branch (SLIC, per-segment statistics, and in anc
 host-side random draws) does not depend on the DRN features, so it runs on an auxiliary stream
 while the DRN forward (MFMA-bound, MIOpen) occupies the main stream; they join before pooling.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -30,15 +32,24 @@ class BatchResult(object):
         self.check_retry()
         return self.cluster.cpu().numpy(), self.road.cpu().numpy()
 
-    def check_retry(self):
-        """k = 2 only: an image without a cluster-0 pixel sends the reference into its retry (:201-205), which
-        repeats the same deterministic failure until the interpreter raises RecursionError — same outcome here,
-        checked when the results are fetched (the flags are device-side, the batch loop stays asynchronous)."""
-        fail = getattr(self, 'retry_fail', None)
-        if fail is not None and bool(fail.any().item()):
+    def check_retry(self, flags=None, strict=None):
+        """k = 2 only (flags: a host copy of `retry_fail` the caller downloaded itself).  An image without a
+        cluster-0 pixel sends the reference into its retry (:201-205), which for k = 2 repeats the same
+        deterministic failure until the interpreter raises RecursionError.  strict (args.strict_retry /
+        SPA_STRICT_RETRY=1): raise RecursionError here as well; default: print the reference's message once per
+        such image and keep the batch — a run of 20 k images is not lost to one image without road.  Checked when
+        the results are fetched: the flags are device-side and the batch loop stays asynchronous."""
+        fail = getattr(self, 'retry_fail', None) if flags is None else flags
+        if fail is None or not bool(fail.any().item()):
+            return
+        bad = fail.nonzero().flatten().tolist()
+        if strict is None:
+            strict = getattr(self, 'strict_retry', False) or os.environ.get('SPA_STRICT_RETRY') == '1'
+        for _ in bad:
             print('\nSomehow KMeans seems failed. Try again\n')
+        if strict:
             raise RecursionError(RETRY_MESSAGE + ' (image(s) %s of the batch have no cluster-0 pixel; k = 2 repeats '
-                                 'the same failure)' % fail.nonzero().flatten().tolist())
+                                 'the same failure)' % bad)
 
 
 RETRY_MESSAGE = 'maximum recursion depth exceeded: weighted_kmeans retry, batch_spalign_kmeans.py:201-205'
@@ -254,29 +265,32 @@ class LabelPipeline(object):
         self._tick('kmeans')
         res = BatchResult(labels=labels, n_labels=n_labels, offsets=seg['off'], count=seg['count'],
                           X=X, prior=seg['prior'], assign=assign, info=info, cluster=cluster,
-                          road=road, fmap=fmap, retry_fail=fail)
+                          road=road, fmap=fmap, retry_fail=fail,
+                          strict_retry=bool(getattr(self.args, 'strict_retry', False)))
         if check_status:
             self.eng.raise_on_status()
             res.check_retry()
         return res
 
-    def stage_ms(self):
-        """Device-event durations of the last run() in ms.  With two streams the superpixel
+    def stage_ms(self, events=None):
+        """Device-event durations of the last run() in ms (or of the run whose `events` = dict(pipe._ev) the
+        caller kept and knows to be complete: then nothing is synchronised).  With two streams the superpixel
         branch overlaps the DRN forward, so the stages do not add up to the step time."""
-        torch.cuda.synchronize()
-        e = self._ev
+        if events is None:
+            torch.cuda.synchronize()
+        e = self._ev if events is None else events
         return {'time_feature_maps': e['start'].elapsed_time(e['features']),
                 'time_superpixel': e['sp_start'].elapsed_time(e['superpixel']),
                 'time_roialign': e['superpixel'].elapsed_time(e['segments']) + e['joined'].elapsed_time(e['describe']),
                 'time_prior': 0.0,
                 'time_kmeans': e['describe'].elapsed_time(e['kmeans'])}
 
-    def elapsed_times(self):
+    def elapsed_times(self, events=None):
         """Stage times of the last run() in seconds, under the reference's result.json keys
         (:428-458) plus time_feature_maps (the baselines' key, direct_clustering.py:292-294).
         The prior is computed inside the segment-statistics pass: its share is reported under
         time_roialign and time_prior is 0."""
-        return {k: v / 1000.0 for k, v in self.stage_ms().items()}
+        return {k: v / 1000.0 for k, v in self.stage_ms(events).items()}
 
 
 class HostStream(object):

@@ -310,7 +310,7 @@ def test_kmeans_retry_branch_follows_the_reference(eng, capsys):
     assert capsys.readouterr().out.count('Somehow KMeans seems failed') == int(g['n_retry'])
     assert np.array_equal(outs[0], g['cl0']) and np.array_equal(outs[1], g['cl1'])
     # k = 2
-    args2 = types.SimpleNamespace(n_clusters=2, seed=1111)
+    args2 = types.SimpleNamespace(n_clusters=2, seed=1111, strict_retry=True)
     with pytest.raises(RecursionError):
         ops.batch_weighted_kmeans(args2, g['sps2'].astype(np.int64), g['X2'], g['w2'], [int(v) for v in g['n_per2']])
     pipe2 = pipeline.LabelPipeline(args2, model=None, engine=eng, pool_mode='mean', overlap=False)
@@ -319,7 +319,12 @@ def test_kmeans_retry_branch_follows_the_reference(eng, capsys):
     assign, info, cluster, road, fail = pipe2.cluster(dev(g['sps2'].astype(np.int32)), off, dev(g['X2']), dev(g['w2']))
     assert fail.cpu().tolist() == [False, True]
     with pytest.raises(RecursionError):
-        pipeline.BatchResult(cluster=cluster, road=road, retry_fail=fail).masks_to_host()
+        pipeline.BatchResult(cluster=cluster, road=road, retry_fail=fail, strict_retry=True).masks_to_host()
+    # default: the reference's message, the batch survives
+    pipeline.BatchResult(cluster=cluster, road=road, retry_fail=fail).masks_to_host()
+    args2.strict_retry = False
+    ops.batch_weighted_kmeans(args2, g['sps2'].astype(np.int64), g['X2'], g['w2'], [int(v) for v in g['n_per2']])
+    assert capsys.readouterr().out.count('Somehow KMeans seems failed') >= 3
     eng.raise_on_status()
 
 

@@ -56,17 +56,24 @@ def test_drn_on_gpu_matches_reference_maps(mods):
 @pytest.mark.parametrize('dtype', ['bf16', 'fp32'])
 def test_drn_streams_two_equals_one(mods, synth, dtype):
     """DRN.batch_predict(streams=2): both halves run the fused stem concurrently on side streams with ONE context;
-    every call owns its normalised-image scratch, so the maps equal the single-stream forward bit for bit
-    (the bf16 stem used to share the context-wide workspace between the streams)."""
+    every call owns its normalised-image scratch, so the maps equal those of the same two halves run one after the
+    other on one stream (same shapes, hence the same MIOpen solvers) bit for bit — the bf16 stem used to share the
+    context-wide workspace between the streams."""
     td = {'bf16': torch.bfloat16, 'fp32': torch.float32}[dtype]
     m = mods.drn.create_drn('drn_d_22', device='cuda', dtype=td)
     x = synth.synth_batch(list(range(40, 48)), 256, 512)
     for _ in range(3):
-        _, one = m.batch_predict(x, need=[1, 7], streams=1)
+        _, one = m.batch_predict(x, sub_batch=4, need=[1, 7], streams=1)
         _, two = m.batch_predict(x, need=[1, 7], streams=2)
         torch.cuda.synchronize()
         for i in (1, 7):
-            assert torch.equal(one[i], two[i]), i
+            if dtype == 'bf16':
+                assert torch.equal(one[i], two[i]), i
+            else:
+                # float32: MIOpen's solver for a layer may accumulate through atomics (split-K), so two runs of the
+                # same shapes agree to rounding only; a stem race would show as O(1) differences
+                scale = float(one[i].abs().max())
+                assert float((one[i] - two[i]).abs().max()) <= 2e-5 * scale, i
 
 
 def test_five_ops_drop_in(mods, orc, synth):
@@ -203,6 +210,52 @@ def test_cli_drivers_on_synthetic_pngs(mods, orc, synth, tmp_path):
     for fn in img_fns:
         m = np.asarray(Image.open(out2 / os.path.basename(fn)))
         assert m.shape == (2 * H, 2 * W) and set(np.unique(m)) <= {0, 1}
+
+
+def test_driver_sixty_images_every_line_scored_like_the_oracle(mods, orc, synth, tmp_path):
+    """README.md:99-107 / batch_spalign_kmeans.py:538-548 at the reference's batch size: 60 PNGs, --batchsize 30,
+    run through the root-level script as a child process (the way create_*_labels.sh starts it), then
+    utils/mean_result.py.  Every result.json line carries the confusion the oracle computes from the saved .npy
+    mask and the decoded ground truth, the batch loop produced each image exactly once, the summary's pooled
+    precision / recall follow from the summed counts."""
+    import subprocess
+    from PIL import Image
+    H, W, n = 128, 256, 60
+    img_fns, lab_fns = [], []
+    for i in range(n):
+        img = synth.synth_image(300 + i, H, W, integer_valued=True).astype(np.uint8)
+        fn = str(tmp_path / ('burg_%06d_000019_leftImg8bit.png' % i))
+        Image.fromarray(img.transpose(1, 2, 0)).save(fn)
+        lf = str(tmp_path / ('burg_%06d_000019_gtFine_labelIds.png' % i))
+        Image.fromarray(synth.synth_gt_labels(300 + i, H, W)).save(lf)
+        img_fns.append(fn); lab_fns.append(lf)
+    (tmp_path / 'imgs.txt').write_text('\n'.join(img_fns) + '\n')
+    (tmp_path / 'labs.txt').write_text('\n'.join(lab_fns) + '\n')
+    out = tmp_path / 'out'
+    cmd = [sys.executable, os.path.join(ROOT, 'batch_spalign_kmeans.py'), '--superpixel_method', 'slic',
+           '--n_slic_segments', '40', '--n_clusters', '2', '--resize_shape', str(H), str(W), '--batchsize', '30',
+           '--out_dir', str(out), '--img_file_list', str(tmp_path / 'imgs.txt'),
+           '--label_file_list', str(tmp_path / 'labs.txt'), '--start_index', '0', '--end_index', str(n),
+           '--arch', 'drn_d_22', '--pool_mode', 'mean', '--no_figure']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in open(out / 'result.json')]
+    assert [l['img_fn'] for l in lines] == img_fns                   # two full batches, index order, no repeats
+    tp = fp = fn_ = 0
+    for l in lines:
+        base = os.path.splitext(os.path.basename(l['img_fn']))[0]
+        road = np.load(out / (base + '.npy'))
+        allc = np.load(out / (base + '_all_cluster.npy'))
+        assert np.array_equal(road, (allc == 0).astype(np.uint8))
+        sc = orc.confusion(road, orc.create_label_mask(np.asarray(Image.open(l['label_fn']))))
+        assert (l['TP'], l['FP'], l['FN']) == (sc['TP'], sc['FP'], sc['FN'])
+        assert l['road_iou'] == sc['road_iou'] and l['batchsize'] == 30 and l['n_slic_segments'] == 40
+        tp, fp, fn_ = tp + sc['TP'], fp + sc['FP'], fn_ + sc['FN']
+    m = subprocess.run([sys.executable, os.path.join(ROOT, 'utils', 'mean_result.py'), str(out / 'result.json')],
+                       capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert m.returncode == 0, m.stderr[-1000:]
+    txt = open(out / 'summary.txt').read()
+    assert ('Precision\t:%s' % (tp / (tp + fp))) in txt and ('Recall\t:%s' % (tp / (tp + fn_))) in txt
 
 
 def test_driver_gpu_input_stage_equals_host_resize(mods, synth, tmp_path):
