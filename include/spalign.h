@@ -45,7 +45,8 @@ extern "C" {
 #define SPA_ST_SLIC_EMPTY_SEGMENT 0x01u  /* informational: a seed lost all pixels; NaN centre, dead afterwards (as skimage) */
 #define SPA_ST_SLIC_UNCOVERED 0x02u      /* a pixel fell outside every 2S search window         */
 #define SPA_ST_CONN_OVERSIZE 0x04u       /* a component reached max_size: handled by the slow exact path */
-#define SPA_ST_POOL_SLOT_OVERFLOW 0x08u  /* > SPA_CELL_SLOTS superpixels touch one feature pixel */
+#define SPA_ST_POOL_SLOT_OVERFLOW 0x08u  /* retired: a feature pixel touched by > SPA_CELL_SLOTS superpixels is handled (its
+                                            weights are recomputed on demand), the bit is never set */
 #define SPA_ST_KMEANS_BARRIER 0x10u      /* grid barrier timed out (should never happen)        */
 #define SPA_ST_LABEL_RANGE 0x20u         /* a label outside [0, S) was met                      */
 #define SPA_ST_RNG_UNDERRUN 0x40u        /* the device random stream ran dry (spa_pyrandom_dev_generate too small) */

@@ -192,24 +192,24 @@ void orc_anchor_pool(const float *fmap, int64_t C, int64_t fh, int64_t fw,
  * raster order of the image pixels for bilinear); then
  *   out[s][c] = ( sum over feature pixels in raster order of Wt * F[c][cell] ) / total_s
  * evaluated in float32, multiply and add rounded separately, total_s = float32(count_s).
- * Returns 0, or -1 if a feature pixel is touched by more than 64 segments.
+ * Returns 0 (a feature pixel may be touched by any number of segments).
  */
-#define ORC_SLOTS 64
+typedef struct { int32_t n, cap; int32_t *lab; float *w; } orc_cell;
+
 int orc_mean_pool(const float *fmap, int64_t C, int64_t fh, int64_t fw,
                   int64_t sc, int64_t sy, int64_t sx,
                   const int32_t *labels, int64_t H, int64_t W, int64_t S, int mode,
                   float *out)
 {
     int64_t ncell = fh * fw;
-    int32_t *slot_lab = (int32_t *)malloc((size_t)ncell * ORC_SLOTS * sizeof(int32_t));
-    float *slot_w = (float *)calloc((size_t)ncell * ORC_SLOTS, sizeof(float));
-    int32_t *slot_n = (int32_t *)calloc((size_t)ncell, sizeof(int32_t));
+    /* per feature pixel: the (segment, weight) pairs in order of first appearance, as many as there are */
+    orc_cell *cellv = (orc_cell *)calloc((size_t)ncell, sizeof(orc_cell));
     int64_t *count = (int64_t *)calloc((size_t)S, sizeof(int64_t));
     int rc = 0;
     for (int64_t i = 0; i < H * W; ++i) count[labels[i]] += 1;
     /* cell-major accumulation in raster order of the image pixels */
-    for (int64_t y = 0; y < H && rc == 0; ++y)
-        for (int64_t x = 0; x < W && rc == 0; ++x) {
+    for (int64_t y = 0; y < H; ++y)
+        for (int64_t x = 0; x < W; ++x) {
             int32_t s = labels[y * W + x];
             int64_t cells[4]; float taps[4]; int nt;
             if (mode == 0) {
@@ -230,35 +230,38 @@ int orc_mean_pool(const float *fmap, int64_t C, int64_t fh, int64_t fw,
                 nt = 4;
             }
             for (int t = 0; t < nt; ++t) {
-                int64_t cell = cells[t];
-                int j = 0, n = slot_n[cell];
-                while (j < n && slot_lab[cell * ORC_SLOTS + j] != s) ++j;
+                orc_cell *cl = cellv + cells[t];
+                int j = 0, n = cl->n;
+                while (j < n && cl->lab[j] != s) ++j;
                 if (j == n) {
-                    if (n == ORC_SLOTS) { rc = -1; break; }
-                    slot_lab[cell * ORC_SLOTS + n] = s; slot_n[cell] = n + 1;
+                    if (n == cl->cap) {
+                        cl->cap = cl->cap ? 2 * cl->cap : 8;
+                        cl->lab = (int32_t *)realloc(cl->lab, (size_t)cl->cap * sizeof(int32_t));
+                        cl->w = (float *)realloc(cl->w, (size_t)cl->cap * sizeof(float));
+                    }
+                    cl->lab[n] = s; cl->w[n] = 0.0f; cl->n = n + 1;
                 }
-                slot_w[cell * ORC_SLOTS + j] += taps[t];
+                cl->w[j] += taps[t];
             }
         }
-    if (rc == 0) {
-        memset(out, 0, (size_t)S * C * sizeof(float));
-        for (int64_t cell = 0; cell < ncell; ++cell) {
-            int64_t y = cell / fw, x = cell % fw;
-            for (int j = 0; j < slot_n[cell]; ++j) {
-                int32_t s = slot_lab[cell * ORC_SLOTS + j];
-                float w = slot_w[cell * ORC_SLOTS + j];
-                float *o = out + (int64_t)s * C;
-                for (int64_t c = 0; c < C; ++c) {
-                    float prod = w * fmap[c * sc + y * sy + x * sx];
-                    o[c] = o[c] + prod;
-                }
+    memset(out, 0, (size_t)S * C * sizeof(float));
+    for (int64_t cell = 0; cell < ncell; ++cell) {
+        int64_t y = cell / fw, x = cell % fw;
+        for (int j = 0; j < cellv[cell].n; ++j) {
+            int32_t s = cellv[cell].lab[j];
+            float w = cellv[cell].w[j];
+            float *o = out + (int64_t)s * C;
+            for (int64_t c = 0; c < C; ++c) {
+                float prod = w * fmap[c * sc + y * sy + x * sx];
+                o[c] = o[c] + prod;
             }
-        }
-        for (int64_t s = 0; s < S; ++s) {
-            float tot = (float)count[s];
-            for (int64_t c = 0; c < C; ++c) out[s * C + c] = out[s * C + c] / tot;
         }
     }
-    free(slot_lab); free(slot_w); free(slot_n); free(count);
+    for (int64_t s = 0; s < S; ++s) {
+        float tot = (float)count[s];
+        for (int64_t c = 0; c < C; ++c) out[s * C + c] = out[s * C + c] / tot;
+    }
+    for (int64_t cell = 0; cell < ncell; ++cell) { free(cellv[cell].lab); free(cellv[cell].w); }
+    free(cellv); free(count);
     return rc;
 }

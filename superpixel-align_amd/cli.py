@@ -158,7 +158,7 @@ class PinnedRing(object):
 
     def upload(self, arrays, device, pool=None):
         """list of equally shaped arrays -> (len, ...) device tensor, enqueued on the current stream."""
-        slot = self.take((len(arrays),) + tuple(arrays[0].shape), torch.from_numpy(arrays[0]).dtype)
+        slot = self.take((len(arrays),) + tuple(arrays[0].shape), getattr(torch, str(arrays[0].dtype)))
         dst = slot[0].numpy()
 
         def put(j):

@@ -39,6 +39,7 @@ extern "C" int spa_ctx_create(int device, spa_ctx **out)
     spa_ctx *ctx = (spa_ctx *)calloc(1, sizeof(spa_ctx));
     ctx->device = device;
     ctx->n_cu = prop.multiProcessorCount;
+    if (const char *e = getenv("SPA_SLIC_GENERAL")) ctx->slic_force_general = atoi(e) != 0;
     SPA_HIP(hipMalloc((void **)&ctx->d_status, sizeof(uint32_t)));
     SPA_HIP(hipMemset(ctx->d_status, 0, sizeof(uint32_t)));
     *out = ctx;

@@ -155,45 +155,22 @@ extern "C" int spa_pool_anchor(spa_ctx *ctx, const void *fmap, const spa_fmap_de
 // that sample it, accumulated in raster order of the image pixels.
 // ---------------------------------------------------------------------------------------
 struct CellSlots { int n; int lab[SPA_CELL_SLOTS]; float w[SPA_CELL_SLOTS]; };
+#define CELL_OVERFLOW (-1)      // n of a cell more than SPA_CELL_SLOTS superpixels touch: weights recomputed on demand
 
-__global__ __launch_bounds__(256) void k_cell_weights(const int32_t *__restrict__ labels, int H,
-                                                      int W, int fh, int fw, int sampling,
-                                                      const int32_t *__restrict__ offsets,
-                                                      CellSlots *__restrict__ cells,
-                                                      uint32_t *__restrict__ status)
+// every (image pixel, tap weight) that samples feature pixel (u, v), in raster order of the image pixels:
+// f(label, tap).  sampling 0: nearest (image pixel (y, x) samples (y*fh//H, x*fw//W), tap 1);
+// 1: chainer F.resize_images (u = y*(fh-1)/(H-1), 4 taps, float32 weights, taps of one pixel in the order
+// (u0,v0) (u0,v1) (u1,v0) (u1,v1); several may hit this cell)
+template <typename F>
+__device__ __forceinline__ void cell_taps(const int32_t *__restrict__ L, int H, int W, int fh, int fw,
+                                          int sampling, int u, int v, F f)
 {
-    __shared__ int s_lab[SPA_CELL_SLOTS * 256];
-    __shared__ float s_w[SPA_CELL_SLOTS * 256];
-    const int b = blockIdx.y;
-    const int cell = blockIdx.x * 256 + threadIdx.x;
-    if (cell >= fh * fw) return;
-    const int S = offsets[b + 1] - offsets[b];
-    const int u = cell / fw, v = cell - u * fw;
-    const int32_t *L = labels + (long long)b * H * W;
-    const int t = threadIdx.x;
-    int n = 0;
-    bool overflow = false;
-    auto add = [&](int s, float tap) {
-        int j = 0;
-        while (j < n && s_lab[j * 256 + t] != s) ++j;
-        if (j == n) {
-            if (n == SPA_CELL_SLOTS) { overflow = true; return; }
-            s_lab[n * 256 + t] = s; s_w[n * 256 + t] = 0.0f; ++n;
-        }
-        s_w[j * 256 + t] = s_w[j * 256 + t] + tap;
-    };
     if (sampling == 0) {
-        // image pixel (y, x) samples feature pixel (y*fh//H, x*fw//W)
         const int ylo = (int)(((long long)u * H + fh - 1) / fh), yhi = (int)(((long long)(u + 1) * H + fh - 1) / fh);
         const int xlo = (int)(((long long)v * W + fw - 1) / fw), xhi = (int)(((long long)(v + 1) * W + fw - 1) / fw);
         for (int y = ylo; y < yhi; ++y)
-            for (int x = xlo; x < xhi; ++x) {
-                int s = L[(long long)y * W + x];
-                if (s < 0 || s >= S) { atomicOr(status, SPA_ST_LABEL_RANGE); continue; }
-                add(s, 1.0f);
-            }
+            for (int x = xlo; x < xhi; ++x) f(L[(long long)y * W + x], 1.0f);
     } else {
-        // chainer F.resize_images: u = y*(fh-1)/(H-1), 4 taps, float32 weights
         const float ry = (H > 1) ? ((float)(fh - 1) / (float)(H - 1)) : 0.0f;
         const float rx = (W > 1) ? ((float)(fw - 1) / (float)(W - 1)) : 0.0f;
         int ylo = 0, yhi = H - 1, xlo = 0, xhi = W - 1;
@@ -211,20 +188,68 @@ __global__ __launch_bounds__(256) void k_cell_weights(const int32_t *__restrict_
                 int v1 = v0 + 1 < fw ? v0 + 1 : fw - 1;
                 if (v0 != v && v1 != v) continue;
                 float fv = vv - (float)v0;
-                int s = L[(long long)y * W + x];
-                if (s < 0 || s >= S) { atomicOr(status, SPA_ST_LABEL_RANGE); continue; }
-                // taps in the order (u0,v0) (u0,v1) (u1,v0) (u1,v1); several may hit this cell
-                if (u0 == u && v0 == v) add(s, (1.0f - fu) * (1.0f - fv));
-                if (u0 == u && v1 == v) add(s, (1.0f - fu) * fv);
-                if (u1 == u && v0 == v) add(s, fu * (1.0f - fv));
-                if (u1 == u && v1 == v) add(s, fu * fv);
+                const int s = L[(long long)y * W + x];
+                if (u0 == u && v0 == v) f(s, (1.0f - fu) * (1.0f - fv));
+                if (u0 == u && v1 == v) f(s, (1.0f - fu) * fv);
+                if (u1 == u && v0 == v) f(s, fu * (1.0f - fv));
+                if (u1 == u && v1 == v) f(s, fu * fv);
             }
         }
     }
-    if (overflow) atomicOr(status, SPA_ST_POOL_SLOT_OVERFLOW);
+}
+
+__global__ __launch_bounds__(256) void k_cell_weights(const int32_t *__restrict__ labels, int H,
+                                                      int W, int fh, int fw, int sampling,
+                                                      const int32_t *__restrict__ offsets,
+                                                      CellSlots *__restrict__ cells,
+                                                      uint32_t *__restrict__ status)
+{
+    __shared__ int s_lab[SPA_CELL_SLOTS * 256];
+    __shared__ float s_w[SPA_CELL_SLOTS * 256];
+    const int b = blockIdx.y;
+    const int cell = blockIdx.x * 256 + threadIdx.x;
+    if (cell >= fh * fw) return;
+    const int S = offsets[b + 1] - offsets[b];
+    const int u = cell / fw, v = cell - u * fw;
+    const int32_t *L = labels + (long long)b * H * W;
+    const int t = threadIdx.x;
+    int n = 0;
+    bool overflow = false, range = false;
+    cell_taps(L, H, W, fh, fw, sampling, u, v, [&](int s, float tap) {
+        if (s < 0 || s >= S) { range = true; return; }
+        int j = 0;
+        while (j < n && s_lab[j * 256 + t] != s) ++j;
+        if (j == n) {
+            if (n == SPA_CELL_SLOTS) { overflow = true; return; }
+            s_lab[n * 256 + t] = s; s_w[n * 256 + t] = 0.0f; ++n;
+        }
+        s_w[j * 256 + t] = s_w[j * 256 + t] + tap;
+    });
+    if (range) atomicOr(status, SPA_ST_LABEL_RANGE);
     CellSlots *o = cells + (long long)b * fh * fw + cell;
-    o->n = n;
-    for (int j = 0; j < n; ++j) { o->lab[j] = s_lab[j * 256 + t]; o->w[j] = s_w[j * 256 + t]; }
+    // more superpixels than slots (felzenszwalb with a small min_size puts up to one segment per pixel under a
+    // feature pixel): the cell is flagged and whoever asks for a segment's weight recomputes it from the labels,
+    // pixels in the same raster order, hence the same float32 sum (cell_weight)
+    o->n = overflow ? CELL_OVERFLOW : n;
+    if (!overflow)
+        for (int j = 0; j < n; ++j) { o->lab[j] = s_lab[j * 256 + t]; o->w[j] = s_w[j * 256 + t]; }
+}
+
+// weight of superpixel s at feature pixel (u, v): slot lookup, or the recomputation for a flagged cell
+__device__ __forceinline__ bool cell_weight(const CellSlots *__restrict__ cs, int s, const int32_t *__restrict__ L,
+                                            int H, int W, int fh, int fw, int sampling, int u, int v, float &w)
+{
+    const int nn = cs->n;
+    for (int j = 0; j < nn; ++j)
+        if (cs->lab[j] == s) { w = cs->w[j]; return true; }
+    if (nn != CELL_OVERFLOW) return false;
+    bool found = false;
+    float acc = 0.0f;
+    cell_taps(L, H, W, fh, fw, sampling, u, v, [&](int l, float tap) {
+        if (l == s) { acc = acc + tap; found = true; }
+    });
+    w = acc;
+    return found;
 }
 
 // Step 2: one workgroup per superpixel.  All 256 threads first search the feature pixels of the
@@ -240,6 +265,7 @@ __global__ __launch_bounds__(256) void k_pool_mean(const void *__restrict__ fmap
                                                    const int32_t *__restrict__ bbox,
                                                    const int32_t *__restrict__ count,
                                                    const CellSlots *__restrict__ cells,
+                                                   const int32_t *__restrict__ labels,
                                                    const double *__restrict__ centroid,
                                                    int append_pos, void *__restrict__ X,
                                                    int x_dtype, long long ld)
@@ -281,10 +307,8 @@ __global__ __launch_bounds__(256) void k_pool_mean(const void *__restrict__ fmap
                 long long fo = 0;
                 if (ci < ncell) {
                     const int u = u0 + ci / bwc, v = v0 + ci % bwc;
-                    const CellSlots *cs = cb + (long long)u * fw + v;
-                    const int nn = cs->n;
-                    for (int j = 0; j < nn; ++j)
-                        if (cs->lab[j] == s) { w = cs->w[j]; found = true; break; }
+                    found = cell_weight(cb + (long long)u * fw + v, s, labels + (long long)b * H * W, H, W, fh, fw,
+                                        sampling, u, v, w);
                     fo = fb + u * sy + v * sx;
                 }
                 const unsigned long long m = __ballot(found);
@@ -354,6 +378,7 @@ __global__ __launch_bounds__(POOLV_THREADS) void k_pool_mean_vec(const void *__r
                                                                  const int32_t *__restrict__ bbox,
                                                                  const int32_t *__restrict__ count,
                                                                  const CellSlots *__restrict__ cells,
+                                                                 const int32_t *__restrict__ labels,
                                                                  const double *__restrict__ centroid,
                                                                  int append_pos, void *__restrict__ X,
                                                                  int x_dtype, long long ld)
@@ -431,10 +456,8 @@ __global__ __launch_bounds__(POOLV_THREADS) void k_pool_mean_vec(const void *__r
                 long long fo = 0;
                 if (ci < ncell) {
                     const int u = u0 + ci / bwc, v = v0 + ci % bwc;
-                    const CellSlots *cs = cb + (long long)u * fw + v;
-                    const int nn = cs->n;
-                    for (int j = 0; j < nn; ++j)
-                        if (cs->lab[j] == s) { w = cs->w[j]; found = true; break; }
+                    found = cell_weight(cb + (long long)u * fw + v, s, labels + (long long)b * H * W, H, W, fh, fw,
+                                        sampling, u, v, w);
                     fo = (fb + u * sy + v * sx) * ES;
                 }
                 const unsigned long long m = __ballot(found);
@@ -521,7 +544,7 @@ extern "C" int spa_pool_mean(spa_ctx *ctx, const void *fmap, const spa_fmap_desc
 #define POOLV_LAUNCH(DT, NP)                                                                                    \
             hipLaunchKernelGGL((k_pool_mean_vec<DT, NP>), dim3(Ncap), dim3(nthr), 0, s, fmap, d->C, d->fh,            \
                                d->fw, (long long)d->stride_b, (long long)d->stride_y, (long long)d->stride_x, B, H,  \
-                               W, sampling, offsets, (const int32_t *)ctx->ws[WS_BBOX], count, cells, centroid,      \
+                               W, sampling, offsets, (const int32_t *)ctx->ws[WS_BBOX], count, cells, labels, centroid, \
                                append_pos, X, x_dtype, (long long)ld)
             if (d->dtype == 0) {
                 if (np == 1) POOLV_LAUNCH(0, 1); else if (np == 2) POOLV_LAUNCH(0, 2); else POOLV_LAUNCH(0, 4);
@@ -534,7 +557,7 @@ extern "C" int spa_pool_mean(spa_ctx *ctx, const void *fmap, const spa_fmap_desc
     }
     hipLaunchKernelGGL(k_pool_mean, dim3(Ncap), dim3(256), 0, s, fmap, d->dtype, d->C, d->fh, d->fw,
                        (long long)d->stride_b, (long long)d->stride_y, (long long)d->stride_x, B, H,
-                       W, sampling, offsets, (const int32_t *)ctx->ws[WS_BBOX], count, cells, centroid,
+                       W, sampling, offsets, (const int32_t *)ctx->ws[WS_BBOX], count, cells, labels, centroid,
                        append_pos, X, x_dtype, (long long)ld);
     SPA_LAUNCH_CHECK();
     return SPA_OK;

@@ -19,6 +19,9 @@
 #include "spa_common.h"
 #include "spa_glibcf.h"
 
+int spa_slic_core_general_f32(spa_ctx *ctx, const float *lab, int32_t B, int32_t H, int32_t W, int32_t n_segments,
+                              int32_t max_iter, int32_t *labels, float *centres, void *stream);
+
 // ------------------------------------------------------------------------------------
 // rgb -> scaled Lab (skimage/color/colorconv.py:657-661, :950-969), float32 steps in the
 // reference's order; np.power(float32, 2.4) = powf(x, 2.4f) and np.cbrt = cbrtf as the C library of the
@@ -827,8 +830,11 @@ extern "C" int spa_slic_core(spa_ctx *ctx, const float *lab, int32_t B, int32_t 
     rc = spa_ws_reserve(ctx, WS_CENTRES, (size_t)B * nC * CEN_WORDS * 4, (void **)&cen);
     if (rc != SPA_OK) return rc;
     const int s2y = 2 * pl.win_step_y, s2x = 2 * pl.win_step_x;
-    SPA_ARG(W <= 64 * 8 * UPD_PWMAX);         // occupancy words: <= 64 pieces of 64 pixels per row
-    SPA_ARG(4 * pl.win_step_y + 24 < (1 << 19)); // stream codes keep the row in the upper 20 bits
+    // occupancy words hold <= 64 pieces of 64 pixels per row, stream codes keep the row in the upper 20 bits, the
+    // centre table is read by 32-bit offsets: anything else takes the general float32 kernels (spa_slic64.hip:
+    // same arithmetic and order, untuned), as does SPA_SLIC_GENERAL=1 (tests compare the two paths)
+    if (W > 64 * 8 * UPD_PWMAX || 4 * pl.win_step_y + 24 >= (1 << 19) || ctx->slic_force_general)
+        return spa_slic_core_general_f32(ctx, lab, B, H, W, n_segments, max_iter, labels, centres, stream);
     const int HG = (H + 7) / 8;
     const int PW = (((W + 63) / 64) + 7) / 8;      // mask words per (centre, 8-row group)
     unsigned long long *rowmask;

@@ -193,6 +193,42 @@ def test_slic_full_batch_vs_oracle(eng, orc, synth):
         assert int(n_labels[b]) == ref.max() + 1
 
 
+def test_slic_rows_wider_than_4096_pixels(orc, synth):
+    """Images the tuned SLIC kernels do not take (their occupancy masks hold 64 pieces of 64 pixels per row) run on
+    the general float32 kernels (csrc/spa_slic64.hip, the Cython core's other instantiation): a 40 x 4500 and a
+    96 x 5000 image against the oracle, whole call from RGB; and the general kernels forced onto a golden fixture
+    (SPA_SLIC_GENERAL=1) give the tuned kernels' / scikit-image's labels and float32 centres bit for bit."""
+    engine = importlib.import_module('superpixel-align_amd.engine')
+    e = engine.Engine()
+    try:
+        for seed, H, W, n in [(31, 40, 4500, 30), (32, 96, 5000, 120)]:
+            img = synth.synth_image(seed, H, W)
+            labels, n_labels = e.slic(dev(img[None]), n)
+            e.raise_on_status()
+            ref = orc.slic(img, n)
+            assert np.array_equal(labels[0].cpu().numpy().astype(np.int64), ref), (H, W)
+            assert int(n_labels[0]) == ref.max() + 1
+    finally:
+        e.close()
+    os.environ['SPA_SLIC_GENERAL'] = '1'
+    try:
+        eg = engine.Engine()
+    finally:
+        del os.environ['SPA_SLIC_GENERAL']
+    try:
+        g = golden('slic_s2_256x512_n100')
+        img = synth.synth_image(2, 256, 512)
+        lab = orc.rgb2lab_scaled(img)
+        pre, cen = eg.slic_core(dev(lab.transpose(2, 0, 1)[None]), 100, want_centres=True)
+        assert np.array_equal(pre[0].cpu().numpy(), g['pre'].astype(np.int32))
+        assert np.array_equal(cen[0].cpu().numpy().view(np.int32), g['centres'].view(np.int32))
+        labels, _ = eg.slic(dev(img[None]), 100)
+        assert np.array_equal(labels[0].cpu().numpy(), g['e2e_skimage'].astype(np.int32))
+        eg.raise_on_status()
+    finally:
+        eg.close()
+
+
 def _batch_labels(orc, synth, seeds, H, W, n):
     imgs = synth.synth_batch(seeds, H, W)
     sps = np.stack([orc.slic(im, n) for im in imgs])
@@ -487,6 +523,52 @@ def test_mean_pool_bit_exact(eng, orc, synth, sampling):
             s = S // 2
             np.testing.assert_allclose(ref[s], up[:, sps[b] == s].mean(axis=1), rtol=1e-4, atol=1e-5)
         o += S
+
+
+@pytest.mark.parametrize('sampling', ['nearest', 'bilinear'])
+def test_mean_pool_more_than_sixteen_superpixels_per_feature_pixel(eng, orc, synth, sampling):
+    """Mean pooling when a feature pixel is touched by more superpixels than its 16 slots hold (used to be a
+    hard SpalignError): (a) a label map with one segment per 2x2 block — 16 segments under every 8x8 cell, up to
+    ~80 within reach of a bilinear cell; (b) felzenszwalb (300, 0.8, 20) at 224x224, the reference launchers'
+    setting (batch_spalign_kmeans.py:301-307), whose 20-pixel segments crowd the 28x28 map.  Bit exact with the
+    oracle, no status bit."""
+    H, W, C = 64, 96, 24
+    fine = (np.arange(H)[:, None] // 2) * (W // 2) + (np.arange(W)[None, :] // 2)
+    coarse = (np.arange(H)[:, None] // 16) * (W // 16) + (np.arange(W)[None, :] // 16)
+    sps = np.stack([fine, coarse, np.where(np.arange(W)[None, :] < W // 2, fine, fine.max() + 1 + coarse)])
+    sps = np.stack([np.unique(m, return_inverse=True)[1].reshape(H, W) for m in sps]).astype(np.int32)
+    n_per = [int(m.max()) + 1 for m in sps]
+    N = sum(n_per)
+    fm = synth.synth_feature_map(21, C, H // 8, W // 8, batch=3)
+    fmap = dev(fm).contiguous(memory_format=torch.channels_last)
+    labels = dev(sps)
+    off = eng.segment_offsets(dev(np.array(n_per, np.int32)))
+    count, centroid, _ = eng.segment_stats(labels, off, N)
+    X = eng.pool_mean(fmap, labels, off, N, count, sampling, None, False).cpu().numpy()
+    eng.raise_on_status(ignore=0)
+    o = 0
+    for b, S in enumerate(n_per):
+        ref = orc.mean_pool(fm[b], sps[b], sampling, S)
+        assert np.array_equal(X[o:o + S].view(np.int32), ref.view(np.int32)), b
+        o += S
+    # (b) the reference operating point
+    imgs = np.stack([synth.synth_scene(60 + i, 224, 224) for i in range(2)])
+    lab, n_lab = eng.felzenszwalb(dev(imgs), 300.0, 0.8, 20)
+    sp = lab.cpu().numpy()
+    n_per = [int(v) for v in n_lab]
+    cells = [len(np.unique(sp[0][8 * u:8 * u + 8, 8 * v:8 * v + 8])) for u in range(28) for v in range(28)]
+    fm = synth.synth_feature_map(22, 32, 28, 28, batch=2)
+    off = eng.segment_offsets(n_lab)
+    N = sum(n_per)
+    count, centroid, _ = eng.segment_stats(lab, off, N)
+    X = eng.pool_mean(dev(fm).contiguous(memory_format=torch.channels_last), lab, off, N, count, sampling, None, False).cpu().numpy()
+    eng.raise_on_status(ignore=0)
+    o = 0
+    for b, S in enumerate(n_per):
+        ref = orc.mean_pool(fm[b], sp[b], sampling, S)
+        assert np.array_equal(X[o:o + S].view(np.int32), ref.view(np.int32)), b
+        o += S
+    print('most superpixels under one 8x8 cell of the felzenszwalb map:', max(cells))
 
 
 def test_pool_bf16_features(eng, orc, synth):
