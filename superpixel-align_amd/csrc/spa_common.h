@@ -113,7 +113,7 @@ struct spa_ctx {
     int conn_attr_done;
     int conn_claim_ready;          // the BFS claim words are all-INF (set once per allocation)
     size_t conn_claim_bytes;
-    int upd_wg_per_cu;
+    int upd_wg_per_cu, upd_wg_per_cu8;
     int slic_force_general;      // SPA_SLIC_GENERAL=1 at context creation: spa_slic_core takes the general kernels
     int zero_line_ready, conv_attr_done, fz_attr_done;
     int rng_seeded;

@@ -514,31 +514,187 @@ __global__ __launch_bounds__(1024) void k_slic_order(const uint32_t *__restrict_
 
 // PWM = occupancy words per 8-row group the image width needs: 4 (<= 2048 pixels, 16-bit list entries)
 // or 8 (<= 4096 pixels, 32-bit list entries)
+//
+// Workgroup = UPD2_NSEG gather waves + ONE chain wave.  A gather wave owns one segment at a time and does
+// everything above except the sums: it publishes its rounds of 128 staged pixels (five rows y, x, L, a, b) in a
+// two-slot ring of LDS and goes on gathering.  The chain wave carries the running sums of ALL the workgroup's
+// segments at once: lanes 5g..5g+4 walk the five rows of gather wave g's next published round, so one dependent
+// float32 add instruction advances 60 chains instead of 5 (the chain adds were half of the kernel's vector
+// instructions with 5 of 64 lanes useful).  Per segment the order of the additions is unchanged — raster order,
+// one chain — hence the same bits.  Waves talk through LDS words only (ready / consumed message counters per
+// ring, no workgroup barrier: the gather waves keep four rounds of global loads in flight and a barrier's waitcnt
+// would drain them); a ring message is a data round (header = fill), the end of a segment (the chain wave
+// divides, derives the next search window and writes the centre record) or the end of the queue.
+#ifndef UPD2_NSEG
+#define UPD2_NSEG 8            // measured per launch (30 images): 12/1024 0.372 ms, 6/1024 0.372, 10/1536 0.365, 8/2048 0.358,
+#endif                       // 6/512 0.400, 12/512 0.394 (gather waves / index-buffer pixels); without the Lab loads 0.290
+#define UPD2_D 2                          // ring slots per gather wave
+#define UPD2_ROW (UPD_ROUND + 4)          // 132 floats: lane l's row starts 4 l banks on (16-byte reads, 64 banks)
+#ifndef UPD2_ICAP
+#define UPD2_ICAP 2048
+#endif
+#define UPD2_MSG_END 0x40000000
+#define UPD2_MSG_QUIT 0x20000000
+template <int PWM> struct Upd2Lds {
+    typedef typename UpdEntry<PWM>::type entry_t;
+    static constexpr size_t stage = 0;
+    static constexpr size_t idx = stage + (size_t)UPD2_NSEG * UPD2_D * 5 * UPD2_ROW * 4;
+    static constexpr size_t plist = idx + (size_t)UPD2_NSEG * UPD2_ICAP * 4;
+    static constexpr size_t ctrl = plist + (size_t)UPD2_NSEG * UPD_PCAP * sizeof(entry_t);
+    // ctrl words: ready[NSEG] | consumed[NSEG] | hdr[NSEG][D] | segid[NSEG][D]
+    static constexpr size_t bytes = ctrl;      // (the control words are a static LDS array of the kernel)
+};
+
+__device__ __forceinline__ void upd2_lds_settle()       // this wave's LDS operations have completed; loads in flight stay
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 template <int PWM>
-__global__ __launch_bounds__(256)
-void k_slic_update(const float *__restrict__ lab, uint32_t *__restrict__ cen, int nC, int B, int H,
+__global__ __launch_bounds__((UPD2_NSEG + 1) * 64)
+void k_slic_update2(const float *__restrict__ lab, uint32_t *__restrict__ cen, int nC, int B, int H,
                    int W, int s2y, int s2x, unsigned long long *__restrict__ rowmask, int HG, int PW,
                    unsigned long long *__restrict__ fine, int RW, int PWF, int per_xcd,
                    const int *__restrict__ order, int *__restrict__ qhead,
                    uint32_t *__restrict__ status)
 {
-    __shared__ __attribute__((aligned(16))) float stage_s[UPD_WAVES][5 * UPD_ROW];
-    __shared__ unsigned idx_s[UPD_WAVES][UPD_ICAP];
+    extern __shared__ __attribute__((aligned(16))) char upd2_lds[];
     typedef typename UpdEntry<PWM>::type entry_t;
+    typedef Upd2Lds<PWM> LD;
     constexpr int PB = UpdEntry<PWM>::piece_bits;
-    __shared__ entry_t plist_s[UPD_WAVES][UPD_PCAP];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int xcd = (int)(blockIdx.x & 7u);          // workgroups are dealt round-robin to the XCDs
     const int qlo = xcd * per_xcd, qn = min(B * nC, qlo + per_xcd) - qlo;
-    float *st = stage_s[wv];
-    unsigned *idx = idx_s[wv];
-    entry_t *plist = plist_s[wv];
+    float *stage = (float *)(upd2_lds + LD::stage);
+    // control words in a STATIC LDS array, read and written with relaxed workgroup-scope atomics: plain ds_read /
+    // ds_write.  (A volatile pointer into the dynamic block loses its address space: the compiler then emits flat
+    // loads with s_waitcnt vmcnt(0), which drains the gather waves' Lab loads at every poll — measured: half of
+    // the launch.)
+    __shared__ int ctrl_s[UPD2_NSEG * (2 + 2 * UPD2_D)];
+    int *ready = ctrl_s;
+    int *consumed = ready + UPD2_NSEG;
+    int *hdr = consumed + UPD2_NSEG;                            // [NSEG][D]
+    int *segid = hdr + UPD2_NSEG * UPD2_D;                      // [NSEG][D]
+#define UPD2_LD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define UPD2_ST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+    if (tid < UPD2_NSEG * 2) ready[tid] = 0;                    // ready | consumed
+    __syncthreads();
+    if (wv == UPD2_NSEG) {
+        // ---------------------------------------------------------------- the chain wave
+        const int g = lane / 5, f = lane - g * 5;
+        const bool active = g < UPD2_NSEG;
+        const int gl = active ? g : 0;
+        int r = 0;                 // messages of ring g taken so far
+        float acc = 0.0f;          // running sum of feature f (y, x, L, a, b) of ring g's current segment
+        unsigned n = 0;            // its pixel count
+        bool quit = !active;
+        for (;;) {
+            const bool avail = !quit && UPD2_LD(ready + gl) > r;
+            if (!__ballot(avail)) {
+                if (!__ballot(!quit)) break;
+                __builtin_amdgcn_s_sleep(2);
+                continue;
+            }
+            asm volatile("" ::: "memory");
+            const int slot = r & (UPD2_D - 1);
+            const int h = avail ? UPD2_LD(hdr + gl * UPD2_D + slot) : 0;
+            const bool data = avail && h > 0 && h <= UPD_ROUND;
+            if (data) {
+                // lane walks feature row f of the round: four 16-byte LDS reads per 16 dependent adds, the reads
+                // of the next 16 pixels in flight meanwhile; the gather wave padded the row with zeros up to
+                // UPD_ROUND, and x + 0.0f = x exactly, so every round is summed over its whole length
+                const float4 *r4 = (const float4 *)(stage + ((gl * UPD2_D + slot) * 5 + f) * UPD2_ROW);
+                float4 q0 = r4[0], q1 = r4[1], q2 = r4[2], q3 = r4[3];
+                float4 n0, n1, n2, n3;
+#define UPD_ADD16(a0, a1, a2, a3)                                                          \
+    acc = acc + a0.x; acc = acc + a0.y; acc = acc + a0.z; acc = acc + a0.w;                \
+    acc = acc + a1.x; acc = acc + a1.y; acc = acc + a1.z; acc = acc + a1.w;                \
+    acc = acc + a2.x; acc = acc + a2.y; acc = acc + a2.z; acc = acc + a2.w;                \
+    acc = acc + a3.x; acc = acc + a3.y; acc = acc + a3.z; acc = acc + a3.w;
+#define UPD_PIN(a0, a1, a2, a3)                                                            \
+    asm volatile("" : "+v"(a0.x), "+v"(a0.y), "+v"(a0.z), "+v"(a0.w), "+v"(a1.x), "+v"(a1.y), "+v"(a1.z), "+v"(a1.w)); \
+    asm volatile("" : "+v"(a2.x), "+v"(a2.y), "+v"(a2.z), "+v"(a2.w), "+v"(a3.x), "+v"(a3.y), "+v"(a3.z), "+v"(a3.w));
+#pragma unroll
+                for (int j = 0; j < UPD_ROUND; j += 32) {
+                    n0 = r4[(j >> 2) + 4]; n1 = r4[(j >> 2) + 5]; n2 = r4[(j >> 2) + 6]; n3 = r4[(j >> 2) + 7];
+                    __builtin_amdgcn_sched_barrier(0);
+                    UPD_ADD16(q0, q1, q2, q3)
+                    UPD_PIN(n0, n1, n2, n3)
+                    if (j + 32 < UPD_ROUND) {
+                        q0 = r4[(j >> 2) + 8]; q1 = r4[(j >> 2) + 9]; q2 = r4[(j >> 2) + 10]; q3 = r4[(j >> 2) + 11];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    UPD_ADD16(n0, n1, n2, n3)
+                    if (j + 32 < UPD_ROUND) { UPD_PIN(q0, q1, q2, q3) }
+                }
+                n += (unsigned)h;
+            }
+            // ---- end of a segment: mean, next window, centre record (wave-uniform section: the shuffles)
+            const bool end = avail && h == UPD2_MSG_END;
+            if (__ballot(end)) {
+                const float mean = acc / (float)n;      // segments[k, c] /= n_segment_elems[k]
+                const int g5 = gl * 5;
+                const float cy = __shfl(mean, g5), cx = __shfl(mean, g5 + 1);
+                const float cl = __shfl(mean, g5 + 2), ca = __shfl(mean, g5 + 3), cbb = __shfl(mean, g5 + 4);
+                if (end && f == 0) {
+                    uint32_t *c = cen + (long long)UPD2_LD(segid + gl * UPD2_D + slot) * CEN_WORDS;
+                    if (n == 0u) {
+                        // the seed lost all its pixels: scikit-image's 0/0 gives it a NaN centre, a NaN distance never
+                        // wins `distance > dist_center`, and the NaN -> index casts that size its window yield an empty
+                        // range (x86-64), so it stays dead for the remaining sweeps (tests/golden/slic_starve_*.npz).
+                        // Here: NaN centre + empty window (never a candidate of any tile, no pixel ever again); the
+                        // status bit is informational.
+                        atomicOr(status, SPA_ST_SLIC_EMPTY_SEGMENT);
+                        const uint32_t qnan = 0x7fc00000u;
+                        c[0] = qnan; c[1] = qnan; c[2] = qnan; c[3] = qnan; c[4] = qnan;
+                        c[6] = 0u; c[7] = 0u; c[8] = 0u; c[9] = 0u;
+                        c[10] = 0u;
+                    } else {
+                        int ny0, ny1, nx0, nx1;
+                        slic_window(cy, cx, s2y, s2x, H, W, ny0, ny1, nx0, nx1);
+                        c[0] = __float_as_uint(cy); c[1] = __float_as_uint(cx);
+                        c[2] = __float_as_uint(cl); c[3] = __float_as_uint(ca); c[4] = __float_as_uint(cbb);
+                        c[6] = (uint32_t)ny0; c[7] = (uint32_t)ny1; c[8] = (uint32_t)nx0; c[9] = (uint32_t)nx1;
+                        c[10] = n;
+                    }
+                }
+                if (end) { acc = 0.0f; n = 0u; }
+            }
+            if (avail && h == UPD2_MSG_QUIT) quit = true;
+            if (avail) {
+                r += 1;
+                upd2_lds_settle();                       // the round has been read
+                if (f == 0) UPD2_ST(consumed + gl, r);
+            }
+        }
+        return;
+    }
+    // ------------------------------------------------------------------- gather waves
+    unsigned *idx = (unsigned *)(upd2_lds + LD::idx) + wv * UPD2_ICAP;
+    entry_t *plist = (entry_t *)(upd2_lds + LD::plist) + wv * UPD_PCAP;
     const unsigned W4 = (unsigned)W * 4u;
+    int msgs = 0;                  // messages this wave has published
+    // next free ring slot (waits for the chain wave when both are in use)
+    auto ring_slot = [&]() -> int {
+        while (UPD2_LD(consumed + wv) + UPD2_D <= msgs) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        return msgs & (UPD2_D - 1);
+    };
+    auto publish = [&](int slot, int header, int seg_) {
+        upd2_lds_settle();
+        if (lane == 0) { UPD2_ST(hdr + wv * UPD2_D + slot, header); UPD2_ST(segid + wv * UPD2_D + slot, seg_); }
+        upd2_lds_settle();
+        msgs += 1;
+        if (lane == 0) UPD2_ST(ready + wv, msgs);
+    };
   for (;;) {
     int qi = 0;
     if (lane == 0) qi = atomicAdd(qhead + xcd, 1);
     qi = __builtin_amdgcn_readfirstlane(qi);
-    if (qi >= qn) return;
+    if (qi >= qn) {
+        publish(ring_slot(), UPD2_MSG_QUIT, 0);
+        return;
+    }
     const int seg = __builtin_amdgcn_readfirstlane(order[qlo + qi]);
     const int b = seg / nC;
     const int k = seg - b * nC;
@@ -552,8 +708,6 @@ void k_slic_update(const float *__restrict__ lab, uint32_t *__restrict__ cen, in
     unsigned long long *fm = fine + ((long long)b * nC + k) * RW * PWF;
     const int pc0 = wx0 >> 6;
 
-    float acc = 0.0f;          // lanes 0..4: running sums of y, x, L, a, b
-    unsigned n = 0;            // pixel count
     UPD_T0();
 
     const int g0 = wy0 >> 3, g1 = (wy1 - 1) >> 3;
@@ -640,7 +794,7 @@ void k_slic_update(const float *__restrict__ lab, uint32_t *__restrict__ cen, in
             }
             const int cnt = __popc(mlo) + __popc(mhi);
             const int inc = upd_wave_scan(cnt);
-            const bool take = (e0 + lane < npieces) && inc <= UPD_ICAP;
+            const bool take = (e0 + lane < npieces) && inc <= UPD2_ICAP;
             const int m = __popcll(__ballot(take));               // >= 1: one entry is at most 64 pixels
             T = __builtin_amdgcn_readlane(inc, m - 1);
             if (take) {
@@ -678,9 +832,13 @@ void k_slic_update(const float *__restrict__ lab, uint32_t *__restrict__ cen, in
                 const unsigned v = idx[ok ? lr * UPD_ROUND + p : 0];
                 const unsigned off = (unsigned)(ybase + (int)(v >> UPD_XBITS)) * W4 + ((v & ((1u << UPD_XBITS) - 1u)) << 2);
                 R.code[g] = ok ? v : 0xFFFFFFFFu;
+#ifdef SPA_UPD_NOLOAD          // experiment: how much of the launch is the Lab gather itself
+                R.vL[g] = __uint_as_float(off); R.vA[g] = 1.0f; R.vB[g] = 2.0f;
+#else
                 R.vL[g] = *(const float *)((const char *)pL + off);
                 R.vA[g] = *(const float *)((const char *)pA + off);
                 R.vB[g] = *(const float *)((const char *)pB + off);
+#endif
             }
             lr += live ? 1 : 0;
             inflight += live ? 1 : 0;
@@ -688,64 +846,35 @@ void k_slic_update(const float *__restrict__ lab, uint32_t *__restrict__ cen, in
         auto consume = [&](const UpdRound &R) {
             const int fill = R.fill;
             if (fill == 0) return;                         // idle round (its loads hit one cached line)
+            UPD_T(5)
+            const int slot = ring_slot();
+            UPD_T(3)
+            float *st = stage + (wv * UPD2_D + slot) * 5 * UPD2_ROW;
             if (fill == UPD_ROUND) {                       // full round: every lane is a pixel
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
                     float *d = st + g * 64 + lane;
-                    d[0 * UPD_ROW] = (float)(ybase + (int)(R.code[g] >> UPD_XBITS));
-                    d[1 * UPD_ROW] = (float)(int)(R.code[g] & ((1u << UPD_XBITS) - 1u));
-                    d[2 * UPD_ROW] = R.vL[g];
-                    d[3 * UPD_ROW] = R.vA[g];
-                    d[4 * UPD_ROW] = R.vB[g];
+                    d[0 * UPD2_ROW] = (float)(ybase + (int)(R.code[g] >> UPD_XBITS));
+                    d[1 * UPD2_ROW] = (float)(int)(R.code[g] & ((1u << UPD_XBITS) - 1u));
+                    d[2 * UPD2_ROW] = R.vL[g];
+                    d[3 * UPD2_ROW] = R.vA[g];
+                    d[4 * UPD2_ROW] = R.vB[g];
                 }
             } else {                                       // last round of a part: zeros behind the end
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
                     const bool ok = R.code[g] != 0xFFFFFFFFu;
                     float *d = st + g * 64 + lane;
-                    d[0 * UPD_ROW] = ok ? (float)(ybase + (int)(R.code[g] >> UPD_XBITS)) : 0.0f;
-                    d[1 * UPD_ROW] = ok ? (float)(int)(R.code[g] & ((1u << UPD_XBITS) - 1u)) : 0.0f;
-                    d[2 * UPD_ROW] = ok ? R.vL[g] : 0.0f;
-                    d[3 * UPD_ROW] = ok ? R.vA[g] : 0.0f;
-                    d[4 * UPD_ROW] = ok ? R.vB[g] : 0.0f;
+                    d[0 * UPD2_ROW] = ok ? (float)(ybase + (int)(R.code[g] >> UPD_XBITS)) : 0.0f;
+                    d[1 * UPD2_ROW] = ok ? (float)(int)(R.code[g] & ((1u << UPD_XBITS) - 1u)) : 0.0f;
+                    d[2 * UPD2_ROW] = ok ? R.vL[g] : 0.0f;
+                    d[3 * UPD2_ROW] = ok ? R.vA[g] : 0.0f;
+                    d[4 * UPD2_ROW] = ok ? R.vB[g] : 0.0f;
                 }
             }
-            wave_lds_sync();
+            publish(slot, fill, seg);
             UPD_T(2)
-            if (lane < 5) {
-                // lane f walks feature row f: four 16-byte LDS reads per 16 dependent adds; the
-                // reads of the next 16 pixels are in flight while this step's adds run (the empty
-                // asm pins the prefetched registers so the compiler keeps the software pipeline)
-                const float4 *r4 = (const float4 *)(st + lane * UPD_ROW);
-                float4 q0 = r4[0], q1 = r4[1], q2 = r4[2], q3 = r4[3];
-                float4 n0, n1, n2, n3;
-#define UPD_ADD16(a0, a1, a2, a3)                                                          \
-    acc = acc + a0.x; acc = acc + a0.y; acc = acc + a0.z; acc = acc + a0.w;                \
-    acc = acc + a1.x; acc = acc + a1.y; acc = acc + a1.z; acc = acc + a1.w;                \
-    acc = acc + a2.x; acc = acc + a2.y; acc = acc + a2.z; acc = acc + a2.w;                \
-    acc = acc + a3.x; acc = acc + a3.y; acc = acc + a3.z; acc = acc + a3.w;
-#define UPD_PIN(a0, a1, a2, a3)                                                            \
-    asm volatile("" : "+v"(a0.x), "+v"(a0.y), "+v"(a0.z), "+v"(a0.w), "+v"(a1.x), "+v"(a1.y), "+v"(a1.z), "+v"(a1.w)); \
-    asm volatile("" : "+v"(a2.x), "+v"(a2.y), "+v"(a2.z), "+v"(a2.w), "+v"(a3.x), "+v"(a3.y), "+v"(a3.z), "+v"(a3.w));
-                for (int j = 0;;) {
-                    n0 = r4[(j >> 2) + 4]; n1 = r4[(j >> 2) + 5]; n2 = r4[(j >> 2) + 6]; n3 = r4[(j >> 2) + 7];
-                    __builtin_amdgcn_sched_barrier(0);
-                    UPD_ADD16(q0, q1, q2, q3)
-                    UPD_PIN(n0, n1, n2, n3)
-                    j += 16;
-                    if (j >= fill) break;
-                    q0 = r4[(j >> 2) + 4]; q1 = r4[(j >> 2) + 5]; q2 = r4[(j >> 2) + 6]; q3 = r4[(j >> 2) + 7];
-                    __builtin_amdgcn_sched_barrier(0);
-                    UPD_ADD16(n0, n1, n2, n3)
-                    UPD_PIN(q0, q1, q2, q3)
-                    j += 16;
-                    if (j >= fill) break;
-                }
-            }
-            n += (unsigned)fill;
             inflight -= 1;
-            wave_lds_sync();
-            UPD_T(3)
         };
 
         // straight-line schedule, no branch around the loads of an issue(): the compiler's vmcnt
@@ -775,32 +904,7 @@ void k_slic_update(const float *__restrict__ lab, uint32_t *__restrict__ cen, in
         UPD_T(4)
     }
     UPD_TFLUSH(qhead)
-    if (n == 0u) {
-        // the seed lost all its pixels: scikit-image's 0/0 gives it a NaN centre, a NaN distance never
-        // wins `distance > dist_center`, and the NaN -> index casts that size its window yield an empty
-        // range (x86-64), so it stays dead for the remaining sweeps (tests/golden/slic_starve_*.npz).
-        // Here: NaN centre + empty window (never a candidate of any tile, no pixel ever again); the
-        // status bit is informational.
-        if (lane == 0) {
-            atomicOr(status, SPA_ST_SLIC_EMPTY_SEGMENT);
-            const uint32_t qnan = 0x7fc00000u;
-            c[0] = qnan; c[1] = qnan; c[2] = qnan; c[3] = qnan; c[4] = qnan;
-            c[6] = 0u; c[7] = 0u; c[8] = 0u; c[9] = 0u;
-            c[10] = 0u;
-        }
-        continue;
-    }
-    float mean = acc / (float)n;      // segments[k, c] /= n_segment_elems[k]
-    float cy = __shfl(mean, 0), cx = __shfl(mean, 1);
-    float cl = __shfl(mean, 2), ca = __shfl(mean, 3), cbb = __shfl(mean, 4);
-    if (lane == 0) {
-        int ny0, ny1, nx0, nx1;
-        slic_window(cy, cx, s2y, s2x, H, W, ny0, ny1, nx0, nx1);
-        c[0] = __float_as_uint(cy); c[1] = __float_as_uint(cx);
-        c[2] = __float_as_uint(cl); c[3] = __float_as_uint(ca); c[4] = __float_as_uint(cbb);
-        c[6] = (uint32_t)ny0; c[7] = (uint32_t)ny1; c[8] = (uint32_t)nx0; c[9] = (uint32_t)nx1;
-        c[10] = n;
-    }
+    publish(ring_slot(), UPD2_MSG_END, seg);           // the chain wave closes the segment
   }
 }
 
@@ -856,11 +960,18 @@ extern "C" int spa_slic_core(spa_ctx *ctx, const float *lab, int32_t B, int32_t 
     if (rc != SPA_OK) return rc;
     int *upd_qhead = upd_order + upd_total;
     if (!ctx->upd_wg_per_cu) {         // per context = per device
-        SPA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->upd_wg_per_cu, (const void *)k_slic_update<8>, 256, 0));
+        SPA_HIP(hipFuncSetAttribute((const void *)k_slic_update2<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Upd2Lds<4>::bytes));
+        SPA_HIP(hipFuncSetAttribute((const void *)k_slic_update2<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Upd2Lds<8>::bytes));
+        SPA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->upd_wg_per_cu, (const void *)k_slic_update2<4>,
+                                                             (UPD2_NSEG + 1) * 64, Upd2Lds<4>::bytes));
+        SPA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&ctx->upd_wg_per_cu8, (const void *)k_slic_update2<8>,
+                                                             (UPD2_NSEG + 1) * 64, Upd2Lds<8>::bytes));
         if (ctx->upd_wg_per_cu < 1) ctx->upd_wg_per_cu = 1;
+        if (ctx->upd_wg_per_cu8 < 1) ctx->upd_wg_per_cu8 = 1;
     }
-    int upd_grid = ctx->upd_wg_per_cu * ctx->n_cu;
-    if (upd_grid > (upd_total + UPD_WAVES - 1) / UPD_WAVES) upd_grid = (upd_total + UPD_WAVES - 1) / UPD_WAVES;
+    const bool upd_narrow = PW <= 4 && 4 * pl.win_step_y + 24 < 2048;
+    int upd_grid = (upd_narrow ? ctx->upd_wg_per_cu : ctx->upd_wg_per_cu8) * ctx->n_cu;
+    if (upd_grid > (upd_total + UPD2_NSEG - 1) / UPD2_NSEG) upd_grid = (upd_total + UPD2_NSEG - 1) / UPD2_NSEG;
     upd_grid = (upd_grid + 7) & ~7;
     const unsigned mean_px = (unsigned)(((long long)H * W) / nC) ? (unsigned)(((long long)H * W) / nC) : 1u;
     hipLaunchKernelGGL(k_slic_init, dim3((nC + 127) / 128, B), dim3(128), 0, s, cen, nC,
@@ -882,12 +993,12 @@ extern "C" int spa_slic_core(spa_ctx *ctx, const float *lab, int32_t B, int32_t 
             SpaProfScope prof_(ctx, PROF_SLIC_UPDATE, s);
             hipLaunchKernelGGL(k_slic_order, dim3(8), dim3(1024), 0, s, cen, upd_total, upd_per_xcd, mean_px,
                                upd_order, upd_qhead);
-            if (PW <= 4 && 4 * pl.win_step_y + 24 < 2048)
-                hipLaunchKernelGGL(k_slic_update<4>, dim3(upd_grid), dim3(256), 0, s, lab, cen, nC, B,
+            if (upd_narrow)
+                hipLaunchKernelGGL(k_slic_update2<4>, dim3(upd_grid), dim3((UPD2_NSEG + 1) * 64), Upd2Lds<4>::bytes, s, lab, cen, nC, B,
                                    H, W, s2y, s2x, rowmask, HG, PW, fine, RW, PWF, upd_per_xcd,
                                    (const int *)upd_order, upd_qhead, ctx->d_status);
             else
-                hipLaunchKernelGGL(k_slic_update<8>, dim3(upd_grid), dim3(256), 0, s, lab, cen, nC, B,
+                hipLaunchKernelGGL(k_slic_update2<8>, dim3(upd_grid), dim3((UPD2_NSEG + 1) * 64), Upd2Lds<8>::bytes, s, lab, cen, nC, B,
                                    H, W, s2y, s2x, rowmask, HG, PW, fine, RW, PWF, upd_per_xcd,
                                    (const int *)upd_order, upd_qhead, ctx->d_status);
             SPA_LAUNCH_CHECK();

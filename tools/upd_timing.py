@@ -32,7 +32,7 @@ torch.cuda.synchronize()
 total = a.batch * lib_mod.make_plan(1024, 2048, a.n).n_centroids
 host = (ctypes.c_uint64 * 6)()
 lib_mod.check(lib_mod.lib().spa_debug_peek(eng._ctx, which, (total + 8) * 4 + 32, 48, host))
-lab = ['piece list', 'index expansion', 'issue+stage (incl. load waits)', 'chain', 'round loop rest', '-']
+lab = ['piece list', 'index expansion', 'stage rows (incl. load waits) + publish', 'wait for a ring slot (chain wave)', 'round loop rest', 'issue rounds (index reads, addresses, loads)']
 tot = sum(host)
 for name, v in zip(lab, host):
     print('%-32s %14d cycles  %5.1f %%' % (name, v, 100.0 * v / max(tot, 1)))
