@@ -150,24 +150,28 @@ __global__ __launch_bounds__(256) void k_fz_blur_x(const double *__restrict__ in
 // edge index -> endpoints; families in the reference's concatenation order
 struct FzGeom { int H, W; long long nR, nD, nDR, nE; };
 
-__device__ __forceinline__ void fz_endpoints(const FzGeom &g, long long idx, int &a, int &b)
+__device__ __forceinline__ void fz_endpoints(const FzGeom &g, long long idx64, int &a, int &b)
 {
-    const int W = g.W;
-    if (idx < g.nR) {
-        int y = (int)(idx / (W - 1)), x = (int)(idx % (W - 1)) + 1;
-        a = y * W + x; b = a - 1;
-    } else if (idx < g.nR + g.nD) {
-        long long i = idx - g.nR;
-        int y = (int)(i / W) + 1, x = (int)(i % W);
-        a = y * W + x; b = a - W;
-    } else if (idx < g.nR + g.nD + g.nDR) {
-        long long i = idx - g.nR - g.nD;
-        int y = (int)(i / (W - 1)) + 1, x = (int)(i % (W - 1)) + 1;
-        a = y * W + x; b = a - W - 1;
+    // nE < 2^32 (checked by the caller): 32-bit unsigned divisions, a fifth of the instructions of 64-bit ones —
+    // the passes decode an edge index per thread and chunk, and that was half of a chunk's time
+    const unsigned W = (unsigned)g.W, idx = (unsigned)idx64;
+    const unsigned nR = (unsigned)g.nR, nD = (unsigned)g.nD, nDR = (unsigned)g.nDR;
+    if (idx < nR) {
+        const unsigned y = idx / (W - 1), x = idx - y * (W - 1) + 1;
+        a = (int)(y * W + x); b = a - 1;
+    } else if (idx < nR + nD) {
+        const unsigned i = idx - nR;
+        const unsigned y = i / W + 1, x = i - (y - 1) * W;
+        a = (int)(y * W + x); b = a - (int)W;
+    } else if (idx < nR + nD + nDR) {
+        const unsigned i = idx - nR - nD;
+        const unsigned q = i / (W - 1);
+        const unsigned y = q + 1, x = i - q * (W - 1) + 1;
+        a = (int)(y * W + x); b = a - (int)W - 1;
     } else {
-        long long i = idx - g.nR - g.nD - g.nDR;
-        int y = (int)(i / (W - 1)), x = (int)(i % (W - 1)) + 1;
-        a = y * W + x; b = a + W - 1;
+        const unsigned i = idx - nR - nD - nDR;
+        const unsigned y = i / (W - 1), x = i - y * (W - 1) + 1;
+        a = (int)(y * W + x); b = a + (int)W - 1;
     }
 }
 
@@ -205,6 +209,7 @@ __global__ void k_fz_init(int *__restrict__ parent, int *__restrict__ size, doub
         for (int i = 0; i < 4; ++i) st[threadIdx.x].cnt[i] = 0;
         for (int i = 0; i < 3; ++i) st[threadIdx.x].pad[i] = 0;
     }
+    if (blockIdx.x == 0 && threadIdx.x < 16) ((int *)((char *)st + 64 * sizeof(FzImg)))[64 + threadIdx.x] = 0;    // pass diagnostics
 }
 
 __device__ __forceinline__ void fz_group_sync(unsigned *ctr, unsigned G, unsigned &epoch, uint32_t *status)
@@ -475,6 +480,385 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass(const unsigned long long
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// The pass with the state of the roots a window touches in LDS, one 1 024-thread workgroup per image.
+//  * LIVE edges only.  An edge whose endpoints already share a component can never merge anything (components only
+//    grow), and in the clean-up pass neither can an edge between two components of at least min_size pixels.  Most
+//    of the sorted list is dead by the time the pass reaches it (a 224x224 image: ~50 k merges out of 200 k edges;
+//    a smooth full-size image: 8.4 M edges for at most 2 M merges), so the workgroup first walks chunks of 1 024
+//    sorted positions, tests them against the current forest and compacts the live ones, in order, into the
+//    window — a window is 1 024 LIVE edges however many positions that takes.
+//  * A window touches at most 2 048 components; their roots are entered into an open-addressing table in LDS at
+//    the start of the window — key and size packed in one word, the internal cost, the reservation word — and
+//    every round of the window (find, merge test, reservations, propagation, decisions) runs on that table: a
+//    round costs workgroup barriers and LDS latencies instead of four or five dependent L2 round trips
+//    (~11 us -> ~2-3 us).  Merged components keep the cell of their surviving root (always one of the two that
+//    were entered); the cells go back to the global size / cost arrays when the window is done.
+//  * LPAR: images of <= 57 000 pixels keep the parent array in LDS as 16-bit indices as well (224x224, the
+//    reference's operating point); larger ones chase it through L2 (kept shallow by the flattening sweeps).
+// Decisions are those of k_fz_pass: same tests on the same values in the same order.
+// ---------------------------------------------------------------------------------------
+#define FZL_EMPTY 0xFFFFFFFFu
+#define FZ_CK 2
+// one wave's LDS and global accesses have completed and are visible to its own lanes
+__device__ __forceinline__ void fz_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <bool LPAR>
+__global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long long *__restrict__ keys,
+                                                            const unsigned *__restrict__ vals, FzGeom g,
+                                                            int *__restrict__ parent, int *__restrict__ size,
+                                                            double *__restrict__ cint, double scale, int min_size,
+                                                            int mode, const int *__restrict__ zcount,
+                                                            int flatten_every, int cells, int *__restrict__ diag)
+{
+    const int b = blockIdx.x;
+    const int npix = g.H * g.W;
+    const unsigned long long *K = keys + (long long)b * g.nE;
+    const unsigned *V = vals + (long long)b * g.nE;
+    int *P = parent + (long long)b * npix;
+    int *S = size + (long long)b * npix;
+    double *CI = cint + (long long)b * npix;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    extern __shared__ __attribute__((aligned(16))) unsigned char fzl[];
+    unsigned short *lpar = (unsigned short *)fzl;
+    double *lci = (double *)(fzl + (LPAR ? (((size_t)npix * 2 + 15) & ~(size_t)15) : 0));
+    unsigned *lkey = (unsigned *)(lci + cells);            // LPAR: (root << 16) | size; else root, size in lsz
+    unsigned *lres = lkey + cells;                         // reservation: (tag << 10) | position in the window
+    unsigned *lsz = lres + cells;                          // !LPAR only
+    unsigned *wbuf = LPAR ? lsz : lsz + cells;             // the window: sorted positions of its live edges
+    __shared__ int wave_cnt[2 * FZ_CK * (FZ_THREADS / 64)];
+    __shared__ unsigned cut_s[2];
+    __shared__ int tail_ea[64], tail_eb[64];
+    __shared__ double tail_cost[64];
+    auto getp = [&](int i) -> int {
+        if (LPAR) { const unsigned v = lpar[i]; return v == 0xFFFFu ? -1 : (int)v; }
+        return P[i];
+    };
+    auto setp = [&](int i, int v) { if (LPAR) lpar[i] = (unsigned short)v; else P[i] = v; };
+    auto find = [&](int i) { int p; while ((p = getp(i)) >= 0) i = p; return i; };
+    auto hash = [&](int root) -> int {
+        return (int)(((unsigned long long)(((unsigned)root * 2654435761u) >> 8) * (unsigned)cells) >> 24);
+    };
+    auto keyroot = [&](unsigned w) -> unsigned { return LPAR ? (w >> 16) : w; };
+    auto lookup = [&](int root) -> int {                   // the root is in the table
+        int h = hash(root);
+        for (;;) {
+            const unsigned w = __hip_atomic_load(lkey + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (w != FZL_EMPTY && keyroot(w) == (unsigned)root) return h;
+            h = h + 1 == cells ? 0 : h + 1;
+        }
+    };
+    auto enter = [&](int root) -> int {
+        int h = hash(root);
+        for (;;) {
+            unsigned w = __hip_atomic_load(lkey + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (w == FZL_EMPTY) {
+                w = atomicCAS(lkey + h, FZL_EMPTY, LPAR ? (unsigned)root << 16 : (unsigned)root);
+                if (w == FZL_EMPTY) {                       // this thread's cell: fetch the root's state
+                    if (LPAR) __hip_atomic_store(lkey + h, ((unsigned)root << 16) | (unsigned)S[root], __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else lsz[h] = (unsigned)S[root];
+                    if (mode == 0) lci[h] = CI[root];
+                    return h;
+                }
+            }
+            if (keyroot(w) == (unsigned)root) return h;
+            h = h + 1 == cells ? 0 : h + 1;
+        }
+    };
+    auto csize = [&](int c) -> unsigned { return LPAR ? (lkey[c] & 0xFFFFu) : lsz[c]; };
+    if (LPAR) {
+        for (int p = tid; p < npix; p += FZ_THREADS) { const int q = P[p]; lpar[p] = q < 0 ? (unsigned short)0xFFFFu : (unsigned short)q; }
+    }
+    __syncthreads();
+
+    int win = 0, chunks = 0, rounds = 0, trounds = 0;
+    long long tc[5] = {0, 0, 0, 0, 0};        // diagnostics: cycles of flatten | collect | window set-up | full rounds | tail
+    long long t_ = (long long)__builtin_readcyclecounter();
+#define FZ_T(i) { const long long n_ = (long long)__builtin_readcyclecounter(); tc[i] += n_ - t_; t_ = n_; }
+    long long cursor = zcount[b];                           // zero-cost edges: done up front
+    unsigned vpre[FZ_CK];
+    long long vpre_at = -1;
+    int step_par = 0;
+    if (tid == 0) { cut_s[0] = 0xFFFFFFFFu; cut_s[1] = 0xFFFFFFFFu; }
+    __syncthreads();
+    while (cursor < g.nE) {
+        if ((win++ % flatten_every) == 0) {
+            for (int p = tid; p < npix; p += FZ_THREADS) {
+                const int q = getp(p);
+                if (q >= 0) { const int r = find(q); if (r != q) setp(p, r); }
+            }
+            __syncthreads();
+        }
+        FZ_T(0)
+        // ---- collect the next (up to) 1 024 live edges, in sorted order
+        int nlive = 0;
+        while (nlive < FZ_THREADS && cursor < g.nE) {
+            // FZ_CK chunks of 1 024 sorted positions per step; the edge indices of the next step are already on
+            // their way (vpre, loaded for `vpre_at`), the step's counters alternate between two LDS sets so that
+            // a step needs two barriers
+            chunks += FZ_CK;
+            unsigned vcur[FZ_CK];
+#pragma unroll
+            for (int k = 0; k < FZ_CK; ++k) {
+                const long long e = cursor + (long long)k * FZ_THREADS + tid;
+                vcur[k] = vpre_at == cursor ? vpre[k] : (e < g.nE ? V[e] : 0u);
+            }
+            {
+                const long long nx = cursor + (long long)FZ_CK * FZ_THREADS;
+#pragma unroll
+                for (int k = 0; k < FZ_CK; ++k) {
+                    const long long e = nx + (long long)k * FZ_THREADS + tid;
+                    vpre[k] = e < g.nE ? V[e] : 0u;
+                }
+                vpre_at = nx;
+            }
+            bool live[FZ_CK];
+            unsigned long long m[FZ_CK];
+            int *wc = wave_cnt + (step_par ? FZ_CK * (FZ_THREADS / 64) : 0);
+            unsigned *cut = cut_s + step_par;
+#pragma unroll
+            for (int k = 0; k < FZ_CK; ++k) {
+                const long long e = cursor + (long long)k * FZ_THREADS + tid;
+                live[k] = false;
+                if (e < g.nE) {
+                    int a, c;
+                    fz_endpoints(g, (long long)vcur[k], a, c);
+                    const int ra_ = find(a), rb_ = find(c);
+                    live[k] = ra_ != rb_;
+                    if (live[k] && mode == 1) live[k] = S[ra_] < min_size || S[rb_] < min_size;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < FZ_CK; ++k) {
+                m[k] = __ballot(live[k]);
+                if (lane == 0) wc[k * (FZ_THREADS / 64) + wv] = __popcll(m[k]);
+            }
+            if (tid == 0) cut_s[step_par ^ 1] = 0xFFFFFFFFu;     // the next step's
+            __syncthreads();
+            int run = nlive;
+#pragma unroll
+            for (int k = 0; k < FZ_CK; ++k) {
+                int off = run;
+#pragma unroll
+                for (int i = 0; i < FZ_THREADS / 64; ++i) { const int c = wc[k * (FZ_THREADS / 64) + i]; if (i < wv) off += c; run += c; }
+                if (live[k]) {
+                    const long long e = cursor + (long long)k * FZ_THREADS + tid;
+                    const int pos = off + (int)spa_rank_in_mask(m[k]);
+                    if (pos < FZ_THREADS) wbuf[pos] = (unsigned)e;
+                    else atomicMin(cut, (unsigned)e);       // the first live edge that does not fit starts the next window
+                }
+            }
+            __syncthreads();
+            if (run > FZ_THREADS) { cursor = (long long)*cut; nlive = FZ_THREADS; }
+            else { nlive = run; cursor += (long long)FZ_CK * FZ_THREADS; }
+            step_par ^= 1;
+        }
+        FZ_T(1)
+        if (nlive == 0) break;
+        // ---- the window
+        for (int i = tid; i < cells; i += FZ_THREADS) { lkey[i] = FZL_EMPTY; lres[i] = 0xFFFFFFFFu; }
+        bool pend = tid < nlive;
+        int ea = 0, eb = 0;
+        double cost = 0.0;
+        if (pend) {
+            const unsigned e = wbuf[tid];
+            fz_endpoints(g, (long long)V[e], ea, eb);
+            cost = __longlong_as_double((long long)K[e]);
+        }
+        __syncthreads();
+        int ra = 0, rb = 0, ca = 0, cb = 0;
+        if (pend) {
+            ra = find(ea); rb = find(eb);
+            if (ra == rb) pend = false;                     // same component for ever
+            else { ca = enter(ra); cb = enter(rb); }
+        }
+        __syncthreads();
+        FZ_T(2)
+        for (unsigned round = 0;; ++round) {
+            ++rounds;
+            const unsigned tag = 0x3FFFFFu - round;
+            const unsigned mykey = (tag << 10) | (unsigned)tid;
+            bool want = false, resv = false;
+            // ---- phase 1: roots and the merge test against the current state; edges that want to merge reserve
+            // both components with their position in the window
+            if (pend) {
+                if (round) {
+                    // from the roots of the last round (one LDS read each while they still are roots)
+                    const int na = find(ra), nb = find(rb);
+                    if (na == nb) pend = false;
+                    else {
+                        if (na != ra) { ra = na; ca = lookup(ra); }
+                        if (nb != rb) { rb = nb; cb = lookup(rb); }
+                    }
+                }
+                if (pend) {
+                    const int wa = (int)csize(ca), wb = (int)csize(cb);
+                    if (mode == 0) {
+                        const float t0 = (float)(lci[ca] + scale / (double)wa);
+                        const float t1 = (float)(lci[cb] + scale / (double)wb);
+                        want = cost < (double)(t0 < t1 ? t0 : t1);
+                    } else {
+                        want = wa < min_size || wb < min_size;
+                    }
+                    if (want) { atomicMin(lres + ca, mykey); atomicMin(lres + cb, mykey); resv = true; }
+                }
+            }
+            __syncthreads();
+            // ---- propagation: an edge that does not want to merge NOW may want to once an earlier reserved edge
+            // has changed one of its components, so while it waits it holds its components too
+            for (;;) {
+                int changed = 0;
+                if (pend && !resv) {
+                    const unsigned ma = __hip_atomic_load(lres + ca, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const unsigned mb = __hip_atomic_load(lres + cb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const unsigned pa = (ma >> 10) == tag ? (ma & 1023u) : 0xFFFFFFFFu;
+                    const unsigned pb = (mb >> 10) == tag ? (mb & 1023u) : 0xFFFFFFFFu;
+                    if (pa < (unsigned)tid || pb < (unsigned)tid) {
+                        atomicMin(lres + ca, mykey);
+                        atomicMin(lres + cb, mykey);
+                        resv = true;
+                        changed = 1;
+                    }
+                }
+                if (__syncthreads_or(changed) == 0) break;
+            }
+            // ---- phase 2: decide every edge no earlier reservation can influence
+            int left = 0;
+            if (pend) {
+                const unsigned ma = lres[ca], mb = lres[cb];
+                const unsigned pa = (ma >> 10) == tag ? (ma & 1023u) : 0xFFFFFFFFu;
+                const unsigned pb = (mb >> 10) == tag ? (mb & 1023u) : 0xFFFFFFFFu;
+                if (pa < (unsigned)tid || pb < (unsigned)tid) {
+                    left = 1;                                // waits for an earlier edge
+                } else {
+                    if (want) {
+                        const bool a_lo = ra < rb;
+                        const int lo_r = a_lo ? ra : rb, hi_r = a_lo ? rb : ra, c_lo = a_lo ? ca : cb;
+                        const unsigned ns = csize(ca) + csize(cb);
+                        setp(hi_r, lo_r);
+                        if (LPAR) lkey[c_lo] = ((unsigned)lo_r << 16) | ns; else lsz[c_lo] = ns;
+                        if (mode == 0) lci[c_lo] = cost;
+                    }
+                    pend = false;
+                }
+            }
+            const int nleft = __syncthreads_count(left);
+            if (nleft == 0) break;
+            if (nleft <= 64) {
+                FZ_T(3)
+                // ---- the tail of the window on ONE wave.  What is left after the first rounds is a chain of
+                // dependent merges into a growing component: a few edges, one more decided per round.  The
+                // pending edges move (in order) to the lanes of wave 0, which plays the remaining rounds with
+                // wave-level synchronisation only — a round then costs LDS latencies, not workgroup barriers.
+                const unsigned long long pm = __ballot(pend);
+                if (lane == 0) wave_cnt[wv] = __popcll(pm);
+                __syncthreads();
+                if (pend) {
+                    int off = 0;
+#pragma unroll
+                    for (int i = 0; i < FZ_THREADS / 64; ++i) if (i < wv) off += wave_cnt[i];
+                    const int q = off + (int)spa_rank_in_mask(pm);
+                    tail_ea[q] = ra; tail_eb[q] = rb; tail_cost[q] = cost;       // the roots stand for the endpoints
+                }
+                __syncthreads();
+                if (wv == 0) {
+                    bool tp = lane < nleft;
+                    int tra = tp ? tail_ea[lane] : 0, trb = tp ? tail_eb[lane] : 0, tca = -1, tcb = -1;
+                    const double tcost = tp ? tail_cost[lane] : 0.0;
+                    for (unsigned tr = round + 1; __ballot(tp); ++tr) {
+                        ++trounds;
+                        const unsigned tag = 0x3FFFFFu - tr;
+                        const unsigned mykey = (tag << 10) | (unsigned)lane;
+                        bool want = false, resv = false;
+                        if (tp) {
+                            const int na = find(tra), nb = find(trb);
+                            if (na == nb) tp = false;
+                            else {
+                                if (na != tra || tca < 0) { tra = na; tca = lookup(tra); }
+                                if (nb != trb || tcb < 0) { trb = nb; tcb = lookup(trb); }
+                            }
+                        }
+                        if (tp) {
+                            const int wa = (int)csize(tca), wb = (int)csize(tcb);
+                            if (mode == 0) {
+                                const float t0 = (float)(lci[tca] + scale / (double)wa);
+                                const float t1 = (float)(lci[tcb] + scale / (double)wb);
+                                want = tcost < (double)(t0 < t1 ? t0 : t1);
+                            } else {
+                                want = wa < min_size || wb < min_size;
+                            }
+                            if (want) { atomicMin(lres + tca, mykey); atomicMin(lres + tcb, mykey); resv = true; }
+                        }
+                        fz_wave_sync();
+                        for (;;) {
+                            bool changed = false;
+                            if (tp && !resv) {
+                                const unsigned ma = __hip_atomic_load(lres + tca, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                const unsigned mb = __hip_atomic_load(lres + tcb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                const unsigned pa = (ma >> 10) == tag ? (ma & 1023u) : 0xFFFFFFFFu;
+                                const unsigned pb = (mb >> 10) == tag ? (mb & 1023u) : 0xFFFFFFFFu;
+                                if (pa < (unsigned)lane || pb < (unsigned)lane) {
+                                    atomicMin(lres + tca, mykey);
+                                    atomicMin(lres + tcb, mykey);
+                                    resv = true;
+                                    changed = true;
+                                }
+                            }
+                            fz_wave_sync();
+                            if (!__ballot(changed)) break;
+                        }
+                        if (tp) {
+                            const unsigned ma = __hip_atomic_load(lres + tca, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            const unsigned mb = __hip_atomic_load(lres + tcb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            const unsigned pa = (ma >> 10) == tag ? (ma & 1023u) : 0xFFFFFFFFu;
+                            const unsigned pb = (mb >> 10) == tag ? (mb & 1023u) : 0xFFFFFFFFu;
+                            if (!(pa < (unsigned)lane || pb < (unsigned)lane)) {
+                                if (want) {
+                                    const bool a_lo = tra < trb;
+                                    const int lo_r = a_lo ? tra : trb, hi_r = a_lo ? trb : tra, c_lo = a_lo ? tca : tcb;
+                                    const unsigned ns = csize(tca) + csize(tcb);
+                                    setp(hi_r, lo_r);
+                                    if (LPAR) lkey[c_lo] = ((unsigned)lo_r << 16) | ns; else lsz[c_lo] = ns;
+                                    if (mode == 0) lci[c_lo] = tcost;
+                                }
+                                tp = false;
+                            }
+                        }
+                        fz_wave_sync();
+                    }
+                }
+                __syncthreads();
+                FZ_T(4)
+                break;
+            }
+        }
+        FZ_T(3)
+        // the window's cells back to the global state (a cell whose root was merged away holds stale values for a
+        // pixel that is no root any more: never read again)
+        for (int i = tid; i < cells; i += FZ_THREADS) {
+            const unsigned w = lkey[i];
+            if (w != FZL_EMPTY) {
+                S[keyroot(w)] = (int)csize(i);
+                if (mode == 0) CI[keyroot(w)] = lci[i];
+            }
+        }
+        __syncthreads();
+    }
+    if (LPAR) {
+        __syncthreads();
+        for (int p = tid; p < npix; p += FZ_THREADS) { const unsigned v = lpar[p]; P[p] = v == 0xFFFFu ? -1 : (int)v; }
+    }
+    if (tid == 0 && diag) {
+        atomicAdd(diag + 0, win); atomicAdd(diag + 1, chunks); atomicAdd(diag + 2, rounds); atomicAdd(diag + 3, trounds);
+        for (int i = 0; i < 5; ++i) atomicAdd(diag + 4 + i, (int)(tc[i] >> 10));
+    }
+}
+
 // labels = rank of the root among the roots in raster order (np.unique(flat, return_inverse=True)[1])
 __global__ __launch_bounds__(256) void k_fz_count_roots(const int *__restrict__ parent, int npix,
                                                         int *__restrict__ blk, int nblk)
@@ -621,7 +1005,7 @@ static int fz_run(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t 
     if ((rc = spa_ws_reserve(ctx, WS_FZ_STATE, (size_t)B * npix * 16, (void **)&cint)) != SPA_OK) return rc;
     mark = (unsigned long long *)(cint + (size_t)B * npix);
     if ((rc = spa_ws_reserve(ctx, WS_BLK, (size_t)B * 2 * nblk * 4, (void **)&blk)) != SPA_OK) return rc;
-    if ((rc = spa_ws_reserve(ctx, WS_CONNMISC, 64 * sizeof(FzImg) + 64 * sizeof(int), (void **)&st)) != SPA_OK) return rc;
+    if ((rc = spa_ws_reserve(ctx, WS_CONNMISC, 64 * sizeof(FzImg) + 128 * sizeof(int), (void **)&st)) != SPA_OK) return rc;
     size_t tmp_bytes = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys0, keys1, vals0, vals1, (int)g.nE, 0, 64, s);
     tmp_bytes = (tmp_bytes + 255) & ~(size_t)255;
@@ -680,13 +1064,38 @@ static int fz_run(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t 
     const double k = scale / 255.0;
     const bool ldsp = G == 1 && npix <= 65535;
     const size_t lds_par = ldsp ? (size_t)npix * 2 : 0;
-    if (ldsp && !ctx->fz_attr_done) {
+    if (ldsp && !(ctx->fz_attr_done & 1)) {
         SPA_HIP(hipFuncSetAttribute((const void *)k_fz_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-        ctx->fz_attr_done = 1;
+        ctx->fz_attr_done |= 1;
     }
+    // the window's root table (+ the parent array of a small image) in LDS
+    const size_t lds_limit = 156 * 1024;
+    const size_t par_bytes = ((size_t)npix * 2 + 15) & ~(size_t)15;
+    const bool lpar = G == 1 && npix <= 65535 && par_bytes + 2560 * 16 + FZ_THREADS * 4 <= lds_limit;
+    long long cells = lpar ? (long long)((lds_limit - par_bytes - FZ_THREADS * 4) / 16) : 4096;
+    if (cells > 4096) cells = 4096;
+    // (larger images: the table kernel with the parent array in L2 measured 0.90 s per full-size image against 0.60 s of
+    // k_fz_pass — their passes are chains of hundreds of dependent rounds per window, and a round of the table kernel
+    // still chases the parent array through L2; SPA_FZ_TAB_LARGE=1 selects it for experiments)
+    const bool tab = G == 1 && !getenv("SPA_FZ_NO_LDS_STATE") && (lpar || getenv("SPA_FZ_TAB_LARGE"));
+    const size_t tab_lds = lpar ? par_bytes + (size_t)cells * 16 + FZ_THREADS * 4 : (size_t)cells * 20 + FZ_THREADS * 4;
+    if (tab && !(ctx->fz_attr_done & 2)) {
+        SPA_HIP(hipFuncSetAttribute((const void *)k_fz_pass_tab<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
+        SPA_HIP(hipFuncSetAttribute((const void *)k_fz_pass_tab<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
+        ctx->fz_attr_done |= 2;
+    }
+    int *diag = zcount + 64;              // windows, chunks, rounds of the batch (diagnostics, spa_debug_peek)
     for (int mode = 0; mode < 2; ++mode) {
         const unsigned r0 = mode ? 0x40000000u : 0u;
-        if (ldsp)
+        if (tab && lpar)
+            hipLaunchKernelGGL(k_fz_pass_tab<true>, dim3(B), dim3(FZ_THREADS), tab_lds, s,
+                               (const unsigned long long *)keys1, (const unsigned *)vals1, g, parent, size, cint, k,
+                               min_size, mode, (const int *)zcount, flatten_every, (int)cells, diag);
+        else if (tab)
+            hipLaunchKernelGGL(k_fz_pass_tab<false>, dim3(B), dim3(FZ_THREADS), tab_lds, s,
+                               (const unsigned long long *)keys1, (const unsigned *)vals1, g, parent, size, cint, k,
+                               min_size, mode, (const int *)zcount, flatten_every, (int)cells, diag);
+        else if (ldsp)
             hipLaunchKernelGGL(k_fz_pass<true>, dim3(G, B), dim3(FZ_THREADS), lds_par, s, (const unsigned long long *)keys1,
                                (const unsigned *)vals1, g, parent, size, cint, mark, st, k, min_size, mode, r0,
                                (const int *)zcount, flatten_every, ctx->d_status);
