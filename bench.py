@@ -80,7 +80,7 @@ def parse():
     p.add_argument('--integer_images', action='store_true',
                    help='integer-valued synthetic images (what decoded 8-bit PNGs are): k_rgb2lab takes its 256-entry sRGB table path')
     p.add_argument('--device_rng', action='store_true', help='anchor mode: draw the anchors on the device (spa_anchor_ranks_dev)')
-    p.add_argument('--miopen_conv', action='store_true', help='bf16: leave the heavy 3x3 layers to MIOpen (A/B against spa_conv3x3_bf16)')
+    p.add_argument('--miopen_conv', action='store_true', help='leave the stride-1 3x3 layers to MIOpen (A/B against spa_conv3x3_bf16 / spa_conv3x3_f32)')
     p.add_argument('--overlap', action='store_true',
                    help='run the superpixel branch on a second stream under the DRN forward (+5%% '
                         'images/s; per-kernel durations then include contention, so the roofline '
@@ -102,6 +102,9 @@ LIMITERS = {
     'k_kmeans': 'latency: numpy-ordered float64 sums (one serial chain per cluster and column, ~10 cycles per member row) and '
                 'two grid barriers per Lloyd iteration',
     'k_rgb2lab': 'DP VALU: binary64 exp/log emulation of the float32 power and cube root (bit-defined transcendental)',
+    'k_conv3x3_f32(all)': 'float32 MFMA pipe: 0.88-0.89 of the 157.3 TFLOP/s peak on the 256/512-channel layers (MIOpen\'s hand-written '
+                          'assembly reaches 0.88 on the same box, without the epilogue); the 64/128-channel layers (a sixth of the '
+                          'launches\' time) run at 0.65-0.78: a K step is short there and its barrier + load wait shows',
     'k_conv3x3_bf16(all)': 'LDS-read + MFMA loop on random operands tops out at 1 220-1 300 TFLOP/s with the global loads '
                            'compiled out (clock give-back under dense bf16 MFMA); pixel-tile loads cost the rest',
 }
@@ -283,7 +286,7 @@ def main():
         gpu=local, n_clusters=a.n_clusters, use_feature_maps=[7], pool_mode=a.pool_mode,
         mean_sampling='nearest', drn_sub_batch=a.drn_sub_batch or None, drn_streams=a.drn_streams,
         device_rng=a.device_rng)
-    drn._EPILOGUE['own_conv'] = not a.miopen_conv
+    drn._EPILOGUE['own_conv'] = drn._EPILOGUE['own_conv32'] = not a.miopen_conv
     model = drn.create_drn(a.arch, device='cuda:%d' % local, dtype=dtype)
     overlap = a.overlap or a.pool_mode == 'anchor'
     pipe = pipeline.LabelPipeline(args, model, overlap=overlap)
@@ -404,11 +407,14 @@ def main():
             tf = stem_flops(B, H, W) / (avg * 1e-3) / 1e12
             ent.update(bound='mfma', achieved=round(tf, 2), peak=FP32_MATRIX_PEAK_TF, unit='TFLOP/s',
                        frac=round(tf / FP32_MATRIX_PEAK_TF, 4), flops_per_launch=stem_flops(B, H, W))
-        elif name.startswith('k_conv3x3_bf16'):
-            # libspalign's bf16 implicit-GEMM convolutions (the heavy 3x3 layers): family entry, all launches
+        elif name.startswith('k_conv3x3_'):
+            # libspalign's implicit-GEMM convolutions (the stride-1 3x3 layers, bf16 or float32 matrix cores):
+            # family entry over all launches; FLOPs = 2 * MACs of exactly those layers (counted by drn.py)
+            pk = BF16_MATRIX_PEAK_TF if name.startswith('k_conv3x3_bf16') else FP32_MATRIX_PEAK_TF
             tf = conv_flops / a.steps / (ms / a.steps * 1e-3) / 1e12
-            ent.update(bound='mfma', achieved=round(tf, 1), peak=BF16_MATRIX_PEAK_TF, unit='TFLOP/s',
-                       frac=round(tf / BF16_MATRIX_PEAK_TF, 4), flops_per_step=conv_flops / a.steps)
+            ent.update(bound='mfma', achieved=round(tf, 1), peak=pk, unit='TFLOP/s',
+                       frac=round(tf / pk, 4), flops_per_step=conv_flops / a.steps,
+                       flops_per_launch=conv_flops / max(1, n))
         else:
             if name.startswith('k_bias_act'):
                 ab = bias_bytes / max(1, bias_launches)          # average over the 23 layers' shapes
@@ -458,9 +464,10 @@ def main():
         'host_to_host': h2h,
         'drn': {'bound': 'mfma', 'achieved': round(drn_tf, 2), 'peak': peak_tf, 'unit': 'TFLOP/s',
                 'frac': round(drn_tf / peak_tf, 4), 'ms_per_step': round(drn_ms, 3),
-                'note': ('bf16: the 256/512-channel dilated 3x3 layers (~80 % of the FLOPs) are libspalign\'s bf16 '
-                         'implicit-GEMM convolution with the bias/residual/ReLU epilogue fused (k_conv3x3_bf16, see '
-                         '`kernels`), the stem is its bf16-MFMA kernel; the light layers are PyTorch-ROCm (MIOpen)'
+                'note': ('the stride-1 3x3 layers from 64 channels up (~93 % of the FLOPs) are libspalign\'s implicit-GEMM '
+                         'convolution on the %s matrix cores with the bias/residual/ReLU epilogue fused (k_conv3x3_%s, see '
+                         '`kernels`), the stem is its own MFMA kernel; the stride-2 and 1x1 layers are PyTorch-ROCm (MIOpen)'
+                         % (('bf16', 'bf16') if a.dtype == 'bf16' else ('float32', 'f32'))
                          if conv_flops > 0 else
                          'the big convolutions are PyTorch-ROCm (MIOpen); libspalign adds the fused float32-MFMA stem '
                          'of DRN-D (normalise + layer0 + layer1, k_drn_stem_d) and the bias/residual/ReLU epilogues')},

@@ -115,6 +115,16 @@ int spa_conv3x3_bf16(spa_ctx *ctx, const void *x, int32_t B, int32_t H, int32_t 
                      const void *wt, int32_t Cout, const float *bias, const void *residual,
                      int32_t relu, int32_t dilation, void *y, void *stream);
 
+/* The same layers of the float32 network on the float32 matrix cores (v_mfma_f32_16x16x4_f32), epilogue fused: every
+ * stride-1 3x3 (dilated) convolution from 64 channels up (models/drn.py:230-285, the BasicBlocks' conv1 / conv2 and
+ * the plain layers 7-8).  x (B,H,W,Cin) float32 channels-last; wt (Cout,9,Cin) float32 = the (Cout,Cin,3,3) weight
+ * permuted to (n, ky, kx, c); bias (Cout) float32; residual (B,H,W,Cout) float32 or NULL; y (B,H,W,Cout) float32.
+ * Cin % 32 == 0, Cout % 64 == 0, dilation <= 4, every pointer 16-byte aligned.  Float32 products and sums (an fmaf
+ * chain per output): agrees with a float32 convolution to summation-order rounding. */
+int spa_conv3x3_f32(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                    const float *wt, int32_t Cout, const float *bias, const float *residual,
+                    int32_t relu, int32_t dilation, float *y, void *stream);
+
 /* ---- input stage ---------------------------------------------------------------------------
  * replaces the host resize of ResizeImageDataset.get_example (datasets/resize_image_dataset.py:31-34:
  * chainercv.transforms.resize(image, resize_shape, 3)) as Pillow computes it on an 8-bit image, channel by

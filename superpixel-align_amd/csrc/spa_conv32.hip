@@ -1,0 +1,213 @@
+// float32 implicit-GEMM 3x3 (dilated) convolution for the stride-1 3x3 layers of the float32 DRN (models/drn.py:
+// 230-285: every BasicBlock / plain layer from 64 channels up, ~90 % of the network's FLOPs) on the float32 matrix
+// cores (v_mfma_f32_16x16x4_f32: an exact fmaf chain per output, float32 in, float32 accumulate), with the bias left
+// by the folded BatchNorm, the residual add of a BasicBlock and the ReLU fused into the epilogue — the float32
+// network otherwise pays a separate read-modify-write pass over every convolution output (k_bias_act, 13 ms per 30
+// images) plus MIOpen's own zero-fill of the output its split-K kernels accumulate into (4.5 ms).
+//
+//   Y[b, y, x, n] = relu?( bias[n] + res[b, y, x, n] + sum_{tap, c} X[b, y + dy(tap)*d, x + dx(tap)*d, c] * Wt[n, tap, c] )
+//
+// Same mapping as the bf16 kernel (spa_conv.hip): GEMM with M = Cout (weights are the MFMA A operand), N = 256
+// consecutive pixels of one image row, K = 9 * Cin walked as (dy, 32 input channels, dx) — LDS rows are 128 bytes
+// = 32 float32 channels, 16-byte chunks XOR-swizzled by (row & 7) on the source address, ONE row segment of
+// 256 + 2*4 pixels per (dy, channel step) serving the three dx taps at a row offset, everything global -> LDS by
+// 16-byte global_load_lds, two buffers of each, 8 waves.  The float32 matrix pipe is 16x slower than the bf16 one
+// for the same bytes of operands, so a K step here is ~16 000 MFMA cycles per SIMD against one workgroup barrier
+// and 43 KB of loads: the loop is MFMA bound by a wide margin.
+#include "spa_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define C32_BN 256            // pixels per workgroup
+#define C32_BK 32             // K step (input channels of one tap): 128-byte LDS rows
+#define C32_THREADS 512
+#define C32_TILE_BYTES (256 * C32_BK * 4)          // one operand tile: 32 KB
+#define C32_HALO 4                                 // pixels either side of the 256-pixel segment: dilation <= 4
+#define C32_XSEG_BYTES ((256 + 2 * C32_HALO) * C32_BK * 4)   // 33 row blocks of 8 pixels
+
+template <int HAS_RES, int BM>
+__global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__restrict__ X, const float *__restrict__ Wt,
+                                                             const float *__restrict__ bias,
+                                                             const float *__restrict__ R, float *__restrict__ Y,
+                                                             const char *__restrict__ zero_line, int B, int H, int W,
+                                                             int Cin, int Cout, int dil, int relu, int xtiles,
+                                                             int ntiles, int total_tiles)
+{
+    extern __shared__ __attribute__((aligned(1024))) char lds32[];   // [2] weight tiles 32 KB | [2] pixel segments 33 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // XCD-aware tile order: consecutive workgroup ids go round-robin over the 8 XCDs; give every XCD a
+    // contiguous range of tiles (neighbouring rows of one image share two of their three input rows in L2)
+    const int nwg = total_tiles;
+    int id = blockIdx.x;
+    {
+        const int q = nwg / 8, rem = nwg % 8, xcd = id % 8, idx = id / 8;
+        id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+    }
+    // tile id -> (pixel tile, channel tile): the channel tiles of one pixel tile are adjacent
+    const int nt = id % ntiles, pt = id / ntiles;
+    const int xt = pt % xtiles, row_id = pt / xtiles;               // row_id = b * H + y
+    const int y = row_id % H;
+    const int x0 = xt * C32_BN, n0 = nt * BM;
+    constexpr int WN = BM == 64 ? 8 : 4;                 // waves along the pixels
+    constexpr int MI = BM == 256 ? 8 : 4;                // 16-channel MFMA tiles per wave
+    constexpr int NJ = 256 / WN / 16;                    // 16-pixel MFMA tiles per wave
+    constexpr int WROWS = MI * 16;                       // channels per wave
+
+    // K order: (dy, 32-channel step, dx).  The three dx taps of one (dy, k step) read the SAME input pixels
+    // shifted by the dilation: one row segment of 256 + 2*C32_HALO pixels is staged per (dy, k step) — a third
+    // of it with each of the previous group's three K steps — and the taps read it at a row offset.  A K step
+    // thus moves 32 KB of weights + 11 KB of pixels instead of 32 + 32.
+    char *wbuf = lds32, *xbuf = lds32 + 2 * C32_TILE_BYTES;
+    const int sub = lane >> 3, cs = lane & 7;
+    const int chunk_byte = (cs ^ sub) << 4;        // staged row = block * 8 + sub: (row & 7) = sub for every block
+    const char *wbase = (const char *)(Wt + (long long)n0 * 9 * Cin);
+    const char *xbase = (const char *)(X + (long long)row_id * W * Cin);      // input row y, pixel 0
+    const int ks = Cin / C32_BK;
+    const int nk = 9 * ks, ngroups = 3 * ks;
+
+    auto stage_w = [&](int t, int buf) {
+        const int g = t / 3, dxi = t - g * 3;
+        const int dyi = g / ks, kc = g - dyi * ks;
+        const char *wk = wbase + ((long long)(dyi * 3 + dxi) * Cin + (long long)kc * C32_BK) * 4 + chunk_byte;
+        char *dst = wbuf + buf * C32_TILE_BYTES;
+#pragma unroll
+        for (int r = 0; r < BM / 64; ++r) {
+            const int blk = r * 8 + wave;                       // 8 rows = 1 KB per instruction
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wk + (long long)(blk * 8 + sub) * 9 * Cin * 4),
+                                             (__attribute__((address_space(3))) void *)(dst + blk * 1024), 16, 0, 0);
+        }
+    };
+    // one third (11 of 33 row blocks) of the pixel segment of group g
+    auto stage_x = [&](int g, int third) {
+        const int dyi = g / ks, kc = g - dyi * ks;
+        const int yy = y + (dyi - 1) * dil;
+        const bool yok = yy >= 0 && yy < H;
+        const char *xk = xbase + ((long long)(dyi - 1) * dil * W) * Cin * 4 + (long long)kc * C32_BK * 4 + chunk_byte;
+        char *dst = xbuf + (g & 1) * C32_XSEG_BYTES;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int i = r * 8 + wave;
+            if (i >= 11) break;
+            const int blk = third * 11 + i;
+            const int px = x0 - C32_HALO + blk * 8 + sub;
+            const bool ok = yok && px >= 0 && px < W;
+            // a zero line for padding pixels (its 128 bytes are read at the chunk offset only)
+            const char *src = ok ? xk + (long long)px * Cin * 4 : zero_line + chunk_byte;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(dst + blk * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- accumulators: wave (wm, wn) owns channels [wm*WROWS, +WROWS) x pixels [wn*NJ*16, +NJ*16)
+    const int wm = wave / WN, wn = wave % WN;
+    f32x4 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fk = lane >> 4;                     // fragment row, 16-byte k chunk inside a 32-k step
+
+    stage_w(0, 0);
+    stage_x(0, 0); stage_x(0, 1); stage_x(0, 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        const int g = t / 3, dxi = t - g * 3;
+        // (the loads of the next K step go out in one burst: spreading them between the MFMA groups was
+        // measured 20 % slower — every global_load_lds re-programs M0 and breaks the MFMA stream)
+        if (t + 1 < nk) stage_w(t + 1, cur ^ 1);
+        if (g + 1 < ngroups) stage_x(g + 1, dxi);
+        const char *lw = wbuf + cur * C32_TILE_BYTES, *lx = xbuf + (g & 1) * C32_XSEG_BYTES;
+        const int xshift = C32_HALO + (dxi - 1) * dil + wn * (NJ * 16) + frow;      // segment row of fragment 0
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            // a lane's 16 bytes are channels (kk*16 + fk*4 .. +3) of its row: MFMA q of the four multiplies channel
+            // kk*16 + 4*kgroup + q of every k group (A and B use the same assignment, so the products pair up)
+            f32x4 wf[MI], pf[NJ];
+            const int chunk = kk * 4 + fk;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int row = wm * WROWS + i * 16 + frow;
+                wf[i] = *(const f32x4 *)(lw + row * 128 + ((chunk ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int row = xshift + j * 16;
+                pf[j] = *(const f32x4 *)(lx + row * 128 + ((chunk ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][q], pf[j][q], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds channels c..c+3 (c = tile channel base + (lane>>4)*4) of pixel (lane & 15)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int xx = x0 + wn * (NJ * 16) + j * 16 + (lane & 15);
+        if (xx >= W) continue;
+        const long long pix = (long long)row_id * W + xx;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int c = n0 + wm * WROWS + i * 16 + (lane >> 4) * 4;
+            const float4 bv = *(const float4 *)(bias + c);
+            float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y, v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
+            if (HAS_RES) {
+                const float4 rr = *(const float4 *)(R + pix * Cout + c);
+                v0 += rr.x; v1 += rr.y; v2 += rr.z; v3 += rr.w;
+            }
+            if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+            *(float4 *)(Y + pix * Cout + c) = make_float4(v0, v1, v2, v3);
+        }
+    }
+}
+
+// x (B,H,W,Cin) float32 channels-last, wt (Cout,9,Cin) float32 (tap = ky*3 + kx), bias (Cout) float32,
+// residual (B,H,W,Cout) float32 or NULL, y (B,H,W,Cout) float32.  stride 1, padding = dilation.
+extern "C" int spa_conv3x3_f32(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                               const float *wt, int32_t Cout, const float *bias, const float *residual,
+                               int32_t relu, int32_t dilation, float *y, void *stream)
+{
+    SPA_ARG(ctx && x && wt && bias && y && B > 0 && H > 0 && W > 0 && dilation >= 1);
+    SPA_ARG(Cin % C32_BK == 0 && Cout % 64 == 0 && dilation <= C32_HALO);
+    SPA_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)wt % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)bias % 16) == 0);
+    SPA_ARG(((uintptr_t)residual % 16) == 0);
+    hipStream_t s = spa_stream(stream);
+    char *zero;
+    int rc = spa_ws_reserve(ctx, WS_ZERO_LINE, 4096, (void **)&zero);
+    if (rc != SPA_OK) return rc;
+    if (!ctx->zero_line_ready) {
+        SPA_HIP(hipMemsetAsync(zero, 0, 4096, s));
+        ctx->zero_line_ready = 1;
+    }
+    const int bm = Cout % 256 == 0 ? 256 : (Cout % 128 == 0 ? 128 : 64);
+    const int xtiles = (W + C32_BN - 1) / C32_BN, ntiles = Cout / bm;
+    const long long total = (long long)B * H * xtiles * ntiles;
+    SPA_ARG(total < (1ll << 31));
+    const size_t lds = 2 * (size_t)C32_TILE_BYTES + 2 * (size_t)C32_XSEG_BYTES;
+    if (!ctx->conv32_attr_done) {
+#define C32_ATTR(R, M) SPA_HIP(hipFuncSetAttribute((const void *)k_conv3x3_f32<R, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
+        C32_ATTR(0, 256); C32_ATTR(1, 256); C32_ATTR(0, 128); C32_ATTR(1, 128); C32_ATTR(0, 64); C32_ATTR(1, 64);
+#undef C32_ATTR
+        ctx->conv32_attr_done = 1;
+    }
+    SpaProfScope prof_(ctx, PROF_DRN_CONV32, s);
+#define C32_LAUNCH(R, M)                                                                                                 \
+    hipLaunchKernelGGL((k_conv3x3_f32<R, M>), dim3((unsigned)total), dim3(C32_THREADS), lds, s, x, wt, bias, residual, y,  \
+                       (const char *)zero, B, H, W, Cin, Cout, dilation, relu, xtiles, ntiles, (int)total)
+    if (residual) {
+        if (bm == 256) C32_LAUNCH(1, 256); else if (bm == 128) C32_LAUNCH(1, 128); else C32_LAUNCH(1, 64);
+    } else {
+        if (bm == 256) C32_LAUNCH(0, 256); else if (bm == 128) C32_LAUNCH(0, 128); else C32_LAUNCH(0, 64);
+    }
+#undef C32_LAUNCH
+    SPA_LAUNCH_CHECK();
+    return SPA_OK;
+}

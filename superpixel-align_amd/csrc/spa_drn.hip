@@ -61,21 +61,37 @@ extern "C" int spa_drn_normalise(spa_ctx *ctx, const float *x, int32_t B, int32_
     return SPA_OK;
 }
 
-// float32: 4 channels (16 bytes) per thread
+// float32: 4 channels (16 bytes) per thread and step, four steps in flight.  The bias index is a 32-bit mask (channel
+// counts are powers of two in the DRN) or a 32-bit remainder: the 64-bit `i % c4` of the first version cost ~100
+// vector instructions per 16 bytes and made this "streaming" kernel instruction bound (0.60 of the HBM roof).
+template <bool POW2>
 __global__ __launch_bounds__(256) void k_bias_act_f32(float *__restrict__ y, const float *__restrict__ bias,
-                                                      const float *__restrict__ res, long long n4, int c4,
+                                                      const float *__restrict__ res, unsigned n4, unsigned c4,
                                                       int relu)
 {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-        float4 v = ((const float4 *)y)[i];
-        const float4 bb = ((const float4 *)bias)[i % c4];
+    const unsigned stride = gridDim.x * 256u;
+    const float4 *b4 = (const float4 *)bias;
+    auto bidx = [&](unsigned i) -> unsigned { return POW2 ? (i & (c4 - 1u)) : (i % c4); };
+    auto apply = [&](float4 v, const float4 bb, const float4 r) -> float4 {
         v.x = v.x + bb.x; v.y = v.y + bb.y; v.z = v.z + bb.z; v.w = v.w + bb.w;
-        if (res) {
-            const float4 r = ((const float4 *)res)[i];
-            v.x = v.x + r.x; v.y = v.y + r.y; v.z = v.z + r.z; v.w = v.w + r.w;
-        }
+        if (res) { v.x = v.x + r.x; v.y = v.y + r.y; v.z = v.z + r.z; v.w = v.w + r.w; }
         if (relu) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
-        ((float4 *)y)[i] = v;
+        return v;
+    };
+    unsigned i = blockIdx.x * 256u + threadIdx.x;
+    const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (; (unsigned long long)i + 3ull * stride < n4; i += 4u * stride) {
+        float4 v[4], r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = ((const float4 *)y)[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r[u] = res ? ((const float4 *)res)[i + u * stride] : zero;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ((float4 *)y)[i + u * stride] = apply(v[u], b4[bidx(i + u * stride)], r[u]);
+    }
+    for (; i < n4; i += stride) {
+        const float4 r = res ? ((const float4 *)res)[i] : zero;
+        ((float4 *)y)[i] = apply(((const float4 *)y)[i], b4[bidx(i)], r);
     }
 }
 
@@ -85,9 +101,10 @@ __global__ __launch_bounds__(256) void k_bias_act_bf16(unsigned short *__restric
                                                        const unsigned short *__restrict__ res, long long n8,
                                                        int c8, int relu)
 {
+    const bool pow2 = (c8 & (c8 - 1)) == 0;          // wave-uniform: no 64-bit remainder per vector
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
         uint4 raw = ((const uint4 *)y)[i];
-        const uint4 braw = ((const uint4 *)bias)[i % c8];
+        const uint4 braw = ((const uint4 *)bias)[pow2 ? ((unsigned)i & (unsigned)(c8 - 1)) : (unsigned)(i % c8)];
         uint4 rraw = make_uint4(0, 0, 0, 0);
         if (res) rraw = ((const uint4 *)res)[i];
         unsigned w[4] = {raw.x, raw.y, raw.z, raw.w}, bw[4] = {braw.x, braw.y, braw.z, braw.w};
@@ -122,10 +139,19 @@ extern "C" int spa_bias_act(spa_ctx *ctx, void *y, int32_t dtype, int64_t rows, 
     const long long n = rows * C / vec;
     long long gx = (n + 255) / 256;
     if (gx > 4096) gx = 4096;
-    if (dtype == 0)
-        hipLaunchKernelGGL(k_bias_act_f32, dim3((unsigned)gx), dim3(256), 0, spa_stream(stream), (float *)y,
-                           (const float *)bias, (const float *)residual, n, C / vec, relu);
-    else
+    if (dtype == 0) {
+        SPA_ARG(n < (1ll << 32) - 4ll * 4096 * 256);           // 32-bit vector indices (64 GB of float32)
+        const unsigned c4 = (unsigned)(C / vec);
+        long long g4 = (n + 1023) / 1024;                      // four vectors per thread and step
+        if (g4 > 8192) g4 = 8192;
+        if (g4 < 1) g4 = 1;
+        if ((c4 & (c4 - 1u)) == 0u)
+            hipLaunchKernelGGL(k_bias_act_f32<true>, dim3((unsigned)g4), dim3(256), 0, spa_stream(stream), (float *)y,
+                               (const float *)bias, (const float *)residual, (unsigned)n, c4, relu);
+        else
+            hipLaunchKernelGGL(k_bias_act_f32<false>, dim3((unsigned)g4), dim3(256), 0, spa_stream(stream), (float *)y,
+                               (const float *)bias, (const float *)residual, (unsigned)n, c4, relu);
+    } else
         hipLaunchKernelGGL(k_bias_act_bf16, dim3((unsigned)gx), dim3(256), 0, spa_stream(stream),
                            (unsigned short *)y, (const unsigned short *)bias,
                            (const unsigned short *)residual, n, C / vec, relu);

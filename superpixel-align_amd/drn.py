@@ -58,7 +58,7 @@ def _conv(cin, cout, k, stride=1, dilation=1):
 
 # set by DRN.prepare() on a GPU: libspalign's fused bias/residual/ReLU; 'bytes' accumulates the algorithmic
 # HBM bytes of its launches (read y + write y [+ read residual]) for bench.py's roofline entry
-_EPILOGUE = {'engine': None, 'bytes': 0, 'launches': 0, 'own_conv': True, 'conv_flops': 0.0}
+_EPILOGUE = {'engine': None, 'bytes': 0, 'launches': 0, 'own_conv': True, 'own_conv32': True, 'conv_flops': 0.0}
 
 
 def conv_bias_act(conv, bn, x, residual=None, relu=True):
@@ -77,6 +77,13 @@ def conv_bias_act(conv, bn, x, residual=None, relu=True):
             # in its epilogue (no separate elementwise pass, one rounding to bf16)
             _EPILOGUE['conv_flops'] += 2.0 * x.shape[0] * x.shape[2] * x.shape[3] * conv.out_channels * 9 * conv.in_channels
             return eng.conv3x3_bf16(x, packed[0], packed[1], residual, relu, conv.dilation[0])
+        packed32 = getattr(conv, '_spa_packed32', None)
+        if (packed32 is not None and x.dtype == torch.float32 and _EPILOGUE['own_conv32']
+                and x.is_contiguous(memory_format=torch.channels_last)
+                and (residual is None or residual.is_contiguous(memory_format=torch.channels_last))):
+            # the same layers of the float32 network: libspalign's float32-MFMA implicit GEMM, epilogue fused
+            _EPILOGUE['conv_flops'] += 2.0 * x.shape[0] * x.shape[2] * x.shape[3] * conv.out_channels * 9 * conv.in_channels
+            return eng.conv3x3_f32(x, packed32[0], packed32[1], residual, relu, conv.dilation[0])
         y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation)
         vec = 4 if y.dtype == torch.float32 else 8
         if (y.is_contiguous(memory_format=torch.channels_last) and y.shape[1] % vec == 0
@@ -218,6 +225,13 @@ class DRN(nn.Module):
             for m in self.modules():
                 if isinstance(m, nn.Conv2d):
                     m._spa_packed = None
+                    m._spa_packed32 = None
+                    # operands of spa_conv3x3_f32: the same layers of the float32 network (Cin % 32 == 0)
+                    if (dtype == torch.float32 and self.folded and m.kernel_size == (3, 3) and m.stride == (1, 1)
+                            and m.padding == m.dilation and m.dilation[0] == m.dilation[1] <= 4 and m.groups == 1
+                            and m.in_channels % 32 == 0 and m.out_channels % 64 == 0 and m.bias is not None):
+                        wt = m.weight.detach().permute(0, 2, 3, 1).reshape(m.out_channels, 9, m.in_channels)
+                        m._spa_packed32 = (wt.contiguous().float(), m.bias.detach().float().contiguous())
                     # operands of spa_conv3x3_bf16: 3x3, stride 1, padding = dilation, Cin % 64 == 0,
                     # Cout % 64 == 0 (layers 3-8 of the DRN: all 3x3 stride-1 layers from 64 channels up), bf16 network,
                     # BatchNorm folded

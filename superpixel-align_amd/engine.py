@@ -143,6 +143,22 @@ class Engine(object):
                                      _ptr(bias), _ptr(residual), 1 if relu else 0, self._s()))
         return y
 
+    def conv3x3_f32(self, x, wt, bias, residual=None, relu=True, dilation=1):
+        """relu?(conv3x3(x; stride 1, padding = dilation) + bias [+ residual]) on the float32 matrix cores.
+        x (B,Cin,H,W) float32 in channels-last storage, wt (Cout,9,Cin) float32, bias (Cout) float32."""
+        B, Cin, H, W = x.shape
+        Cout = wt.shape[0]
+        assert x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
+        assert wt.dtype == torch.float32 and wt.is_contiguous() and tuple(wt.shape) == (Cout, 9, Cin)
+        assert bias.dtype == torch.float32 and bias.is_contiguous()
+        y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        if residual is not None:
+            assert residual.dtype == torch.float32 and residual.shape == y.shape and \
+                residual.is_contiguous(memory_format=torch.channels_last)
+        check(self._lib.spa_conv3x3_f32(self._ctx, _ptr(x), B, H, W, Cin, _ptr(wt), Cout, _ptr(bias),
+                                        _ptr(residual), 1 if relu else 0, int(dilation), _ptr(y), self._s()))
+        return y
+
     def conv3x3_bf16(self, x, wt, bias, residual=None, relu=True, dilation=1):
         """relu?(conv3x3(x; stride 1, padding = dilation) + bias [+ residual]) on the bf16 matrix cores.
         x (B,Cin,H,W) bfloat16 in channels-last storage, wt (Cout,9,Cin) bfloat16, bias (Cout) float32."""

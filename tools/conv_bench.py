@@ -14,11 +14,52 @@ import torch.nn.functional as F
 ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=30)
 ap.add_argument('--quick', action='store_true')
+ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'], help='fp32: spa_conv3x3_f32 against MIOpen float32')
 a = ap.parse_args()
 engine = importlib.import_module('superpixel-align_amd.engine')
 eng = engine.Engine()
 torch.backends.cudnn.benchmark = True
 torch.manual_seed(0)
+
+
+def run32(B, Cin, Cout, H, W, dil, res, reps=3):
+    x = torch.randn((B, Cin, H, W), device='cuda').contiguous(memory_format=torch.channels_last)
+    w = torch.randn((Cout, Cin, 3, 3), device='cuda') * (2.0 / (9 * Cin)) ** 0.5
+    w_cl = w.contiguous(memory_format=torch.channels_last)
+    bias = torch.randn((Cout,), device='cuda')
+    r = torch.randn((B, Cout, H, W), device='cuda').contiguous(memory_format=torch.channels_last) if res else None
+    wt = w.permute(0, 2, 3, 1).reshape(Cout, 9, Cin).contiguous()
+    y = eng.conv3x3_f32(x, wt, bias, r, True, dil)
+    nb = min(B, 2)
+    ref = F.conv2d(x[:nb].double(), w.double(), bias.double(), 1, dil, dil)
+    if res:
+        ref = ref + r[:nb].double()
+    ref = torch.relu(ref)
+    err = (y[:nb].double() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    mi = torch.relu(F.conv2d(x[:nb], w_cl, bias, 1, dil, dil) + (r[:nb] if res else 0))
+    err_mi = (mi.double() - ref).abs().max().item()
+
+    def t(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    ms_own = t(lambda: eng.conv3x3_f32(x, wt, bias, r, True, dil))
+    ms_ref = t(lambda: F.conv2d(x, w_cl, None, 1, dil, dil))
+    ms_full = t(lambda: eng.bias_act_(F.conv2d(x, w_cl, None, 1, dil, dil), bias, r, True))
+    fl = 2.0 * B * H * W * Cout * 9 * Cin
+    print('fp32 B %d  %4d -> %4d  %dx%d dil %d res %d | err vs float64 %.2e of scale (MIOpen %.2e) | own %.3f ms %.1f TF (%.3f of 157.3) | '
+          'MIOpen conv only %.3f ms %.1f TF, + epilogue pass %.3f ms' % (B, Cin, Cout, H, W, dil, int(res), err / scale, err_mi / scale,
+                                                                       ms_own, fl / ms_own / 1e9, fl / ms_own / 1e9 / 157.3,
+                                                                       ms_ref, fl / ms_ref / 1e9, ms_full))
+    return err / scale
 
 
 def run(B, Cin, Cout, H, W, dil, res, reps=5):
@@ -58,7 +99,17 @@ def run(B, Cin, Cout, H, W, dil, res, reps=5):
     return err / scale
 
 
-if a.quick:
+if a.dtype == 'fp32':
+    run32(2, 64, 256, 16, 40, 1, False)
+    run32(1, 128, 256, 24, 300, 2, True)
+    run32(2, 32, 64, 20, 300, 3, True)
+    if not a.quick:
+        B = a.batch
+        for Cin, Cout, dil, res, H, W in [(64, 64, 1, True, 256, 512), (128, 128, 1, True, 128, 256), (128, 256, 2, False, 128, 256),
+                                          (256, 256, 2, True, 128, 256), (256, 512, 4, False, 128, 256), (512, 512, 4, True, 128, 256),
+                                          (512, 512, 2, False, 128, 256), (512, 512, 1, False, 128, 256)]:
+            run32(B, Cin, Cout, H, W, dil, res)
+elif a.quick:
     run(2, 64, 256, 16, 40, 1, False)
     run(1, 128, 256, 24, 300, 2, True)
 else:
