@@ -464,7 +464,7 @@ def main():
         'host_to_host': h2h,
         'drn': {'bound': 'mfma', 'achieved': round(drn_tf, 2), 'peak': peak_tf, 'unit': 'TFLOP/s',
                 'frac': round(drn_tf / peak_tf, 4), 'ms_per_step': round(drn_ms, 3),
-                'note': ('the stride-1 3x3 layers from 64 channels up (~93 % of the FLOPs) are libspalign\'s implicit-GEMM '
+                'note': ('the stride-1 3x3 layers from 64 channels up (~93 %% of the FLOPs) are libspalign\'s implicit-GEMM '
                          'convolution on the %s matrix cores with the bias/residual/ReLU epilogue fused (k_conv3x3_%s, see '
                          '`kernels`), the stem is its own MFMA kernel; the stride-2 and 1x1 layers are PyTorch-ROCm (MIOpen)'
                          % (('bf16', 'bf16') if a.dtype == 'bf16' else ('float32', 'f32'))

@@ -124,6 +124,11 @@ int spa_conv3x3_bf16(spa_ctx *ctx, const void *x, int32_t B, int32_t H, int32_t 
 int spa_conv3x3_f32(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W, int32_t Cin,
                     const float *wt, int32_t Cout, const float *bias, const float *residual,
                     int32_t relu, int32_t dilation, float *y, void *stream);
+/* the 1x1 stride-1 projection of a BasicBlock whose channel count changes (models/drn.py:195-203 `downsample`,
+ * layers 5 and 6): wt (Cout,Cin) float32; otherwise as spa_conv3x3_f32. */
+int spa_conv1x1_f32(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                    const float *wt, int32_t Cout, const float *bias, const float *residual,
+                    int32_t relu, float *y, void *stream);
 
 /* ---- input stage ---------------------------------------------------------------------------
  * replaces the host resize of ResizeImageDataset.get_example (datasets/resize_image_dataset.py:31-34:

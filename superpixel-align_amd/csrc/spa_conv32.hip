@@ -25,7 +25,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define C32_HALO 4                                 // pixels either side of the 256-pixel segment: dilation <= 4
 #define C32_XSEG_BYTES ((256 + 2 * C32_HALO) * C32_BK * 4)   // 33 row blocks of 8 pixels
 
-template <int HAS_RES, int BM>
+// TAPS = 9: 3x3 (dilated), padding = dilation; TAPS = 1: the 1x1 projection of a BasicBlock (models/drn.py:23-57,
+// stride 1): the same loop with the centre tap only (wt (Cout, 1, Cin), one K step per 32 channels)
+template <int HAS_RES, int BM, int TAPS>
 __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__restrict__ X, const float *__restrict__ Wt,
                                                              const float *__restrict__ bias,
                                                              const float *__restrict__ R, float *__restrict__ Y,
@@ -60,26 +62,26 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
     char *wbuf = lds32, *xbuf = lds32 + 2 * C32_TILE_BYTES;
     const int sub = lane >> 3, cs = lane & 7;
     const int chunk_byte = (cs ^ sub) << 4;        // staged row = block * 8 + sub: (row & 7) = sub for every block
-    const char *wbase = (const char *)(Wt + (long long)n0 * 9 * Cin);
+    const char *wbase = (const char *)(Wt + (long long)n0 * TAPS * Cin);
     const char *xbase = (const char *)(X + (long long)row_id * W * Cin);      // input row y, pixel 0
     const int ks = Cin / C32_BK;
-    const int nk = 9 * ks, ngroups = 3 * ks;
+    const int nk = TAPS * ks, ngroups = TAPS == 9 ? 3 * ks : ks;
 
     auto stage_w = [&](int t, int buf) {
-        const int g = t / 3, dxi = t - g * 3;
-        const int dyi = g / ks, kc = g - dyi * ks;
+        const int g = TAPS == 9 ? t / 3 : t, dxi = TAPS == 9 ? t - g * 3 : 0;
+        const int dyi = TAPS == 9 ? g / ks : 0, kc = g - dyi * ks;
         const char *wk = wbase + ((long long)(dyi * 3 + dxi) * Cin + (long long)kc * C32_BK) * 4 + chunk_byte;
         char *dst = wbuf + buf * C32_TILE_BYTES;
 #pragma unroll
         for (int r = 0; r < BM / 64; ++r) {
             const int blk = r * 8 + wave;                       // 8 rows = 1 KB per instruction
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wk + (long long)(blk * 8 + sub) * 9 * Cin * 4),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wk + (long long)(blk * 8 + sub) * TAPS * Cin * 4),
                                              (__attribute__((address_space(3))) void *)(dst + blk * 1024), 16, 0, 0);
         }
     };
     // one third (11 of 33 row blocks) of the pixel segment of group g
     auto stage_x = [&](int g, int third) {
-        const int dyi = g / ks, kc = g - dyi * ks;
+        const int dyi = TAPS == 9 ? g / ks : 1, kc = TAPS == 9 ? g - dyi * ks : g;
         const int yy = y + (dyi - 1) * dil;
         const bool yok = yy >= 0 && yy < H;
         const char *xk = xbase + ((long long)(dyi - 1) * dil * W) * Cin * 4 + (long long)kc * C32_BK * 4 + chunk_byte;
@@ -113,11 +115,14 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
     __syncthreads();
     for (int t = 0; t < nk; ++t) {
         const int cur = t & 1;
-        const int g = t / 3, dxi = t - g * 3;
+        const int g = TAPS == 9 ? t / 3 : t, dxi = TAPS == 9 ? t - g * 3 : 1;
         // (the loads of the next K step go out in one burst: spreading them between the MFMA groups was
         // measured 20 % slower — every global_load_lds re-programs M0 and breaks the MFMA stream)
         if (t + 1 < nk) stage_w(t + 1, cur ^ 1);
-        if (g + 1 < ngroups) stage_x(g + 1, dxi);
+        if (g + 1 < ngroups) {
+            if (TAPS == 9) stage_x(g + 1, dxi);
+            else { stage_x(g + 1, 0); stage_x(g + 1, 1); stage_x(g + 1, 2); }
+        }
         const char *lw = wbuf + cur * C32_TILE_BYTES, *lx = xbuf + (g & 1) * C32_XSEG_BYTES;
         const int xshift = C32_HALO + (dxi - 1) * dil + wn * (NJ * 16) + frow;      // segment row of fragment 0
 #pragma unroll
@@ -169,11 +174,12 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
     }
 }
 
-// x (B,H,W,Cin) float32 channels-last, wt (Cout,9,Cin) float32 (tap = ky*3 + kx), bias (Cout) float32,
+// x (B,H,W,Cin) float32 channels-last, wt (Cout,taps,Cin) float32 (tap = ky*3 + kx), bias (Cout) float32,
 // residual (B,H,W,Cout) float32 or NULL, y (B,H,W,Cout) float32.  stride 1, padding = dilation.
-extern "C" int spa_conv3x3_f32(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W, int32_t Cin,
-                               const float *wt, int32_t Cout, const float *bias, const float *residual,
-                               int32_t relu, int32_t dilation, float *y, void *stream)
+template <int TAPS>
+static int conv_f32_launch(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                           const float *wt, int32_t Cout, const float *bias, const float *residual,
+                           int32_t relu, int32_t dilation, float *y, void *stream)
 {
     SPA_ARG(ctx && x && wt && bias && y && B > 0 && H > 0 && W > 0 && dilation >= 1);
     SPA_ARG(Cin % C32_BK == 0 && Cout % 64 == 0 && dilation <= C32_HALO);
@@ -192,15 +198,16 @@ extern "C" int spa_conv3x3_f32(spa_ctx *ctx, const float *x, int32_t B, int32_t 
     const long long total = (long long)B * H * xtiles * ntiles;
     SPA_ARG(total < (1ll << 31));
     const size_t lds = 2 * (size_t)C32_TILE_BYTES + 2 * (size_t)C32_XSEG_BYTES;
-    if (!ctx->conv32_attr_done) {
-#define C32_ATTR(R, M) SPA_HIP(hipFuncSetAttribute((const void *)k_conv3x3_f32<R, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
+    const int bit = TAPS == 9 ? 1 : 2;
+    if (!(ctx->conv32_attr_done & bit)) {
+#define C32_ATTR(R, M) SPA_HIP(hipFuncSetAttribute((const void *)k_conv3x3_f32<R, M, TAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
         C32_ATTR(0, 256); C32_ATTR(1, 256); C32_ATTR(0, 128); C32_ATTR(1, 128); C32_ATTR(0, 64); C32_ATTR(1, 64);
 #undef C32_ATTR
-        ctx->conv32_attr_done = 1;
+        ctx->conv32_attr_done |= bit;
     }
     SpaProfScope prof_(ctx, PROF_DRN_CONV32, s);
 #define C32_LAUNCH(R, M)                                                                                                 \
-    hipLaunchKernelGGL((k_conv3x3_f32<R, M>), dim3((unsigned)total), dim3(C32_THREADS), lds, s, x, wt, bias, residual, y,  \
+    hipLaunchKernelGGL((k_conv3x3_f32<R, M, TAPS>), dim3((unsigned)total), dim3(C32_THREADS), lds, s, x, wt, bias, residual, y,  \
                        (const char *)zero, B, H, W, Cin, Cout, dilation, relu, xtiles, ntiles, (int)total)
     if (residual) {
         if (bm == 256) C32_LAUNCH(1, 256); else if (bm == 128) C32_LAUNCH(1, 128); else C32_LAUNCH(1, 64);
@@ -210,4 +217,19 @@ extern "C" int spa_conv3x3_f32(spa_ctx *ctx, const float *x, int32_t B, int32_t 
 #undef C32_LAUNCH
     SPA_LAUNCH_CHECK();
     return SPA_OK;
+}
+
+extern "C" int spa_conv3x3_f32(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                               const float *wt, int32_t Cout, const float *bias, const float *residual,
+                               int32_t relu, int32_t dilation, float *y, void *stream)
+{
+    return conv_f32_launch<9>(ctx, x, B, H, W, Cin, wt, Cout, bias, residual, relu, dilation, y, stream);
+}
+
+// the 1x1 stride-1 projection (wt (Cout, Cin)): same kernel, centre tap only
+extern "C" int spa_conv1x1_f32(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                               const float *wt, int32_t Cout, const float *bias, const float *residual,
+                               int32_t relu, float *y, void *stream)
+{
+    return conv_f32_launch<1>(ctx, x, B, H, W, Cin, wt, Cout, bias, residual, relu, 1, y, stream);
 }

@@ -82,7 +82,7 @@ def conv_bias_act(conv, bn, x, residual=None, relu=True):
                 and x.is_contiguous(memory_format=torch.channels_last)
                 and (residual is None or residual.is_contiguous(memory_format=torch.channels_last))):
             # the same layers of the float32 network: libspalign's float32-MFMA implicit GEMM, epilogue fused
-            _EPILOGUE['conv_flops'] += 2.0 * x.shape[0] * x.shape[2] * x.shape[3] * conv.out_channels * 9 * conv.in_channels
+            _EPILOGUE['conv_flops'] += 2.0 * x.shape[0] * x.shape[2] * x.shape[3] * conv.out_channels * packed32[0].shape[1] * conv.in_channels
             return eng.conv3x3_f32(x, packed32[0], packed32[1], residual, relu, conv.dilation[0])
         y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation)
         vec = 4 if y.dtype == torch.float32 else 8
@@ -231,6 +231,12 @@ class DRN(nn.Module):
                             and m.padding == m.dilation and m.dilation[0] == m.dilation[1] <= 4 and m.groups == 1
                             and m.in_channels % 32 == 0 and m.out_channels % 64 == 0 and m.bias is not None):
                         wt = m.weight.detach().permute(0, 2, 3, 1).reshape(m.out_channels, 9, m.in_channels)
+                        m._spa_packed32 = (wt.contiguous().float(), m.bias.detach().float().contiguous())
+                    # ... and the 1x1 stride-1 projections (layers 5 and 6): the same kernel, centre tap only
+                    if (dtype == torch.float32 and self.folded and m.kernel_size == (1, 1) and m.stride == (1, 1)
+                            and m.padding == (0, 0) and m.groups == 1 and m.in_channels % 32 == 0
+                            and m.out_channels % 64 == 0 and m.bias is not None):
+                        wt = m.weight.detach().reshape(m.out_channels, 1, m.in_channels)
                         m._spa_packed32 = (wt.contiguous().float(), m.bias.detach().float().contiguous())
                     # operands of spa_conv3x3_bf16: 3x3, stride 1, padding = dilation, Cin % 64 == 0,
                     # Cout % 64 == 0 (layers 3-8 of the DRN: all 3x3 stride-1 layers from 64 channels up), bf16 network,

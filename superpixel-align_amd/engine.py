@@ -149,14 +149,19 @@ class Engine(object):
         B, Cin, H, W = x.shape
         Cout = wt.shape[0]
         assert x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
-        assert wt.dtype == torch.float32 and wt.is_contiguous() and tuple(wt.shape) == (Cout, 9, Cin)
+        taps = wt.shape[1]
+        assert wt.dtype == torch.float32 and wt.is_contiguous() and tuple(wt.shape) == (Cout, taps, Cin) and taps in (1, 9)
         assert bias.dtype == torch.float32 and bias.is_contiguous()
         y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
         if residual is not None:
             assert residual.dtype == torch.float32 and residual.shape == y.shape and \
                 residual.is_contiguous(memory_format=torch.channels_last)
-        check(self._lib.spa_conv3x3_f32(self._ctx, _ptr(x), B, H, W, Cin, _ptr(wt), Cout, _ptr(bias),
-                                        _ptr(residual), 1 if relu else 0, int(dilation), _ptr(y), self._s()))
+        if taps == 1:           # (Cout, 1, Cin): the 1x1 projection
+            check(self._lib.spa_conv1x1_f32(self._ctx, _ptr(x), B, H, W, Cin, _ptr(wt), Cout, _ptr(bias),
+                                            _ptr(residual), 1 if relu else 0, _ptr(y), self._s()))
+        else:
+            check(self._lib.spa_conv3x3_f32(self._ctx, _ptr(x), B, H, W, Cin, _ptr(wt), Cout, _ptr(bias),
+                                            _ptr(residual), 1 if relu else 0, int(dilation), _ptr(y), self._s()))
         return y
 
     def conv3x3_bf16(self, x, wt, bias, residual=None, relu=True, dilation=1):

@@ -62,6 +62,34 @@ def run32(B, Cin, Cout, H, W, dil, res, reps=3):
     return err / scale
 
 
+def run32_1x1(B, Cin, Cout, H, W, reps=3):
+    x = torch.randn((B, Cin, H, W), device='cuda').contiguous(memory_format=torch.channels_last)
+    w = torch.randn((Cout, Cin, 1, 1), device='cuda') * (2.0 / Cin) ** 0.5
+    bias = torch.randn((Cout,), device='cuda')
+    wt = w.reshape(Cout, 1, Cin).contiguous()
+    y = eng.conv3x3_f32(x, wt, bias, None, False, 1)
+    nb = min(B, 2)
+    ref = F.conv2d(x[:nb].double(), w.double(), bias.double())
+    err = (y[:nb].double() - ref).abs().max().item() / ref.abs().max().item()
+    def t(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    ms_own = t(lambda: eng.conv3x3_f32(x, wt, bias, None, False, 1))
+    w_cl = w.contiguous(memory_format=torch.channels_last)
+    ms_full = t(lambda: eng.bias_act_(F.conv2d(x, w_cl), bias, None, False))
+    fl = 2.0 * B * H * W * Cout * Cin
+    print('fp32 1x1 B %d %4d -> %4d %dx%d | err vs float64 %.2e | own %.3f ms %.1f TF | MIOpen + epilogue pass %.3f ms'
+          % (B, Cin, Cout, H, W, err, ms_own, fl / ms_own / 1e9, ms_full))
+
+
 def run(B, Cin, Cout, H, W, dil, res, reps=5):
     x = torch.randn((B, Cin, H, W), device='cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     w = (torch.randn((Cout, Cin, 3, 3), device='cuda') * (2.0 / (9 * Cin)) ** 0.5).to(torch.bfloat16)
@@ -103,6 +131,10 @@ if a.dtype == 'fp32':
     run32(2, 64, 256, 16, 40, 1, False)
     run32(1, 128, 256, 24, 300, 2, True)
     run32(2, 32, 64, 20, 300, 3, True)
+    run32_1x1(2, 64, 128, 20, 300)
+    if not a.quick:
+        run32_1x1(a.batch, 128, 256, 128, 256)
+        run32_1x1(a.batch, 256, 512, 128, 256)
     if not a.quick:
         B = a.batch
         for Cin, Cout, dil, res, H, W in [(64, 64, 1, True, 256, 512), (128, 128, 1, True, 128, 256), (128, 256, 2, False, 128, 256),
