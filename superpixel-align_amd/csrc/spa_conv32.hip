@@ -15,6 +15,7 @@
 // for the same bytes of operands, so a K step here is ~16 000 MFMA cycles per SIMD against one workgroup barrier
 // and 43 KB of loads: the loop is MFMA bound by a wide margin.
 #include "spa_common.h"
+#include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -27,7 +28,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // TAPS = 9: 3x3 (dilated), padding = dilation; TAPS = 1: the 1x1 projection of a BasicBlock (models/drn.py:23-57,
 // stride 1): the same loop with the centre tap only (wt (Cout, 1, Cin), one K step per 32 channels)
-template <int HAS_RES, int BM, int TAPS>
+// BN = pixels per workgroup: 256, or 128 for the narrow channel tiles (BM 64 / 128): their K steps are short (a
+// quarter / half of the MFMA work per barrier), and with half the pixel segment two or three workgroups fit a CU
+// (67 / 51 KB of LDS), so one workgroup's barrier and load wait hide under another's matrix work
+template <int HAS_RES, int BM, int TAPS, int BN>
 __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__restrict__ X, const float *__restrict__ Wt,
                                                              const float *__restrict__ bias,
                                                              const float *__restrict__ R, float *__restrict__ Y,
@@ -49,17 +53,20 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
     const int nt = id % ntiles, pt = id / ntiles;
     const int xt = pt % xtiles, row_id = pt / xtiles;               // row_id = b * H + y
     const int y = row_id % H;
-    const int x0 = xt * C32_BN, n0 = nt * BM;
+    const int x0 = xt * BN, n0 = nt * BM;
     constexpr int WN = BM == 64 ? 8 : 4;                 // waves along the pixels
     constexpr int MI = BM == 256 ? 8 : 4;                // 16-channel MFMA tiles per wave
-    constexpr int NJ = 256 / WN / 16;                    // 16-pixel MFMA tiles per wave
+    constexpr int NJ = BN / WN / 16;                     // 16-pixel MFMA tiles per wave
+    constexpr int XBLK = (BN + 2 * C32_HALO) / 8;        // 8-pixel row blocks of the pixel segment: 33 or 17
+    constexpr int XTHIRD = (XBLK + 2) / 3;               // staged per K step: 11 or 6
+    constexpr int XSEG = XBLK * 8 * 128;                 // bytes
     constexpr int WROWS = MI * 16;                       // channels per wave
 
     // K order: (dy, 32-channel step, dx).  The three dx taps of one (dy, k step) read the SAME input pixels
     // shifted by the dilation: one row segment of 256 + 2*C32_HALO pixels is staged per (dy, k step) — a third
     // of it with each of the previous group's three K steps — and the taps read it at a row offset.  A K step
     // thus moves 32 KB of weights + 11 KB of pixels instead of 32 + 32.
-    char *wbuf = lds32, *xbuf = lds32 + 2 * C32_TILE_BYTES;
+    char *wbuf = lds32, *xbuf = lds32 + 2 * (BM * 128);
     const int sub = lane >> 3, cs = lane & 7;
     const int chunk_byte = (cs ^ sub) << 4;        // staged row = block * 8 + sub: (row & 7) = sub for every block
     const char *wbase = (const char *)(Wt + (long long)n0 * TAPS * Cin);
@@ -71,7 +78,7 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
         const int g = TAPS == 9 ? t / 3 : t, dxi = TAPS == 9 ? t - g * 3 : 0;
         const int dyi = TAPS == 9 ? g / ks : 0, kc = g - dyi * ks;
         const char *wk = wbase + ((long long)(dyi * 3 + dxi) * Cin + (long long)kc * C32_BK) * 4 + chunk_byte;
-        char *dst = wbuf + buf * C32_TILE_BYTES;
+        char *dst = wbuf + buf * (BM * 128);
 #pragma unroll
         for (int r = 0; r < BM / 64; ++r) {
             const int blk = r * 8 + wave;                       // 8 rows = 1 KB per instruction
@@ -85,12 +92,13 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
         const int yy = y + (dyi - 1) * dil;
         const bool yok = yy >= 0 && yy < H;
         const char *xk = xbase + ((long long)(dyi - 1) * dil * W) * Cin * 4 + (long long)kc * C32_BK * 4 + chunk_byte;
-        char *dst = xbuf + (g & 1) * C32_XSEG_BYTES;
+        char *dst = xbuf + (g & 1) * XSEG;
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < (XTHIRD + 7) / 8; ++r) {
             const int i = r * 8 + wave;
-            if (i >= 11) break;
-            const int blk = third * 11 + i;
+            if (i >= XTHIRD) break;
+            const int blk = third * XTHIRD + i;
+            if (blk >= XBLK) break;
             const int px = x0 - C32_HALO + blk * 8 + sub;
             const bool ok = yok && px >= 0 && px < W;
             // a zero line for padding pixels (its 128 bytes are read at the chunk offset only)
@@ -123,7 +131,7 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
             if (TAPS == 9) stage_x(g + 1, dxi);
             else { stage_x(g + 1, 0); stage_x(g + 1, 1); stage_x(g + 1, 2); }
         }
-        const char *lw = wbuf + cur * C32_TILE_BYTES, *lx = xbuf + (g & 1) * C32_XSEG_BYTES;
+        const char *lw = wbuf + cur * (BM * 128), *lx = xbuf + (g & 1) * XSEG;
         const int xshift = C32_HALO + (dxi - 1) * dil + wn * (NJ * 16) + frow;      // segment row of fragment 0
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -194,26 +202,30 @@ static int conv_f32_launch(spa_ctx *ctx, const float *x, int32_t B, int32_t H, i
         ctx->zero_line_ready = 1;
     }
     const int bm = Cout % 256 == 0 ? 256 : (Cout % 128 == 0 ? 128 : 64);
-    const int xtiles = (W + C32_BN - 1) / C32_BN, ntiles = Cout / bm;
+    const int bn = bm == 256 || getenv("SPA_CONV32_BN256") ? 256 : 128;
+    const int xtiles = (W + bn - 1) / bn, ntiles = Cout / bm;
     const long long total = (long long)B * H * xtiles * ntiles;
     SPA_ARG(total < (1ll << 31));
-    const size_t lds = 2 * (size_t)C32_TILE_BYTES + 2 * (size_t)C32_XSEG_BYTES;
+    const size_t lds = 2 * (size_t)bm * 128 + 2 * (size_t)(bn + 2 * C32_HALO) * 128;
     const int bit = TAPS == 9 ? 1 : 2;
     if (!(ctx->conv32_attr_done & bit)) {
-#define C32_ATTR(R, M) SPA_HIP(hipFuncSetAttribute((const void *)k_conv3x3_f32<R, M, TAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
-        C32_ATTR(0, 256); C32_ATTR(1, 256); C32_ATTR(0, 128); C32_ATTR(1, 128); C32_ATTR(0, 64); C32_ATTR(1, 64);
+#define C32_ATTR(R, M, N) SPA_HIP(hipFuncSetAttribute((const void *)k_conv3x3_f32<R, M, TAPS, N>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                      2 * M * 128 + 2 * (N + 2 * C32_HALO) * 128))
+        C32_ATTR(0, 256, 256); C32_ATTR(1, 256, 256); C32_ATTR(0, 128, 256); C32_ATTR(1, 128, 256); C32_ATTR(0, 64, 256); C32_ATTR(1, 64, 256);
+        C32_ATTR(0, 128, 128); C32_ATTR(1, 128, 128); C32_ATTR(0, 64, 128); C32_ATTR(1, 64, 128);
 #undef C32_ATTR
         ctx->conv32_attr_done |= bit;
     }
     SpaProfScope prof_(ctx, PROF_DRN_CONV32, s);
-#define C32_LAUNCH(R, M)                                                                                                 \
-    hipLaunchKernelGGL((k_conv3x3_f32<R, M, TAPS>), dim3((unsigned)total), dim3(C32_THREADS), lds, s, x, wt, bias, residual, y,  \
+#define C32_LAUNCH(R, M, N)                                                                                                 \
+    hipLaunchKernelGGL((k_conv3x3_f32<R, M, TAPS, N>), dim3((unsigned)total), dim3(C32_THREADS), lds, s, x, wt, bias, residual, y,  \
                        (const char *)zero, B, H, W, Cin, Cout, dilation, relu, xtiles, ntiles, (int)total)
-    if (residual) {
-        if (bm == 256) C32_LAUNCH(1, 256); else if (bm == 128) C32_LAUNCH(1, 128); else C32_LAUNCH(1, 64);
-    } else {
-        if (bm == 256) C32_LAUNCH(0, 256); else if (bm == 128) C32_LAUNCH(0, 128); else C32_LAUNCH(0, 64);
-    }
+#define C32_PICK(R)                                                                     \
+    if (bm == 256) C32_LAUNCH(R, 256, 256);                                             \
+    else if (bm == 128) { if (bn == 256) C32_LAUNCH(R, 128, 256); else C32_LAUNCH(R, 128, 128); } \
+    else { if (bn == 256) C32_LAUNCH(R, 64, 256); else C32_LAUNCH(R, 64, 128); }
+    if (residual) { C32_PICK(1) } else { C32_PICK(0) }
+#undef C32_PICK
 #undef C32_LAUNCH
     SPA_LAUNCH_CHECK();
     return SPA_OK;
