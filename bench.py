@@ -81,6 +81,7 @@ def parse():
                    help='integer-valued synthetic images (what decoded 8-bit PNGs are): k_rgb2lab takes its 256-entry sRGB table path')
     p.add_argument('--device_rng', action='store_true', help='anchor mode: draw the anchors on the device (spa_anchor_ranks_dev)')
     p.add_argument('--miopen_conv', action='store_true', help='leave the stride-1 3x3 layers to MIOpen (A/B against spa_conv3x3_bf16 / spa_conv3x3_f32)')
+    p.add_argument('--no_winograd', action='store_true', help='float32: direct convolution (spa_conv3x3_f32) on the 256/512-channel layers too')
     p.add_argument('--overlap', action='store_true',
                    help='run the superpixel branch on a second stream under the DRN forward (+5%% '
                         'images/s; per-kernel durations then include contention, so the roofline '
@@ -102,6 +103,9 @@ LIMITERS = {
     'k_kmeans': 'latency: numpy-ordered float64 sums (one serial chain per cluster and column, ~10 cycles per member row) and '
                 'two grid barriers per Lloyd iteration',
     'k_rgb2lab': 'DP VALU: binary64 exp/log emulation of the float32 power and cube root (bit-defined transcendental)',
+    'conv3x3_winograd_f32(all)': 'the 16 GEMMs run at ~0.82 of the float32 matrix peak (K = Cin is 16 K steps: prologue and the 4x larger '
+                                 'output tile weigh more than in the 144-step direct kernel); the two transforms stream V and M (4x the '
+                                 'activations each) through HBM: ~5 of the 21 ms of a 512 -> 512 layer',
     'k_conv3x3_f32(all)': 'float32 MFMA pipe: 0.88-0.89 of the 157.3 TFLOP/s peak on the 256/512-channel layers (MIOpen\'s hand-written '
                           'assembly reaches 0.88 on the same box, without the epilogue); the 64/128-channel layers (a sixth of the '
                           'launches\' time) run at 0.65-0.78: a K step is short there and its barrier + load wait shows',
@@ -287,6 +291,7 @@ def main():
         mean_sampling='nearest', drn_sub_batch=a.drn_sub_batch or None, drn_streams=a.drn_streams,
         device_rng=a.device_rng)
     drn._EPILOGUE['own_conv'] = drn._EPILOGUE['own_conv32'] = not a.miopen_conv
+    drn._EPILOGUE['winograd'] = not a.no_winograd
     model = drn.create_drn(a.arch, device='cuda:%d' % local, dtype=dtype)
     overlap = a.overlap or a.pool_mode == 'anchor'
     pipe = pipeline.LabelPipeline(args, model, overlap=overlap)
@@ -326,6 +331,8 @@ def main():
     drn._EPILOGUE['bytes'] = 0
     drn._EPILOGUE['launches'] = 0
     drn._EPILOGUE['conv_flops'] = 0.0
+    drn._EPILOGUE['wino_flops'] = 0.0
+    drn._EPILOGUE['wino_direct_flops'] = 0.0
 
     dist.barrier()
     torch.cuda.synchronize()
@@ -350,6 +357,7 @@ def main():
     eng.raise_on_status()
     bias_bytes, bias_launches = drn._EPILOGUE['bytes'], drn._EPILOGUE['launches']
     conv_flops = drn._EPILOGUE['conv_flops']
+    wino_flops, wino_direct = drn._EPILOGUE['wino_flops'], drn._EPILOGUE['wino_direct_flops']
 
     for e in evs:
         pipe._ev = e
@@ -407,6 +415,15 @@ def main():
             tf = stem_flops(B, H, W) / (avg * 1e-3) / 1e12
             ent.update(bound='mfma', achieved=round(tf, 2), peak=FP32_MATRIX_PEAK_TF, unit='TFLOP/s',
                        frac=round(tf / FP32_MATRIX_PEAK_TF, 4), flops_per_launch=stem_flops(B, H, W))
+        elif name.startswith('conv3x3_winograd'):
+            # Winograd F(2x2,3x3) layers (input transform + 16 float32-MFMA GEMMs + output transform per launch):
+            # `achieved` = the matrix FLOPs actually executed (16/36 of the direct form's) over the whole launch,
+            # transforms included; `effective` = the direct form's FLOPs over the same time
+            tf = wino_flops / a.steps / (ms / a.steps * 1e-3) / 1e12
+            ent.update(bound='mfma', achieved=round(tf, 1), peak=FP32_MATRIX_PEAK_TF, unit='TFLOP/s',
+                       frac=round(tf / FP32_MATRIX_PEAK_TF, 4), flops_per_step=wino_flops / a.steps,
+                       flops_per_launch=wino_flops / max(1, n),
+                       effective_TFLOPs_direct_equivalent=round(wino_direct / a.steps / (ms / a.steps * 1e-3) / 1e12, 1))
         elif name.startswith('k_conv3x3_'):
             # libspalign's implicit-GEMM convolutions (the stride-1 3x3 layers, bf16 or float32 matrix cores):
             # family entry over all launches; FLOPs = 2 * MACs of exactly those layers (counted by drn.py)
@@ -443,7 +460,8 @@ def main():
                 'limiter': e.get('limiter'),
                 'selection': 'largest ms_per_step among all hand-written kernel families of libspalign (see `kernels`)'}
     drn_ms = stage['time_feature_maps'] / a.steps
-    flops = drn.flops_per_image(a.arch, H, W) * B
+    flops_direct = drn.flops_per_image(a.arch, H, W) * B
+    flops = flops_direct - (wino_direct - wino_flops) / a.steps        # executed: the Winograd layers multiply 16/36 as much
     drn_tf = flops / (drn_ms * 1e-3) / 1e12
     tp = allrec[:, 4].sum(); fp = allrec[:, 2].sum(); fn = allrec[:, 3].sum()
     out = {
@@ -464,6 +482,7 @@ def main():
         'host_to_host': h2h,
         'drn': {'bound': 'mfma', 'achieved': round(drn_tf, 2), 'peak': peak_tf, 'unit': 'TFLOP/s',
                 'frac': round(drn_tf / peak_tf, 4), 'ms_per_step': round(drn_ms, 3),
+                'effective_TFLOPs_direct_equivalent': round(flops_direct / (drn_ms * 1e-3) / 1e12, 2),
                 'note': ('the stride-1 3x3 layers from 64 channels up (~93 %% of the FLOPs) are libspalign\'s implicit-GEMM '
                          'convolution on the %s matrix cores with the bias/residual/ReLU epilogue fused (k_conv3x3_%s, see '
                          '`kernels`), the stem is its own MFMA kernel; the stride-2 and 1x1 layers are PyTorch-ROCm (MIOpen)'

@@ -130,6 +130,17 @@ int spa_conv1x1_f32(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t 
                     const float *wt, int32_t Cout, const float *bias, const float *residual,
                     int32_t relu, float *y, void *stream);
 
+/* The heaviest of those layers by the minimal filtering algorithm F(2x2,3x3) (Winograd): 2.25x fewer float32
+ * multiplications than the direct form, float32 transforms and products — as close to a float64 convolution as
+ * the direct float32 one (spa_wino.hip).  u (16,Cout,Cin) float32 = (G g G^T) of every (output, input) channel
+ * pair, position-major; v_scratch / m_scratch: 16 * spa_wino_tiles(B,H,W,dilation) * Cin resp. Cout floats owned by
+ * the caller; the rest as spa_conv3x3_f32 (any dilation >= 1). */
+int64_t spa_wino_tiles(int32_t B, int32_t H, int32_t W, int32_t dilation);
+int spa_conv3x3_wino_f32(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                         const float *u, int32_t Cout, const float *bias, const float *residual,
+                         int32_t relu, int32_t dilation, float *v_scratch, float *m_scratch, float *y,
+                         void *stream);
+
 /* ---- input stage ---------------------------------------------------------------------------
  * replaces the host resize of ResizeImageDataset.get_example (datasets/resize_image_dataset.py:31-34:
  * chainercv.transforms.resize(image, resize_shape, 3)) as Pillow computes it on an 8-bit image, channel by

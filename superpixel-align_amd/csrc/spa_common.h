@@ -92,7 +92,7 @@ enum {
 enum {
     PROF_RGB2LAB = 0, PROF_SLIC_ASSIGN, PROF_SLIC_UPDATE, PROF_CONNECT, PROF_STATS,
     PROF_CELL_WEIGHTS, PROF_POOL_MEAN, PROF_POOL_ANCHOR, PROF_KMEANS, PROF_PAINT,
-    PROF_DRN_STEM, PROF_DRN_BIAS_ACT, PROF_DRN_CONV, PROF_DRN_CONV32, PROF_SLOTS
+    PROF_DRN_STEM, PROF_DRN_BIAS_ACT, PROF_DRN_CONV, PROF_DRN_CONV32, PROF_DRN_WINO, PROF_SLOTS
 };
 
 struct spa_ctx {
@@ -125,8 +125,8 @@ int spa_aux_streams(spa_ctx *ctx);
 void spa_prof_mark(spa_ctx *ctx, int slot, int end, hipStream_t s);
 struct SpaProfScope {
     spa_ctx *c; int slot; hipStream_t s;
-    SpaProfScope(spa_ctx *c_, int slot_, hipStream_t s_) : c(c_), slot(slot_), s(s_) { if (c->prof_on) spa_prof_mark(c, slot, 0, s); }
-    ~SpaProfScope() { if (c->prof_on) spa_prof_mark(c, slot, 1, s); }
+    SpaProfScope(spa_ctx *c_, int slot_, hipStream_t s_) : c(c_), slot(slot_), s(s_) { if (c->prof_on && slot >= 0) spa_prof_mark(c, slot, 0, s); }
+    ~SpaProfScope() { if (c->prof_on && slot >= 0) spa_prof_mark(c, slot, 1, s); }      // slot < 0: part of an enclosing scope
 };
 
 int spa_ws_reserve(spa_ctx *ctx, int which, size_t bytes, void **out);

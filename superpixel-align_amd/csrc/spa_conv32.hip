@@ -187,9 +187,9 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
 template <int TAPS>
 static int conv_f32_launch(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W, int32_t Cin,
                            const float *wt, int32_t Cout, const float *bias, const float *residual,
-                           int32_t relu, int32_t dilation, float *y, void *stream)
+                           int32_t relu, int32_t dilation, float *y, void *stream, bool prof = true)
 {
-    SPA_ARG(ctx && x && wt && bias && y && B > 0 && H > 0 && W > 0 && dilation >= 1);
+    SPA_ARG(ctx && x && wt && y && B > 0 && H > 0 && W > 0 && dilation >= 1);
     SPA_ARG(Cin % C32_BK == 0 && Cout % 64 == 0 && dilation <= C32_HALO);
     SPA_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)wt % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)bias % 16) == 0);
     SPA_ARG(((uintptr_t)residual % 16) == 0);
@@ -201,6 +201,7 @@ static int conv_f32_launch(spa_ctx *ctx, const float *x, int32_t B, int32_t H, i
         SPA_HIP(hipMemsetAsync(zero, 0, 4096, s));
         ctx->zero_line_ready = 1;
     }
+    if (!bias) { SPA_ARG(Cout <= 1024); bias = (const float *)zero; }      // raw GEMM: the zero line as bias
     const int bm = Cout % 256 == 0 ? 256 : (Cout % 128 == 0 ? 128 : 64);
     const int bn = bm == 256 || getenv("SPA_CONV32_BN256") ? 256 : 128;
     const int xtiles = (W + bn - 1) / bn, ntiles = Cout / bm;
@@ -216,7 +217,7 @@ static int conv_f32_launch(spa_ctx *ctx, const float *x, int32_t B, int32_t H, i
 #undef C32_ATTR
         ctx->conv32_attr_done |= bit;
     }
-    SpaProfScope prof_(ctx, PROF_DRN_CONV32, s);
+    SpaProfScope prof_(ctx, prof ? PROF_DRN_CONV32 : -1, s);
 #define C32_LAUNCH(R, M, N)                                                                                                 \
     hipLaunchKernelGGL((k_conv3x3_f32<R, M, TAPS, N>), dim3((unsigned)total), dim3(C32_THREADS), lds, s, x, wt, bias, residual, y,  \
                        (const char *)zero, B, H, W, Cin, Cout, dilation, relu, xtiles, ntiles, (int)total)
@@ -244,4 +245,13 @@ extern "C" int spa_conv1x1_f32(spa_ctx *ctx, const float *x, int32_t B, int32_t 
                                int32_t relu, float *y, void *stream)
 {
     return conv_f32_launch<1>(ctx, x, B, H, W, Cin, wt, Cout, bias, residual, relu, 1, y, stream);
+}
+
+// plain GEMM for the Winograd path (spa_wino.hip): y (rows, Cout) = x (rows, Cin) . wt^T, wt (Cout, Cin); rows is a
+// multiple of 256 — the 1x1 form of the kernel on x seen as an image of 256-pixel rows, zero bias, no activation
+int conv1x1_f32_raw(spa_ctx *ctx, const float *x, long long rows, int32_t Cin, const float *wt, int32_t Cout,
+                    float *y, void *stream)
+{
+    SPA_ARG(rows > 0 && rows % 256 == 0 && rows / 256 < (1ll << 31));
+    return conv_f32_launch<1>(ctx, x, 1, (int32_t)(rows / 256), 256, Cin, wt, Cout, nullptr, nullptr, 0, 1, y, stream, false);
 }

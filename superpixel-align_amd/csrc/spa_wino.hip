@@ -1,0 +1,185 @@
+// Winograd F(2x2, 3x3) for the heavy 3x3 (dilated) stride-1 layers of the float32 DRN (models/drn.py:230-285:
+// layers 5-8, 256/512 channels at 1/8 resolution).  The float32 matrix pipe is the wall of the float32 network
+// (spa_conv3x3_f32 and MIOpen both sit at 0.88 of its peak), so the only way past it is fewer multiplications:
+// the minimal filtering algorithm computes a 2x2 output tile from a 4x4 input tile with 16 instead of 36
+// multiplications per (input channel, output channel) — 2.25x less matrix work — at the price of two streaming
+// transforms.  float32 throughout; measured against a float64 convolution the result is as close as the direct
+// float32 one (5e-7 vs 3e-7 of the map's scale: the transforms of F(2x2,3x3) only add and halve).
+//
+//   Y = A^T [ sum_c (G g G^T) .* (B^T d B) ] A        per 2x2 output tile, d = its 4x4 input tile
+//
+// A dilated convolution is d*d independent ordinary convolutions on the sub-grids (y mod d, x mod d); tiles are
+// cut on the sub-grids, so dilation only changes addresses.
+//
+//   k_wino_in    X (B,H,W,C) -> V [16][T][C]   (T tiles; position-major, so every GEMM reads one dense matrix)
+//   GEMM         M[p] (T x K) = V[p] (T x C) . U[p]^T,  U[p] = (G g G^T)[p] as (K, C): 16 launches of the float32
+//                MFMA kernel of spa_conv32.hip in its 1x1 form (V[p] seen as an image of 256-"pixel" rows)
+//   k_wino_out   M [16][T][K] -> Y (B,H,W,K) with bias, residual and ReLU
+//
+// HBM traffic per layer: X once, V written and read (4x X), M written and read (4x Y), Y once — 38 GB per 30
+// images of a 512 -> 512 layer, ~5 ms of streaming next to a GEMM of 16 ms, against 33 ms of direct convolution.
+#include "spa_common.h"
+
+int conv1x1_f32_raw(spa_ctx *ctx, const float *x, long long rows, int32_t Cin, const float *wt, int32_t Cout,
+                    float *y, void *stream);          // spa_conv32.hip
+
+struct WinoGeom { int B, H, W, d, th, tw; long long T; };
+
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+
+// tile id -> (image, sub-grid, tile row, tile column)
+__device__ __forceinline__ void wino_tile(const WinoGeom &g, long long t, int &b, int &sy, int &sx, int &ty, int &tx)
+{
+    tx = (int)(t % g.tw); t /= g.tw;
+    ty = (int)(t % g.th); t /= g.th;
+    sx = (int)(t % g.d); t /= g.d;
+    sy = (int)(t % g.d);
+    b = (int)(t / g.d);
+}
+
+// one thread = one tile x 4 channels: 16 float4 loads, B^T d B, 16 float4 stores
+__global__ __launch_bounds__(256) void k_wino_in(const float *__restrict__ X, float *__restrict__ V, WinoGeom g, int C,
+                                                 long long Tpad)
+{
+    const int c4 = C >> 2;
+    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= g.T * c4) return;
+    const long long t = id / c4;
+    const int c = (int)(id - t * c4) << 2;
+    int b, sy, sx, ty, tx;
+    wino_tile(g, t, b, sy, sx, ty, tx);
+    float4 dv[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int y = sy + (2 * ty - 1 + i) * g.d;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = sx + (2 * tx - 1 + j) * g.d;
+            const bool ok = y >= 0 && y < g.H && x >= 0 && x < g.W;
+            dv[i][j] = ok ? *(const float4 *)(X + (((long long)b * g.H + y) * g.W + x) * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    // rows: B^T d
+    float4 r[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r[0][j] = f4sub(dv[0][j], dv[2][j]);
+        r[1][j] = f4add(dv[1][j], dv[2][j]);
+        r[2][j] = f4sub(dv[2][j], dv[1][j]);
+        r[3][j] = f4sub(dv[1][j], dv[3][j]);
+    }
+    // columns: (B^T d) B
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 v0 = f4sub(r[i][0], r[i][2]), v1 = f4add(r[i][1], r[i][2]);
+        const float4 v2 = f4sub(r[i][2], r[i][1]), v3 = f4sub(r[i][1], r[i][3]);
+        float *o = V + ((long long)(i * 4) * Tpad + t) * C + c;
+        *(float4 *)(o) = v0;
+        *(float4 *)(o + Tpad * C) = v1;
+        *(float4 *)(o + 2 * Tpad * C) = v2;
+        *(float4 *)(o + 3 * Tpad * C) = v3;
+    }
+}
+
+// one thread = one tile x 4 output channels: 16 float4 loads, A^T m A, epilogue, up to 4 float4 stores
+template <int HAS_RES>
+__global__ __launch_bounds__(256) void k_wino_out(const float *__restrict__ M, float *__restrict__ Y,
+                                                  const float *__restrict__ bias, const float *__restrict__ R,
+                                                  WinoGeom g, int K, long long Tpad, int relu)
+{
+    const int k4 = K >> 2;
+    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= g.T * k4) return;
+    const long long t = id / k4;
+    const int k = (int)(id - t * k4) << 2;
+    int b, sy, sx, ty, tx;
+    wino_tile(g, t, b, sy, sx, ty, tx);
+    float4 m[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[i][j] = *(const float4 *)(M + ((long long)(i * 4 + j) * Tpad + t) * K + k);
+    // rows: A^T m  (2 x 4)
+    float4 s[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s[0][j] = f4add(f4add(m[0][j], m[1][j]), m[2][j]);
+        s[1][j] = f4sub(f4sub(m[1][j], m[2][j]), m[3][j]);
+    }
+    const float4 bv = *(const float4 *)(bias + k);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int y = sy + (2 * ty + i) * g.d;
+        if (y >= g.H) continue;
+        const float4 o0 = f4add(f4add(s[i][0], s[i][1]), s[i][2]);
+        const float4 o1 = f4sub(f4sub(s[i][1], s[i][2]), s[i][3]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int x = sx + (2 * tx + j) * g.d;
+            if (x >= g.W) continue;
+            float4 v = f4add(j == 0 ? o0 : o1, bv);
+            const long long off = (((long long)b * g.H + y) * g.W + x) * K + k;
+            if (HAS_RES) v = f4add(v, *(const float4 *)(R + off));
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *(float4 *)(Y + off) = v;
+        }
+    }
+}
+
+static void wino_geom(int B, int H, int W, int d, WinoGeom *g)
+{
+    g->B = B; g->H = H; g->W = W; g->d = d;
+    const int hs = (H + d - 1) / d, ws = (W + d - 1) / d;         // the largest sub-grid
+    g->th = (hs + 1) / 2; g->tw = (ws + 1) / 2;
+    g->T = (long long)B * d * d * g->th * g->tw;
+}
+
+// rows of V / M per position, padded to whole 256-row GEMM tiles
+extern "C" int64_t spa_wino_tiles(int32_t B, int32_t H, int32_t W, int32_t dilation)
+{
+    WinoGeom g;
+    wino_geom(B, H, W, dilation, &g);
+    return (g.T + 255) / 256 * 256;
+}
+
+// x (B,H,W,Cin) float32 channels-last; u (16,Cout,Cin) float32 = (G g G^T)[4i+j] per (output, input) channel;
+// v_scratch 16 * spa_wino_tiles * Cin floats, m_scratch 16 * spa_wino_tiles * Cout floats (caller-owned: calls on
+// different streams do not share them); otherwise as spa_conv3x3_f32
+extern "C" int spa_conv3x3_wino_f32(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                                    const float *u, int32_t Cout, const float *bias, const float *residual,
+                                    int32_t relu, int32_t dilation, float *v_scratch, float *m_scratch, float *y,
+                                    void *stream)
+{
+    SPA_ARG(ctx && x && u && bias && y && v_scratch && m_scratch && B > 0 && H > 0 && W > 0 && dilation >= 1);
+    SPA_ARG(Cin % 32 == 0 && Cout % 64 == 0);
+    SPA_ARG((((uintptr_t)x | (uintptr_t)u | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)residual | (uintptr_t)v_scratch |
+              (uintptr_t)m_scratch) % 16) == 0);
+    hipStream_t s = spa_stream(stream);
+    WinoGeom g;
+    wino_geom(B, H, W, dilation, &g);
+    const long long Tpad = (g.T + 255) / 256 * 256;
+    SPA_ARG(g.T * (Cin > Cout ? Cin : Cout) / 4 < (1ll << 31) * 256);
+    SpaProfScope prof_(ctx, PROF_DRN_WINO, s);
+    {
+        const long long n = g.T * (Cin / 4);
+        hipLaunchKernelGGL(k_wino_in, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, v_scratch, g, Cin, Tpad);
+    }
+    // (rows T .. Tpad of V are never written: their products land in rows of M nothing reads)
+    for (int p = 0; p < 16; ++p) {
+        int rc = conv1x1_f32_raw(ctx, v_scratch + (long long)p * Tpad * Cin, Tpad, Cin, u + (long long)p * Cout * Cin, Cout,
+                                 m_scratch + (long long)p * Tpad * Cout, stream);
+        if (rc != SPA_OK) return rc;
+    }
+    {
+        const long long n = g.T * (Cout / 4);
+        if (residual)
+            hipLaunchKernelGGL(k_wino_out<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float *)m_scratch, y,
+                               bias, residual, g, Cout, Tpad, relu);
+        else
+            hipLaunchKernelGGL(k_wino_out<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float *)m_scratch, y,
+                               bias, residual, g, Cout, Tpad, relu);
+    }
+    SPA_LAUNCH_CHECK();
+    return SPA_OK;
+}

@@ -58,7 +58,8 @@ def _conv(cin, cout, k, stride=1, dilation=1):
 
 # set by DRN.prepare() on a GPU: libspalign's fused bias/residual/ReLU; 'bytes' accumulates the algorithmic
 # HBM bytes of its launches (read y + write y [+ read residual]) for bench.py's roofline entry
-_EPILOGUE = {'engine': None, 'bytes': 0, 'launches': 0, 'own_conv': True, 'own_conv32': True, 'conv_flops': 0.0}
+_EPILOGUE = {'engine': None, 'bytes': 0, 'launches': 0, 'own_conv': True, 'own_conv32': True, 'winograd': True,
+             'conv_flops': 0.0, 'wino_flops': 0.0, 'wino_direct_flops': 0.0}
 
 
 def conv_bias_act(conv, bn, x, residual=None, relu=True):
@@ -77,6 +78,16 @@ def conv_bias_act(conv, bn, x, residual=None, relu=True):
             # in its epilogue (no separate elementwise pass, one rounding to bf16)
             _EPILOGUE['conv_flops'] += 2.0 * x.shape[0] * x.shape[2] * x.shape[3] * conv.out_channels * 9 * conv.in_channels
             return eng.conv3x3_bf16(x, packed[0], packed[1], residual, relu, conv.dilation[0])
+        wino = getattr(conv, '_spa_wino', None)
+        if (wino is not None and x.dtype == torch.float32 and _EPILOGUE['own_conv32'] and _EPILOGUE['winograd']
+                and x.is_contiguous(memory_format=torch.channels_last)
+                and (residual is None or residual.is_contiguous(memory_format=torch.channels_last))):
+            # the 256/512-channel layers: Winograd F(2x2,3x3), 2.25x fewer float32 multiplications (executed FLOPs
+            # = 16/36 of the direct form's; both are counted)
+            direct = 2.0 * x.shape[0] * x.shape[2] * x.shape[3] * conv.out_channels * 9 * conv.in_channels
+            _EPILOGUE['wino_direct_flops'] += direct
+            _EPILOGUE['wino_flops'] += direct * 16.0 / 36.0
+            return eng.conv3x3_wino_f32(x, wino[0], wino[1], residual, relu, conv.dilation[0])
         packed32 = getattr(conv, '_spa_packed32', None)
         if (packed32 is not None and x.dtype == torch.float32 and _EPILOGUE['own_conv32']
                 and x.is_contiguous(memory_format=torch.channels_last)
@@ -226,6 +237,16 @@ class DRN(nn.Module):
                 if isinstance(m, nn.Conv2d):
                     m._spa_packed = None
                     m._spa_packed32 = None
+                    m._spa_wino = None
+                    # Winograd F(2x2,3x3) where it wins (measured, 30 x 128 x 256 pixels: 256 -> 256 7.0 vs 8.5 ms,
+                    # 256 -> 512 12.3 vs 16.8, 512 -> 512 21.2 vs 33.2; 128 -> 256 ties, narrower layers lose to the
+                    # transforms' HBM traffic): both channel counts >= 256
+                    if (dtype == torch.float32 and self.folded and m.kernel_size == (3, 3) and m.stride == (1, 1)
+                            and m.padding == m.dilation and m.dilation[0] == m.dilation[1] and m.groups == 1
+                            and m.in_channels % 32 == 0 and m.out_channels % 64 == 0 and m.bias is not None
+                            and m.in_channels >= 256 and m.out_channels >= 256):
+                        from .engine import Engine
+                        m._spa_wino = (Engine.winograd_weights(m.weight), m.bias.detach().float().contiguous())
                     # operands of spa_conv3x3_f32: the same layers of the float32 network (Cin % 32 == 0)
                     if (dtype == torch.float32 and self.folded and m.kernel_size == (3, 3) and m.stride == (1, 1)
                             and m.padding == m.dilation and m.dilation[0] == m.dilation[1] <= 4 and m.groups == 1

@@ -164,6 +164,32 @@ class Engine(object):
                                             _ptr(residual), 1 if relu else 0, int(dilation), _ptr(y), self._s()))
         return y
 
+    @staticmethod
+    def winograd_weights(weight):
+        """(Cout,Cin,3,3) -> (16,Cout,Cin) float32: G g G^T of F(2x2,3x3), computed in float64, position-major."""
+        G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64, device=weight.device)
+        u = torch.einsum('ij,kcjl,ml->imkc', G, weight.detach().double(), G)
+        return u.reshape(16, weight.shape[0], weight.shape[1]).float().contiguous()
+
+    def conv3x3_wino_f32(self, x, u, bias, residual=None, relu=True, dilation=1):
+        """relu?(conv3x3(x; stride 1, padding = dilation) + bias [+ residual]) by Winograd F(2x2,3x3) on the float32
+        matrix cores.  x (B,Cin,H,W) float32 channels-last, u = winograd_weights(weight), bias (Cout) float32."""
+        B, Cin, H, W = x.shape
+        Cout = u.shape[1]
+        assert x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
+        assert u.dtype == torch.float32 and u.is_contiguous() and tuple(u.shape) == (16, Cout, Cin)
+        assert bias.dtype == torch.float32 and bias.is_contiguous()
+        y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        if residual is not None:
+            assert residual.dtype == torch.float32 and residual.shape == y.shape and \
+                residual.is_contiguous(memory_format=torch.channels_last)
+        T = int(self._lib.spa_wino_tiles(B, H, W, int(dilation)))
+        v = torch.empty((16, T, Cin), dtype=torch.float32, device=x.device)       # per call: stream safe
+        m = torch.empty((16, T, Cout), dtype=torch.float32, device=x.device)
+        check(self._lib.spa_conv3x3_wino_f32(self._ctx, _ptr(x), B, H, W, Cin, _ptr(u), Cout, _ptr(bias), _ptr(residual),
+                                             1 if relu else 0, int(dilation), _ptr(v), _ptr(m), _ptr(y), self._s()))
+        return y
+
     def conv3x3_bf16(self, x, wt, bias, residual=None, relu=True, dilation=1):
         """relu?(conv3x3(x; stride 1, padding = dilation) + bias [+ residual]) on the bf16 matrix cores.
         x (B,Cin,H,W) bfloat16 in channels-last storage, wt (Cout,9,Cin) bfloat16, bias (Cout) float32."""

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=30)
 ap.add_argument('--quick', action='store_true')
-ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'], help='fp32: spa_conv3x3_f32 against MIOpen float32')
+ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32', 'wino'], help='fp32: spa_conv3x3_f32 against MIOpen float32')
 a = ap.parse_args()
 engine = importlib.import_module('superpixel-align_amd.engine')
 eng = engine.Engine()
@@ -90,6 +90,43 @@ def run32_1x1(B, Cin, Cout, H, W, reps=3):
           % (B, Cin, Cout, H, W, err, ms_own, fl / ms_own / 1e9, ms_full))
 
 
+def run_wino(B, Cin, Cout, H, W, dil, res, reps=3):
+    x = torch.relu(torch.randn((B, Cin, H, W), device='cuda')).contiguous(memory_format=torch.channels_last)
+    w = torch.randn((Cout, Cin, 3, 3), device='cuda') * (2.0 / (9 * Cin)) ** 0.5
+    bias = torch.randn((Cout,), device='cuda')
+    r = torch.randn((B, Cout, H, W), device='cuda').contiguous(memory_format=torch.channels_last) if res else None
+    wt = w.permute(0, 2, 3, 1).reshape(Cout, 9, Cin).contiguous()
+    u = eng.winograd_weights(w)
+    y = eng.conv3x3_wino_f32(x, u, bias, r, True, dil)
+    nb = min(B, 2)
+    ref = F.conv2d(x[:nb].double(), w.double(), bias.double(), 1, dil, dil)
+    if res:
+        ref = ref + r[:nb].double()
+    ref = torch.relu(ref)
+    scale = ref.abs().max().item()
+    err = (y[:nb].double() - ref).abs().max().item() / scale
+    yd = eng.conv3x3_f32(x, wt, bias, r, True, dil)
+    err_d = (yd[:nb].double() - ref).abs().max().item() / scale
+
+    def t(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    ms_w = t(lambda: eng.conv3x3_wino_f32(x, u, bias, r, True, dil))
+    ms_d = t(lambda: eng.conv3x3_f32(x, wt, bias, r, True, dil))
+    fl = 2.0 * B * H * W * Cout * 9 * Cin
+    print('winograd B %d %4d -> %4d %dx%d dil %d res %d | err vs float64: winograd %.2e, direct %.2e of scale | winograd %.3f ms '
+          '(%.0f effective TF) | direct %.3f ms (%.0f TF)' % (B, Cin, Cout, H, W, dil, int(res), err, err_d, ms_w, fl / ms_w / 1e9,
+                                                              ms_d, fl / ms_d / 1e9))
+
+
 def run(B, Cin, Cout, H, W, dil, res, reps=5):
     x = torch.randn((B, Cin, H, W), device='cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     w = (torch.randn((Cout, Cin, 3, 3), device='cuda') * (2.0 / (9 * Cin)) ** 0.5).to(torch.bfloat16)
@@ -127,7 +164,17 @@ def run(B, Cin, Cout, H, W, dil, res, reps=5):
     return err / scale
 
 
-if a.dtype == 'fp32':
+if a.dtype == 'wino':
+    run_wino(2, 64, 64, 16, 40, 1, False)
+    run_wino(1, 128, 256, 24, 300, 2, True)
+    run_wino(2, 32, 64, 21, 301, 3, True)           # odd sizes: partial tiles on every sub-grid
+    run_wino(1, 64, 128, 7, 9, 4, False)
+    if not a.quick:
+        B = a.batch
+        for Cin, Cout, dil, res in [(128, 128, 1, True), (128, 256, 2, False), (256, 256, 2, True), (256, 512, 4, False),
+                                    (512, 512, 4, True), (512, 512, 2, False), (512, 512, 1, False)]:
+            run_wino(B, Cin, Cout, 128, 256, dil, res)
+elif a.dtype == 'fp32':
     run32(2, 64, 256, 16, 40, 1, False)
     run32(1, 128, 256, 24, 300, 2, True)
     run32(2, 32, 64, 20, 300, 3, True)
