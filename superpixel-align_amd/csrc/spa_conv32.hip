@@ -37,23 +37,41 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
                                                              const float *__restrict__ R, float *__restrict__ Y,
                                                              const char *__restrict__ zero_line, int B, int H, int W,
                                                              int Cin, int Cout, int dil, int relu, int xtiles,
-                                                             int ntiles, int total_tiles)
+                                                             int ntiles, int total_tiles, int zcount, long long xz,
+                                                             long long wz, long long yz)
 {
     extern __shared__ __attribute__((aligned(1024))) char lds32[];   // [2] weight tiles 32 KB | [2] pixel segments 33 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-aware tile order: consecutive workgroup ids go round-robin over the 8 XCDs; give every XCD a
     // contiguous range of tiles (neighbouring rows of one image share two of their three input rows in L2)
+    // PERSISTENT tile loop: a workgroup takes tiles vid = blockIdx.x, + gridDim.x, ... of zcount problems of
+    // total_tiles tiles each (zcount > 1: the 16 GEMMs of a Winograd layer, operands xz / wz / yz elements apart).
+    // The first K step of the NEXT tile is staged before the epilogue of the current one, so the stores of a
+    // 256 x 256 output tile (the bulk of a short-K GEMM's overhead) drain under the next tile's loads and matrix work.
+    const long long all_tiles = (long long)zcount * total_tiles;
     const int nwg = total_tiles;
-    int id = blockIdx.x;
-    {
-        const int q = nwg / 8, rem = nwg % 8, xcd = id % 8, idx = id / 8;
-        id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
-    }
-    // tile id -> (pixel tile, channel tile): the channel tiles of one pixel tile are adjacent
-    const int nt = id % ntiles, pt = id / ntiles;
-    const int xt = pt % xtiles, row_id = pt / xtiles;               // row_id = b * H + y
-    const int y = row_id % H;
-    const int x0 = xt * BN, n0 = nt * BM;
+    int row_id, y, x0, n0;
+    const char *wbase, *xbase;
+    float *ybase;
+    const float *rbase;
+    auto locate = [&](long long vid) {
+        const int z = (int)(vid / total_tiles);
+        int id = (int)(vid - (long long)z * total_tiles);
+        {
+            const int q = nwg / 8, rem = nwg % 8, xcd = id % 8, idx = id / 8;
+            id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+        }
+        // tile id -> (pixel tile, channel tile): the channel tiles of one pixel tile are adjacent
+        const int nt = id % ntiles, pt = id / ntiles;
+        const int xt = pt % xtiles;
+        row_id = pt / xtiles;                                           // b * H + y
+        y = row_id % H;
+        x0 = xt * BN; n0 = nt * BM;
+        wbase = (const char *)(Wt + (long long)z * wz + (long long)n0 * TAPS * Cin);
+        xbase = (const char *)(X + (long long)z * xz + (long long)row_id * W * Cin);      // input row y, pixel 0
+        ybase = Y + (long long)z * yz;
+        rbase = R + (long long)z * yz;
+    };
     constexpr int WN = BM == 64 ? 8 : 4;                 // waves along the pixels
     constexpr int MI = BM == 256 ? 8 : 4;                // 16-channel MFMA tiles per wave
     constexpr int NJ = BN / WN / 16;                     // 16-pixel MFMA tiles per wave
@@ -69,8 +87,6 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
     char *wbuf = lds32, *xbuf = lds32 + 2 * (BM * 128);
     const int sub = lane >> 3, cs = lane & 7;
     const int chunk_byte = (cs ^ sub) << 4;        // staged row = block * 8 + sub: (row & 7) = sub for every block
-    const char *wbase = (const char *)(Wt + (long long)n0 * TAPS * Cin);
-    const char *xbase = (const char *)(X + (long long)row_id * W * Cin);      // input row y, pixel 0
     const int ks = Cin / C32_BK;
     const int nk = TAPS * ks, ngroups = TAPS == 9 ? 3 * ks : ks;
 
@@ -110,16 +126,31 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
 
     // ---- accumulators: wave (wm, wn) owns channels [wm*WROWS, +WROWS) x pixels [wn*NJ*16, +NJ*16)
     const int wm = wave / WN, wn = wave % WN;
+    const int frow = lane & 15, fk = lane >> 4;                     // fragment row, 16-byte k chunk inside a 32-k step
+    long long vid = blockIdx.x;
+    if (vid >= all_tiles) return;
+    bool first_tile = true;
+    const bool counted_wait = (W % BN) == 0;          // every lane of every epilogue store is live
+    locate(vid);
+    stage_w(0, 0);
+    stage_x(0, 0); stage_x(0, 1); stage_x(0, 2);
+  for (;;) {
     f32x4 acc[MI][NJ];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int frow = lane & 15, fk = lane >> 4;                     // fragment row, 16-byte k chunk inside a 32-k step
-
-    stage_w(0, 0);
-    stage_x(0, 0); stage_x(0, 1); stage_x(0, 2);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the staged loads of this tile's first K step must have landed.  They were issued BEFORE the previous tile's
+    // epilogue stores (vmcnt counts both, in order), so when every wave issued exactly MI*NJ stores after them —
+    // full tiles, no residual loads in between — waiting until MI*NJ operations remain is enough and the stores
+    // keep draining under this tile's matrix work
+    if (!HAS_RES && counted_wait && !first_tile) {
+        static_assert(MI * NJ <= 63, "vmcnt range");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MI * NJ) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    first_tile = false;
     __syncthreads();
     for (int t = 0; t < nk; ++t) {
         const int cur = t & 1;
@@ -161,25 +192,39 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
         __syncthreads();
     }
 
+    // ---- the next tile's first K step goes out now (every wave has passed the last barrier: both buffer pairs are
+    // free); the epilogue below needs the current tile's coordinates, so they are saved first
+    const int e_row = row_id, e_x0 = x0, e_n0 = n0;
+    float *e_y = ybase;
+    const float *e_r = rbase;
+    vid += gridDim.x;
+    const bool more = vid < all_tiles;
+    if (more) {
+        locate(vid);
+        stage_w(0, 0);
+        stage_x(0, 0); stage_x(0, 1); stage_x(0, 2);
+    }
     // ---- epilogue: lane holds channels c..c+3 (c = tile channel base + (lane>>4)*4) of pixel (lane & 15)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int xx = x0 + wn * (NJ * 16) + j * 16 + (lane & 15);
+        const int xx = e_x0 + wn * (NJ * 16) + j * 16 + (lane & 15);
         if (xx >= W) continue;
-        const long long pix = (long long)row_id * W + xx;
+        const long long pix = (long long)e_row * W + xx;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-            const int c = n0 + wm * WROWS + i * 16 + (lane >> 4) * 4;
+            const int c = e_n0 + wm * WROWS + i * 16 + (lane >> 4) * 4;
             const float4 bv = *(const float4 *)(bias + c);
             float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y, v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
             if (HAS_RES) {
-                const float4 rr = *(const float4 *)(R + pix * Cout + c);
+                const float4 rr = *(const float4 *)(e_r + pix * Cout + c);
                 v0 += rr.x; v1 += rr.y; v2 += rr.z; v3 += rr.w;
             }
             if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-            *(float4 *)(Y + pix * Cout + c) = make_float4(v0, v1, v2, v3);
+            *(float4 *)(e_y + pix * Cout + c) = make_float4(v0, v1, v2, v3);
         }
     }
+    if (!more) break;
+  }
 }
 
 // x (B,H,W,Cin) float32 channels-last, wt (Cout,taps,Cin) float32 (tap = ky*3 + kx), bias (Cout) float32,
@@ -187,7 +232,8 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
 template <int TAPS>
 static int conv_f32_launch(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W, int32_t Cin,
                            const float *wt, int32_t Cout, const float *bias, const float *residual,
-                           int32_t relu, int32_t dilation, float *y, void *stream, bool prof = true)
+                           int32_t relu, int32_t dilation, float *y, void *stream, bool prof = true, int zcount = 1,
+                           long long xz = 0, long long wz = 0, long long yz = 0)
 {
     SPA_ARG(ctx && x && wt && y && B > 0 && H > 0 && W > 0 && dilation >= 1);
     SPA_ARG(Cin % C32_BK == 0 && Cout % 64 == 0 && dilation <= C32_HALO);
@@ -218,9 +264,14 @@ static int conv_f32_launch(spa_ctx *ctx, const float *x, int32_t B, int32_t H, i
         ctx->conv32_attr_done |= bit;
     }
     SpaProfScope prof_(ctx, prof ? PROF_DRN_CONV32 : -1, s);
+    // persistent workgroups: as many as are resident at once (LDS: one per CU for the wide tiles, two or three for the
+    // 128-pixel ones), each looping over its share of the tiles
+    const int per_cu = lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3);
+    long long grid = (long long)ctx->n_cu * per_cu;
+    if (grid > total * zcount) grid = total * zcount;
 #define C32_LAUNCH(R, M, N)                                                                                                 \
-    hipLaunchKernelGGL((k_conv3x3_f32<R, M, TAPS, N>), dim3((unsigned)total), dim3(C32_THREADS), lds, s, x, wt, bias, residual, y,  \
-                       (const char *)zero, B, H, W, Cin, Cout, dilation, relu, xtiles, ntiles, (int)total)
+    hipLaunchKernelGGL((k_conv3x3_f32<R, M, TAPS, N>), dim3((unsigned)grid), dim3(C32_THREADS), lds, s, x, wt, bias, residual, y,  \
+                       (const char *)zero, B, H, W, Cin, Cout, dilation, relu, xtiles, ntiles, (int)total, zcount, xz, wz, yz)
 #define C32_PICK(R)                                                                     \
     if (bm == 256) C32_LAUNCH(R, 256, 256);                                             \
     else if (bm == 128) { if (bn == 256) C32_LAUNCH(R, 128, 256); else C32_LAUNCH(R, 128, 128); } \
@@ -247,11 +298,13 @@ extern "C" int spa_conv1x1_f32(spa_ctx *ctx, const float *x, int32_t B, int32_t 
     return conv_f32_launch<1>(ctx, x, B, H, W, Cin, wt, Cout, bias, residual, relu, 1, y, stream);
 }
 
-// plain GEMM for the Winograd path (spa_wino.hip): y (rows, Cout) = x (rows, Cin) . wt^T, wt (Cout, Cin); rows is a
+// plain GEMMs for the Winograd path (spa_wino.hip): y (rows, Cout) = x (rows, Cin) . wt^T, wt (Cout, Cin); rows is a
 // multiple of 256 — the 1x1 form of the kernel on x seen as an image of 256-pixel rows, zero bias, no activation
 int conv1x1_f32_raw(spa_ctx *ctx, const float *x, long long rows, int32_t Cin, const float *wt, int32_t Cout,
-                    float *y, void *stream)
+                    float *y, void *stream, int zcount)
 {
-    SPA_ARG(rows > 0 && rows % 256 == 0 && rows / 256 < (1ll << 31));
-    return conv_f32_launch<1>(ctx, x, 1, (int32_t)(rows / 256), 256, Cin, wt, Cout, nullptr, nullptr, 0, 1, y, stream, false);
+    SPA_ARG(rows > 0 && rows % 256 == 0 && rows / 256 < (1ll << 31) && zcount >= 1);
+    // zcount problems in one launch: operands rows * Cin / Cout * Cin / rows * Cout elements apart
+    return conv_f32_launch<1>(ctx, x, 1, (int32_t)(rows / 256), 256, Cin, wt, Cout, nullptr, nullptr, 0, 1, y, stream, false,
+                              zcount, rows * Cin, (long long)Cout * Cin, rows * Cout);
 }

@@ -12,8 +12,9 @@
 // cut on the sub-grids, so dilation only changes addresses.
 //
 //   k_wino_in    X (B,H,W,C) -> V [16][T][C]   (T tiles; position-major, so every GEMM reads one dense matrix)
-//   GEMM         M[p] (T x K) = V[p] (T x C) . U[p]^T,  U[p] = (G g G^T)[p] as (K, C): 16 launches of the float32
-//                MFMA kernel of spa_conv32.hip in its 1x1 form (V[p] seen as an image of 256-"pixel" rows)
+//   GEMM         M[p] (T x K) = V[p] (T x C) . U[p]^T,  U[p] = (G g G^T)[p] as (K, C): the float32 MFMA kernel of
+//                spa_conv32.hip in its 1x1 form (V[p] seen as an image of 256-"pixel" rows), all 16 in one
+//                launch of persistent workgroups
 //   k_wino_out   M [16][T][K] -> Y (B,H,W,K) with bias, residual and ReLU
 //
 // HBM traffic per layer: X once, V written and read (4x X), M written and read (4x Y), Y once — 38 GB per 30
@@ -21,7 +22,7 @@
 #include "spa_common.h"
 
 int conv1x1_f32_raw(spa_ctx *ctx, const float *x, long long rows, int32_t Cin, const float *wt, int32_t Cout,
-                    float *y, void *stream);          // spa_conv32.hip
+                    float *y, void *stream, int zcount);          // spa_conv32.hip
 
 struct WinoGeom { int B, H, W, d, th, tw; long long T; };
 
@@ -166,9 +167,9 @@ extern "C" int spa_conv3x3_wino_f32(spa_ctx *ctx, const float *x, int32_t B, int
         hipLaunchKernelGGL(k_wino_in, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, v_scratch, g, Cin, Tpad);
     }
     // (rows T .. Tpad of V are never written: their products land in rows of M nothing reads)
-    for (int p = 0; p < 16; ++p) {
-        int rc = conv1x1_f32_raw(ctx, v_scratch + (long long)p * Tpad * Cin, Tpad, Cin, u + (long long)p * Cout * Cin, Cout,
-                                 m_scratch + (long long)p * Tpad * Cout, stream);
+    {
+        // the 16 GEMMs as ONE launch of persistent workgroups
+        int rc = conv1x1_f32_raw(ctx, v_scratch, Tpad, Cin, u, Cout, m_scratch, stream, 16);
         if (rc != SPA_OK) return rc;
     }
     {
