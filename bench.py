@@ -333,6 +333,8 @@ def main():
     drn._EPILOGUE['conv_flops'] = 0.0
     drn._EPILOGUE['wino_flops'] = 0.0
     drn._EPILOGUE['wino_direct_flops'] = 0.0
+    drn._EPILOGUE['wino_bytes'] = 0.0
+    drn._EPILOGUE['wino_launches'] = 0
 
     dist.barrier()
     torch.cuda.synchronize()
@@ -358,6 +360,7 @@ def main():
     bias_bytes, bias_launches = drn._EPILOGUE['bytes'], drn._EPILOGUE['launches']
     conv_flops = drn._EPILOGUE['conv_flops']
     wino_flops, wino_direct = drn._EPILOGUE['wino_flops'], drn._EPILOGUE['wino_direct_flops']
+    wino_bytes = drn._EPILOGUE['wino_bytes'] / max(1, drn._EPILOGUE['wino_launches'])      # per launch, by construction
 
     for e in evs:
         pipe._ev = e
@@ -423,7 +426,10 @@ def main():
             ent.update(bound='mfma', achieved=round(tf, 1), peak=FP32_MATRIX_PEAK_TF, unit='TFLOP/s',
                        frac=round(tf / FP32_MATRIX_PEAK_TF, 4), flops_per_step=wino_flops / a.steps,
                        flops_per_launch=wino_flops / max(1, n),
-                       effective_TFLOPs_direct_equivalent=round(wino_direct / a.steps / (ms / a.steps * 1e-3) / 1e12, 1))
+                       effective_TFLOPs_direct_equivalent=round(wino_direct / a.steps / (ms / a.steps * 1e-3) / 1e12, 1),
+                       hbm_bytes_per_launch_by_construction=int(wino_bytes),
+                       hbm_GBs_by_construction=round(wino_bytes / (avg * 1e-3) / 1e9, 1),
+                       traffic=pmc_traffic(name, B, H, W, wino_bytes))
         elif name.startswith('k_conv3x3_'):
             # libspalign's implicit-GEMM convolutions (the stride-1 3x3 layers, bf16 or float32 matrix cores):
             # family entry over all launches; FLOPs = 2 * MACs of exactly those layers (counted by drn.py)

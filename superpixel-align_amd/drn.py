@@ -59,7 +59,7 @@ def _conv(cin, cout, k, stride=1, dilation=1):
 # set by DRN.prepare() on a GPU: libspalign's fused bias/residual/ReLU; 'bytes' accumulates the algorithmic
 # HBM bytes of its launches (read y + write y [+ read residual]) for bench.py's roofline entry
 _EPILOGUE = {'engine': None, 'bytes': 0, 'launches': 0, 'own_conv': True, 'own_conv32': True, 'winograd': True,
-             'conv_flops': 0.0, 'wino_flops': 0.0, 'wino_direct_flops': 0.0}
+             'conv_flops': 0.0, 'wino_flops': 0.0, 'wino_direct_flops': 0.0, 'wino_bytes': 0.0, 'wino_launches': 0}
 
 
 def conv_bias_act(conv, bn, x, residual=None, relu=True):
@@ -87,6 +87,10 @@ def conv_bias_act(conv, bn, x, residual=None, relu=True):
             direct = 2.0 * x.shape[0] * x.shape[2] * x.shape[3] * conv.out_channels * 9 * conv.in_channels
             _EPILOGUE['wino_direct_flops'] += direct
             _EPILOGUE['wino_flops'] += direct * 16.0 / 36.0
+            # HBM bytes by construction: X read, V (4x X) written and read, M (4x Y) written and read, Y written, R read
+            px = x.shape[0] * x.shape[2] * x.shape[3]
+            _EPILOGUE['wino_bytes'] += 4.0 * px * (9 * conv.in_channels + (10 if residual is not None else 9) * conv.out_channels)
+            _EPILOGUE['wino_launches'] += 1
             return eng.conv3x3_wino_f32(x, wino[0], wino[1], residual, relu, conv.dilation[0])
         packed32 = getattr(conv, '_spa_packed32', None)
         if (packed32 is not None and x.dtype == torch.float32 and _EPILOGUE['own_conv32']

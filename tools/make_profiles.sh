@@ -4,14 +4,14 @@
 #   2. rocprofv3 --kernel-trace --stats of the default bench    -> gpurun_out/final_stats/
 #   3. HBM traffic PMC passes (FETCH_SIZE, WRITE_SIZE; separate passes) over tools/prof_stages.py
 #   4. the other operating points (one JSON line each)          -> gpurun_out/final_variant_*.json
-# then, in the build container:  python tools/write_profiles.py r2_final
+# then, in the build container:  python tools/write_profiles.py r3_final
 export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/final_stats gpurun_out/final_pmc_*
 python3 bench.py > gpurun_out/final_bench_line.json 2> gpurun_out/final_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final_stats -- python3 bench.py --no_cpu_baseline > gpurun_out/final_stats_bench_line.json 2> gpurun_out/final_stats.err
 for P in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $P --kernel-trace --output-format csv -d gpurun_out/final_pmc_$P -- python3 tools/prof_stages.py --batch 8 --reps 2 --bias_act > gpurun_out/final_pmc_$P.log 2>&1
+  rocprofv3 --pmc $P --kernel-trace --output-format csv -d gpurun_out/final_pmc_$P -- python3 tools/prof_stages.py --batch 8 --reps 2 --bias_act --wino > gpurun_out/final_pmc_$P.log 2>&1
 done
 python3 tools/pmc_summary.py gpurun_out/final_pmc_FETCH_SIZE > gpurun_out/final_pmc_fetch.txt
 python3 tools/pmc_summary.py gpurun_out/final_pmc_WRITE_SIZE > gpurun_out/final_pmc_write.txt
@@ -25,5 +25,7 @@ v anchor --pool_mode anchor
 v anchor_bf16 --pool_mode anchor --dtype bf16
 v anchor_bf16_device_rng --pool_mode anchor --dtype bf16 --device_rng
 v integer_images --integer_images
+v no_winograd --no_winograd
+v miopen_conv --miopen_conv
 v reference_operating_point --superpixel_method felzenszwalb --height 224 --width 224 --arch drn_c_26 --pool_mode anchor --n_clusters 4
 ls -la gpurun_out | tail -20

@@ -27,6 +27,8 @@ ap.add_argument('--reps', type=int, default=3)
 ap.add_argument('--pool_mode', default='mean')
 ap.add_argument('--bias_act', action='store_true', help='also run the DRN epilogue kernel (k_bias_act) on the shapes of '
                 'the heavy layers, for the PMC traffic passes')
+ap.add_argument('--wino', action='store_true', help='also run one Winograd layer (512 -> 512, dilation 2) and one direct '
+                'float32 layer (128 -> 128) at 1/8 resolution, for the PMC traffic passes')
 a = ap.parse_args()
 
 spa = importlib.import_module('superpixel-align_amd')
@@ -63,3 +65,19 @@ if a.bias_act:
             pipe.eng.bias_act_(y, bias, r, True)
     torch.cuda.synchronize()
     print('bias_act: 512 ch + residual, 512 ch, 256 ch + residual at %dx%d, %d launches each' % (a.height // 8, a.width // 8, a.reps))
+
+if a.wino:
+    eng = pipe.eng
+    h, w = a.height // 8, a.width // 8
+    x = torch.relu(torch.randn((a.batch, 512, h, w), device='cuda')).contiguous(memory_format=torch.channels_last)
+    wt = torch.randn((512, 512, 3, 3), device='cuda') * (2.0 / (9 * 512)) ** 0.5
+    u, b = eng.winograd_weights(wt), torch.randn((512,), device='cuda')
+    for _ in range(a.reps):
+        eng.conv3x3_wino_f32(x, u, b, None, True, 2)
+    x2 = torch.relu(torch.randn((a.batch, 128, h, w), device='cuda')).contiguous(memory_format=torch.channels_last)
+    w2 = (torch.randn((128, 128, 3, 3), device='cuda') * (2.0 / (9 * 128)) ** 0.5).permute(0, 2, 3, 1).reshape(128, 9, 128).contiguous()
+    b2 = torch.randn((128,), device='cuda')
+    for _ in range(a.reps):
+        eng.conv3x3_f32(x2, w2, b2, None, True, 1)
+    torch.cuda.synchronize()
+    print('winograd 512 -> 512 dil 2 and direct 128 -> 128 at %dx%d, %d launches each' % (h, w, a.reps))

@@ -12,7 +12,7 @@ import sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 go = os.path.join(root, 'gpurun_out')
 prof = os.path.join(root, 'profiles')
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r2_final'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r3_final'
 
 # ---- 1. kernel stats of the default bench
 stats = glob.glob(os.path.join(go, 'final_stats', '**', '*kernel_stats.csv'), recursive=True)[0]
@@ -66,10 +66,12 @@ alg = {'k_rgb2lab': 24 * px, 'k_slic_assign': 16 * px, 'k_slic_update': 16 * px,
        'k_pool_mean': 512 * 128 * 256 * 4 + px * 4, 'k_cell_weights': 4 * px + 128 * 256 * 16,
        'k_conn_relabel': 12 * px, 'k_ccl_merge': 8 * px}
 wide = {'k_rgb2lab', 'k_slic_assign', 'k_paint', 'k_pool_mean', 'k_pool_mean_vec<0, 1>', 'k_conn_relabel',
-        'k_cell_weights', 'k_run_rows', 'k_bbox_count_lds', 'k_seg_moments'}      # 16 B/lane streaming reads
+        'k_cell_weights', 'k_run_rows', 'k_bbox_count_lds', 'k_seg_moments', 'k_wino_in', 'k_wino_out<0>',
+        'k_conv3x3_f32<0, 256, 1, 256>', 'k_conv3x3_f32<0, 128, 9, 128>'}      # 16 B/lane streaming reads
 families = {'connectivity(all)': ('k_run_', 'k_conn_', 'k_small_bbox'),
             'segment_stats(all)': ('k_stats_', 'k_bbox_', 'k_seg_moments', 'k_offsets')}
-alias = {'k_pool_mean_vec<0, 1>': 'k_pool_mean', 'k_slic_update<4>': 'k_slic_update', 'k_kmeans<double, 2>': 'k_kmeans'}
+alias = {'k_pool_mean_vec<0, 1>': 'k_pool_mean', 'k_slic_update<4>': 'k_slic_update', 'k_slic_update2<4>': 'k_slic_update',
+         'k_kmeans<double, 2>': 'k_kmeans'}
 alg['connectivity(all)'] = 8 * px
 alg['segment_stats(all)'] = 4 * px
 lines = ['# HBM traffic per launch from PMC counters (%s), batch 8, 1024x2048, MI355X' % tag,
@@ -108,6 +110,19 @@ if 'k_bias_act_f32' in fe:
     lines.append('')
     lines.append('k_bias_act_f32 on the 512 ch + residual / 512 ch / 256 ch + residual layer shapes: %.1f MB per launch on average = %.2fx the algorithmic bytes'
                  % (hbm / 1e6, ratio['k_bias_act(all)']))
+# one Winograd layer (prof_stages.py --wino: 512 -> 512, dilation 2): input transform + the batched GEMM launch + output
+# transform against the bytes the design moves by construction (X, V written + read = 8X, M written + read = 8Y, Y)
+if 'k_wino_in' in fe:
+    tot = 0.0
+    for kname in ('k_wino_in', 'k_conv3x3_f32<0, 256, 1, 256>', 'k_wino_out<0>'):
+        key = [k for k in fe if k.replace('void ', '') == kname]
+        if key:
+            tot += fe[key[0]][1] * 1024 * 2 + wr.get(key[0], (0, 0.0))[1] * 1024
+    built = 4.0 * B * (1024 // 8) * (2048 // 8) * (9 * 512 + 9 * 512)
+    ratio['conv3x3_winograd_f32(all)'] = tot / built
+    lines.append('')
+    lines.append('Winograd layer 512 -> 512 (k_wino_in + 16 GEMMs in one k_conv3x3_f32<0,256,1,256> launch + k_wino_out): %.1f MB per '
+                 'launch = %.2fx the %.1f MB the design moves by construction (X + 8X + 8Y + Y)' % (tot / 1e6, tot / built, built / 1e6))
 passes = fe.get('k_rgb2lab', (1, 0))[0]
 lines.append('')
 lines.append('families (all launches of one pass summed; %d passes profiled):' % passes)
