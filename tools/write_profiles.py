@@ -15,11 +15,13 @@ prof = os.path.join(root, 'profiles')
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r3_final'
 
 # ---- 1. kernel stats of the default bench
-stats = glob.glob(os.path.join(go, 'final_stats', '**', '*kernel_stats.csv'), recursive=True)[0]
+stats = max(glob.glob(os.path.join(go, 'final_stats', '**', '*kernel_stats.csv'), recursive=True), key=os.path.getmtime)   # newest
 rows = list(csv.DictReader(open(stats)))
 for r in rows:
     r['short'] = re.sub(r'^void ', '', r['Name']).split('(')[0]
 ours = [r for r in rows if re.match(r'(void )?k_', r['Name'])]
+for r in ours:
+    r['short'] = re.sub(r'^void ', '', r['Name']).split('(')[0]
 ours.sort(key=lambda r: -float(r['TotalDurationNs']))
 lines = ['# %s: rocprofv3 --kernel-trace --stats of the default bench' % tag,
          'command: rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no_cpu_baseline',
