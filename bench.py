@@ -103,10 +103,12 @@ LIMITERS = {
     'k_kmeans': 'latency: numpy-ordered float64 sums (one serial chain per cluster and column, ~10 cycles per member row) and '
                 'two grid barriers per Lloyd iteration',
     'k_rgb2lab': 'DP VALU: binary64 exp/log emulation of the float32 power and cube root (bit-defined transcendental)',
-    'conv3x3_winograd_f32(all)': 'the 16 GEMMs run at ~0.82 of the float32 matrix peak (K = Cin is 16 K steps: prologue and the 4x larger '
-                                 'output tile weigh more than in the 144-step direct kernel); the two transforms stream V and M (4x the '
-                                 'activations each) through HBM: ~5 of the 21 ms of a 512 -> 512 layer',
-    'k_conv3x3_f32(all)': 'float32 MFMA pipe: 0.88-0.89 of the 157.3 TFLOP/s peak on the 256/512-channel layers (MIOpen\'s hand-written '
+    'k_conv3x3_f32<taps 1>(GEMM form, all)': 'float32 MFMA pipe.  K = Cin is 8-16 K steps per 256 x 256 tile against 144 in the 3x3 form, so the '
+                                             'tile prologue and the store of the output tile weigh more (0.83 against 0.88 of the peak) although the '
+                                             'workgroups are persistent and stage the next tile before their epilogue',
+    'k_wino_in': 'HBM: reads X, writes V = 4x X (position-major, dense rows)',
+    'k_wino_out': 'HBM: reads M = 4x Y (+ the residual), writes Y',
+    'k_conv3x3_f32<taps 9>(all)': 'float32 MFMA pipe: 0.88-0.89 of the 157.3 TFLOP/s peak on the 256/512-channel layers (MIOpen\'s hand-written '
                           'assembly reaches 0.88 on the same box, without the epilogue); the 64/128-channel layers (a sixth of the '
                           'launches\' time) run at 0.65-0.78: a K step is short there and its barrier + load wait shows',
     'k_conv3x3_bf16(all)': 'LDS-read + MFMA loop on random operands tops out at 1 220-1 300 TFLOP/s with the global loads '
@@ -331,10 +333,8 @@ def main():
     drn._EPILOGUE['bytes'] = 0
     drn._EPILOGUE['launches'] = 0
     drn._EPILOGUE['conv_flops'] = 0.0
-    drn._EPILOGUE['wino_flops'] = 0.0
-    drn._EPILOGUE['wino_direct_flops'] = 0.0
-    drn._EPILOGUE['wino_bytes'] = 0.0
-    drn._EPILOGUE['wino_launches'] = 0
+    for key in ('gemm_flops', 'gemm_launches', 'gemm_bytes', 'wino_direct_flops', 'wino_in_bytes', 'wino_out_bytes', 'wino_launches'):
+        drn._EPILOGUE[key] = 0
 
     dist.barrier()
     torch.cuda.synchronize()
@@ -359,8 +359,9 @@ def main():
     eng.raise_on_status()
     bias_bytes, bias_launches = drn._EPILOGUE['bytes'], drn._EPILOGUE['launches']
     conv_flops = drn._EPILOGUE['conv_flops']
-    wino_flops, wino_direct = drn._EPILOGUE['wino_flops'], drn._EPILOGUE['wino_direct_flops']
-    wino_bytes = drn._EPILOGUE['wino_bytes'] / max(1, drn._EPILOGUE['wino_launches'])      # per launch, by construction
+    E = drn._EPILOGUE
+    gemm_flops, wino_direct = E['gemm_flops'], E['wino_direct_flops']
+    wino_saved = wino_direct * (1.0 - 16.0 / 36.0)                 # multiplications Winograd does not execute
 
     for e in evs:
         pipe._ev = e
@@ -418,18 +419,21 @@ def main():
             tf = stem_flops(B, H, W) / (avg * 1e-3) / 1e12
             ent.update(bound='mfma', achieved=round(tf, 2), peak=FP32_MATRIX_PEAK_TF, unit='TFLOP/s',
                        frac=round(tf / FP32_MATRIX_PEAK_TF, 4), flops_per_launch=stem_flops(B, H, W))
-        elif name.startswith('conv3x3_winograd'):
-            # Winograd F(2x2,3x3) layers (input transform + 16 float32-MFMA GEMMs + output transform per launch):
-            # `achieved` = the matrix FLOPs actually executed (16/36 of the direct form's) over the whole launch,
-            # transforms included; `effective` = the direct form's FLOPs over the same time
-            tf = wino_flops / a.steps / (ms / a.steps * 1e-3) / 1e12
+        elif name.startswith('k_conv3x3_f32<taps 1>'):
+            # the GEMM form of the float32 MFMA kernel: the 1x1 projections and, above all, the 16 GEMMs of every
+            # Winograd layer (one launch each).  FLOPs = the products actually executed (a Winograd layer multiplies
+            # 16/36 of what the direct form would), counted by drn.py
+            tf = gemm_flops / a.steps / (ms / a.steps * 1e-3) / 1e12
             ent.update(bound='mfma', achieved=round(tf, 1), peak=FP32_MATRIX_PEAK_TF, unit='TFLOP/s',
-                       frac=round(tf / FP32_MATRIX_PEAK_TF, 4), flops_per_step=wino_flops / a.steps,
-                       flops_per_launch=wino_flops / max(1, n),
-                       effective_TFLOPs_direct_equivalent=round(wino_direct / a.steps / (ms / a.steps * 1e-3) / 1e12, 1),
-                       hbm_bytes_per_launch_by_construction=int(wino_bytes),
-                       hbm_GBs_by_construction=round(wino_bytes / (avg * 1e-3) / 1e9, 1),
-                       traffic=pmc_traffic(name, B, H, W, wino_bytes))
+                       frac=round(tf / FP32_MATRIX_PEAK_TF, 4), flops_per_step=gemm_flops / a.steps,
+                       flops_per_launch=gemm_flops / max(1, n),
+                       hbm_bytes_per_launch_by_construction=int(E['gemm_bytes'] / max(1, E['gemm_launches'])),
+                       traffic=pmc_traffic(name, B, H, W, E['gemm_bytes'] / max(1, E['gemm_launches'])))
+        elif name in ('k_wino_in', 'k_wino_out'):
+            ab = (E['wino_in_bytes'] if name == 'k_wino_in' else E['wino_out_bytes']) / max(1, E['wino_launches'])
+            gbs = ab / (avg * 1e-3) / 1e9
+            ent.update(bound='hbm', achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4),
+                       algorithmic_bytes_per_launch=int(ab), traffic=pmc_traffic(name, B, H, W, ab))
         elif name.startswith('k_conv3x3_'):
             # libspalign's implicit-GEMM convolutions (the stride-1 3x3 layers, bf16 or float32 matrix cores):
             # family entry over all launches; FLOPs = 2 * MACs of exactly those layers (counted by drn.py)
@@ -467,7 +471,7 @@ def main():
                 'selection': 'largest ms_per_step among all hand-written kernel families of libspalign (see `kernels`)'}
     drn_ms = stage['time_feature_maps'] / a.steps
     flops_direct = drn.flops_per_image(a.arch, H, W) * B
-    flops = flops_direct - (wino_direct - wino_flops) / a.steps        # executed: the Winograd layers multiply 16/36 as much
+    flops = flops_direct - wino_saved / a.steps                        # executed: the Winograd layers multiply 16/36 as much
     drn_tf = flops / (drn_ms * 1e-3) / 1e12
     tp = allrec[:, 4].sum(); fp = allrec[:, 2].sum(); fn = allrec[:, 3].sum()
     out = {

@@ -263,7 +263,8 @@ static int conv_f32_launch(spa_ctx *ctx, const float *x, int32_t B, int32_t H, i
 #undef C32_ATTR
         ctx->conv32_attr_done |= bit;
     }
-    SpaProfScope prof_(ctx, prof ? PROF_DRN_CONV32 : -1, s);
+    // one slot per kernel form: the 3x3 convolutions, and the GEMM form (1x1 projections and the Winograd GEMM batches)
+    SpaProfScope prof_(ctx, prof ? (TAPS == 9 ? PROF_DRN_CONV32 : PROF_DRN_GEMM32) : -1, s);
     // persistent workgroups: as many as are resident at once (LDS: one per CU for the wide tiles, two or three for the
     // 128-pixel ones), each looping over its share of the tiles
     const int per_cu = lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3);
@@ -305,6 +306,6 @@ int conv1x1_f32_raw(spa_ctx *ctx, const float *x, long long rows, int32_t Cin, c
 {
     SPA_ARG(rows > 0 && rows % 256 == 0 && rows / 256 < (1ll << 31) && zcount >= 1);
     // zcount problems in one launch: operands rows * Cin / Cout * Cin / rows * Cout elements apart
-    return conv_f32_launch<1>(ctx, x, 1, (int32_t)(rows / 256), 256, Cin, wt, Cout, nullptr, nullptr, 0, 1, y, stream, false,
+    return conv_f32_launch<1>(ctx, x, 1, (int32_t)(rows / 256), 256, Cin, wt, Cout, nullptr, nullptr, 0, 1, y, stream, true,
                               zcount, rows * Cin, (long long)Cout * Cin, rows * Cout);
 }

@@ -29,6 +29,15 @@ struct WinoGeom { int B, H, W, d, th, tw; long long T; };
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 
+// workgroup ids go round-robin over the 8 XCDs; give every XCD (= every L2) a contiguous range of tiles, so that the
+// rows two vertically adjacent tiles share are fetched into one L2, not eight (PMC: k_wino_in read 2.2x its input)
+__device__ __forceinline__ long long wino_block()
+{
+    const long long nb = gridDim.x, id = blockIdx.x;
+    const long long q = nb / 8, rem = nb % 8, xcd = id % 8, idx = id / 8;
+    return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+}
+
 // tile id -> (image, sub-grid, tile row, tile column)
 __device__ __forceinline__ void wino_tile(const WinoGeom &g, long long t, int &b, int &sy, int &sx, int &ty, int &tx)
 {
@@ -44,7 +53,7 @@ __global__ __launch_bounds__(256) void k_wino_in(const float *__restrict__ X, fl
                                                  long long Tpad)
 {
     const int c4 = C >> 2;
-    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long id = wino_block() * 256 + threadIdx.x;
     if (id >= g.T * c4) return;
     const long long t = id / c4;
     const int c = (int)(id - t * c4) << 2;
@@ -90,7 +99,7 @@ __global__ __launch_bounds__(256) void k_wino_out(const float *__restrict__ M, f
                                                   WinoGeom g, int K, long long Tpad, int relu)
 {
     const int k4 = K >> 2;
-    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long id = wino_block() * 256 + threadIdx.x;
     if (id >= g.T * k4) return;
     const long long t = id / k4;
     const int k = (int)(id - t * k4) << 2;
@@ -161,8 +170,8 @@ extern "C" int spa_conv3x3_wino_f32(spa_ctx *ctx, const float *x, int32_t B, int
     wino_geom(B, H, W, dilation, &g);
     const long long Tpad = (g.T + 255) / 256 * 256;
     SPA_ARG(g.T * (Cin > Cout ? Cin : Cout) / 4 < (1ll << 31) * 256);
-    SpaProfScope prof_(ctx, PROF_DRN_WINO, s);
     {
+        SpaProfScope prof_(ctx, PROF_WINO_IN, s);
         const long long n = g.T * (Cin / 4);
         hipLaunchKernelGGL(k_wino_in, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, v_scratch, g, Cin, Tpad);
     }
@@ -173,6 +182,7 @@ extern "C" int spa_conv3x3_wino_f32(spa_ctx *ctx, const float *x, int32_t B, int
         if (rc != SPA_OK) return rc;
     }
     {
+        SpaProfScope prof_(ctx, PROF_WINO_OUT, s);
         const long long n = g.T * (Cout / 4);
         if (residual)
             hipLaunchKernelGGL(k_wino_out<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float *)m_scratch, y,

@@ -59,7 +59,8 @@ def _conv(cin, cout, k, stride=1, dilation=1):
 # set by DRN.prepare() on a GPU: libspalign's fused bias/residual/ReLU; 'bytes' accumulates the algorithmic
 # HBM bytes of its launches (read y + write y [+ read residual]) for bench.py's roofline entry
 _EPILOGUE = {'engine': None, 'bytes': 0, 'launches': 0, 'own_conv': True, 'own_conv32': True, 'winograd': True,
-             'conv_flops': 0.0, 'wino_flops': 0.0, 'wino_direct_flops': 0.0, 'wino_bytes': 0.0, 'wino_launches': 0}
+             'conv_flops': 0.0, 'gemm_flops': 0.0, 'gemm_launches': 0, 'gemm_bytes': 0.0, 'wino_direct_flops': 0.0, 'wino_in_bytes': 0.0,
+             'wino_out_bytes': 0.0, 'wino_launches': 0}
 
 
 def conv_bias_act(conv, bn, x, residual=None, relu=True):
@@ -86,10 +87,13 @@ def conv_bias_act(conv, bn, x, residual=None, relu=True):
             # = 16/36 of the direct form's; both are counted)
             direct = 2.0 * x.shape[0] * x.shape[2] * x.shape[3] * conv.out_channels * 9 * conv.in_channels
             _EPILOGUE['wino_direct_flops'] += direct
-            _EPILOGUE['wino_flops'] += direct * 16.0 / 36.0
-            # HBM bytes by construction: X read, V (4x X) written and read, M (4x Y) written and read, Y written, R read
+            _EPILOGUE['gemm_flops'] += direct * 16.0 / 36.0
+            _EPILOGUE['gemm_launches'] += 1
+            _EPILOGUE['gemm_bytes'] += 4.0 * x.shape[0] * x.shape[2] * x.shape[3] * 4 * (conv.in_channels + conv.out_channels)   # V read, M written
+            # HBM bytes by construction: k_wino_in reads X and writes V (4x X); k_wino_out reads M (4x Y) [+ R], writes Y
             px = x.shape[0] * x.shape[2] * x.shape[3]
-            _EPILOGUE['wino_bytes'] += 4.0 * px * (9 * conv.in_channels + (10 if residual is not None else 9) * conv.out_channels)
+            _EPILOGUE['wino_in_bytes'] += 4.0 * px * 5 * conv.in_channels
+            _EPILOGUE['wino_out_bytes'] += 4.0 * px * (6 if residual is not None else 5) * conv.out_channels
             _EPILOGUE['wino_launches'] += 1
             return eng.conv3x3_wino_f32(x, wino[0], wino[1], residual, relu, conv.dilation[0])
         packed32 = getattr(conv, '_spa_packed32', None)
@@ -97,7 +101,13 @@ def conv_bias_act(conv, bn, x, residual=None, relu=True):
                 and x.is_contiguous(memory_format=torch.channels_last)
                 and (residual is None or residual.is_contiguous(memory_format=torch.channels_last))):
             # the same layers of the float32 network: libspalign's float32-MFMA implicit GEMM, epilogue fused
-            _EPILOGUE['conv_flops'] += 2.0 * x.shape[0] * x.shape[2] * x.shape[3] * conv.out_channels * packed32[0].shape[1] * conv.in_channels
+            fl = 2.0 * x.shape[0] * x.shape[2] * x.shape[3] * conv.out_channels * packed32[0].shape[1] * conv.in_channels
+            if packed32[0].shape[1] == 1:           # the GEMM form of the kernel (1x1 projection)
+                _EPILOGUE['gemm_flops'] += fl
+                _EPILOGUE['gemm_launches'] += 1
+                _EPILOGUE['gemm_bytes'] += 4.0 * x.shape[0] * x.shape[2] * x.shape[3] * (conv.in_channels + conv.out_channels)
+            else:
+                _EPILOGUE['conv_flops'] += fl
             return eng.conv3x3_f32(x, packed32[0], packed32[1], residual, relu, conv.dilation[0])
         y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation)
         vec = 4 if y.dtype == torch.float32 else 8

@@ -102,9 +102,10 @@ for k in sorted(fe):
 # the DRN epilogue kernel on the heavy layers' shapes (prof_stages.py --bias_act): bytes per launch vary with the
 # layer, so its entry is the RATIO of HBM bytes to algorithmic bytes (8 B per element, 12 with a residual)
 ratio = {}
-if 'k_bias_act_f32' in fe:
-    n_l, f_kb = fe['k_bias_act_f32']
-    w_kb = wr.get('k_bias_act_f32', (0, 0.0))[1]
+bkey = [k for k in fe if k.replace('void ', '').startswith('k_bias_act_f32')]
+if bkey:
+    n_l, f_kb = fe[bkey[0]]
+    w_kb = wr.get(bkey[0], (0, 0.0))[1]
     hbm = (f_kb * 2 + w_kb) * 1024                      # 16-byte loads: FETCH_SIZE x 2
     el = lambda C: B * C * (1024 // 8) * (2048 // 8) * 4  # bytes of one float32 activation
     alg_mean = (3 * el(512) + 2 * el(512) + 3 * el(256)) / 3.0
@@ -112,19 +113,22 @@ if 'k_bias_act_f32' in fe:
     lines.append('')
     lines.append('k_bias_act_f32 on the 512 ch + residual / 512 ch / 256 ch + residual layer shapes: %.1f MB per launch on average = %.2fx the algorithmic bytes'
                  % (hbm / 1e6, ratio['k_bias_act(all)']))
-# one Winograd layer (prof_stages.py --wino: 512 -> 512, dilation 2): input transform + the batched GEMM launch + output
-# transform against the bytes the design moves by construction (X, V written + read = 8X, M written + read = 8Y, Y)
+# one Winograd layer (prof_stages.py --wino: 512 -> 512, dilation 2): input transform, the batched GEMM launch, output
+# transform, each against the bytes it moves by construction (bench.py scales these ratios to its launches' mix)
+def hbm_of(kname):
+    key = [k for k in fe if k.replace('void ', '') == kname]
+    return (fe[key[0]][1] * 1024 * 2 + wr.get(key[0], (0, 0.0))[1] * 1024) if key else None
 if 'k_wino_in' in fe:
-    tot = 0.0
-    for kname in ('k_wino_in', 'k_conv3x3_f32<0, 256, 1, 256>', 'k_wino_out<0>'):
-        key = [k for k in fe if k.replace('void ', '') == kname]
-        if key:
-            tot += fe[key[0]][1] * 1024 * 2 + wr.get(key[0], (0, 0.0))[1] * 1024
-    built = 4.0 * B * (1024 // 8) * (2048 // 8) * (9 * 512 + 9 * 512)
-    ratio['conv3x3_winograd_f32(all)'] = tot / built
-    lines.append('')
-    lines.append('Winograd layer 512 -> 512 (k_wino_in + 16 GEMMs in one k_conv3x3_f32<0,256,1,256> launch + k_wino_out): %.1f MB per '
-                 'launch = %.2fx the %.1f MB the design moves by construction (X + 8X + 8Y + Y)' % (tot / 1e6, tot / built, built / 1e6))
+    act = 4.0 * B * (1024 // 8) * (2048 // 8) * 512           # one 512-channel activation at 1/8 resolution
+    for kname, bench_name, built, what in (
+            ('k_wino_in', 'k_wino_in', 5 * act, 'X read + V = 4X written'),
+            ('k_conv3x3_f32<0, 256, 1, 256>', 'k_conv3x3_f32<taps 1>(GEMM form, all)', 8 * act, 'V = 4X read + M = 4Y written'),
+            ('k_wino_out<0>', 'k_wino_out', 5 * act, 'M = 4Y read + Y written')):
+        h = hbm_of(kname)
+        if h:
+            ratio[bench_name] = h / built
+            traffic.pop(kname, None)
+            lines.append('%-32s %8.1f MB per launch = %.2fx the %.1f MB it moves by construction (%s)' % (kname, h / 1e6, h / built, built / 1e6, what))
 passes = fe.get('k_rgb2lab', (1, 0))[0]
 lines.append('')
 lines.append('families (all launches of one pass summed; %d passes profiled):' % passes)
