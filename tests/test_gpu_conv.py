@@ -1,0 +1,118 @@
+"""GPU tests of libspalign's own DRN convolutions (models/drn.py:230-285 layers): the float32-MFMA implicit-GEMM
+kernel in its 3x3 and 1x1 forms and the Winograd F(2x2,3x3) path, each against a float64 convolution of the same
+operands (torch, the floating-point reference of this tier) — the tolerance is the summation-order rounding of a
+float32 convolution, far inside the 1e-4 of the feature contract — and the bf16 kernel against a float32 convolution
+of the same bf16 values."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+F = torch.nn.functional
+
+
+@pytest.fixture(scope='module')
+def eng():
+    engine = importlib.import_module('superpixel-align_amd.engine')
+    e = engine.Engine()
+    yield e
+    e.close()
+
+
+def _operands(B, Cin, Cout, H, W, k, res, seed):
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    x = torch.relu(torch.randn((B, Cin, H, W), device='cuda', generator=g)).contiguous(memory_format=torch.channels_last)
+    w = torch.randn((Cout, Cin, k, k), device='cuda', generator=g) * (2.0 / (k * k * Cin)) ** 0.5
+    bias = torch.randn((Cout,), device='cuda', generator=g)
+    r = torch.randn((B, Cout, H, W), device='cuda', generator=g).contiguous(memory_format=torch.channels_last) if res else None
+    return x, w, bias, r
+
+
+def _ref64(x, w, bias, r, relu, dil):
+    y = F.conv2d(x.double(), w.double(), bias.double(), 1, dil * (w.shape[2] // 2), dil)
+    if r is not None:
+        y = y + r.double()
+    return torch.relu(y) if relu else y
+
+
+# (B, Cin, Cout, H, W, dilation, residual, relu): every channel tile (64 / 128 / 256), both pixel tiles, partial
+# tiles in x, rows whose dilated taps leave the image, the three dilations of the network
+CASES = [(2, 32, 64, 20, 300, 1, True, True), (1, 64, 64, 17, 130, 1, False, True), (2, 64, 128, 9, 70, 3, True, False),
+         (1, 128, 256, 24, 300, 2, True, True), (1, 256, 512, 8, 260, 4, False, True), (3, 96, 192, 5, 33, 1, False, False)]
+
+
+@pytest.mark.parametrize('B,Cin,Cout,H,W,dil,res,relu', CASES)
+def test_conv3x3_f32_matches_float64(eng, B, Cin, Cout, H, W, dil, res, relu):
+    x, w, bias, r = _operands(B, Cin, Cout, H, W, 3, res, 1)
+    wt = w.permute(0, 2, 3, 1).reshape(Cout, 9, Cin).contiguous()
+    y = eng.conv3x3_f32(x, wt, bias, r, relu, dil)
+    ref = _ref64(x, w, bias, r, relu, dil)
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    scale = float(ref.abs().max())
+    assert float((y.double() - ref).abs().max()) <= 4e-6 * scale
+
+
+@pytest.mark.parametrize('B,Cin,Cout,H,W', [(2, 64, 128, 20, 300), (1, 128, 256, 13, 257), (2, 256, 512, 6, 40)])
+def test_conv1x1_f32_matches_float64(eng, B, Cin, Cout, H, W):
+    """the 1x1 projection of a BasicBlock (models/drn.py:195-203): the GEMM form of the same kernel"""
+    x, w, bias, _ = _operands(B, Cin, Cout, H, W, 1, False, 2)
+    y = eng.conv3x3_f32(x, w.reshape(Cout, 1, Cin).contiguous(), bias, None, False, 1)
+    ref = _ref64(x, w, bias, None, False, 1)
+    assert float((y.double() - ref).abs().max()) <= 4e-6 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize('B,Cin,Cout,H,W,dil,res,relu', CASES + [(1, 64, 128, 7, 9, 4, False, True), (2, 32, 64, 21, 301, 3, True, True)])
+def test_conv3x3_winograd_f32_matches_float64(eng, B, Cin, Cout, H, W, dil, res, relu):
+    """Winograd F(2x2,3x3) on the sub-grids of the dilation, odd sizes (partial tiles on every sub-grid) included:
+    as close to a float64 convolution as the direct float32 kernel."""
+    x, w, bias, r = _operands(B, Cin, Cout, H, W, 3, res, 3)
+    u = eng.winograd_weights(w)
+    assert tuple(u.shape) == (16, Cout, Cin)
+    y = eng.conv3x3_wino_f32(x, u, bias, r, relu, dil)
+    ref = _ref64(x, w, bias, r, relu, dil)
+    scale = float(ref.abs().max())
+    assert float((y.double() - ref).abs().max()) <= 4e-6 * scale
+    # and it is the direct kernel's result to rounding
+    yd = eng.conv3x3_f32(x, w.permute(0, 2, 3, 1).reshape(Cout, 9, Cin).contiguous(), bias, r, relu, dil)
+    assert float((y - yd).abs().max()) <= 6e-6 * scale
+
+
+def test_winograd_layers_inside_the_network(eng):
+    """DRN-D-22 float32 with and without the Winograd / own-convolution paths: the map the pipeline pools (index 7)
+    agrees to 2e-5 of its scale (north star: 1e-4), and the Winograd path really ran."""
+    drn = importlib.import_module('superpixel-align_amd.drn')
+    synth = importlib.import_module('superpixel-align_amd.synth')
+    m = drn.create_drn('drn_d_22', device='cuda', dtype=torch.float32)
+    x = synth.synth_batch([3, 4], 256, 512)
+    E = drn._EPILOGUE
+    saved = (E['winograd'], E['own_conv32'])
+    try:
+        E['winograd'], E['own_conv32'] = True, True
+        E['wino_launches'] = 0
+        _, a = m.batch_predict(x, need=[7])
+        assert E['wino_launches'] == 9                    # layers 5-8: both channel counts >= 256
+        E['winograd'] = False
+        _, b = m.batch_predict(x, need=[7])
+        E['own_conv32'] = False
+        _, c = m.batch_predict(x, need=[7])
+    finally:
+        E['winograd'], E['own_conv32'] = saved
+    scale = float(c[7].abs().max())
+    assert float((a[7] - c[7]).abs().max()) <= 2e-5 * scale
+    assert float((b[7] - c[7]).abs().max()) <= 2e-5 * scale
+
+
+@pytest.mark.parametrize('B,Cin,Cout,H,W,dil,res', [(2, 64, 256, 16, 40, 1, False), (1, 128, 256, 24, 300, 2, True), (2, 64, 64, 20, 300, 1, True)])
+def test_conv3x3_bf16_matches_float32_of_the_same_values(eng, B, Cin, Cout, H, W, dil, res):
+    x, w, bias, r = _operands(B, Cin, Cout, H, W, 3, res, 4)
+    xb, wb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last), w.to(torch.bfloat16)
+    rb = r.to(torch.bfloat16).contiguous(memory_format=torch.channels_last) if res else None
+    y = eng.conv3x3_bf16(xb, wb.permute(0, 2, 3, 1).reshape(Cout, 9, Cin).contiguous(), bias, rb, True, dil)
+    ref = F.conv2d(xb.float(), wb.float(), bias, 1, dil, dil)
+    if res:
+        ref = ref + rb.float()
+    ref = torch.relu(ref)
+    assert float((y.float() - ref).abs().max()) <= 1e-2 * float(ref.abs().max())      # one rounding to bf16 at the end
