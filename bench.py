@@ -81,6 +81,7 @@ def parse():
                    help='integer-valued synthetic images (what decoded 8-bit PNGs are): k_rgb2lab takes its 256-entry sRGB table path')
     p.add_argument('--device_rng', action='store_true', help='anchor mode: draw the anchors on the device (spa_anchor_ranks_dev)')
     p.add_argument('--miopen_conv', action='store_true', help='leave the stride-1 3x3 layers to MIOpen (A/B against spa_conv3x3_bf16 / spa_conv3x3_f32)')
+    p.add_argument('--winograd', type=int, default=4, choices=[2, 4], help='float32: F(4x4,3x3) (default) or F(2x2,3x3) tiles')
     p.add_argument('--no_winograd', action='store_true', help='float32: direct convolution (spa_conv3x3_f32) on the 256/512-channel layers too')
     p.add_argument('--overlap', action='store_true',
                    help='run the superpixel branch on a second stream under the DRN forward (+5%% '
@@ -293,7 +294,7 @@ def main():
         mean_sampling='nearest', drn_sub_batch=a.drn_sub_batch or None, drn_streams=a.drn_streams,
         device_rng=a.device_rng)
     drn._EPILOGUE['own_conv'] = drn._EPILOGUE['own_conv32'] = not a.miopen_conv
-    drn._EPILOGUE['winograd'] = not a.no_winograd
+    drn._EPILOGUE['winograd'] = 0 if a.no_winograd else a.winograd
     model = drn.create_drn(a.arch, device='cuda:%d' % local, dtype=dtype)
     overlap = a.overlap or a.pool_mode == 'anchor'
     pipe = pipeline.LabelPipeline(args, model, overlap=overlap)
@@ -333,7 +334,7 @@ def main():
     drn._EPILOGUE['bytes'] = 0
     drn._EPILOGUE['launches'] = 0
     drn._EPILOGUE['conv_flops'] = 0.0
-    for key in ('gemm_flops', 'gemm_launches', 'gemm_bytes', 'wino_direct_flops', 'wino_in_bytes', 'wino_out_bytes', 'wino_launches'):
+    for key in ('gemm_flops', 'gemm_launches', 'gemm_bytes', 'wino_direct_flops', 'wino_saved_flops', 'wino_in_bytes', 'wino_out_bytes', 'wino_launches'):
         drn._EPILOGUE[key] = 0
 
     dist.barrier()
@@ -361,7 +362,7 @@ def main():
     conv_flops = drn._EPILOGUE['conv_flops']
     E = drn._EPILOGUE
     gemm_flops, wino_direct = E['gemm_flops'], E['wino_direct_flops']
-    wino_saved = wino_direct * (1.0 - 16.0 / 36.0)                 # multiplications Winograd does not execute
+    wino_saved = E['wino_saved_flops']                             # multiplications Winograd does not execute
 
     for e in evs:
         pipe._ev = e

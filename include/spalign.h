@@ -141,6 +141,16 @@ int spa_conv3x3_wino_f32(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int
                          int32_t relu, int32_t dilation, float *v_scratch, float *m_scratch, float *y,
                          void *stream);
 
+/* F(4x4,3x3): 4x fewer multiplications than the direct form, V / M 2.25x the activations.  Interpolation points
+ * 0, 1, -1, 1/2, -2, infinity (spa_wino.hip gives the matrices and the measured float32 accuracy: through DRN-D-22 the
+ * final map is as close to the float64 network as with direct float32 convolutions).  u (36,Cout,Cin) = (G g G^T)[6i+j];
+ * scratch of 36 * spa_wino4_tiles(...) rows; the rest as spa_conv3x3_wino_f32. */
+int64_t spa_wino4_tiles(int32_t B, int32_t H, int32_t W, int32_t dilation);
+int spa_conv3x3_wino4_f32(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                          const float *u, int32_t Cout, const float *bias, const float *residual,
+                          int32_t relu, int32_t dilation, float *v_scratch, float *m_scratch, float *y,
+                          void *stream);
+
 /* ---- input stage ---------------------------------------------------------------------------
  * replaces the host resize of ResizeImageDataset.get_example (datasets/resize_image_dataset.py:31-34:
  * chainercv.transforms.resize(image, resize_shape, 3)) as Pillow computes it on an 8-bit image, channel by

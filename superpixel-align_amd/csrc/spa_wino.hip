@@ -194,3 +194,176 @@ extern "C" int spa_conv3x3_wino_f32(spa_ctx *ctx, const float *x, int32_t B, int
     SPA_LAUNCH_CHECK();
     return SPA_OK;
 }
+
+// =========================================================================================================
+// F(4x4, 3x3): a 4x4 output tile from a 6x6 input tile with 36 instead of 144 multiplications per channel pair —
+// 4x less matrix work than the direct form, V and M 2.25x the activations instead of 4x.  Interpolation points
+// 0, 1, -1, 1/2, -2, infinity (NOT the textbook 0, +-1, +-2: measured in float32 on a 256 -> 256 layer the textbook set
+// is 1.0e-5 of the map's scale from a float64 convolution, this set 4.7e-6; through the whole DRN-D-22 the final map is
+// 1.1e-6 from the float64 network against 2.4e-6 for direct float32 convolutions and 0.8e-6 for F(2x2,3x3), tools/wino_points.py).
+//
+//   B^T = | 2 -3 -4  3  2  0 |     A^T = | 1  1  1   1    1  0 |     G = | 1/2    0     0   |
+//         | 0 -2  1  5  2  0 |           | 0  1 -1  1/2  -2  0 |         | 1/6   1/6   1/6  |
+//         | 0 -2  5 -1 -2  0 |           | 0  1  1  1/4   4  0 |         | 1/6  -1/6   1/6  |
+//         | 0  2  1 -2 -1  0 |           | 0  1 -1  1/8  -8  1 |         | 16/15 8/15  4/15 |
+//         | 0  1 -2 -1  2  0 |                                           | 1/30 -1/15  2/15 |
+//         | 0  2 -3 -4  3  2 |                                           |  0     0    1/2  |
+// (row 3 of B^T is the generated row / 16 and row 3 of G x 16: powers of two, no rounding.)
+// A thread owns one tile x 2 channels (float2): 36 values in flight.
+// =========================================================================================================
+__device__ __forceinline__ float2 f2(float a, float b) { return make_float2(a, b); }
+__device__ __forceinline__ float2 operator+(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 operator-(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 operator*(float s, float2 a) { return make_float2(s * a.x, s * a.y); }
+
+// y = B^T x for a 6-vector of float2
+__device__ __forceinline__ void wino4_bt(const float2 (&x)[6], float2 (&y)[6])
+{
+    y[0] = 2.0f * (x[0] + x[4]) + 3.0f * (x[3] - x[1]) - 4.0f * x[2];
+    y[1] = 2.0f * (x[4] - x[1]) + x[2] + 5.0f * x[3];
+    y[2] = 5.0f * x[2] - 2.0f * (x[1] + x[4]) - x[3];
+    y[3] = 2.0f * (x[1] - x[3]) + x[2] - x[4];
+    y[4] = (x[1] - x[3]) + 2.0f * (x[4] - x[2]);
+    y[5] = 2.0f * (x[1] + x[5]) + 3.0f * (x[4] - x[2]) - 4.0f * x[3];
+}
+
+// y = A^T x: 4 outputs from 6
+__device__ __forceinline__ void wino4_at(const float2 (&x)[6], float2 (&y)[4])
+{
+    y[0] = ((x[0] + x[1]) + x[2]) + (x[3] + x[4]);
+    y[1] = (x[1] - x[2]) + (0.5f * x[3] - 2.0f * x[4]);
+    y[2] = (x[1] + x[2]) + (0.25f * x[3] + 4.0f * x[4]);
+    y[3] = ((x[1] - x[2]) + (0.125f * x[3] - 8.0f * x[4])) + x[5];
+}
+
+__global__ __launch_bounds__(256) void k_wino4_in(const float *__restrict__ X, float *__restrict__ V, WinoGeom g, int C,
+                                                  long long Tpad)
+{
+    const int c2 = C >> 1;
+    const long long id = wino_block() * 256 + threadIdx.x;
+    if (id >= g.T * c2) return;
+    const long long t = id / c2;
+    const int c = (int)(id - t * c2) << 1;
+    int b, sy, sx, ty, tx;
+    wino_tile(g, t, b, sy, sx, ty, tx);
+    // columns first: r[a][:] = (row a of d) . B  (6 values), then rows: out[i][j] = sum_a Bt[i][a] r[a][j]
+    float2 r[6][6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        const int y = sy + (4 * ty - 1 + a) * g.d;
+        float2 dv[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int x = sx + (4 * tx - 1 + j) * g.d;
+            const bool ok = y >= 0 && y < g.H && x >= 0 && x < g.W;
+            dv[j] = ok ? *(const float2 *)(X + (((long long)b * g.H + y) * g.W + x) * C + c) : make_float2(0.f, 0.f);
+        }
+        wino4_bt(dv, r[a]);
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const float2 col[6] = {r[0][j], r[1][j], r[2][j], r[3][j], r[4][j], r[5][j]};
+        float2 o[6];
+        wino4_bt(col, o);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) *(float2 *)(V + ((long long)(i * 6 + j) * Tpad + t) * C + c) = o[i];
+    }
+}
+
+template <int HAS_RES>
+__global__ __launch_bounds__(256) void k_wino4_out(const float *__restrict__ M, float *__restrict__ Y,
+                                                   const float *__restrict__ bias, const float *__restrict__ R,
+                                                   WinoGeom g, int K, long long Tpad, int relu)
+{
+    const int k2 = K >> 1;
+    const long long id = wino_block() * 256 + threadIdx.x;
+    if (id >= g.T * k2) return;
+    const long long t = id / k2;
+    const int k = (int)(id - t * k2) << 1;
+    int b, sy, sx, ty, tx;
+    wino_tile(g, t, b, sy, sx, ty, tx);
+    // rows: s[:][j] = A^T m[:][j] (4 x 6), then columns
+    float2 s[4][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        float2 col[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) col[i] = *(const float2 *)(M + ((long long)(i * 6 + j) * Tpad + t) * K + k);
+        float2 o[4];
+        wino4_at(col, o);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[i][j] = o[i];
+    }
+    const float2 bv = *(const float2 *)(bias + k);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int y = sy + (4 * ty + i) * g.d;
+        float2 o[4];
+        wino4_at(s[i], o);
+        if (y >= g.H) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = sx + (4 * tx + j) * g.d;
+            if (x >= g.W) continue;
+            float2 v = o[j] + bv;
+            const long long off = (((long long)b * g.H + y) * g.W + x) * K + k;
+            if (HAS_RES) v = v + *(const float2 *)(R + off);
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
+            *(float2 *)(Y + off) = v;
+        }
+    }
+}
+
+static void wino4_geom(int B, int H, int W, int d, WinoGeom *g)
+{
+    g->B = B; g->H = H; g->W = W; g->d = d;
+    const int hs = (H + d - 1) / d, ws = (W + d - 1) / d;
+    g->th = (hs + 3) / 4; g->tw = (ws + 3) / 4;
+    g->T = (long long)B * d * d * g->th * g->tw;
+}
+
+extern "C" int64_t spa_wino4_tiles(int32_t B, int32_t H, int32_t W, int32_t dilation)
+{
+    WinoGeom g;
+    wino4_geom(B, H, W, dilation, &g);
+    return (g.T + 255) / 256 * 256;
+}
+
+// as spa_conv3x3_wino_f32 with u (36,Cout,Cin) = (G g G^T)[6i+j] of the matrices above and scratch of
+// 36 * spa_wino4_tiles rows
+extern "C" int spa_conv3x3_wino4_f32(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                                     const float *u, int32_t Cout, const float *bias, const float *residual,
+                                     int32_t relu, int32_t dilation, float *v_scratch, float *m_scratch, float *y,
+                                     void *stream)
+{
+    SPA_ARG(ctx && x && u && bias && y && v_scratch && m_scratch && B > 0 && H > 0 && W > 0 && dilation >= 1);
+    SPA_ARG(Cin % 32 == 0 && Cout % 64 == 0);
+    SPA_ARG((((uintptr_t)x | (uintptr_t)u | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)residual | (uintptr_t)v_scratch |
+              (uintptr_t)m_scratch) % 16) == 0);
+    hipStream_t s = spa_stream(stream);
+    WinoGeom g;
+    wino4_geom(B, H, W, dilation, &g);
+    const long long Tpad = (g.T + 255) / 256 * 256;
+    SPA_ARG(g.T * (Cin > Cout ? Cin : Cout) / 2 < (1ll << 31) * 256);
+    {
+        SpaProfScope prof_(ctx, PROF_WINO_IN, s);
+        const long long n = g.T * (Cin / 2);
+        hipLaunchKernelGGL(k_wino4_in, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, v_scratch, g, Cin, Tpad);
+    }
+    {
+        int rc = conv1x1_f32_raw(ctx, v_scratch, Tpad, Cin, u, Cout, m_scratch, stream, 36);
+        if (rc != SPA_OK) return rc;
+    }
+    {
+        SpaProfScope prof_(ctx, PROF_WINO_OUT, s);
+        const long long n = g.T * (Cout / 2);
+        if (residual)
+            hipLaunchKernelGGL(k_wino4_out<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float *)m_scratch, y,
+                               bias, residual, g, Cout, Tpad, relu);
+        else
+            hipLaunchKernelGGL(k_wino4_out<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float *)m_scratch, y,
+                               bias, residual, g, Cout, Tpad, relu);
+    }
+    SPA_LAUNCH_CHECK();
+    return SPA_OK;
+}

@@ -58,7 +58,7 @@ def _conv(cin, cout, k, stride=1, dilation=1):
 
 # set by DRN.prepare() on a GPU: libspalign's fused bias/residual/ReLU; 'bytes' accumulates the algorithmic
 # HBM bytes of its launches (read y + write y [+ read residual]) for bench.py's roofline entry
-_EPILOGUE = {'engine': None, 'bytes': 0, 'launches': 0, 'own_conv': True, 'own_conv32': True, 'winograd': True,
+_EPILOGUE = {'engine': None, 'bytes': 0, 'launches': 0, 'own_conv': True, 'own_conv32': True, 'winograd': 4, 'wino_saved_flops': 0.0,
              'conv_flops': 0.0, 'gemm_flops': 0.0, 'gemm_launches': 0, 'gemm_bytes': 0.0, 'wino_direct_flops': 0.0, 'wino_in_bytes': 0.0,
              'wino_out_bytes': 0.0, 'wino_launches': 0}
 
@@ -79,21 +79,24 @@ def conv_bias_act(conv, bn, x, residual=None, relu=True):
             # in its epilogue (no separate elementwise pass, one rounding to bf16)
             _EPILOGUE['conv_flops'] += 2.0 * x.shape[0] * x.shape[2] * x.shape[3] * conv.out_channels * 9 * conv.in_channels
             return eng.conv3x3_bf16(x, packed[0], packed[1], residual, relu, conv.dilation[0])
-        wino = getattr(conv, '_spa_wino', None)
-        if (wino is not None and x.dtype == torch.float32 and _EPILOGUE['own_conv32'] and _EPILOGUE['winograd']
+        tile = _EPILOGUE['winograd']                   # 4 (default), 2 or 0/False
+        wino = getattr(conv, '_spa_wino', {}).get(4 if tile == 4 else 2) if tile else None
+        if (wino is not None and x.dtype == torch.float32 and _EPILOGUE['own_conv32']
                 and x.is_contiguous(memory_format=torch.channels_last)
                 and (residual is None or residual.is_contiguous(memory_format=torch.channels_last))):
-            # the 256/512-channel layers: Winograd F(2x2,3x3), 2.25x fewer float32 multiplications (executed FLOPs
-            # = 16/36 of the direct form's; both are counted)
+            # Winograd: F(4x4,3x3) multiplies 36/144 = 1/4 of the direct form's products and expands the activations
+            # 2.25x (V, M); F(2x2,3x3) 16/36 and 4x.  Executed and direct-equivalent FLOPs are both counted.
+            frac, expand = (0.25, 2.25) if wino[0].shape[0] == 36 else (16.0 / 36.0, 4.0)
             direct = 2.0 * x.shape[0] * x.shape[2] * x.shape[3] * conv.out_channels * 9 * conv.in_channels
             _EPILOGUE['wino_direct_flops'] += direct
-            _EPILOGUE['gemm_flops'] += direct * 16.0 / 36.0
+            _EPILOGUE['wino_saved_flops'] += direct * (1.0 - frac)
+            _EPILOGUE['gemm_flops'] += direct * frac
             _EPILOGUE['gemm_launches'] += 1
-            _EPILOGUE['gemm_bytes'] += 4.0 * x.shape[0] * x.shape[2] * x.shape[3] * 4 * (conv.in_channels + conv.out_channels)   # V read, M written
-            # HBM bytes by construction: k_wino_in reads X and writes V (4x X); k_wino_out reads M (4x Y) [+ R], writes Y
             px = x.shape[0] * x.shape[2] * x.shape[3]
-            _EPILOGUE['wino_in_bytes'] += 4.0 * px * 5 * conv.in_channels
-            _EPILOGUE['wino_out_bytes'] += 4.0 * px * (6 if residual is not None else 5) * conv.out_channels
+            _EPILOGUE['gemm_bytes'] += 4.0 * px * expand * (conv.in_channels + conv.out_channels)      # V read, M written
+            # HBM bytes by construction: k_wino_in reads X and writes V; k_wino_out reads M [+ R] and writes Y
+            _EPILOGUE['wino_in_bytes'] += 4.0 * px * (1 + expand) * conv.in_channels
+            _EPILOGUE['wino_out_bytes'] += 4.0 * px * ((2 if residual is not None else 1) + expand) * conv.out_channels
             _EPILOGUE['wino_launches'] += 1
             return eng.conv3x3_wino_f32(x, wino[0], wino[1], residual, relu, conv.dilation[0])
         packed32 = getattr(conv, '_spa_packed32', None)
@@ -251,16 +254,20 @@ class DRN(nn.Module):
                 if isinstance(m, nn.Conv2d):
                     m._spa_packed = None
                     m._spa_packed32 = None
-                    m._spa_wino = None
-                    # Winograd F(2x2,3x3) where it wins (measured, 30 x 128 x 256 pixels: 256 -> 256 7.0 vs 8.5 ms,
-                    # 256 -> 512 12.3 vs 16.8, 512 -> 512 21.2 vs 33.2; 128 -> 256 ties, narrower layers lose to the
-                    # transforms' HBM traffic): both channel counts >= 256
+                    m._spa_wino = {}
+                    # Winograd where it wins (measured, 30 x 128 x 256 pixels, ms direct / F(2x2) / F(4x4)):
+                    #   512 -> 512  33.2 / 19.8 / 11.9     256 -> 512  16.8 / 11.6 / 7.0     256 -> 256  8.5 / 6.6 / 4.2
+                    #   128 -> 256   4.3 /  4.1 /  2.6     128 -> 128   2.4 /  2.4 / 1.6      64 -> 64 (256 x 512)  2.6 / - / 2.7
+                    # F(4x4,3x3) from 128 input channels up, F(2x2,3x3) (kept as an option) from 256
                     if (dtype == torch.float32 and self.folded and m.kernel_size == (3, 3) and m.stride == (1, 1)
                             and m.padding == m.dilation and m.dilation[0] == m.dilation[1] and m.groups == 1
                             and m.in_channels % 32 == 0 and m.out_channels % 64 == 0 and m.bias is not None
-                            and m.in_channels >= 256 and m.out_channels >= 256):
+                            and m.in_channels >= 128 and m.out_channels >= 128):
                         from .engine import Engine
-                        m._spa_wino = (Engine.winograd_weights(m.weight), m.bias.detach().float().contiguous())
+                        bias32 = m.bias.detach().float().contiguous()
+                        m._spa_wino[4] = (Engine.winograd_weights(m.weight, 4), bias32)
+                        if m.in_channels >= 256 and m.out_channels >= 256:
+                            m._spa_wino[2] = (Engine.winograd_weights(m.weight, 2), bias32)
                     # operands of spa_conv3x3_f32: the same layers of the float32 network (Cin % 32 == 0)
                     if (dtype == torch.float32 and self.folded and m.kernel_size == (3, 3) and m.stride == (1, 1)
                             and m.padding == m.dilation and m.dilation[0] == m.dilation[1] <= 4 and m.groups == 1

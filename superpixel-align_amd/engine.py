@@ -165,29 +165,39 @@ class Engine(object):
         return y
 
     @staticmethod
-    def winograd_weights(weight):
-        """(Cout,Cin,3,3) -> (16,Cout,Cin) float32: G g G^T of F(2x2,3x3), computed in float64, position-major."""
-        G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64, device=weight.device)
+    def winograd_weights(weight, tile=2):
+        """(Cout,Cin,3,3) -> (n*n,Cout,Cin) float32: G g G^T of F(tile x tile, 3x3), computed in float64, position-major.
+        tile 2: points 0, 1, -1, inf (n = 4); tile 4: points 0, 1, -1, 1/2, -2, inf (n = 6; csrc/spa_wino.hip)."""
+        if tile == 2:
+            G = [[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]]
+        else:
+            G = [[1 / 2, 0, 0], [1 / 6, 1 / 6, 1 / 6], [1 / 6, -1 / 6, 1 / 6], [16 / 15, 8 / 15, 4 / 15],
+                 [1 / 30, -1 / 15, 2 / 15], [0, 0, 1 / 2]]
+        G = torch.tensor(G, dtype=torch.float64, device=weight.device)
         u = torch.einsum('ij,kcjl,ml->imkc', G, weight.detach().double(), G)
-        return u.reshape(16, weight.shape[0], weight.shape[1]).float().contiguous()
+        return u.reshape(G.shape[0] ** 2, weight.shape[0], weight.shape[1]).float().contiguous()
 
     def conv3x3_wino_f32(self, x, u, bias, residual=None, relu=True, dilation=1):
-        """relu?(conv3x3(x; stride 1, padding = dilation) + bias [+ residual]) by Winograd F(2x2,3x3) on the float32
-        matrix cores.  x (B,Cin,H,W) float32 channels-last, u = winograd_weights(weight), bias (Cout) float32."""
+        """relu?(conv3x3(x; stride 1, padding = dilation) + bias [+ residual]) by Winograd F(2x2,3x3) (u of 16
+        positions) or F(4x4,3x3) (36 positions) on the float32 matrix cores.  x (B,Cin,H,W) float32 channels-last,
+        u = winograd_weights(weight, tile), bias (Cout) float32."""
         B, Cin, H, W = x.shape
-        Cout = u.shape[1]
+        npos, Cout = u.shape[0], u.shape[1]
+        assert npos in (16, 36)
         assert x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
-        assert u.dtype == torch.float32 and u.is_contiguous() and tuple(u.shape) == (16, Cout, Cin)
+        assert u.dtype == torch.float32 and u.is_contiguous() and tuple(u.shape) == (npos, Cout, Cin)
         assert bias.dtype == torch.float32 and bias.is_contiguous()
         y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
         if residual is not None:
             assert residual.dtype == torch.float32 and residual.shape == y.shape and \
                 residual.is_contiguous(memory_format=torch.channels_last)
-        T = int(self._lib.spa_wino_tiles(B, H, W, int(dilation)))
-        v = torch.empty((16, T, Cin), dtype=torch.float32, device=x.device)       # per call: stream safe
-        m = torch.empty((16, T, Cout), dtype=torch.float32, device=x.device)
-        check(self._lib.spa_conv3x3_wino_f32(self._ctx, _ptr(x), B, H, W, Cin, _ptr(u), Cout, _ptr(bias), _ptr(residual),
-                                             1 if relu else 0, int(dilation), _ptr(v), _ptr(m), _ptr(y), self._s()))
+        tiles, fn = (self._lib.spa_wino_tiles, self._lib.spa_conv3x3_wino_f32) if npos == 16 else \
+            (self._lib.spa_wino4_tiles, self._lib.spa_conv3x3_wino4_f32)
+        T = int(tiles(B, H, W, int(dilation)))
+        v = torch.empty((npos, T, Cin), dtype=torch.float32, device=x.device)       # per call: stream safe
+        m = torch.empty((npos, T, Cout), dtype=torch.float32, device=x.device)
+        check(fn(self._ctx, _ptr(x), B, H, W, Cin, _ptr(u), Cout, _ptr(bias), _ptr(residual),
+                 1 if relu else 0, int(dilation), _ptr(v), _ptr(m), _ptr(y), self._s()))
         return y
 
     def conv3x3_bf16(self, x, wt, bias, residual=None, relu=True, dilation=1):

@@ -14,6 +14,7 @@ import torch.nn.functional as F
 ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=30)
 ap.add_argument('--quick', action='store_true')
+ap.add_argument('--tile', type=int, default=4, choices=[2, 4], help='--dtype wino: F(2x2,3x3) or F(4x4,3x3)')
 ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32', 'wino'], help='fp32: spa_conv3x3_f32 against MIOpen float32')
 a = ap.parse_args()
 engine = importlib.import_module('superpixel-align_amd.engine')
@@ -90,13 +91,13 @@ def run32_1x1(B, Cin, Cout, H, W, reps=3):
           % (B, Cin, Cout, H, W, err, ms_own, fl / ms_own / 1e9, ms_full))
 
 
-def run_wino(B, Cin, Cout, H, W, dil, res, reps=3):
+def run_wino(B, Cin, Cout, H, W, dil, res, reps=3, tile=2):
     x = torch.relu(torch.randn((B, Cin, H, W), device='cuda')).contiguous(memory_format=torch.channels_last)
     w = torch.randn((Cout, Cin, 3, 3), device='cuda') * (2.0 / (9 * Cin)) ** 0.5
     bias = torch.randn((Cout,), device='cuda')
     r = torch.randn((B, Cout, H, W), device='cuda').contiguous(memory_format=torch.channels_last) if res else None
     wt = w.permute(0, 2, 3, 1).reshape(Cout, 9, Cin).contiguous()
-    u = eng.winograd_weights(w)
+    u = eng.winograd_weights(w, tile)
     y = eng.conv3x3_wino_f32(x, u, bias, r, True, dil)
     nb = min(B, 2)
     ref = F.conv2d(x[:nb].double(), w.double(), bias.double(), 1, dil, dil)
@@ -122,8 +123,8 @@ def run_wino(B, Cin, Cout, H, W, dil, res, reps=3):
     ms_w = t(lambda: eng.conv3x3_wino_f32(x, u, bias, r, True, dil))
     ms_d = t(lambda: eng.conv3x3_f32(x, wt, bias, r, True, dil))
     fl = 2.0 * B * H * W * Cout * 9 * Cin
-    print('winograd B %d %4d -> %4d %dx%d dil %d res %d | err vs float64: winograd %.2e, direct %.2e of scale | winograd %.3f ms '
-          '(%.0f effective TF) | direct %.3f ms (%.0f TF)' % (B, Cin, Cout, H, W, dil, int(res), err, err_d, ms_w, fl / ms_w / 1e9,
+    print('winograd F(%dx%d,3x3) B %d %4d -> %4d %dx%d dil %d res %d | err vs float64: winograd %.2e, direct %.2e of scale | winograd %.3f ms '
+          '(%.0f effective TF) | direct %.3f ms (%.0f TF)' % (tile, tile, B, Cin, Cout, H, W, dil, int(res), err, err_d, ms_w, fl / ms_w / 1e9,
                                                               ms_d, fl / ms_d / 1e9))
 
 
@@ -165,15 +166,16 @@ def run(B, Cin, Cout, H, W, dil, res, reps=5):
 
 
 if a.dtype == 'wino':
-    run_wino(2, 64, 64, 16, 40, 1, False)
-    run_wino(1, 128, 256, 24, 300, 2, True)
-    run_wino(2, 32, 64, 21, 301, 3, True)           # odd sizes: partial tiles on every sub-grid
-    run_wino(1, 64, 128, 7, 9, 4, False)
+    run_wino(2, 64, 64, 16, 40, 1, False, tile=a.tile)
+    run_wino(1, 128, 256, 24, 300, 2, True, tile=a.tile)
+    run_wino(2, 32, 64, 21, 301, 3, True, tile=a.tile)           # odd sizes: partial tiles on every sub-grid
+    run_wino(1, 64, 128, 7, 9, 4, False, tile=a.tile)
     if not a.quick:
         B = a.batch
+        run_wino(B, 64, 64, 256, 512, 1, True, tile=a.tile)
         for Cin, Cout, dil, res in [(128, 128, 1, True), (128, 256, 2, False), (256, 256, 2, True), (256, 512, 4, False),
                                     (512, 512, 4, True), (512, 512, 2, False), (512, 512, 1, False)]:
-            run_wino(B, Cin, Cout, 128, 256, dil, res)
+            run_wino(B, Cin, Cout, 128, 256, dil, res, tile=a.tile)
 elif a.dtype == 'fp32':
     run32(2, 64, 256, 16, 40, 1, False)
     run32(1, 128, 256, 24, 300, 2, True)
