@@ -38,7 +38,7 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
                                                              const char *__restrict__ zero_line, int B, int H, int W,
                                                              int Cin, int Cout, int dil, int relu, int xtiles,
                                                              int ntiles, int total_tiles, int zcount, long long xz,
-                                                             long long wz, long long yz)
+                                                             long long wz, long long yz, int late_prefetch)
 {
     extern __shared__ __attribute__((aligned(1024))) char lds32[];   // [2] weight tiles 32 KB | [2] pixel segments 33 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -90,6 +90,7 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
     const int ks = Cin / C32_BK;
     const int nk = TAPS * ks, ngroups = TAPS == 9 ? 3 * ks : ks;
 
+    int pw_par = 0, px_par = 0;                  // buffer parities carried from tile to tile
     auto stage_w = [&](int t, int buf) {
         const int g = TAPS == 9 ? t / 3 : t, dxi = TAPS == 9 ? t - g * 3 : 0;
         const int dyi = TAPS == 9 ? g / ks : 0, kc = g - dyi * ks;
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
         const int yy = y + (dyi - 1) * dil;
         const bool yok = yy >= 0 && yy < H;
         const char *xk = xbase + ((long long)(dyi - 1) * dil * W) * Cin * 4 + (long long)kc * C32_BK * 4 + chunk_byte;
-        char *dst = xbuf + (g & 1) * XSEG;
+        char *dst = xbuf + ((g + px_par) & 1) * XSEG;
 #pragma unroll
         for (int r = 0; r < (XTHIRD + 7) / 8; ++r) {
             const int i = r * 8 + wave;
@@ -124,6 +125,26 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
         }
     };
 
+    // GEMM form (TAPS == 1): no tap ever reads beside the tile, so the segment is exactly the BN rows of the tile —
+    // BN/64 loads per wave and K step at precomputed row addresses (a row beyond the image is clamped to the last
+    // one: its products land in columns the epilogue never stores)
+    const char *xrow[BN / 64];
+    auto locate_rows = [&]() {
+#pragma unroll
+        for (int r = 0; r < BN / 64; ++r) {
+            int px = x0 + (r * 8 + wave) * 8 + sub;
+            px = px < W ? px : W - 1;
+            xrow[r] = xbase + (long long)px * Cin * 4 + chunk_byte;
+        }
+    };
+    auto stage_x1 = [&](int g) {
+        char *dst = xbuf + ((g + px_par) & 1) * XSEG;
+#pragma unroll
+        for (int r = 0; r < BN / 64; ++r)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xrow[r] + (long long)g * C32_BK * 4),
+                                             (__attribute__((address_space(3))) void *)(dst + (r * 8 + wave) * 1024), 16, 0, 0);
+    };
+
     // ---- accumulators: wave (wm, wn) owns channels [wm*WROWS, +WROWS) x pixels [wn*NJ*16, +NJ*16)
     const int wm = wave / WN, wn = wave % WN;
     const int frow = lane & 15, fk = lane >> 4;                     // fragment row, 16-byte k chunk inside a 32-k step
@@ -133,7 +154,12 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
     const bool counted_wait = (W % BN) == 0;          // every lane of every epilogue store is live
     locate(vid);
     stage_w(0, 0);
-    stage_x(0, 0); stage_x(0, 1); stage_x(0, 2);
+    if (TAPS == 1) { locate_rows(); stage_x1(0); }
+    else { stage_x(0, 0); stage_x(0, 1); stage_x(0, 2); }
+    int e_row = 0, e_x0 = 0, e_n0 = 0;
+    float *e_y = nullptr;
+    const float *e_r = nullptr;
+    bool more = false;
   for (;;) {
     f32x4 acc[MI][NJ];
 #pragma unroll
@@ -153,17 +179,36 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
     first_tile = false;
     __syncthreads();
     for (int t = 0; t < nk; ++t) {
-        const int cur = t & 1;
+        const int cur = (t + pw_par) & 1;
         const int g = TAPS == 9 ? t / 3 : t, dxi = TAPS == 9 ? t - g * 3 : 1;
         // (the loads of the next K step go out in one burst: spreading them between the MFMA groups was
         // measured 20 % slower — every global_load_lds re-programs M0 and breaks the MFMA stream)
         if (t + 1 < nk) stage_w(t + 1, cur ^ 1);
         if (g + 1 < ngroups) {
             if (TAPS == 9) stage_x(g + 1, dxi);
-            else { stage_x(g + 1, 0); stage_x(g + 1, 1); stage_x(g + 1, 2); }
+            else stage_x1(g + 1);
         }
-        const char *lw = wbuf + cur * (BM * 128), *lx = xbuf + (g & 1) * XSEG;
-        const int xshift = C32_HALO + (dxi - 1) * dil + wn * (NJ * 16) + frow;      // segment row of fragment 0
+        if (t + 1 == nk && !late_prefetch) {
+            // LAST K step of the tile: nothing of this tile is left to load and the other buffer of each pair is
+            // free, so the NEXT tile's first K step is staged now and travels under this step's matrix work (staged
+            // after the loop it cost its full latency with the matrix pipe idle: ~7 us per tile, 5 % of a 16-step
+            // tile and 20 % of a 4-step one).  The epilogue below needs this tile's coordinates: saved first.
+            e_row = row_id; e_x0 = x0; e_n0 = n0; e_y = ybase; e_r = rbase;
+            vid += gridDim.x;
+            more = vid < all_tiles;
+            if (more) {
+                const int npw = (pw_par + nk) & 1, npx = (px_par + ngroups) & 1;
+                const int spw = pw_par, spx = px_par;
+                locate(vid);
+                pw_par = npw; px_par = npx;             // the staging lambdas address the next tile's buffers
+                stage_w(0, npw);
+                if (TAPS == 1) { locate_rows(); stage_x1(0); }
+                else { stage_x(0, 0); stage_x(0, 1); stage_x(0, 2); }
+                pw_par = spw; px_par = spx;             // this step still reads this tile's
+            }
+        }
+        const char *lw = wbuf + cur * (BM * 128), *lx = xbuf + ((g + px_par) & 1) * XSEG;
+        const int xshift = (TAPS == 9 ? C32_HALO + (dxi - 1) * dil : 0) + wn * (NJ * 16) + frow;      // segment row of fragment 0
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             // a lane's 16 bytes are channels (kk*16 + fk*4 .. +3) of its row: MFMA q of the four multiplies channel
@@ -192,17 +237,18 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
         __syncthreads();
     }
 
-    // ---- the next tile's first K step goes out now (every wave has passed the last barrier: both buffer pairs are
-    // free); the epilogue below needs the current tile's coordinates, so they are saved first
-    const int e_row = row_id, e_x0 = x0, e_n0 = n0;
-    float *e_y = ybase;
-    const float *e_r = rbase;
-    vid += gridDim.x;
-    const bool more = vid < all_tiles;
-    if (more) {
-        locate(vid);
-        stage_w(0, 0);
-        stage_x(0, 0); stage_x(0, 1); stage_x(0, 2);
+    pw_par = (pw_par + nk) & 1;
+    px_par = (px_par + ngroups) & 1;
+    if (late_prefetch) {            // A/B switch (SPA_CONV32_LATE_PREFETCH=1): stage the next tile only now
+        e_row = row_id; e_x0 = x0; e_n0 = n0; e_y = ybase; e_r = rbase;
+        vid += gridDim.x;
+        more = vid < all_tiles;
+        if (more) {
+            locate(vid);
+            stage_w(0, pw_par);
+            if (TAPS == 1) { locate_rows(); stage_x1(0); }
+            else { stage_x(0, 0); stage_x(0, 1); stage_x(0, 2); }
+        }
     }
     // ---- epilogue: lane holds channels c..c+3 (c = tile channel base + (lane>>4)*4) of pixel (lane & 15)
 #pragma unroll
@@ -272,11 +318,12 @@ static int conv_f32_launch(spa_ctx *ctx, const float *x, int32_t B, int32_t H, i
     // persistent workgroups: as many as are resident at once (LDS: one per CU for the wide tiles, two or three for the
     // 128-pixel ones), each looping over its share of the tiles
     const int per_cu = lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3);
+    const int late = getenv("SPA_CONV32_LATE_PREFETCH") ? 1 : 0;
     long long grid = (long long)ctx->n_cu * per_cu;
     if (grid > total * zcount) grid = total * zcount;
 #define C32_LAUNCH(R, M, N)                                                                                                 \
     hipLaunchKernelGGL((k_conv3x3_f32<R, M, TAPS, N>), dim3((unsigned)grid), dim3(C32_THREADS), lds, s, x, wt, bias, residual, y,  \
-                       (const char *)zero, B, H, W, Cin, Cout, dilation, relu, xtiles, ntiles, (int)total, zcount, xz, wz, yz)
+                       (const char *)zero, B, H, W, Cin, Cout, dilation, relu, xtiles, ntiles, (int)total, zcount, xz, wz, yz, late)
 #define C32_PICK(R)                                                                     \
     if (bm == 256) C32_LAUNCH(R, 256, 256);                                             \
     else if (bm == 128) { if (bn == 256) C32_LAUNCH(R, 128, 256); else C32_LAUNCH(R, 128, 128); } \
