@@ -57,6 +57,7 @@ _COMMON_FLAGS = [
     ('--no_figure', dict(action='store_true', default=False)),
     ('--balanced', dict(action='store_true', default=False)),
     ('--io_threads', dict(type=int, default=8)),
+    ('--decode_procs', dict(type=int, default=0)),       # > 0: decode PNGs in this many worker processes (shared-memory slabs)
     ('--strict_retry', dict(action='store_true', default=False)),     # k = 2: die with RecursionError where the reference does
     ('--host_resize', dict(action='store_true', default=False)),      # resize with Pillow on the host threads instead
 ]
@@ -172,6 +173,83 @@ class PinnedRing(object):
         slot[1] = torch.cuda.Event()
         slot[1].record(torch.cuda.current_stream(device))
         return t
+
+
+class ProcessDecoder(object):
+    """Batches of PNGs decoded by worker processes into shared-memory slabs that are registered as pinned host memory
+    (decode_worker.py).  take(idx) -> (images uint8 (B,H,W,3) device tensor, labels uint8 (B,H,W) device tensor, list of
+    label arrays on the host) enqueued on the current stream, or None when a frame of the batch has another size
+    than the first image of the run (the caller then decodes that batch on its threads)."""
+
+    def __init__(self, imgs_ds, labels_ds, batch, n_procs, device, depth=3, host_labels=False):
+        import multiprocessing as mp
+        from concurrent.futures import ProcessPoolExecutor
+        from multiprocessing import shared_memory
+        from . import decode_worker
+        self._w = decode_worker
+        self.imgs, self.labels, self.device = imgs_ds, labels_ds, device
+        first = imgs_ds.get_raw(0)
+        gt0 = labels_ds.get_gray(0)
+        self.ishape, self.gshape = tuple(first.shape), tuple(gt0.shape)
+        self.B, self.host_labels = batch, host_labels
+        self.ibytes = int(np.prod(self.ishape))
+        self.gbytes = int(np.prod(self.gshape))
+        slab = batch * (self.ibytes + self.gbytes)
+        self.slots = []
+        for _ in range(depth):
+            shm = shared_memory.SharedMemory(create=True, size=slab)
+            t = torch.frombuffer(shm.buf, dtype=torch.uint8)
+            try:
+                rc = torch.cuda.cudart().cudaHostRegister(t.data_ptr(), slab, 0)
+                pinned = rc is None or int(rc) == 0
+            except Exception:
+                pinned = False                      # pageable slab: the upload is staged, still correct
+            self.slots.append(dict(shm=shm, t=t, pinned=pinned, ev=None))
+        self.k = 0
+        # spawn, not fork: this process has initialised the GPU
+        self.pool = ProcessPoolExecutor(max_workers=n_procs, mp_context=mp.get_context('spawn'))
+        list(self.pool.map(decode_worker.warm, range(n_procs)))
+
+    def _src(self, ds, i):
+        p = ds._paths[i]
+        if ds._open is not None:                       # zipped dataset: (archive, member)
+            zf = getattr(ds._open, '__self__', None)
+            return (zf.filename, p)
+        return p
+
+    def take(self, idx):
+        slot = self.slots[self.k % len(self.slots)]
+        self.k += 1
+        if slot['ev'] is not None:
+            slot['ev'].synchronize()                   # the slab's last upload has finished
+        n = len(idx)
+        name = slot['shm'].name
+        tasks = [(name, j * self.ibytes, self.ishape, self._src(self.imgs, i)) for j, i in enumerate(idx)]
+        tasks += [(name, self.B * self.ibytes + j * self.gbytes, self.gshape, self._src(self.labels, i)) for j, i in enumerate(idx)]
+        shapes = list(self.pool.map(self._w.decode_into, tasks, chunksize=1))
+        if any(tuple(sh) != (self.ishape if k < n else self.gshape) for k, sh in enumerate(shapes)):
+            return None
+        t = slot['t']
+        img_h = t[:n * self.ibytes].view((n,) + self.ishape)
+        gt_h = t[self.B * self.ibytes:self.B * self.ibytes + n * self.gbytes].view((n,) + self.gshape)
+        img_d = img_h.to(self.device, non_blocking=True)
+        gt_d = gt_h.to(self.device, non_blocking=True)
+        slot['ev'] = torch.cuda.Event()
+        slot['ev'].record(torch.cuda.current_stream(self.device))
+        # the figure writer wants the labels on the host: copies, the slab comes round again before it runs
+        return img_d, gt_d, [np.array(gt_h[j].numpy()) if self.host_labels else None for j in range(n)]
+
+    def close(self):
+        self.pool.shutdown(wait=True, cancel_futures=True)
+        for s in self.slots:
+            try:
+                torch.cuda.cudart().cudaHostUnregister(s['t'].data_ptr())
+            except Exception:
+                pass
+            del s['t']
+            s['shm'].close()
+            s['shm'].unlink()
+        self.slots = []
 
 
 class ImageList(object):
@@ -464,6 +542,7 @@ def main_labelled(argv=None, get=None, make_pipe=None, originals=False, make_mod
 
     pending = []
     keep = []               # pinned buffers the writers of `pending` read from
+    decoder = None
     # the asynchronous loop: LabelPipeline on the GPU (the baselines and the stub-model tests keep the simple one)
     use_async = make_pipe is None and make_model is None
     try:
@@ -482,6 +561,18 @@ def main_labelled(argv=None, get=None, make_pipe=None, originals=False, make_mod
                 tls.stream = torch.cuda.Stream(device=tls.eng.device)
                 tls.ring = PinnedRing()
                 tls.gt_ring = PinnedRing()
+            if decoder is not None:
+                # worker processes decode images and labels into a pinned shared-memory slab; one DMA each
+                with decoder_lock:
+                    with torch.cuda.stream(tls.stream):
+                        got = decoder.take(idx)
+                        if got is not None:
+                            u8, gt_dev, gts = got
+                            shape = tuple(imgs_ds._shape) if imgs_ds._shape is not None else tuple(u8.shape[1:3])
+                            t = tls.eng.resize_bicubic_u8(u8, shape)
+                            ev = torch.cuda.Event()
+                            ev.record(tls.stream)
+                            return t, ev, gts, gt_dev
             # ground truth PNGs of the batch decode alongside its images
             gt_f = [workers.submit(labels_ds.get_gray, i) for i in idx] if use_async else None
             gts = gt_dev = ev = None
@@ -505,6 +596,10 @@ def main_labelled(argv=None, get=None, make_pipe=None, originals=False, make_mod
             del pending[:]
             del keep[:]
 
+        decoder_lock = threading.Lock()
+        if use_async and have_gpu and getattr(args, 'decode_procs', 0) > 0 and not args.host_resize and ranges:
+            decoder = ProcessDecoder(imgs_ds, labels_ds, args.batchsize, args.decode_procs, ops.engine().device,
+                                     host_labels=not args.no_figure)
         depth = 2 if use_async else 1
         queue = [loader.submit(load, lo, hi) for lo, hi in ranges[:depth]]
         if use_async:
@@ -628,6 +723,8 @@ def main_labelled(argv=None, get=None, make_pipe=None, originals=False, make_mod
         drain(ok)
         workers.shutdown()
         loader.shutdown()
+        if decoder is not None:
+            decoder.close()
     if bad:
         raise bad[0].exception()
     if ws > 1:

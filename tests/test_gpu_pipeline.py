@@ -291,6 +291,39 @@ def test_driver_gpu_input_stage_equals_host_resize(mods, synth, tmp_path):
     assert [(x['TP'], x['FP'], x['FN']) for x in a] == [(x['TP'], x['FP'], x['FN']) for x in b]
 
 
+def test_driver_process_decode_equals_thread_decode(mods, synth, tmp_path):
+    """--decode_procs N: PNGs decoded by worker processes into pinned shared-memory slabs (decode_worker.py) give the
+    same masks and result lines as the thread pool; a batch with a frame of another size falls back to the threads."""
+    from PIL import Image
+    H, W, n = 96, 192, 7
+    img_fns, lab_fns = [], []
+    for i in range(n):
+        h, w = (80, 100) if i == 5 else (H, W)
+        img = synth.synth_image(120 + i, h, w, integer_valued=True).astype(np.uint8)
+        fn = str(tmp_path / ('proc_%06d_000019_leftImg8bit.png' % i))
+        Image.fromarray(img.transpose(1, 2, 0)).save(fn)
+        lf = str(tmp_path / ('proc_%06d_000019_gtFine_labelIds.png' % i))
+        Image.fromarray(synth.synth_gt_labels(120 + i, H, W)).save(lf)
+        img_fns.append(fn); lab_fns.append(lf)
+    (tmp_path / 'imgs.txt').write_text('\n'.join(img_fns) + '\n')
+    (tmp_path / 'labs.txt').write_text('\n'.join(lab_fns) + '\n')
+    outs = []
+    for extra in (['--decode_procs', '3'], []):
+        out = tmp_path / ('out' + str(len(outs)))
+        argv = ['--superpixel_method', 'slic', '--n_slic_segments', '20', '--n_clusters', '2',
+                '--resize_shape', '64', '80', '--batchsize', '2', '--out_dir', str(out),
+                '--img_file_list', str(tmp_path / 'imgs.txt'), '--label_file_list', str(tmp_path / 'labs.txt'),
+                '--arch', 'drn_d_22', '--pool_mode', 'mean', '--no_figure'] + extra
+        assert mods.cli.main_labelled(argv) == 0
+        outs.append(out)
+    for fn in img_fns:
+        base = os.path.splitext(os.path.basename(fn))[0]
+        assert np.array_equal(np.load(outs[0] / (base + '.npy')), np.load(outs[1] / (base + '.npy'))), base
+    a = [json.loads(l) for l in open(outs[0] / 'result.json')]
+    b = [json.loads(l) for l in open(outs[1] / 'result.json')]
+    assert [(x['img_fn'], x['TP'], x['FP'], x['FN']) for x in a] == [(x['img_fn'], x['TP'], x['FP'], x['FN']) for x in b]
+
+
 def test_driver_mixed_size_batch_takes_the_host_path(mods, synth, tmp_path):
     """A batch whose source PNGs differ in size (one of them RGBA) cannot be uploaded as one 8-bit tensor: the
     input stage falls back to the host resize on the frames it already decoded and the driver writes the same

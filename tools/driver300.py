@@ -59,6 +59,7 @@ def main():
     ap.add_argument('--dtype', default='fp32')
     ap.add_argument('--arch', default='drn_d_22')
     ap.add_argument('--io_threads', type=int, default=16)
+    ap.add_argument('--decode_procs', type=int, default=0, help='decode PNGs in this many worker processes (0: threads)')
     ap.add_argument('--n_slic_segments', type=int, default=200)
     ap.add_argument('--keep', action='store_true')
     ap.add_argument('--out', default=None)
@@ -94,7 +95,8 @@ def main():
            '--resize_shape', str(a.height), str(a.width), '--batchsize', str(a.batchsize),
            '--img_file_list', os.path.join(d, 'imgs.txt'), '--label_file_list', os.path.join(d, 'labs.txt'),
            '--out_dir', out_dir, '--start_index', '0', '--end_index', str(a.n), '--no_figure',
-           '--arch', a.arch, '--dtype', a.dtype, '--pool_mode', 'mean', '--io_threads', str(a.io_threads)] + a.extra
+           '--arch', a.arch, '--dtype', a.dtype, '--pool_mode', 'mean', '--io_threads', str(a.io_threads),
+           '--decode_procs', str(a.decode_procs)] + a.extra
     t0 = time.time()
     with open(os.path.join(d, 'driver.log'), 'w') as log:
         rc = subprocess.call(cmd, stdout=log, stderr=subprocess.STDOUT, cwd=ROOT)
@@ -115,7 +117,7 @@ def main():
     n_npy = len([f for f in os.listdir(out_dir) if f.endswith('.npy')])
     rec = {
         'tool': 'tools/driver300.py', 'rc': rc, 'n_images': a.n, 'size': [a.height, a.width],
-        'batchsize': a.batchsize, 'dtype': a.dtype, 'arch': a.arch, 'io_threads': a.io_threads,
+        'batchsize': a.batchsize, 'dtype': a.dtype, 'arch': a.arch, 'io_threads': a.io_threads, 'decode_procs': a.decode_procs,
         'command': ' '.join(os.path.basename(c) if c.startswith(ROOT) else c for c in cmd[1:]).replace(d, '$D'),
         'wall_s': round(wall, 2), 'wall_images_per_s': round(a.n / wall, 2),
         'steady_images_per_s': round(steady, 2) if steady else None,
