@@ -246,28 +246,15 @@ __device__ __forceinline__ void wino4_at(const V (&x)[6], V (&y)[4])
     y[3] = ((x[1] - x[2]) + (0.125f * x[3] - 8.0f * x[4])) + x[5];
 }
 
-// F(4x4) tiles are numbered in blocks of 4 x 4 tiles (th, tw rounded up to multiples of 4; a tile beyond the image
-// reads zeros and writes nothing): consecutive workgroups then transform tiles whose 6 x 6 input patches overlap in
-// both directions while they are still in L2 (row-major numbering re-fetched the two shared rows of vertically
-// adjacent tiles from HBM: 2.25x the input read instead of ~1.3x)
+// (numbering the F(4x4) tiles in blocks of 4 x 4 tiles, so that consecutive workgroups transform tiles whose 6 x 6
+// input patches overlap in both directions, was measured: no change — the overlap is served by L2 / MALL anyway —
+// and it padded small sub-grids to multiples of 4 tiles: 4x the work on a 7 x 7 sub-grid.  Row-major it is.)
 static void wino4_geom(int B, int H, int W, int d, WinoGeom *g)
 {
     g->B = B; g->H = H; g->W = W; g->d = d;
     const int hs = (H + d - 1) / d, ws = (W + d - 1) / d;
-    g->th = ((hs + 3) / 4 + 3) / 4 * 4; g->tw = ((ws + 3) / 4 + 3) / 4 * 4;
+    g->th = (hs + 3) / 4; g->tw = (ws + 3) / 4;
     g->T = (long long)B * d * d * g->th * g->tw;
-}
-
-__device__ __forceinline__ void wino4_tile(const WinoGeom &g, long long t, int &b, int &sy, int &sx, int &ty, int &tx)
-{
-    const int in = (int)(t & 15); t >>= 4;
-    const int nbx = g.tw >> 2, nby = g.th >> 2;
-    const int bx = (int)(t % nbx); t /= nbx;
-    const int by = (int)(t % nby); t /= nby;
-    sx = (int)(t % g.d); t /= g.d;
-    sy = (int)(t % g.d);
-    b = (int)(t / g.d);
-    ty = by * 4 + (in >> 2); tx = bx * 4 + (in & 3);
 }
 
 template <typename V>
@@ -281,7 +268,7 @@ __global__ __launch_bounds__(256) void k_wino4_in(const float *__restrict__ X, f
     const long long t = id / c2;
     const int c = (int)(id - t * c2) * VN;
     int b, sy, sx, ty, tx;
-    wino4_tile(g, t, b, sy, sx, ty, tx);
+    wino_tile(g, t, b, sy, sx, ty, tx);
     // columns first: r[a][:] = (row a of d) . B  (6 values), then rows: out[i][j] = sum_a Bt[i][a] r[a][j]
     V r[6][6];
 #pragma unroll
@@ -318,7 +305,7 @@ __global__ __launch_bounds__(256) void k_wino4_out(const float *__restrict__ M, 
     const long long t = id / k2;
     const int k = (int)(id - t * k2) * VN;
     int b, sy, sx, ty, tx;
-    wino4_tile(g, t, b, sy, sx, ty, tx);
+    wino_tile(g, t, b, sy, sx, ty, tx);
     // rows: s[:][j] = A^T m[:][j] (4 x 6), then columns
     V s[4][6];
 #pragma unroll

@@ -100,6 +100,13 @@ def conv_bias_act(conv, bn, x, residual=None, relu=True):
             _EPILOGUE['wino_launches'] += 1
             return eng.conv3x3_wino_f32(x, wino[0], wino[1], residual, relu, conv.dilation[0])
         packed32 = getattr(conv, '_spa_packed32', None)
+        # the direct kernel tiles an image ROW into 256 (128) pixels: on narrow maps most of a tile is padding
+        # (28 pixels at the reference's 224 x 224 operating point: 403 images/s against 2 113 with MIOpen there), so
+        # it is used where a row fills its tiles to 80 % (the Winograd path above flattens the tiles and does not care)
+        if packed32 is not None:
+            bn = 256 if conv.out_channels % 256 == 0 else 128
+            if -(-x.shape[3] // bn) * bn > 1.25 * x.shape[3]:
+                packed32 = None
         if (packed32 is not None and x.dtype == torch.float32 and _EPILOGUE['own_conv32']
                 and x.is_contiguous(memory_format=torch.channels_last)
                 and (residual is None or residual.is_contiguous(memory_format=torch.channels_last))):
