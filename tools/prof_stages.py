@@ -27,7 +27,7 @@ ap.add_argument('--reps', type=int, default=3)
 ap.add_argument('--pool_mode', default='mean')
 ap.add_argument('--bias_act', action='store_true', help='also run the DRN epilogue kernel (k_bias_act) on the shapes of '
                 'the heavy layers, for the PMC traffic passes')
-ap.add_argument('--wino', action='store_true', help='also run one Winograd layer (512 -> 512, dilation 2) and one direct '
+ap.add_argument('--wino', action='store_true', help='also run one Winograd F(4x4,3x3) layer (512 -> 512, dilation 2) and one direct '
                 'float32 layer (128 -> 128) at 1/8 resolution, for the PMC traffic passes')
 a = ap.parse_args()
 
@@ -71,7 +71,7 @@ if a.wino:
     h, w = a.height // 8, a.width // 8
     x = torch.relu(torch.randn((a.batch, 512, h, w), device='cuda')).contiguous(memory_format=torch.channels_last)
     wt = torch.randn((512, 512, 3, 3), device='cuda') * (2.0 / (9 * 512)) ** 0.5
-    u, b = eng.winograd_weights(wt), torch.randn((512,), device='cuda')
+    u, b = eng.winograd_weights(wt, 4), torch.randn((512,), device='cuda')        # F(4x4,3x3): the network's default
     for _ in range(a.reps):
         eng.conv3x3_wino_f32(x, u, b, None, True, 2)
     x2 = torch.relu(torch.randn((a.batch, 128, h, w), device='cuda')).contiguous(memory_format=torch.channels_last)

@@ -68,7 +68,7 @@ alg = {'k_rgb2lab': 24 * px, 'k_slic_assign': 16 * px, 'k_slic_update': 16 * px,
        'k_pool_mean': 512 * 128 * 256 * 4 + px * 4, 'k_cell_weights': 4 * px + 128 * 256 * 16,
        'k_conn_relabel': 12 * px, 'k_ccl_merge': 8 * px}
 wide = {'k_rgb2lab', 'k_slic_assign', 'k_paint', 'k_pool_mean', 'k_pool_mean_vec<0, 1>', 'k_conn_relabel',
-        'k_cell_weights', 'k_run_rows', 'k_bbox_count_lds', 'k_seg_moments', 'k_wino_in', 'k_wino_out<0>',
+        'k_cell_weights', 'k_run_rows', 'k_bbox_count_lds', 'k_seg_moments', 'k_wino_in', 'k_wino_out<0>', 'k_wino4_in<float4>', 'k_wino4_out<0, float4>',
         'k_conv3x3_f32<0, 256, 1, 256>', 'k_conv3x3_f32<0, 128, 9, 128>'}      # 16 B/lane streaming reads
 families = {'connectivity(all)': ('k_run_', 'k_conn_', 'k_small_bbox'),
             'segment_stats(all)': ('k_stats_', 'k_bbox_', 'k_seg_moments', 'k_offsets')}
@@ -90,11 +90,12 @@ for k in sorted(fe):
     name = k.replace('void ', '')
     if not name.startswith('k_'):
         continue
-    f_mb = fe[k][1] * 1024 / 1e6 * (2 if name in wide else 1)
+    is_wide = name in wide or name.startswith(('k_wino4_in<', 'k_wino4_out<'))
+    f_mb = fe[k][1] * 1024 / 1e6 * (2 if is_wide else 1)
     w_mb = wr.get(k, (0, 0.0))[1] * 1024 / 1e6
     tot = f_mb + w_mb
     a = alg.get(name)
-    lines.append('%-22s %8d %11.1f%s %12.1f %12.1f %8s' % (name[:22], fe[k][0], f_mb, '*' if name in wide else ' ',
+    lines.append('%-22s %8d %11.1f%s %12.1f %12.1f %8s' % (name[:22], fe[k][0], f_mb, '*' if is_wide else ' ',
                                                           w_mb, tot, ('%.2fx' % (tot * 1e6 / (a * B))) if a else '-'))
     traffic[name] = tot * 1e6 / B
     if name in alias:
@@ -113,21 +114,22 @@ if bkey:
     lines.append('')
     lines.append('k_bias_act_f32 on the 512 ch + residual / 512 ch / 256 ch + residual layer shapes: %.1f MB per launch on average = %.2fx the algorithmic bytes'
                  % (hbm / 1e6, ratio['k_bias_act(all)']))
-# one Winograd layer (prof_stages.py --wino: 512 -> 512, dilation 2): input transform, the batched GEMM launch, output
+# one Winograd F(4x4,3x3) layer (prof_stages.py --wino: 512 -> 512, dilation 2): input transform, the batched GEMM launch, output
 # transform, each against the bytes it moves by construction (bench.py scales these ratios to its launches' mix)
 def hbm_of(kname):
-    key = [k for k in fe if k.replace('void ', '') == kname]
+    key = [k for k in fe if k.replace('void ', '').startswith(kname)]           # (pmc_summary truncates long template names)
     return (fe[key[0]][1] * 1024 * 2 + wr.get(key[0], (0, 0.0))[1] * 1024) if key else None
-if 'k_wino_in' in fe:
+if any(k.replace('void ', '').startswith('k_wino4_in') for k in fe):
     act = 4.0 * B * (1024 // 8) * (2048 // 8) * 512           # one 512-channel activation at 1/8 resolution
     for kname, bench_name, built, what in (
-            ('k_wino_in', 'k_wino_in', 5 * act, 'X read + V = 4X written'),
-            ('k_conv3x3_f32<0, 256, 1, 256>', 'k_conv3x3_f32<taps 1>(GEMM form, all)', 8 * act, 'V = 4X read + M = 4Y written'),
-            ('k_wino_out<0>', 'k_wino_out', 5 * act, 'M = 4Y read + Y written')):
+            ('k_wino4_in<', 'k_wino_in', 3.25 * act, 'X read + V = 2.25 X written'),
+            ('k_conv3x3_f32<0, 256, 1, 256>', 'k_conv3x3_f32<taps 1>(GEMM form, all)', 4.5 * act, 'V = 2.25 X read + M = 2.25 Y written'),
+            ('k_wino4_out<0', 'k_wino_out', 3.25 * act, 'M = 2.25 Y read + Y written')):
         h = hbm_of(kname)
         if h:
             ratio[bench_name] = h / built
-            traffic.pop(kname, None)
+            for tk in [k for k in traffic if k.startswith(kname)]:
+                traffic.pop(tk, None)
             lines.append('%-32s %8.1f MB per launch = %.2fx the %.1f MB it moves by construction (%s)' % (kname, h / 1e6, h / built, built / 1e6, what))
 passes = fe.get('k_rgb2lab', (1, 0))[0]
 lines.append('')
