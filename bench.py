@@ -104,7 +104,7 @@ LIMITERS = {
     'k_kmeans': 'latency: numpy-ordered float64 sums (one serial chain per cluster and column, ~10 cycles per member row) and '
                 'two grid barriers per Lloyd iteration',
     'k_rgb2lab': 'DP VALU: binary64 exp/log emulation of the float32 power and cube root (bit-defined transcendental)',
-    'k_conv3x3_f32<taps 1>(GEMM form, all)': 'float32 MFMA pipe.  K = Cin is 8-16 K steps per 256 x 256 tile against 144 in the 3x3 form, so the '
+    'k_conv3x3_f32<0, 256, 1, 256>': 'float32 MFMA pipe.  K = Cin is 8-16 K steps per 256 x 256 tile against 144 in the 3x3 form, so the '
                                              'tile prologue and the store of the output tile weigh more (0.83 against 0.88 of the peak) although the '
                                              'workgroups are persistent and stage the next tile before their epilogue',
     'k_wino_in': 'HBM: reads X, writes V = 4x X (position-major, dense rows)',
@@ -334,7 +334,7 @@ def main():
     drn._EPILOGUE['bytes'] = 0
     drn._EPILOGUE['launches'] = 0
     drn._EPILOGUE['conv_flops'] = 0.0
-    for key in ('gemm_flops', 'gemm_launches', 'gemm_bytes', 'wino_direct_flops', 'wino_saved_flops', 'wino_in_bytes', 'wino_out_bytes', 'wino_launches'):
+    for key in ('gemm_flops', 'gemm_launches', 'gemm_bytes', 'gemmn_flops', 'gemmn_launches', 'gemmn_bytes', 'wino_direct_flops', 'wino_saved_flops', 'wino_in_bytes', 'wino_out_bytes', 'wino_launches'):
         drn._EPILOGUE[key] = 0
 
     dist.barrier()
@@ -360,8 +360,8 @@ def main():
     eng.raise_on_status()
     bias_bytes, bias_launches = drn._EPILOGUE['bytes'], drn._EPILOGUE['launches']
     conv_flops = drn._EPILOGUE['conv_flops']
-    E = drn._EPILOGUE
-    gemm_flops, wino_direct = E['gemm_flops'], E['wino_direct_flops']
+    E = dict(drn._EPILOGUE)                 # snapshot: the host-to-host loop below keeps counting
+    wino_direct = E['wino_direct_flops']
     wino_saved = E['wino_saved_flops']                             # multiplications Winograd does not execute
 
     for e in evs:
@@ -420,16 +420,18 @@ def main():
             tf = stem_flops(B, H, W) / (avg * 1e-3) / 1e12
             ent.update(bound='mfma', achieved=round(tf, 2), peak=FP32_MATRIX_PEAK_TF, unit='TFLOP/s',
                        frac=round(tf / FP32_MATRIX_PEAK_TF, 4), flops_per_launch=stem_flops(B, H, W))
-        elif name.startswith('k_conv3x3_f32<taps 1>'):
-            # the GEMM form of the float32 MFMA kernel: the 1x1 projections and, above all, the 16 GEMMs of every
-            # Winograd layer (one launch each).  FLOPs = the products actually executed (a Winograd layer multiplies
-            # 16/36 of what the direct form would), counted by drn.py
-            tf = gemm_flops / a.steps / (ms / a.steps * 1e-3) / 1e12
+        elif name == 'k_conv3x3_f32<0, 256, 1, 256>' or name.startswith('k_conv3x3_f32<taps 1'):
+            # the GEMM form of the float32 MFMA kernel: the 16 / 36 GEMMs of every Winograd layer (one launch each) and
+            # the 1x1 projections.  The 256 x 256-tile instance is one entry (= one rocprofv3 row), the narrow-tile
+            # instances (128-channel layers) another.  FLOPs = the products actually executed (a Winograd layer
+            # multiplies 1/4 resp. 16/36 of what the direct form would), counted by drn.py
+            pre = 'gemm' if name == 'k_conv3x3_f32<0, 256, 1, 256>' else 'gemmn'
+            fl, nl, by = E[pre + '_flops'], max(1, E[pre + '_launches']), E[pre + '_bytes']
+            tf = fl / a.steps / (ms / a.steps * 1e-3) / 1e12
             ent.update(bound='mfma', achieved=round(tf, 1), peak=FP32_MATRIX_PEAK_TF, unit='TFLOP/s',
-                       frac=round(tf / FP32_MATRIX_PEAK_TF, 4), flops_per_step=gemm_flops / a.steps,
-                       flops_per_launch=gemm_flops / max(1, n),
-                       hbm_bytes_per_launch_by_construction=int(E['gemm_bytes'] / max(1, E['gemm_launches'])),
-                       traffic=pmc_traffic(name, B, H, W, E['gemm_bytes'] / max(1, E['gemm_launches'])))
+                       frac=round(tf / FP32_MATRIX_PEAK_TF, 4), flops_per_step=fl / a.steps, flops_per_launch=fl / nl,
+                       hbm_bytes_per_launch_by_construction=int(by / nl),
+                       traffic=pmc_traffic('k_conv3x3_f32<taps 1>(GEMM form, all)', B, H, W, by / nl))
         elif name in ('k_wino_in', 'k_wino_out'):
             ab = (E['wino_in_bytes'] if name == 'k_wino_in' else E['wino_out_bytes']) / max(1, E['wino_launches'])
             gbs = ab / (avg * 1e-3) / 1e9
@@ -494,10 +496,14 @@ def main():
         'drn': {'bound': 'mfma', 'achieved': round(drn_tf, 2), 'peak': peak_tf, 'unit': 'TFLOP/s',
                 'frac': round(drn_tf / peak_tf, 4), 'ms_per_step': round(drn_ms, 3),
                 'effective_TFLOPs_direct_equivalent': round(flops_direct / (drn_ms * 1e-3) / 1e12, 2),
-                'note': ('the stride-1 3x3 layers from 64 channels up (~93 %% of the FLOPs) are libspalign\'s implicit-GEMM '
-                         'convolution on the %s matrix cores with the bias/residual/ReLU epilogue fused (k_conv3x3_%s, see '
-                         '`kernels`), the stem is its own MFMA kernel; the stride-2 and 1x1 layers are PyTorch-ROCm (MIOpen)'
-                         % (('bf16', 'bf16') if a.dtype == 'bf16' else ('float32', 'f32'))
+                'note': ('%s' % ('float32: every stride-1 3x3 layer from 128 channels up runs as Winograd F(4x4,3x3) (input transform, 36 '
+                                 'GEMMs in one launch of the float32-MFMA kernel, output transform with the epilogue fused), the '
+                                 '64-channel layers and the 1x1 projections on the same kernel directly, the stem on its own MFMA kernel; '
+                                 'the five stride-2 layers are PyTorch-ROCm (MIOpen).  `achieved` counts the products actually '
+                                 'executed, `effective_TFLOPs_direct_equivalent` what a direct convolution would have to sustain'
+                                 if a.dtype == 'fp32' else
+                                 'bf16: the stride-1 3x3 layers from 64 channels up are libspalign\'s bf16 implicit-GEMM convolution with '
+                                 'the epilogue fused (k_conv3x3_bf16), the stem its bf16-MFMA kernel; the light layers are MIOpen')
                          if conv_flops > 0 else
                          'the big convolutions are PyTorch-ROCm (MIOpen); libspalign adds the fused float32-MFMA stem '
                          'of DRN-D (normalise + layer0 + layer1, k_drn_stem_d) and the bias/residual/ReLU epilogues')},

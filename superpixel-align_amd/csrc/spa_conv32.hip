@@ -314,7 +314,9 @@ static int conv_f32_launch(spa_ctx *ctx, const float *x, int32_t B, int32_t H, i
         ctx->conv32_attr_done |= bit;
     }
     // one slot per kernel form: the 3x3 convolutions, and the GEMM form (1x1 projections and the Winograd GEMM batches)
-    SpaProfScope prof_(ctx, prof ? (TAPS == 9 ? PROF_DRN_CONV32 : PROF_DRN_GEMM32) : -1, s);
+    // (the GEMM form's 256 x 256 instance has its own slot: it is the kernel with the most time per step, and its
+    // average must be comparable with the rocprofv3 row of exactly that instance)
+    SpaProfScope prof_(ctx, prof ? (TAPS == 9 ? PROF_DRN_CONV32 : (bm == 256 && !residual ? PROF_DRN_GEMM32 : PROF_DRN_GEMM32_N)) : -1, s);
     // persistent workgroups: as many as are resident at once (LDS: one per CU for the wide tiles, two or three for the
     // 128-pixel ones), each looping over its share of the tiles
     const int per_cu = lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3);

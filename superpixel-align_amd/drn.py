@@ -59,7 +59,8 @@ def _conv(cin, cout, k, stride=1, dilation=1):
 # set by DRN.prepare() on a GPU: libspalign's fused bias/residual/ReLU; 'bytes' accumulates the algorithmic
 # HBM bytes of its launches (read y + write y [+ read residual]) for bench.py's roofline entry
 _EPILOGUE = {'engine': None, 'bytes': 0, 'launches': 0, 'own_conv': True, 'own_conv32': True, 'winograd': 4, 'wino_saved_flops': 0.0,
-             'conv_flops': 0.0, 'gemm_flops': 0.0, 'gemm_launches': 0, 'gemm_bytes': 0.0, 'wino_direct_flops': 0.0, 'wino_in_bytes': 0.0,
+             'conv_flops': 0.0, 'gemm_flops': 0.0, 'gemm_launches': 0, 'gemm_bytes': 0.0,
+             'gemmn_flops': 0.0, 'gemmn_launches': 0, 'gemmn_bytes': 0.0, 'wino_direct_flops': 0.0, 'wino_in_bytes': 0.0,
              'wino_out_bytes': 0.0, 'wino_launches': 0}
 
 
@@ -90,10 +91,11 @@ def conv_bias_act(conv, bn, x, residual=None, relu=True):
             direct = 2.0 * x.shape[0] * x.shape[2] * x.shape[3] * conv.out_channels * 9 * conv.in_channels
             _EPILOGUE['wino_direct_flops'] += direct
             _EPILOGUE['wino_saved_flops'] += direct * (1.0 - frac)
-            _EPILOGUE['gemm_flops'] += direct * frac
-            _EPILOGUE['gemm_launches'] += 1
             px = x.shape[0] * x.shape[2] * x.shape[3]
-            _EPILOGUE['gemm_bytes'] += 4.0 * px * expand * (conv.in_channels + conv.out_channels)      # V read, M written
+            key = 'gemm' if conv.out_channels % 256 == 0 else 'gemmn'       # the 256 x 256 instance / the narrow tiles
+            _EPILOGUE[key + '_flops'] += direct * frac
+            _EPILOGUE[key + '_launches'] += 1
+            _EPILOGUE[key + '_bytes'] += 4.0 * px * expand * (conv.in_channels + conv.out_channels)     # V read, M written
             # HBM bytes by construction: k_wino_in reads X and writes V; k_wino_out reads M [+ R] and writes Y
             _EPILOGUE['wino_in_bytes'] += 4.0 * px * (1 + expand) * conv.in_channels
             _EPILOGUE['wino_out_bytes'] += 4.0 * px * ((2 if residual is not None else 1) + expand) * conv.out_channels
@@ -113,9 +115,10 @@ def conv_bias_act(conv, bn, x, residual=None, relu=True):
             # the same layers of the float32 network: libspalign's float32-MFMA implicit GEMM, epilogue fused
             fl = 2.0 * x.shape[0] * x.shape[2] * x.shape[3] * conv.out_channels * packed32[0].shape[1] * conv.in_channels
             if packed32[0].shape[1] == 1:           # the GEMM form of the kernel (1x1 projection)
-                _EPILOGUE['gemm_flops'] += fl
-                _EPILOGUE['gemm_launches'] += 1
-                _EPILOGUE['gemm_bytes'] += 4.0 * x.shape[0] * x.shape[2] * x.shape[3] * (conv.in_channels + conv.out_channels)
+                key = 'gemm' if conv.out_channels % 256 == 0 and residual is None else 'gemmn'
+                _EPILOGUE[key + '_flops'] += fl
+                _EPILOGUE[key + '_launches'] += 1
+                _EPILOGUE[key + '_bytes'] += 4.0 * x.shape[0] * x.shape[2] * x.shape[3] * (conv.in_channels + conv.out_channels)
             else:
                 _EPILOGUE['conv_flops'] += fl
             return eng.conv3x3_f32(x, packed32[0], packed32[1], residual, relu, conv.dilation[0])
