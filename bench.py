@@ -82,6 +82,8 @@ def parse():
     p.add_argument('--device_rng', action='store_true', help='anchor mode: draw the anchors on the device (spa_anchor_ranks_dev)')
     p.add_argument('--miopen_conv', action='store_true', help='leave the stride-1 3x3 layers to MIOpen (A/B against spa_conv3x3_bf16 / spa_conv3x3_f32)')
     p.add_argument('--winograd', type=int, default=4, choices=[2, 4], help='float32: F(4x4,3x3) (default) or F(2x2,3x3) tiles')
+    p.add_argument('--fp32_mfma_gemm', action='store_true', help='float32: the Winograd GEMMs on the float32 matrix instructions '
+                   '(v_mfma_f32_16x16x4_f32) instead of two half-precision planes per operand on the 16-bit ones (same accuracy, 2.7x the matrix time)')
     p.add_argument('--no_winograd', action='store_true', help='float32: direct convolution (spa_conv3x3_f32) on the 256/512-channel layers too')
     p.add_argument('--overlap', action='store_true',
                    help='run the superpixel branch on a second stream under the DRN forward (+5%% '
@@ -295,6 +297,8 @@ def main():
         device_rng=a.device_rng)
     drn._EPILOGUE['own_conv'] = drn._EPILOGUE['own_conv32'] = not a.miopen_conv
     drn._EPILOGUE['winograd'] = 0 if a.no_winograd else a.winograd
+    if a.fp32_mfma_gemm:
+        drn._EPILOGUE['split_gemm'] = False
     model = drn.create_drn(a.arch, device='cuda:%d' % local, dtype=dtype)
     overlap = a.overlap or a.pool_mode == 'anchor'
     pipe = pipeline.LabelPipeline(args, model, overlap=overlap)
@@ -334,7 +338,8 @@ def main():
     drn._EPILOGUE['bytes'] = 0
     drn._EPILOGUE['launches'] = 0
     drn._EPILOGUE['conv_flops'] = 0.0
-    for key in ('gemm_flops', 'gemm_launches', 'gemm_bytes', 'gemmn_flops', 'gemmn_launches', 'gemmn_bytes', 'wino_direct_flops', 'wino_saved_flops', 'wino_in_bytes', 'wino_out_bytes', 'wino_launches'):
+    for key in ('gemm16_flops', 'gemm16_launches', 'gemm16_bytes', 'gemm16n_flops', 'gemm16n_launches', 'gemm16n_bytes',
+                'gemm_flops', 'gemm_launches', 'gemm_bytes', 'gemmn_flops', 'gemmn_launches', 'gemmn_bytes', 'wino_direct_flops', 'wino_saved_flops', 'wino_in_bytes', 'wino_out_bytes', 'wino_launches'):
         drn._EPILOGUE[key] = 0
 
     dist.barrier()
@@ -432,6 +437,18 @@ def main():
                        frac=round(tf / FP32_MATRIX_PEAK_TF, 4), flops_per_step=fl / a.steps, flops_per_launch=fl / nl,
                        hbm_bytes_per_launch_by_construction=int(by / nl),
                        traffic=pmc_traffic('k_conv3x3_f32<taps 1>(GEMM form, all)', B, H, W, by / nl))
+        elif name.startswith('k_gemm_f16x3'):
+            # the Winograd GEMMs on the 16-bit matrix cores at float32 accuracy: every product of the float32 GEMM is three
+            # half-precision matrix products (csrc/spa_gemm16.hip).  achieved = EXECUTED half-precision FLOPs (3 x the
+            # GEMM's) against the dense 16-bit peak; float32_equivalent_tflops = the GEMM's own FLOPs per second
+            pre = 'gemm16' if name == 'k_gemm_f16x3<256, 256>' else 'gemm16n'
+            fl, nl, by = E[pre + '_flops'], max(1, E[pre + '_launches']), E[pre + '_bytes']
+            tf = fl / a.steps / (ms / a.steps * 1e-3) / 1e12
+            ent.update(bound='mfma', achieved=round(3 * tf, 1), peak=BF16_MATRIX_PEAK_TF, unit='TFLOP/s',
+                       frac=round(3 * tf / BF16_MATRIX_PEAK_TF, 4), float32_equivalent_tflops=round(tf, 1),
+                       flops_per_step=3 * fl / a.steps, flops_per_launch=3 * fl / nl,
+                       hbm_bytes_per_launch_by_construction=int(by / nl),
+                       traffic=pmc_traffic(name, B, H, W, by / nl))
         elif name in ('k_wino_in', 'k_wino_out'):
             ab = (E['wino_in_bytes'] if name == 'k_wino_in' else E['wino_out_bytes']) / max(1, E['wino_launches'])
             gbs = ab / (avg * 1e-3) / 1e9
@@ -473,6 +490,7 @@ def main():
                 'limiter': e.get('limiter'),
                 'selection': 'largest ms_per_step among all hand-written kernel families of libspalign (see `kernels`)'}
     drn_ms = stage['time_feature_maps'] / a.steps
+    split16 = a.dtype == 'fp32' and E['gemm16_launches'] + E['gemm16n_launches'] > 0
     flops_direct = drn.flops_per_image(a.arch, H, W) * B
     flops = flops_direct - wino_saved / a.steps                        # executed: the Winograd layers multiply 16/36 as much
     drn_tf = flops / (drn_ms * 1e-3) / 1e12
@@ -493,10 +511,16 @@ def main():
                    'one all_gather of score records'},
         'roofline': roof,
         'host_to_host': h2h,
-        'drn': {'bound': 'mfma', 'achieved': round(drn_tf, 2), 'peak': peak_tf, 'unit': 'TFLOP/s',
-                'frac': round(drn_tf / peak_tf, 4), 'ms_per_step': round(drn_ms, 3),
+        'drn': {'bound': 'mfma' if not split16 else 'mixed: 16-bit mfma (GEMMs) + hbm (Winograd transforms)',
+                'achieved': round(drn_tf, 2), 'peak': peak_tf if not split16 else None, 'unit': 'TFLOP/s',
+                'frac': round(drn_tf / peak_tf, 4) if not split16 else None, 'ms_per_step': round(drn_ms, 3),
                 'effective_TFLOPs_direct_equivalent': round(flops_direct / (drn_ms * 1e-3) / 1e12, 2),
-                'note': ('%s' % ('float32: every stride-1 3x3 layer from 128 channels up runs as Winograd F(4x4,3x3) (input transform, 36 '
+                'note': ('%s' % (('float32 with the Winograd GEMMs on the 16-bit matrix cores: every float32 operand of a GEMM is two half-precision '
+                                  'planes (22 significand bits after an exact power-of-two scaling) and every product three '
+                                  'v_mfma_f32_16x16x32_f16 accumulated in float32 — the final map is as close to the float64 network as with '
+                                  'float32 operands (DESIGN.md section 4); `achieved` = float32-equivalent FLOPs of the network per second, '
+                                  'which the float32 matrix peak (157 TFLOP/s) no longer bounds.  ' if split16 else '') +
+                                 'float32: every stride-1 3x3 layer from 128 channels up runs as Winograd F(4x4,3x3) (input transform, 36 '
                                  'GEMMs in one launch of the float32-MFMA kernel, output transform with the epilogue fused), the '
                                  '64-channel layers and the 1x1 projections on the same kernel directly, the stem on its own MFMA kernel; '
                                  'the five stride-2 layers are PyTorch-ROCm (MIOpen).  `achieved` counts the products actually '

@@ -151,6 +151,22 @@ int spa_conv3x3_wino4_f32(spa_ctx *ctx, const float *x, int32_t B, int32_t H, in
                           int32_t relu, int32_t dilation, float *v_scratch, float *m_scratch, float *y,
                           void *stream);
 
+/* F(4x4,3x3) with its 36 GEMMs on the 16-bit matrix cores at float32 accuracy (spa_gemm16.hip): every float32 operand,
+ * after an exact power-of-two scaling, is two half-precision planes h = rn(x), l = rn(x - h) (22 significand bits) and a
+ * product is three matrix instructions ah.bh + ah.bl + al.bh accumulated in float32; through DRN-D-22 the final map is as
+ * close to the float64 network as with float32 operands (tools/wino_network_error.py).
+ *   u2      (36, Cout, Cin/32, 2, 32) half precision: the planes of t_ij * (G g G^T)[6i+j], t_ij a power of two
+ *   cs      36 floats (host): 2^(p_i + p_j) / t_ij, p = 4 4 4 3 3 4 (the input transform's growth per row)
+ *   amax_in device word: bit pattern of a bound on max |x| (spa_amax_f32, or the amax_out of the call that produced x)
+ *   amax_out device word that receives that bound for y, or NULL
+ * v_scratch 36 * spa_wino4_tiles(...) * Cin * 4 bytes, m_scratch 36 * spa_wino4_tiles(...) * Cout floats; Cout % 128 == 0;
+ * the rest as spa_conv3x3_wino4_f32. */
+int spa_amax_f32(spa_ctx *ctx, const float *x, int64_t n, void *amax, void *stream);
+int spa_conv3x3_wino4_f16s(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                           const void *u2, const float *cs, int32_t Cout, const float *bias, const float *residual,
+                           int32_t relu, int32_t dilation, const void *amax_in, void *amax_out, void *v_scratch,
+                           float *m_scratch, float *y, void *stream);
+
 /* ---- input stage ---------------------------------------------------------------------------
  * replaces the host resize of ResizeImageDataset.get_example (datasets/resize_image_dataset.py:31-34:
  * chainercv.transforms.resize(image, resize_shape, 3)) as Pillow computes it on an 8-bit image, channel by

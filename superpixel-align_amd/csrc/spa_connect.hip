@@ -1494,11 +1494,69 @@ __global__ __launch_bounds__(256) void k_conn_resolve(const int *__restrict__ li
     }
 }
 
+// the final labels of an image WITHOUT an oversize component, straight from the run tables (round 3): a workgroup per
+// row looks up, per run, the final label of the run's component (root run -> its first pixel -> final_) and streams
+// the row out — the label image is written once and nothing per-pixel is read (k_conn_relabel below reads
+// parent[pixel] and gathers final_[parent] per pixel: 12 B per pixel instead of 4 + the row's run table)
+__global__ __launch_bounds__(256) void k_run_relabel(const int *__restrict__ up, const int *__restrict__ runs,
+                                                     const int *__restrict__ rowcnt, const int *__restrict__ final_,
+                                                     const ConnMisc *__restrict__ misc, int32_t *__restrict__ out,
+                                                     int H, int W)
+{
+    extern __shared__ int lds_r[];                 // start x [W] | final label [W]
+    const int b = blockIdx.y, y = blockIdx.x;
+    if (misc[b].n_over > 0) return;                // its components were cut at pixel level: k_conn_relabel
+    const int tid = threadIdx.x;
+    const long long npix = (long long)H * W;
+    const int *UP = up + b * npix, *RA = runs + b * npix, *F = final_ + b * npix;
+    const int *R = RA + (long long)y * W;
+    int32_t *O = out + b * npix + (long long)y * W;
+    const int cnt = rowcnt[(long long)b * H + y];
+    int *sx = lds_r, *sl = lds_r + W;
+    for (int k = tid; k < cnt; k += 256) {
+        const int r = UP[y * W + k];                            // root run id = ry * W + rk
+        const int f = F[(r / W) * W + RA[r]];                    // final_ of the component's first pixel
+        sx[k] = R[k];
+        sl[k] = f < 0 ? 0 : f;
+    }
+    __syncthreads();
+    const bool vec = (W & 3) == 0;
+    for (int x0 = 0; x0 < W; x0 += RUN_CHUNK) {
+        const int xb = x0 + tid * 8;
+        if (xb >= W) continue;
+        int lo = 0, hi = cnt - 1;                               // run of pixel xb: last start <= xb
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (sx[mid] <= xb) lo = mid; else hi = mid - 1;
+        }
+        int k = lo;
+        int nxt = (k + 1 < cnt) ? sx[k + 1] : W;
+        int cur = sl[k];
+        int o8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int x = xb + i;
+            if (x >= nxt && x < W) { ++k; cur = sl[k]; nxt = (k + 1 < cnt) ? sx[k + 1] : W; }
+            o8[i] = cur;
+        }
+        if (vec && xb + 7 < W) {
+            *(int4 *)(O + xb) = make_int4(o8[0], o8[1], o8[2], o8[3]);
+            *(int4 *)(O + xb + 4) = make_int4(o8[4], o8[5], o8[6], o8[7]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (xb + i < W) O[xb + i] = o8[i];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_conn_relabel(const int *__restrict__ parent,
                                                       const int *__restrict__ final_,
+                                                      const ConnMisc *__restrict__ misc,
                                                       int32_t *__restrict__ out, int npix)
 {
     const int b = blockIdx.y;
+    if (misc[b].n_over == 0) return;               // relabelled from its run tables (k_run_relabel)
     const long long o = (long long)b * npix;
     for (int p = blockIdx.x * 256 + threadIdx.x; p < npix; p += gridDim.x * 256) {
         int f = final_[o + parent[o + p]];
@@ -1571,6 +1629,7 @@ extern "C" int spa_enforce_connectivity(spa_ctx *ctx, const int32_t *labels_in, 
     if ((size_t)3 * W * 4 > 48 * 1024 && !(ctx->conn_attr_done & 2)) {
         SPA_HIP(hipFuncSetAttribute((const void *)k_run_border, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         SPA_HIP(hipFuncSetAttribute((const void *)k_run_expand, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        SPA_HIP(hipFuncSetAttribute((const void *)k_run_relabel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         ctx->conn_attr_done |= 2;
     }
     const int n_strips = (H + STRIP_ROWS - 1) / STRIP_ROWS;
@@ -1648,7 +1707,9 @@ extern "C" int spa_enforce_connectivity(spa_ctx *ctx, const int32_t *labels_in, 
     hipLaunchKernelGGL(k_conn_resolve, dim3(64, B), dim3(256), 0, s, big, 1, misc, final_, npix);
     int gr = (npix + 255) / 256;
     if (gr > 2048) gr = 2048;
-    hipLaunchKernelGGL(k_conn_relabel, dim3(gr, B), dim3(256), 0, s, parent, final_, labels_out, npix);
+    hipLaunchKernelGGL(k_run_relabel, dim3(H, B), dim3(256), (size_t)2 * W * 4, s, (const int *)rup, (const int *)runs,
+                       (const int *)rowcnt, (const int *)final_, (const ConnMisc *)misc, labels_out, H, W);
+    hipLaunchKernelGGL(k_conn_relabel, dim3(gr, B), dim3(256), 0, s, parent, final_, (const ConnMisc *)misc, labels_out, npix);
     SPA_LAUNCH_CHECK();
     return SPA_OK;
 }

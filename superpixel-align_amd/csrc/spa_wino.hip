@@ -338,6 +338,163 @@ __global__ __launch_bounds__(256) void k_wino4_out(const float *__restrict__ M, 
     }
 }
 
+// =========================================================================================================
+// F(4x4, 3x3) with the GEMMs on the 16-bit matrix cores at float32 accuracy (spa_gemm16.hip): V is written as two
+// half-precision planes of an exactly (power-of-two) scaled value.
+//   scale of position (i, j):  2^(14 - e - p_i - p_j),  e = exponent of amax >= max |x| over the layer input,
+//   p = ceil(log2(row sums of |B^T|)) = 4 4 4 3 3 4  ->  |V_ij| <= 2^(p_i + p_j) amax, scaled magnitude < 2^15:
+//   half precision cannot overflow, and what it loses at the small end is 2^-25 of that bound in absolute terms
+//   (2^-40 of the layer's largest activation) — its 40 binades are enough for float32-class accuracy of the sums.
+// amax comes from the producer of x (k_wino4_out tracks the maximum of what it stores; k_amax for other producers);
+// the weights' planes carry a static per-position scale t_ij, and k_wino4_out undoes both (cs[i][j] = 2^(p_i+p_j) / t_ij
+// from the host, 2^(e - 14) from amax) while it reads M.
+// =========================================================================================================
+struct WinoScale { float c[36]; };
+
+__device__ __forceinline__ int wino_amax_exp(unsigned bits)
+{
+    int e = (int)(bits >> 23) - 127;
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    return bits == 0u ? 0 : e;
+}
+__device__ __forceinline__ float wino_pow2(int k) { return __uint_as_float((unsigned)(127 + k) << 23); }
+
+// amax[0] = bits of max |x| (as unsigned: non-negative floats order like their bit patterns)
+__global__ __launch_bounds__(256) void k_amax(const float4 *__restrict__ x, long long n4, unsigned *__restrict__ amax)
+{
+    __shared__ unsigned red[4];
+    unsigned m = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 v = x[i];
+        m = max(max(m, __float_as_uint(v.x) & 0x7fffffffu), max(__float_as_uint(v.y) & 0x7fffffffu,
+                max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu)));
+    }
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(red[0], red[1]), max(red[2], red[3]));
+        if (m > *(volatile unsigned *)amax) atomicMax(amax, m);
+    }
+}
+
+__device__ __forceinline__ unsigned wino_pack_h2(float a, float b)
+{
+    const _Float16 ha = (_Float16)a, hb = (_Float16)b;
+    return (unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16);
+}
+
+// one thread = one tile x 4 channels; a lane pair (8 channels) writes 16 bytes of the h plane (even lane) and 16 bytes of
+// the l plane (odd lane) per position
+__global__ __launch_bounds__(256) void k_wino4_in_split(const float *__restrict__ X, char *__restrict__ Vout, WinoGeom g, int C,
+                                                        long long Tpad, const unsigned *__restrict__ amax)
+{
+    const int c4 = C >> 2;
+    const long long id = wino_block() * 256 + threadIdx.x;
+    if (id >= g.T * c4) return;
+    const long long t = id / c4;
+    const int c = (int)(id - t * c4) << 2;
+    int b, sy, sx, ty, tx;
+    wino_tile(g, t, b, sy, sx, ty, tx);
+    const float sb = wino_pow2(14 - wino_amax_exp(*amax));
+    float4 r[6][6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        const int y = sy + (4 * ty - 1 + a) * g.d;
+        float4 dv[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int x = sx + (4 * tx - 1 + j) * g.d;
+            const bool ok = y >= 0 && y < g.H && x >= 0 && x < g.W;
+            dv[j] = ok ? *(const float4 *)(X + (((long long)b * g.H + y) * g.W + x) * C + c) : wino_zero<float4>();
+        }
+        wino4_bt(dv, r[a]);
+    }
+    const bool odd = threadIdx.x & 1;
+    // byte offset of this lane's 16 bytes inside a row: the 8-channel group's h chunk (even lane) or l chunk (odd lane)
+    const int c8 = c & ~7;
+    const long long rowoff = (long long)(c8 >> 5) * 128 + (c8 & 31) * 2 + (odd ? 64 : 0);
+    constexpr float pw[6] = {0.0625f, 0.0625f, 0.0625f, 0.125f, 0.125f, 0.0625f};     // 2^-p
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const float4 col[6] = {r[0][j], r[1][j], r[2][j], r[3][j], r[4][j], r[5][j]};
+        float4 o[6];
+        wino4_bt(col, o);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const float sc = sb * (pw[i] * pw[j]);
+            const float v0 = o[i].x * sc, v1 = o[i].y * sc, v2 = o[i].z * sc, v3 = o[i].w * sc;
+            const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1, h2 = (_Float16)v2, h3 = (_Float16)v3;
+            uint2 hh, ll;
+            hh.x = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+            hh.y = (unsigned)__builtin_bit_cast(unsigned short, h2) | ((unsigned)__builtin_bit_cast(unsigned short, h3) << 16);
+            ll.x = wino_pack_h2(v0 - (float)h0, v1 - (float)h1);
+            ll.y = wino_pack_h2(v2 - (float)h2, v3 - (float)h3);
+            // the even lane hands its l to the odd lane and receives the odd lane's h (quad_perm 1,0,3,2)
+            const unsigned sx_ = odd ? hh.x : ll.x, sy_ = odd ? hh.y : ll.y;
+            const unsigned rx_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)sx_, 0xB1, 0xF, 0xF, true);
+            const unsigned ry_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)sy_, 0xB1, 0xF, 0xF, true);
+            const uint4 st = odd ? make_uint4(rx_, ry_, ll.x, ll.y) : make_uint4(hh.x, hh.y, rx_, ry_);
+            *(uint4 *)(Vout + ((long long)(i * 6 + j) * Tpad + t) * C * 4 + rowoff) = st;
+        }
+    }
+}
+
+// k_wino4_out for the scaled GEMMs: M[i][j] * cs[i][j] * 2^(e - 14); optionally the maximum of what it stores
+template <int HAS_RES>
+__global__ __launch_bounds__(256, 2) void k_wino4_out_s(const float *__restrict__ M, float *__restrict__ Y,
+                                                     const float *__restrict__ bias, const float *__restrict__ R,
+                                                     WinoGeom g, int K, long long Tpad, int relu, WinoScale cs,
+                                                     const unsigned *__restrict__ amax_in, unsigned *__restrict__ amax_out)
+{
+    const int k2 = K >> 2;
+    const long long id = wino_block() * 256 + threadIdx.x;
+    unsigned mx = 0;
+    if (id < g.T * k2) {
+        const long long t = id / k2;
+        const int k = (int)(id - t * k2) << 2;
+        int b, sy, sx, ty, tx;
+        wino_tile(g, t, b, sy, sx, ty, tx);
+        const float inv = wino_pow2(wino_amax_exp(*amax_in) - 14);
+        float4 s[4][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            float4 col[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                col[i] = (cs.c[i * 6 + j] * inv) * *(const float4 *)(M + ((long long)(i * 6 + j) * Tpad + t) * K + k);
+            float4 o[4];
+            wino4_at(col, o);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s[i][j] = o[i];
+        }
+        const float4 bv = *(const float4 *)(bias + k);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int y = sy + (4 * ty + i) * g.d;
+            float4 o[4];
+            wino4_at(s[i], o);
+            if (y >= g.H) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int x = sx + (4 * tx + j) * g.d;
+                if (x >= g.W) continue;
+                float4 v = o[j] + bv;
+                const long long off = (((long long)b * g.H + y) * g.W + x) * K + k;
+                if (HAS_RES) v = v + *(const float4 *)(R + off);
+                if (relu) v = wino_relu(v);
+                *(float4 *)(Y + off) = v;
+                mx = max(max(mx, __float_as_uint(v.x) & 0x7fffffffu), max(__float_as_uint(v.y) & 0x7fffffffu,
+                         max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu)));
+            }
+        }
+    }
+    if (amax_out) {
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+        if ((threadIdx.x & 63) == 0 && mx > *(volatile unsigned *)amax_out) atomicMax(amax_out, mx);
+    }
+}
+
 extern "C" int64_t spa_wino4_tiles(int32_t B, int32_t H, int32_t W, int32_t dilation)
 {
     WinoGeom g;
@@ -395,6 +552,68 @@ extern "C" int spa_conv3x3_wino4_f32(spa_ctx *ctx, const float *x, int32_t B, in
                 hipLaunchKernelGGL((k_wino4_out<0, float4>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float *)m_scratch, y,
                                    bias, residual, g, Cout, Tpad, relu);
         }
+    }
+    SPA_LAUNCH_CHECK();
+    return SPA_OK;
+}
+
+int gemm_f16x3_raw(spa_ctx *ctx, const void *x, long long rows, int32_t Cin, const void *wt, int32_t Cout, float *y,
+                   void *stream, int zcount);          // spa_gemm16.hip
+
+// amax[0] = bit pattern of max |x| over n floats (n a multiple of 4): the scale input of spa_conv3x3_wino4_f16s for a
+// tensor whose producer did not track it
+extern "C" int spa_amax_f32(spa_ctx *ctx, const float *x, int64_t n, void *amax, void *stream)
+{
+    SPA_ARG(ctx && x && amax && n > 0 && n % 4 == 0 && ((uintptr_t)x % 16) == 0);
+    hipStream_t s = spa_stream(stream);
+    SPA_HIP(hipMemsetAsync(amax, 0, 4, s));
+    long long blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_amax, dim3((unsigned)blocks), dim3(256), 0, s, (const float4 *)x, (long long)(n / 4), (unsigned *)amax);
+    SPA_LAUNCH_CHECK();
+    return SPA_OK;
+}
+
+// F(4x4,3x3) with the 36 GEMMs on the 16-bit matrix cores at float32 accuracy.  u2: the two-plane form of the scaled
+// (G g G^T)[6i+j] (36, Cout, Cin/32, 2, 32) half precision; cs: 36 floats 2^(p_i + p_j) / t_ij (host); amax_in: device
+// word holding the bit pattern of a bound on max |x| (spa_amax_f32, or the amax_out of the call that produced x);
+// amax_out: device word that receives the bound for y, or NULL.  The rest as spa_conv3x3_wino4_f32.
+extern "C" int spa_conv3x3_wino4_f16s(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                                      const void *u2, const float *cs, int32_t Cout, const float *bias,
+                                      const float *residual, int32_t relu, int32_t dilation, const void *amax_in,
+                                      void *amax_out, void *v_scratch, float *m_scratch, float *y, void *stream)
+{
+    SPA_ARG(ctx && x && u2 && cs && bias && y && v_scratch && m_scratch && amax_in && B > 0 && H > 0 && W > 0 && dilation >= 1);
+    SPA_ARG(Cin % 32 == 0 && Cout % 128 == 0);
+    SPA_ARG((((uintptr_t)x | (uintptr_t)u2 | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)residual | (uintptr_t)v_scratch |
+              (uintptr_t)m_scratch) % 16) == 0);
+    hipStream_t s = spa_stream(stream);
+    WinoGeom g;
+    wino4_geom(B, H, W, dilation, &g);
+    const long long Tpad = (g.T + 255) / 256 * 256;
+    SPA_ARG(g.T * (Cin > Cout ? Cin : Cout) / 4 < (1ll << 31) * 256);
+    WinoScale sc;
+    for (int i = 0; i < 36; ++i) sc.c[i] = cs[i];
+    if (amax_out) SPA_HIP(hipMemsetAsync(amax_out, 0, 4, s));
+    {
+        SpaProfScope prof_(ctx, PROF_WINO_IN, s);
+        const long long n = g.T * (Cin / 4);
+        hipLaunchKernelGGL(k_wino4_in_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, (char *)v_scratch, g, Cin, Tpad,
+                           (const unsigned *)amax_in);
+    }
+    {
+        int rc = gemm_f16x3_raw(ctx, v_scratch, Tpad, Cin, u2, Cout, m_scratch, stream, 36);
+        if (rc != SPA_OK) return rc;
+    }
+    {
+        SpaProfScope prof_(ctx, PROF_WINO_OUT, s);
+        const long long n = g.T * (Cout / 4);
+        if (residual)
+            hipLaunchKernelGGL((k_wino4_out_s<1>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float *)m_scratch, y,
+                               bias, residual, g, Cout, Tpad, relu, sc, (const unsigned *)amax_in, (unsigned *)amax_out);
+        else
+            hipLaunchKernelGGL((k_wino4_out_s<0>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float *)m_scratch, y,
+                               bias, residual, g, Cout, Tpad, relu, sc, (const unsigned *)amax_in, (unsigned *)amax_out);
     }
     SPA_LAUNCH_CHECK();
     return SPA_OK;

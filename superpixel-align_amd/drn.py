@@ -33,6 +33,7 @@ Module names follow the upstream checkpoint (conv1/bn1/layerN.M.convK/downsample
 `models/drn_c_26.npz` (Chainer) loads through `load_chainer_npz`.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -61,7 +62,12 @@ def _conv(cin, cout, k, stride=1, dilation=1):
 _EPILOGUE = {'engine': None, 'bytes': 0, 'launches': 0, 'own_conv': True, 'own_conv32': True, 'winograd': 4, 'wino_saved_flops': 0.0,
              'conv_flops': 0.0, 'gemm_flops': 0.0, 'gemm_launches': 0, 'gemm_bytes': 0.0,
              'gemmn_flops': 0.0, 'gemmn_launches': 0, 'gemmn_bytes': 0.0, 'wino_direct_flops': 0.0, 'wino_in_bytes': 0.0,
-             'wino_out_bytes': 0.0, 'wino_launches': 0}
+             'wino_out_bytes': 0.0, 'wino_launches': 0,
+             # F(4x4,3x3) GEMMs on the 16-bit matrix cores at float32 accuracy (two half-precision planes per operand, three
+             # products: csrc/spa_gemm16.hip); SPA_SPLIT_GEMM=0 keeps the float32 matrix instructions
+             'split_gemm': os.environ.get('SPA_SPLIT_GEMM', '1') != '0',
+             'gemm16_flops': 0.0, 'gemm16_launches': 0, 'gemm16_bytes': 0.0,
+             'gemm16n_flops': 0.0, 'gemm16n_launches': 0, 'gemm16n_bytes': 0.0}
 
 
 def conv_bias_act(conv, bn, x, residual=None, relu=True):
@@ -92,7 +98,10 @@ def conv_bias_act(conv, bn, x, residual=None, relu=True):
             _EPILOGUE['wino_direct_flops'] += direct
             _EPILOGUE['wino_saved_flops'] += direct * (1.0 - frac)
             px = x.shape[0] * x.shape[2] * x.shape[3]
+            split = wino[0].shape[0] == 36 and _EPILOGUE['split_gemm'] and conv._spa_wino.get('4s')
             key = 'gemm' if conv.out_channels % 256 == 0 else 'gemmn'       # the 256 x 256 instance / the narrow tiles
+            if split:
+                key = key.replace('gemm', 'gemm16')
             _EPILOGUE[key + '_flops'] += direct * frac
             _EPILOGUE[key + '_launches'] += 1
             _EPILOGUE[key + '_bytes'] += 4.0 * px * expand * (conv.in_channels + conv.out_channels)     # V read, M written
@@ -100,6 +109,12 @@ def conv_bias_act(conv, bn, x, residual=None, relu=True):
             _EPILOGUE['wino_in_bytes'] += 4.0 * px * (1 + expand) * conv.in_channels
             _EPILOGUE['wino_out_bytes'] += 4.0 * px * ((2 if residual is not None else 1) + expand) * conv.out_channels
             _EPILOGUE['wino_launches'] += 1
+            if split:
+                # the bound on max |x| that scales V travels with the tensor object from the call that produced it
+                y, am = eng.conv3x3_wino_f16s(x, split[0], split[1], split[2], residual, relu, conv.dilation[0],
+                                              amax_in=getattr(x, '_spa_amax', None))
+                y._spa_amax = am
+                return y
             return eng.conv3x3_wino_f32(x, wino[0], wino[1], residual, relu, conv.dilation[0])
         packed32 = getattr(conv, '_spa_packed32', None)
         # the direct kernel tiles an image ROW into 256 (128) pixels: on narrow maps most of a tile is padding
@@ -276,6 +291,8 @@ class DRN(nn.Module):
                         from .engine import Engine
                         bias32 = m.bias.detach().float().contiguous()
                         m._spa_wino[4] = (Engine.winograd_weights(m.weight, 4), bias32)
+                        if m.out_channels % 128 == 0:
+                            m._spa_wino['4s'] = Engine.winograd_weights_split(m.weight) + (bias32,)
                         if m.in_channels >= 256 and m.out_channels >= 256:
                             m._spa_wino[2] = (Engine.winograd_weights(m.weight, 2), bias32)
                     # operands of spa_conv3x3_f32: the same layers of the float32 network (Cin % 32 == 0)

@@ -200,6 +200,55 @@ class Engine(object):
                  1 if relu else 0, int(dilation), _ptr(v), _ptr(m), _ptr(y), self._s()))
         return y
 
+    @staticmethod
+    def winograd_weights_split(weight):
+        """(Cout,Cin,3,3) -> (u2, cs) for conv3x3_wino_f16s: u2 (36,Cout,Cin/32,2,32) float16 = the two half-precision
+        planes h = rn(t U), l = rn(t U - h) of the F(4x4,3x3) weights U = G g G^T (float64 -> float32) scaled per position by
+        the power of two t that brings the largest magnitude into [2^14, 2^15); cs = 36 float32 2^(p_i + p_j) / t_ij
+        (csrc/spa_wino.hip)."""
+        u = Engine.winograd_weights(weight, 4)                                # (36, Cout, Cin) float32
+        Cout, Cin = u.shape[1], u.shape[2]
+        amax = u.abs().amax(dim=(1, 2)).double().clamp_min(1e-30)
+        t = torch.exp2(14.0 - torch.floor(torch.log2(amax)))                  # per position, exact powers of two
+        us = (u.double() * t.view(36, 1, 1)).float()                          # exact
+        h = us.half()
+        l = (us - h.float()).half()
+        u2 = torch.stack([h.view(36, Cout, Cin // 32, 32), l.view(36, Cout, Cin // 32, 32)], dim=3).contiguous()
+        p = torch.tensor([4, 4, 4, 3, 3, 4], dtype=torch.float64, device=u.device)
+        cs = (torch.exp2(p.view(6, 1) + p.view(1, 6)).reshape(36) / t).float().cpu().numpy().copy()
+        return u2, cs
+
+    def amax(self, x):
+        """device word with the bit pattern of max |x| (the scale input of conv3x3_wino_f16s)"""
+        assert x.dtype == torch.float32 and x.numel() % 4 == 0
+        a = torch.empty(1, dtype=torch.int32, device=x.device)
+        check(self._lib.spa_amax_f32(self._ctx, _ptr(x), x.numel(), _ptr(a), self._s()))
+        return a
+
+    def conv3x3_wino_f16s(self, x, u2, cs, bias, residual=None, relu=True, dilation=1, amax_in=None, track_amax=True):
+        """conv3x3_wino_f32's F(4x4,3x3) with the GEMMs on the 16-bit matrix cores at float32 accuracy (two half-precision
+        planes per operand, three products).  (u2, cs) = winograd_weights_split(weight).  Returns (y, amax of y or None);
+        amax_in: the amax the producing call returned for x (computed here when None)."""
+        B, Cin, H, W = x.shape
+        Cout = u2.shape[1]
+        assert x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
+        assert u2.dtype == torch.float16 and u2.is_contiguous() and tuple(u2.shape) == (36, Cout, Cin // 32, 2, 32)
+        assert bias.dtype == torch.float32 and bias.is_contiguous() and cs.dtype == np.float32 and cs.shape == (36,)
+        y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        if residual is not None:
+            assert residual.dtype == torch.float32 and residual.shape == y.shape and \
+                residual.is_contiguous(memory_format=torch.channels_last)
+        if amax_in is None:
+            amax_in = self.amax(x)
+        amax_out = torch.empty(1, dtype=torch.int32, device=x.device) if track_amax else None
+        T = int(self._lib.spa_wino4_tiles(B, H, W, int(dilation)))
+        v = torch.empty((36, T, Cin), dtype=torch.float32, device=x.device)       # two float16 planes = 4 bytes per element
+        m = torch.empty((36, T, Cout), dtype=torch.float32, device=x.device)
+        check(self._lib.spa_conv3x3_wino4_f16s(self._ctx, _ptr(x), B, H, W, Cin, _ptr(u2), cs.ctypes.data, Cout, _ptr(bias),
+                                               _ptr(residual), 1 if relu else 0, int(dilation), _ptr(amax_in), _ptr(amax_out),
+                                               _ptr(v), _ptr(m), _ptr(y), self._s()))
+        return y, amax_out
+
     def conv3x3_bf16(self, x, wt, bias, residual=None, relu=True, dilation=1):
         """relu?(conv3x3(x; stride 1, padding = dilation) + bias [+ residual]) on the bf16 matrix cores.
         x (B,Cin,H,W) bfloat16 in channels-last storage, wt (Cout,9,Cin) bfloat16, bias (Cout) float32."""
