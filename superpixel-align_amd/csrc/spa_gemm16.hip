@@ -13,9 +13,15 @@
 // instructions per product are 5.3x less matrix time than v_mfma_f32_16x16x4_f32 — the GEMM batches of a Winograd layer
 // (36 GEMMs, K = Cin) stop being bound by the float32 matrix peak, which was the wall of the whole float32 network.
 //
-// Memory layout: identical in bytes to the float32 kernel's.  A row of Cin elements is Cin * 4 bytes; every group of
-// 32 consecutive channels is one 128-byte LDS row = [32 x h | 32 x l], eight 16-byte chunks (chunk q < 4: h of channels
-// 8q..8q+7, chunk 4 + q: their l).  Staging (global_load_lds, XOR swizzle on the source address, two buffers, the next
+// Operands.  Wt (the Winograd weights, static): two planes prepared once — a row of Cin elements is Cin * 4 bytes and every
+// group of 32 consecutive channels is one 128-byte LDS row = [32 x h | 32 x l], eight 16-byte chunks (chunk q < 4: h of
+// channels 8q..8q+7, chunk 4 + q: their l).  X (the transformed activations V): plain float32, exactly what the float32
+// path's input transform writes (same bytes per element as two planes); a lane reads the 32 bytes of its 8 channels,
+// multiplies by the tile's power-of-two scale (position z: 2^(14 - e - p_i - p_j), e from the tracked maximum of the layer
+// input, spa_wino.hip) and splits in registers — 24 vector instructions per fragment next to 3 x MI matrix instructions
+// that consume it, so the split costs the matrix pipe nothing, and the input transform stays the streaming float32 kernel
+// (writing the planes from the transform was measured: 978 us instead of 608 per 15 images of a 512-channel layer, the
+// conversions serialise with its loads and stores at two waves per SIMD).  Staging (global_load_lds, XOR swizzle on the source address, two buffers, the next
 // tile's first K step staged during the last K step, counted vmcnt over the epilogue stores, persistent workgroups on
 // XCD-contiguous tile ranges) is the float32 kernel's (spa_conv32.hip), tile 256 x 256 (or 128 x 128 for 128 output
 // channels), 8 waves; a lane's fragment is one 16-byte chunk per plane, and the K step of 32 channels is 3 x MI x NJ
@@ -25,6 +31,7 @@
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
 
 #define G16_THREADS 512
 
@@ -32,7 +39,7 @@ template <int BM, int BN>
 __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3(const char *__restrict__ X, const char *__restrict__ Wt,
                                                             float *__restrict__ Y, int rows_per_z, int Cin, int Cout,
                                                             int ntiles, int total_tiles, int zcount, long long xz,
-                                                            long long wz, long long yz)
+                                                            long long wz, long long yz, const unsigned *__restrict__ amax)
 {
     extern __shared__ __attribute__((aligned(1024))) char lds16[];   // [2] weight tiles | [2] row tiles, 128 bytes per row
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -41,8 +48,22 @@ __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3(const char *__restri
     int r0, n0;
     const char *wbase, *xbase;
     float *ybase;
+    // scale of the X operand: 2^(14 - e) for the layer, 2^-(p_i + p_j) for position z = 6 i + j (p = 4 4 4 3 3 4)
+    float sb;
+    {
+        const unsigned bits = *amax;
+        int e = (int)(bits >> 23) - 127;
+        e = e < -100 ? -100 : (e > 100 ? 100 : e);
+        sb = __uint_as_float((unsigned)(127 + 14 - (bits == 0u ? 0 : e)) << 23);
+    }
+    float zscale_next = 0.f;
     auto locate = [&](long long vid) {
         const int z = (int)(vid / total_tiles);
+        {
+            const int zi = z / 6, zj = z - zi * 6;
+            const int psum = ((0x433444 >> (4 * zi)) & 15) + ((0x433444 >> (4 * zj)) & 15);
+            zscale_next = sb * __uint_as_float((unsigned)(127 - psum) << 23);
+        }
         int id = (int)(vid - (long long)z * total_tiles);
         {
             const int q = nwg / 8, rem = nwg % 8, xcd = id % 8, idx = id / 8;
@@ -91,6 +112,7 @@ __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3(const char *__restri
     bool first_tile = true;
     locate(vid);
     stage(0, 0);
+    float zscale = zscale_next;
     int e_r0 = 0, e_n0 = 0;
     float *e_y = nullptr;
     bool more = false;
@@ -121,6 +143,8 @@ __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3(const char *__restri
                 if (more) { locate(vid); stage(0, cur ^ 1); }
             }
             const char *lw = wbuf + cur * (BM * 128), *lx = xbuf + cur * (BN * 128);
+            const float sc = zscale;
+            if (t + 1 == nk) zscale = zscale_next;          // (locate() above has moved on to the next tile)
             f16x8 wh[MI], wl[MI], ph[NJ], pl[NJ];
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
@@ -131,8 +155,12 @@ __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3(const char *__restri
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int row = wn * (NJ * 16) + j * 16 + frow;
-                ph[j] = *(const f16x8 *)(lx + row * 128 + ((fk ^ (row & 7)) << 4));
-                pl[j] = *(const f16x8 *)(lx + row * 128 + (((4 + fk) ^ (row & 7)) << 4));
+                // float32 channels 8 fk .. 8 fk + 7 of the row: chunks 2 fk and 2 fk + 1; scale (exact), split
+                const f32x4 a = *(const f32x4 *)(lx + row * 128 + (((2 * fk) ^ (row & 7)) << 4));
+                const f32x4 b = *(const f32x4 *)(lx + row * 128 + (((2 * fk + 1) ^ (row & 7)) << 4));
+                const f32x8 v = (f32x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]} * sc;
+                ph[j] = __builtin_convertvector(v, f16x8);
+                pl[j] = __builtin_convertvector(v - __builtin_convertvector(ph[j], f32x8), f16x8);
             }
             // small terms first: they meet the accumulator while it is small
 #pragma unroll
@@ -165,12 +193,13 @@ __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3(const char *__restri
     }
 }
 
-// zcount problems  y[z] (rows, Cout) float32 = x[z] (rows, Cin) . wt[z]^T, wt[z] (Cout, Cin); x and wt in the two-plane
-// layout of the header (4 bytes per element), rows a multiple of 256, Cin a multiple of 32, Cout of 128
-int gemm_f16x3_raw(spa_ctx *ctx, const void *x, long long rows, int32_t Cin, const void *wt, int32_t Cout, float *y,
-                   void *stream, int zcount)
+// zcount = 36 problems  y[z] (rows, Cout) float32 = (scale_z x[z]) (rows, Cin) . wt[z]^T, wt[z] (Cout, Cin): x float32, wt in
+// the two-plane layout of the header (4 bytes per element); rows a multiple of 256, Cin a multiple of 32, Cout of 128;
+// amax: device word, bit pattern of a bound on the largest magnitude of the layer input (the scale's exponent)
+int gemm_f16x3_raw(spa_ctx *ctx, const float *x, long long rows, int32_t Cin, const void *wt, int32_t Cout, float *y,
+                   void *stream, int zcount, const void *amax)
 {
-    SPA_ARG(ctx && x && wt && y && rows > 0 && rows % 256 == 0 && rows < (1ll << 31) && zcount >= 1);
+    SPA_ARG(ctx && x && wt && y && amax && rows > 0 && rows % 256 == 0 && rows < (1ll << 31) && zcount == 36);
     SPA_ARG(Cin % 32 == 0 && Cout % 128 == 0);
     SPA_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)wt % 16) == 0 && ((uintptr_t)y % 16) == 0);
     hipStream_t s = spa_stream(stream);
@@ -191,10 +220,10 @@ int gemm_f16x3_raw(spa_ctx *ctx, const void *x, long long rows, int32_t Cin, con
     if (grid > total * zcount) grid = total * zcount;
     if (bm == 256)
         hipLaunchKernelGGL((k_gemm_f16x3<256, 256>), dim3((unsigned)grid), dim3(G16_THREADS), lds, s, (const char *)x, (const char *)wt, y,
-                           (int)rows, Cin, Cout, ntiles, (int)total, zcount, rows * Cin, (long long)Cout * Cin, rows * Cout);
+                           (int)rows, Cin, Cout, ntiles, (int)total, zcount, rows * Cin, (long long)Cout * Cin, rows * Cout, (const unsigned *)amax);
     else
         hipLaunchKernelGGL((k_gemm_f16x3<128, 128>), dim3((unsigned)grid), dim3(G16_THREADS), lds, s, (const char *)x, (const char *)wt, y,
-                           (int)rows, Cin, Cout, ntiles, (int)total, zcount, rows * Cin, (long long)Cout * Cin, rows * Cout);
+                           (int)rows, Cin, Cout, ntiles, (int)total, zcount, rows * Cin, (long long)Cout * Cin, rows * Cout, (const unsigned *)amax);
     SPA_LAUNCH_CHECK();
     return SPA_OK;
 }

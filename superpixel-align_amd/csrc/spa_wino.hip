@@ -339,8 +339,9 @@ __global__ __launch_bounds__(256) void k_wino4_out(const float *__restrict__ M, 
 }
 
 // =========================================================================================================
-// F(4x4, 3x3) with the GEMMs on the 16-bit matrix cores at float32 accuracy (spa_gemm16.hip): V is written as two
-// half-precision planes of an exactly (power-of-two) scaled value.
+// F(4x4, 3x3) with the GEMMs on the 16-bit matrix cores at float32 accuracy (spa_gemm16.hip): the GEMM kernel splits V
+// (float32, written by k_wino4_in as for the float32 GEMMs) into two half-precision planes of an exactly (power-of-two)
+// scaled value while it feeds the matrix cores.
 //   scale of position (i, j):  2^(14 - e - p_i - p_j),  e = exponent of amax >= max |x| over the layer input,
 //   p = ceil(log2(row sums of |B^T|)) = 4 4 4 3 3 4  ->  |V_ij| <= 2^(p_i + p_j) amax, scaled magnitude < 2^15:
 //   half precision cannot overflow, and what it loses at the small end is 2^-25 of that bound in absolute terms
@@ -375,68 +376,6 @@ __global__ __launch_bounds__(256) void k_amax(const float4 *__restrict__ x, long
     if (threadIdx.x == 0) {
         m = max(max(red[0], red[1]), max(red[2], red[3]));
         if (m > *(volatile unsigned *)amax) atomicMax(amax, m);
-    }
-}
-
-__device__ __forceinline__ unsigned wino_pack_h2(float a, float b)
-{
-    const _Float16 ha = (_Float16)a, hb = (_Float16)b;
-    return (unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16);
-}
-
-// one thread = one tile x 4 channels; a lane pair (8 channels) writes 16 bytes of the h plane (even lane) and 16 bytes of
-// the l plane (odd lane) per position
-__global__ __launch_bounds__(256) void k_wino4_in_split(const float *__restrict__ X, char *__restrict__ Vout, WinoGeom g, int C,
-                                                        long long Tpad, const unsigned *__restrict__ amax)
-{
-    const int c4 = C >> 2;
-    const long long id = wino_block() * 256 + threadIdx.x;
-    if (id >= g.T * c4) return;
-    const long long t = id / c4;
-    const int c = (int)(id - t * c4) << 2;
-    int b, sy, sx, ty, tx;
-    wino_tile(g, t, b, sy, sx, ty, tx);
-    const float sb = wino_pow2(14 - wino_amax_exp(*amax));
-    float4 r[6][6];
-#pragma unroll
-    for (int a = 0; a < 6; ++a) {
-        const int y = sy + (4 * ty - 1 + a) * g.d;
-        float4 dv[6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int x = sx + (4 * tx - 1 + j) * g.d;
-            const bool ok = y >= 0 && y < g.H && x >= 0 && x < g.W;
-            dv[j] = ok ? *(const float4 *)(X + (((long long)b * g.H + y) * g.W + x) * C + c) : wino_zero<float4>();
-        }
-        wino4_bt(dv, r[a]);
-    }
-    const bool odd = threadIdx.x & 1;
-    // byte offset of this lane's 16 bytes inside a row: the 8-channel group's h chunk (even lane) or l chunk (odd lane)
-    const int c8 = c & ~7;
-    const long long rowoff = (long long)(c8 >> 5) * 128 + (c8 & 31) * 2 + (odd ? 64 : 0);
-    constexpr float pw[6] = {0.0625f, 0.0625f, 0.0625f, 0.125f, 0.125f, 0.0625f};     // 2^-p
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const float4 col[6] = {r[0][j], r[1][j], r[2][j], r[3][j], r[4][j], r[5][j]};
-        float4 o[6];
-        wino4_bt(col, o);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const float sc = sb * (pw[i] * pw[j]);
-            const float v0 = o[i].x * sc, v1 = o[i].y * sc, v2 = o[i].z * sc, v3 = o[i].w * sc;
-            const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1, h2 = (_Float16)v2, h3 = (_Float16)v3;
-            uint2 hh, ll;
-            hh.x = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-            hh.y = (unsigned)__builtin_bit_cast(unsigned short, h2) | ((unsigned)__builtin_bit_cast(unsigned short, h3) << 16);
-            ll.x = wino_pack_h2(v0 - (float)h0, v1 - (float)h1);
-            ll.y = wino_pack_h2(v2 - (float)h2, v3 - (float)h3);
-            // the even lane hands its l to the odd lane and receives the odd lane's h (quad_perm 1,0,3,2)
-            const unsigned sx_ = odd ? hh.x : ll.x, sy_ = odd ? hh.y : ll.y;
-            const unsigned rx_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)sx_, 0xB1, 0xF, 0xF, true);
-            const unsigned ry_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)sy_, 0xB1, 0xF, 0xF, true);
-            const uint4 st = odd ? make_uint4(rx_, ry_, ll.x, ll.y) : make_uint4(hh.x, hh.y, rx_, ry_);
-            *(uint4 *)(Vout + ((long long)(i * 6 + j) * Tpad + t) * C * 4 + rowoff) = st;
-        }
     }
 }
 
@@ -557,8 +496,8 @@ extern "C" int spa_conv3x3_wino4_f32(spa_ctx *ctx, const float *x, int32_t B, in
     return SPA_OK;
 }
 
-int gemm_f16x3_raw(spa_ctx *ctx, const void *x, long long rows, int32_t Cin, const void *wt, int32_t Cout, float *y,
-                   void *stream, int zcount);          // spa_gemm16.hip
+int gemm_f16x3_raw(spa_ctx *ctx, const float *x, long long rows, int32_t Cin, const void *wt, int32_t Cout, float *y,
+                   void *stream, int zcount, const void *amax);          // spa_gemm16.hip
 
 // amax[0] = bit pattern of max |x| over n floats (n a multiple of 4): the scale input of spa_conv3x3_wino4_f16s for a
 // tensor whose producer did not track it
@@ -598,11 +537,10 @@ extern "C" int spa_conv3x3_wino4_f16s(spa_ctx *ctx, const float *x, int32_t B, i
     {
         SpaProfScope prof_(ctx, PROF_WINO_IN, s);
         const long long n = g.T * (Cin / 4);
-        hipLaunchKernelGGL(k_wino4_in_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, (char *)v_scratch, g, Cin, Tpad,
-                           (const unsigned *)amax_in);
+        hipLaunchKernelGGL(k_wino4_in<float4>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, (float *)v_scratch, g, Cin, Tpad);
     }
     {
-        int rc = gemm_f16x3_raw(ctx, v_scratch, Tpad, Cin, u2, Cout, m_scratch, stream, 36);
+        int rc = gemm_f16x3_raw(ctx, (const float *)v_scratch, Tpad, Cin, u2, Cout, m_scratch, stream, 36, amax_in);
         if (rc != SPA_OK) return rc;
     }
     {

@@ -39,8 +39,10 @@ t32 = timed(lambda: eng.conv3x3_wino_f32(x, u, b, res, True, d))
 t16 = timed(lambda: eng.conv3x3_wino_f16s(x, u2, cs, b, res, True, d, amax_in=am))
 fl = 2.0 * 36 * int(eng._lib.spa_wino4_tiles(B, 128, 256, d)) * C * C
 print('layer: float32 operands %.3f ms, two f16 planes %.3f ms' % (t32, t16))
-eng.prof_enable(True)
-for _ in range(3): eng.conv3x3_wino_f32(x, u, b, res, True, d)
-for _ in range(3): eng.conv3x3_wino_f16s(x, u2, cs, b, res, True, d, amax_in=am)
-for name, (ms, n) in eng.prof_read().items():
-    print('%-44s %3d launches  avg %8.1f us%s' % (name, n, ms / n * 1e3, ('  = %.0f TFLOP/s of the GEMM (executed %.0f)' % (fl / (ms / n) / 1e9, (3 if 'f16' in name else 1) * fl / (ms / n) / 1e9)) if 'gemm' in name or '1, 256' in name else ''))
+def show(tag, fn):
+    eng.prof_enable(True)
+    for _ in range(3): fn()
+    for name, (ms, n) in eng.prof_read().items():
+        print('%-18s %-40s %3d launches  avg %8.1f us%s' % (tag, name, n, ms / n * 1e3, ('  = %.0f TFLOP/s of the GEMM (executed %.0f)' % (fl / (ms / n) / 1e9, (3 if 'f16' in name else 1) * fl / (ms / n) / 1e9)) if 'gemm' in name or '1, 256' in name else ''))
+show('float32 operands', lambda: eng.conv3x3_wino_f32(x, u, b, res, True, d))
+show('two f16 planes', lambda: eng.conv3x3_wino_f16s(x, u2, cs, b, res, True, d, amax_in=am))
