@@ -338,7 +338,7 @@ def main():
     drn._EPILOGUE['bytes'] = 0
     drn._EPILOGUE['launches'] = 0
     drn._EPILOGUE['conv_flops'] = 0.0
-    for key in ('gemm16_flops', 'gemm16_launches', 'gemm16_bytes', 'gemm16n_flops', 'gemm16n_launches', 'gemm16n_bytes',
+    for key in ('conv16_flops', 'conv16_launches', 'gemm16_flops', 'gemm16_launches', 'gemm16_bytes', 'gemm16n_flops', 'gemm16n_launches', 'gemm16n_bytes',
                 'gemm_flops', 'gemm_launches', 'gemm_bytes', 'gemmn_flops', 'gemmn_launches', 'gemmn_bytes', 'wino_direct_flops', 'wino_saved_flops', 'wino_in_bytes', 'wino_out_bytes', 'wino_launches'):
         drn._EPILOGUE[key] = 0
 
@@ -437,6 +437,14 @@ def main():
                        frac=round(tf / FP32_MATRIX_PEAK_TF, 4), flops_per_step=fl / a.steps, flops_per_launch=fl / nl,
                        hbm_bytes_per_launch_by_construction=int(by / nl),
                        traffic=pmc_traffic('k_conv3x3_f32<taps 1>(GEMM form, all)', B, H, W, by / nl))
+        elif name == 'k_conv3x3_f32<split>(all)':
+            # the 64-channel 3x3 layers and the 1x1 projections on the 16-bit matrix cores (three half-precision products per
+            # float32 product): executed FLOPs against the dense 16-bit peak; these layers are bound by their activations' traffic
+            fl, nl = E['conv16_flops'], max(1, E['conv16_launches'])
+            tf = fl / a.steps / (ms / a.steps * 1e-3) / 1e12
+            ent.update(bound='mfma', achieved=round(3 * tf, 1), peak=BF16_MATRIX_PEAK_TF, unit='TFLOP/s',
+                       frac=round(3 * tf / BF16_MATRIX_PEAK_TF, 4), float32_equivalent_tflops=round(tf, 1),
+                       flops_per_step=3 * fl / a.steps, flops_per_launch=3 * fl / nl)
         elif name.startswith('k_gemm_f16x3'):
             # the Winograd GEMMs on the 16-bit matrix cores at float32 accuracy: every product of the float32 GEMM is three
             # half-precision matrix products (csrc/spa_gemm16.hip).  achieved = EXECUTED half-precision FLOPs (3 x the
@@ -490,7 +498,7 @@ def main():
                 'limiter': e.get('limiter'),
                 'selection': 'largest ms_per_step among all hand-written kernel families of libspalign (see `kernels`)'}
     drn_ms = stage['time_feature_maps'] / a.steps
-    split16 = a.dtype == 'fp32' and E['gemm16_launches'] + E['gemm16n_launches'] > 0
+    split16 = a.dtype == 'fp32' and E['gemm16_launches'] + E['gemm16n_launches'] + E['conv16_launches'] > 0
     flops_direct = drn.flops_per_image(a.arch, H, W) * B
     flops = flops_direct - wino_saved / a.steps                        # executed: the Winograd layers multiply 16/36 as much
     drn_tf = flops / (drn_ms * 1e-3) / 1e12

@@ -167,6 +167,16 @@ int spa_conv3x3_wino4_f16s(spa_ctx *ctx, const float *x, int32_t B, int32_t H, i
                            int32_t relu, int32_t dilation, const void *amax_in, void *amax_out, void *v_scratch,
                            float *m_scratch, float *y, void *stream);
 
+/* spa_conv3x3_f32 / spa_conv1x1_f32 on the 16-bit matrix cores at float32 accuracy (the direct form of the scheme above,
+ * for the 64-channel layers and the 1x1 projections): wt2 (Cout, taps, Cin/32, 2, 32) half precision = the planes of t * wt,
+ * inv_t = 1 / t (t a power of two); amax_in / amax_out as in spa_conv3x3_wino4_f16s. */
+int spa_conv3x3_f16s(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                     const void *wt2, float inv_t, int32_t Cout, const float *bias, const float *residual,
+                     int32_t relu, int32_t dilation, const void *amax_in, void *amax_out, float *y, void *stream);
+int spa_conv1x1_f16s(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                     const void *wt2, float inv_t, int32_t Cout, const float *bias, const float *residual,
+                     int32_t relu, const void *amax_in, void *amax_out, float *y, void *stream);
+
 /* ---- input stage ---------------------------------------------------------------------------
  * replaces the host resize of ResizeImageDataset.get_example (datasets/resize_image_dataset.py:31-34:
  * chainercv.transforms.resize(image, resize_shape, 3)) as Pillow computes it on an 8-bit image, channel by

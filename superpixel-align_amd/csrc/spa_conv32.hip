@@ -18,6 +18,8 @@
 #include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 #define C32_BN 256            // pixels per workgroup
 #define C32_BK 32             // K step (input channels of one tap): 128-byte LDS rows
@@ -31,14 +33,22 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // BN = pixels per workgroup: 256, or 128 for the narrow channel tiles (BM 64 / 128): their K steps are short (a
 // quarter / half of the MFMA work per barrier), and with half the pixel segment two or three workgroups fit a CU
 // (67 / 51 KB of LDS), so one workgroup's barrier and load wait hide under another's matrix work
-template <int HAS_RES, int BM, int TAPS, int BN>
+// SPLIT (round 3): the same convolution on the 16-bit matrix cores at float32 accuracy (spa_gemm16.hip has the argument):
+// Wt holds, per 32-channel group of a (channel, tap) row, the two half-precision planes [32 x h | 32 x l] of t * w (t a
+// power of two), the pixels stay float32 in memory and in LDS and are scaled by 2^(14 - e) (e = exponent of *amax_in, a
+// bound on max |x|) and split in registers; three v_mfma_f32_16x16x32_f16 replace eight v_mfma_f32_16x16x4_f32 per
+// 32-channel step (5.3x less matrix time).  The epilogue multiplies by unscale = 2^(e - 14) / t before the bias and,
+// when amax_out is given, records the largest magnitude it stores (the next layer's scale).
+template <int HAS_RES, int BM, int TAPS, int BN, bool SPLIT = false>
 __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__restrict__ X, const float *__restrict__ Wt,
                                                              const float *__restrict__ bias,
                                                              const float *__restrict__ R, float *__restrict__ Y,
                                                              const char *__restrict__ zero_line, int B, int H, int W,
                                                              int Cin, int Cout, int dil, int relu, int xtiles,
                                                              int ntiles, int total_tiles, int zcount, long long xz,
-                                                             long long wz, long long yz, int late_prefetch)
+                                                             long long wz, long long yz, int late_prefetch,
+                                                             const unsigned *__restrict__ amax_in = nullptr,
+                                                             unsigned *__restrict__ amax_out = nullptr, float inv_t = 1.f)
 {
     extern __shared__ __attribute__((aligned(1024))) char lds32[];   // [2] weight tiles 32 KB | [2] pixel segments 33 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -156,6 +166,15 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
     stage_w(0, 0);
     if (TAPS == 1) { locate_rows(); stage_x1(0); }
     else { stage_x(0, 0); stage_x(0, 1); stage_x(0, 2); }
+    float sc16 = 1.f, unscale = 1.f;
+    unsigned amx = 0;
+    if (SPLIT) {
+        const unsigned bits = *amax_in;
+        int e = (int)(bits >> 23) - 127;
+        e = bits == 0u ? 0 : (e < -100 ? -100 : (e > 100 ? 100 : e));
+        sc16 = __uint_as_float((unsigned)(127 + 14 - e) << 23);
+        unscale = __uint_as_float((unsigned)(127 - 14 + e) << 23) * inv_t;
+    }
     int e_row = 0, e_x0 = 0, e_n0 = 0;
     float *e_y = nullptr;
     const float *e_r = nullptr;
@@ -209,6 +228,36 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
         }
         const char *lw = wbuf + cur * (BM * 128), *lx = xbuf + ((g + px_par) & 1) * XSEG;
         const int xshift = (TAPS == 9 ? C32_HALO + (dxi - 1) * dil : 0) + wn * (NJ * 16) + frow;      // segment row of fragment 0
+        if constexpr (SPLIT) {
+            f16x8 wh[MI], wl[MI], ph[NJ], pl[NJ];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int row = wm * WROWS + i * 16 + frow;
+                wh[i] = *(const f16x8 *)(lw + row * 128 + ((fk ^ (row & 7)) << 4));
+                wl[i] = *(const f16x8 *)(lw + row * 128 + (((4 + fk) ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int row = xshift + j * 16;
+                const f32x4 a = *(const f32x4 *)(lx + row * 128 + (((2 * fk) ^ (row & 7)) << 4));
+                const f32x4 b = *(const f32x4 *)(lx + row * 128 + (((2 * fk + 1) ^ (row & 7)) << 4));
+                const f32x8 v = (f32x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]} * sc16;
+                ph[j] = __builtin_convertvector(v, f16x8);
+                pl[j] = __builtin_convertvector(v - __builtin_convertvector(ph[j], f32x8), f16x8);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], ph[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], pl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], ph[j], acc[i][j], 0, 0, 0);
+        } else
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             // a lane's 16 bytes are channels (kk*16 + fk*4 .. +3) of its row: MFMA q of the four multiplies channel
@@ -260,17 +309,26 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
         for (int i = 0; i < MI; ++i) {
             const int c = e_n0 + wm * WROWS + i * 16 + (lane >> 4) * 4;
             const float4 bv = *(const float4 *)(bias + c);
-            float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y, v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
+            float v0, v1, v2, v3;
+            if (SPLIT) { v0 = acc[i][j][0] * unscale + bv.x; v1 = acc[i][j][1] * unscale + bv.y; v2 = acc[i][j][2] * unscale + bv.z; v3 = acc[i][j][3] * unscale + bv.w; }
+            else { v0 = acc[i][j][0] + bv.x; v1 = acc[i][j][1] + bv.y; v2 = acc[i][j][2] + bv.z; v3 = acc[i][j][3] + bv.w; }
             if (HAS_RES) {
                 const float4 rr = *(const float4 *)(e_r + pix * Cout + c);
                 v0 += rr.x; v1 += rr.y; v2 += rr.z; v3 += rr.w;
             }
             if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
             *(float4 *)(e_y + pix * Cout + c) = make_float4(v0, v1, v2, v3);
+            if (SPLIT)
+                amx = max(max(amx, __float_as_uint(v0) & 0x7fffffffu), max(__float_as_uint(v1) & 0x7fffffffu,
+                          max(__float_as_uint(v2) & 0x7fffffffu, __float_as_uint(v3) & 0x7fffffffu)));
         }
     }
     if (!more) break;
   }
+    if (SPLIT && amax_out) {
+        for (int o = 32; o > 0; o >>= 1) amx = max(amx, (unsigned)__shfl_xor((int)amx, o));
+        if (lane == 0 && amx > *(volatile unsigned *)amax_out) atomicMax(amax_out, amx);
+    }
 }
 
 // x (B,H,W,Cin) float32 channels-last, wt (Cout,taps,Cin) float32 (tap = ky*3 + kx), bias (Cout) float32,
@@ -279,8 +337,10 @@ template <int TAPS>
 static int conv_f32_launch(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W, int32_t Cin,
                            const float *wt, int32_t Cout, const float *bias, const float *residual,
                            int32_t relu, int32_t dilation, float *y, void *stream, bool prof = true, int zcount = 1,
-                           long long xz = 0, long long wz = 0, long long yz = 0)
+                           long long xz = 0, long long wz = 0, long long yz = 0, const void *amax_in = nullptr,
+                           void *amax_out = nullptr, float inv_t = 0.f)
 {
+    const bool split = amax_in != nullptr;          // wt is then the two-plane form of t * w, inv_t = 1 / t
     SPA_ARG(ctx && x && wt && y && B > 0 && H > 0 && W > 0 && dilation >= 1);
     SPA_ARG(Cin % C32_BK == 0 && Cout % 64 == 0 && dilation <= C32_HALO);
     SPA_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)wt % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)bias % 16) == 0);
@@ -304,6 +364,10 @@ static int conv_f32_launch(spa_ctx *ctx, const float *x, int32_t B, int32_t H, i
     const long long total = (long long)B * H * xtiles * ntiles;
     SPA_ARG(total < (1ll << 31));
     const size_t lds = 2 * (size_t)bm * 128 + 2 * (size_t)(bn + 2 * C32_HALO) * 128;
+    if (split) {
+        SPA_ARG(bias && zcount == 1 && inv_t > 0.f);
+        if (amax_out) SPA_HIP(hipMemsetAsync(amax_out, 0, 4, s));
+    }
     const int bit = TAPS == 9 ? 1 : 2;
     if (!(ctx->conv32_attr_done & bit)) {
 #define C32_ATTR(R, M, N) SPA_HIP(hipFuncSetAttribute((const void *)k_conv3x3_f32<R, M, TAPS, N>, hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -311,12 +375,16 @@ static int conv_f32_launch(spa_ctx *ctx, const float *x, int32_t B, int32_t H, i
         C32_ATTR(0, 256, 256); C32_ATTR(1, 256, 256); C32_ATTR(0, 128, 256); C32_ATTR(1, 128, 256); C32_ATTR(0, 64, 256); C32_ATTR(1, 64, 256);
         C32_ATTR(0, 128, 128); C32_ATTR(1, 128, 128); C32_ATTR(0, 64, 128); C32_ATTR(1, 64, 128);
 #undef C32_ATTR
+#define C32_ATTR(R, M, N) SPA_HIP(hipFuncSetAttribute((const void *)k_conv3x3_f32<R, M, TAPS, N, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                      2 * M * 128 + 2 * (N + 2 * C32_HALO) * 128))
+        C32_ATTR(0, 256, 256); C32_ATTR(1, 256, 256); C32_ATTR(0, 128, 128); C32_ATTR(1, 128, 128); C32_ATTR(0, 64, 128); C32_ATTR(1, 64, 128);
+#undef C32_ATTR
         ctx->conv32_attr_done |= bit;
     }
     // one slot per kernel form: the 3x3 convolutions, and the GEMM form (1x1 projections and the Winograd GEMM batches)
     // (the GEMM form's 256 x 256 instance has its own slot: it is the kernel with the most time per step, and its
     // average must be comparable with the rocprofv3 row of exactly that instance)
-    SpaProfScope prof_(ctx, prof ? (TAPS == 9 ? PROF_DRN_CONV32 : (bm == 256 && !residual ? PROF_DRN_GEMM32 : PROF_DRN_GEMM32_N)) : -1, s);
+    SpaProfScope prof_(ctx, prof ? (split ? PROF_DRN_CONV16 : (TAPS == 9 ? PROF_DRN_CONV32 : (bm == 256 && !residual ? PROF_DRN_GEMM32 : PROF_DRN_GEMM32_N))) : -1, s);
     // persistent workgroups: as many as are resident at once (LDS: one per CU for the wide tiles, two or three for the
     // 128-pixel ones), each looping over its share of the tiles
     const int per_cu = lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3);
@@ -326,6 +394,17 @@ static int conv_f32_launch(spa_ctx *ctx, const float *x, int32_t B, int32_t H, i
 #define C32_LAUNCH(R, M, N)                                                                                                 \
     hipLaunchKernelGGL((k_conv3x3_f32<R, M, TAPS, N>), dim3((unsigned)grid), dim3(C32_THREADS), lds, s, x, wt, bias, residual, y,  \
                        (const char *)zero, B, H, W, Cin, Cout, dilation, relu, xtiles, ntiles, (int)total, zcount, xz, wz, yz, late)
+#define C32_LAUNCH_S(R, M, N)                                                                                               \
+    hipLaunchKernelGGL((k_conv3x3_f32<R, M, TAPS, N, true>), dim3((unsigned)grid), dim3(C32_THREADS), lds, s, x, wt, bias, residual, y,  \
+                       (const char *)zero, B, H, W, Cin, Cout, dilation, relu, xtiles, ntiles, (int)total, zcount, xz, wz, yz, late, \
+                       (const unsigned *)amax_in, (unsigned *)amax_out, inv_t)
+    if (split) {
+        SPA_ARG(bn == (bm == 256 ? 256 : 128));
+        if (residual) { if (bm == 256) C32_LAUNCH_S(1, 256, 256); else if (bm == 128) C32_LAUNCH_S(1, 128, 128); else C32_LAUNCH_S(1, 64, 128); }
+        else { if (bm == 256) C32_LAUNCH_S(0, 256, 256); else if (bm == 128) C32_LAUNCH_S(0, 128, 128); else C32_LAUNCH_S(0, 64, 128); }
+        SPA_LAUNCH_CHECK();
+        return SPA_OK;
+    }
 #define C32_PICK(R)                                                                     \
     if (bm == 256) C32_LAUNCH(R, 256, 256);                                             \
     else if (bm == 128) { if (bn == 256) C32_LAUNCH(R, 128, 256); else C32_LAUNCH(R, 128, 128); } \
@@ -350,6 +429,27 @@ extern "C" int spa_conv1x1_f32(spa_ctx *ctx, const float *x, int32_t B, int32_t 
                                int32_t relu, float *y, void *stream)
 {
     return conv_f32_launch<1>(ctx, x, B, H, W, Cin, wt, Cout, bias, residual, relu, 1, y, stream);
+}
+
+// the same two layers on the 16-bit matrix cores at float32 accuracy (template parameter SPLIT above): wt2 = the two-plane
+// form of t * wt per 32-channel group, (Cout, taps, Cin/32, 2, 32) half precision; inv_t = 1 / t; amax_in / amax_out as in
+// spa_conv3x3_wino4_f16s
+extern "C" int spa_conv3x3_f16s(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                                const void *wt2, float inv_t, int32_t Cout, const float *bias, const float *residual,
+                                int32_t relu, int32_t dilation, const void *amax_in, void *amax_out, float *y, void *stream)
+{
+    SPA_ARG(amax_in);
+    return conv_f32_launch<9>(ctx, x, B, H, W, Cin, (const float *)wt2, Cout, bias, residual, relu, dilation, y, stream, true, 1,
+                              0, 0, 0, amax_in, amax_out, inv_t);
+}
+
+extern "C" int spa_conv1x1_f16s(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                                const void *wt2, float inv_t, int32_t Cout, const float *bias, const float *residual,
+                                int32_t relu, const void *amax_in, void *amax_out, float *y, void *stream)
+{
+    SPA_ARG(amax_in);
+    return conv_f32_launch<1>(ctx, x, B, H, W, Cin, (const float *)wt2, Cout, bias, residual, relu, 1, y, stream, true, 1,
+                              0, 0, 0, amax_in, amax_out, inv_t);
 }
 
 // plain GEMMs for the Winograd path (spa_wino.hip): y (rows, Cout) = x (rows, Cin) . wt^T, wt (Cout, Cin); rows is a

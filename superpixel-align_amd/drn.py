@@ -67,7 +67,7 @@ _EPILOGUE = {'engine': None, 'bytes': 0, 'launches': 0, 'own_conv': True, 'own_c
              # products: csrc/spa_gemm16.hip); SPA_SPLIT_GEMM=0 keeps the float32 matrix instructions
              'split_gemm': os.environ.get('SPA_SPLIT_GEMM', '1') != '0',
              'gemm16_flops': 0.0, 'gemm16_launches': 0, 'gemm16_bytes': 0.0,
-             'gemm16n_flops': 0.0, 'gemm16n_launches': 0, 'gemm16n_bytes': 0.0}
+             'gemm16n_flops': 0.0, 'gemm16n_launches': 0, 'gemm16n_bytes': 0.0, 'conv16_flops': 0.0, 'conv16_launches': 0}
 
 
 def conv_bias_act(conv, bn, x, residual=None, relu=True):
@@ -129,6 +129,15 @@ def conv_bias_act(conv, bn, x, residual=None, relu=True):
                 and (residual is None or residual.is_contiguous(memory_format=torch.channels_last))):
             # the same layers of the float32 network: libspalign's float32-MFMA implicit GEMM, epilogue fused
             fl = 2.0 * x.shape[0] * x.shape[2] * x.shape[3] * conv.out_channels * packed32[0].shape[1] * conv.in_channels
+            p16 = getattr(conv, '_spa_packed16', None)
+            if p16 is not None and _EPILOGUE['split_gemm']:
+                # ... on the 16-bit matrix cores at float32 accuracy (two half-precision planes per operand)
+                _EPILOGUE['conv16_flops'] += fl
+                _EPILOGUE['conv16_launches'] += 1
+                y, am = eng.conv3x3_f16s(x, p16[0], p16[1], packed32[1], residual, relu, conv.dilation[0],
+                                         amax_in=getattr(x, '_spa_amax', None))
+                y._spa_amax = am
+                return y
             if packed32[0].shape[1] == 1:           # the GEMM form of the kernel (1x1 projection)
                 key = 'gemm' if conv.out_channels % 256 == 0 and residual is None else 'gemmn'
                 _EPILOGUE[key + '_flops'] += fl
@@ -273,12 +282,13 @@ class DRN(nn.Module):
         self.eval()
         self._stem = None
         if torch.device(device).type == 'cuda':
-            from .engine import default_engine        # fused glue kernels of libspalign
+            from .engine import default_engine, Engine        # fused glue kernels of libspalign
             _EPILOGUE['engine'] = default_engine()
             for m in self.modules():
                 if isinstance(m, nn.Conv2d):
                     m._spa_packed = None
                     m._spa_packed32 = None
+                    m._spa_packed16 = None
                     m._spa_wino = {}
                     # Winograd where it wins (measured, 30 x 128 x 256 pixels, ms direct / F(2x2) / F(4x4)):
                     #   512 -> 512  33.2 / 19.8 / 11.9     256 -> 512  16.8 / 11.6 / 7.0     256 -> 256  8.5 / 6.6 / 4.2
@@ -288,7 +298,6 @@ class DRN(nn.Module):
                             and m.padding == m.dilation and m.dilation[0] == m.dilation[1] and m.groups == 1
                             and m.in_channels % 32 == 0 and m.out_channels % 64 == 0 and m.bias is not None
                             and m.in_channels >= 128 and m.out_channels >= 128):
-                        from .engine import Engine
                         bias32 = m.bias.detach().float().contiguous()
                         m._spa_wino[4] = (Engine.winograd_weights(m.weight, 4), bias32)
                         if m.out_channels % 128 == 0:
@@ -301,12 +310,14 @@ class DRN(nn.Module):
                             and m.in_channels % 32 == 0 and m.out_channels % 64 == 0 and m.bias is not None):
                         wt = m.weight.detach().permute(0, 2, 3, 1).reshape(m.out_channels, 9, m.in_channels)
                         m._spa_packed32 = (wt.contiguous().float(), m.bias.detach().float().contiguous())
+                        m._spa_packed16 = Engine.split_planes(m._spa_packed32[0])
                     # ... and the 1x1 stride-1 projections (layers 5 and 6): the same kernel, centre tap only
                     if (dtype == torch.float32 and self.folded and m.kernel_size == (1, 1) and m.stride == (1, 1)
                             and m.padding == (0, 0) and m.groups == 1 and m.in_channels % 32 == 0
                             and m.out_channels % 64 == 0 and m.bias is not None):
                         wt = m.weight.detach().reshape(m.out_channels, 1, m.in_channels)
                         m._spa_packed32 = (wt.contiguous().float(), m.bias.detach().float().contiguous())
+                        m._spa_packed16 = Engine.split_planes(m._spa_packed32[0])
                     # operands of spa_conv3x3_bf16: 3x3, stride 1, padding = dilation, Cin % 64 == 0,
                     # Cout % 64 == 0 (layers 3-8 of the DRN: all 3x3 stride-1 layers from 64 channels up), bf16 network,
                     # BatchNorm folded

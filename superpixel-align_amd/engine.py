@@ -165,6 +165,44 @@ class Engine(object):
         return y
 
     @staticmethod
+    def split_planes(wt):
+        """(Cout,taps,Cin) float32 -> (wt2, inv_t) for conv3x3_f16s: wt2 (Cout,taps,Cin/32,2,32) float16 = the planes
+        h = rn(t w), l = rn(t w - h) of the weights scaled by the power of two t that brings the largest magnitude into
+        [2^14, 2^15); inv_t = 1 / t."""
+        Cout, taps, Cin = wt.shape
+        amax = float(wt.abs().max().clamp_min(1e-30))
+        t = 2.0 ** (14 - int(np.floor(np.log2(amax))))
+        ws = (wt.double() * t).float()                                        # exact
+        h = ws.half()
+        l = (ws - h.float()).half()
+        wt2 = torch.stack([h.view(Cout, taps, Cin // 32, 32), l.view(Cout, taps, Cin // 32, 32)], dim=3).contiguous()
+        return wt2, float(1.0 / t)
+
+    def conv3x3_f16s(self, x, wt2, inv_t, bias, residual=None, relu=True, dilation=1, amax_in=None, track_amax=True):
+        """conv3x3_f32 (3x3 or, with one tap, the 1x1 projection) on the 16-bit matrix cores at float32 accuracy: weights as
+        two half-precision planes (split_planes), pixels split in the kernel.  Returns (y, amax of y or None)."""
+        B, Cin, H, W = x.shape
+        Cout, taps = wt2.shape[0], wt2.shape[1]
+        assert x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
+        assert wt2.dtype == torch.float16 and wt2.is_contiguous() and tuple(wt2.shape) == (Cout, taps, Cin // 32, 2, 32) and taps in (1, 9)
+        assert bias.dtype == torch.float32 and bias.is_contiguous()
+        y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        if residual is not None:
+            assert residual.dtype == torch.float32 and residual.shape == y.shape and \
+                residual.is_contiguous(memory_format=torch.channels_last)
+        if amax_in is None:
+            amax_in = self.amax(x)
+        amax_out = torch.empty(1, dtype=torch.int32, device=x.device) if track_amax else None
+        if taps == 1:
+            check(self._lib.spa_conv1x1_f16s(self._ctx, _ptr(x), B, H, W, Cin, _ptr(wt2), ctypes.c_float(inv_t), Cout, _ptr(bias),
+                                             _ptr(residual), 1 if relu else 0, _ptr(amax_in), _ptr(amax_out), _ptr(y), self._s()))
+        else:
+            check(self._lib.spa_conv3x3_f16s(self._ctx, _ptr(x), B, H, W, Cin, _ptr(wt2), ctypes.c_float(inv_t), Cout, _ptr(bias),
+                                             _ptr(residual), 1 if relu else 0, int(dilation), _ptr(amax_in), _ptr(amax_out),
+                                             _ptr(y), self._s()))
+        return y, amax_out
+
+    @staticmethod
     def winograd_weights(weight, tile=2):
         """(Cout,Cin,3,3) -> (n*n,Cout,Cin) float32: G g G^T of F(tile x tile, 3x3), computed in float64, position-major.
         tile 2: points 0, 1, -1, inf (n = 4); tile 4: points 0, 1, -1, 1/2, -2, inf (n = 6; csrc/spa_wino.hip)."""
