@@ -83,6 +83,72 @@ def test_conv3x3_winograd_f32_matches_float64(eng, B, Cin, Cout, H, W, dil, res,
     assert float((y - yd).abs().max()) <= (6e-6 if tile == 2 else 1.2e-5) * scale
 
 
+SPLIT_CASES = [(1, 128, 256, 24, 300, 2, True, True), (1, 256, 512, 8, 260, 4, False, True), (2, 128, 128, 21, 301, 3, True, False),
+               (1, 512, 512, 9, 70, 1, True, True), (3, 160, 384, 5, 33, 1, False, False)]
+
+
+@pytest.mark.parametrize('B,Cin,Cout,H,W,dil,res,relu', SPLIT_CASES)
+def test_conv3x3_winograd_split_planes_matches_float64(eng, B, Cin, Cout, H, W, dil, res, relu):
+    """F(4x4,3x3) with the 36 GEMMs on the 16-bit matrix cores: every float32 operand as two half-precision planes,
+    three products (spa_conv3x3_wino4_f16s).  Same tolerance as the float32-operand form, and the tracked maxima are
+    the tensors' own."""
+    x, w, bias, r = _operands(B, Cin, Cout, H, W, 3, res, 5)
+    x = x * 3.7
+    u2, cs = eng.winograd_weights_split(w)
+    am = eng.amax(x)
+    assert float(am.view(torch.float32)) == float(x.abs().max())
+    y, am_out = eng.conv3x3_wino_f16s(x, u2, cs, bias, r, relu, dil, amax_in=am)
+    ref = _ref64(x, w, bias, r, relu, dil)
+    scale = float(ref.abs().max())
+    assert float((y.double() - ref).abs().max()) <= 1e-5 * scale
+    assert float(am_out.view(torch.float32)) == float(y.abs().max())
+    # against the float32-operand form of the same algorithm: rounding level
+    y32 = eng.conv3x3_wino_f32(x, eng.winograd_weights(w, 4), bias, r, relu, dil)
+    assert float((y - y32).abs().max()) <= 1.5e-5 * scale
+
+
+def test_split_planes_survive_extreme_ranges(eng):
+    """the scale comes from the largest magnitude: a tensor of 1e4-sized activations next to 1e-6-sized ones, an all-zero
+    tensor and a bound far above the actual maximum all stay finite and as accurate as float32 allows"""
+    x, w, bias, r = _operands(1, 128, 128, 16, 40, 3, False, 6)
+    u2, cs = eng.winograd_weights_split(w)
+    xs = x.clone()
+    xs[:, :, :8] *= 1e4
+    xs[:, :, 8:] *= 1e-6
+    y, _ = eng.conv3x3_wino_f16s(xs, u2, cs, bias, None, False, 1)
+    ref = _ref64(xs, w, bias, None, False, 1)
+    assert torch.isfinite(y).all()
+    assert float((y.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    # the small half of the image alone is resolved relative to ITS scale when it is its own tensor
+    y2, _ = eng.conv3x3_wino_f16s((x * 1e-6).contiguous(memory_format=torch.channels_last), u2, cs, torch.zeros_like(bias), None, False, 1)
+    ref2 = _ref64(x * 1e-6, w, torch.zeros_like(bias), None, False, 1)
+    assert float((y2.double() - ref2).abs().max()) <= 1e-5 * float(ref2.abs().max())
+    z = torch.zeros_like(x)
+    y0, am0 = eng.conv3x3_wino_f16s(z, u2, cs, bias, None, True, 2)
+    assert torch.equal(y0, torch.relu(bias).view(1, -1, 1, 1).expand_as(y0).contiguous(memory_format=torch.channels_last))
+    # a loose bound (what a producer that only knows an upper bound would hand over): 2^10 x the maximum
+    loose = (x.abs().max() * 1024.0).reshape(1).view(torch.int32)
+    y3, _ = eng.conv3x3_wino_f16s(x, u2, cs, bias, None, False, 1, amax_in=loose)
+    ref3 = _ref64(x, w, bias, None, False, 1)
+    assert float((y3.double() - ref3).abs().max()) <= 1e-5 * float(ref3.abs().max())
+
+
+@pytest.mark.parametrize('B,Cin,Cout,H,W,dil,res,relu,taps', [(2, 64, 64, 20, 300, 1, True, True, 9), (1, 64, 128, 17, 130, 2, False, True, 9),
+                                                                (1, 128, 256, 13, 257, 1, False, False, 1), (2, 256, 512, 6, 40, 1, False, False, 1),
+                                                                (1, 32, 64, 9, 600, 4, True, False, 9)])
+def test_conv3x3_split_planes_direct_matches_float64(eng, B, Cin, Cout, H, W, dil, res, relu, taps):
+    """the direct kernel on the 16-bit matrix cores (64-channel layers, 1x1 projections): spa_conv3x3_f16s / spa_conv1x1_f16s"""
+    k = 3 if taps == 9 else 1
+    x, w, bias, r = _operands(B, Cin, Cout, H, W, k, res, 7)
+    wt = w.permute(0, 2, 3, 1).reshape(Cout, taps, Cin).contiguous()
+    wt2, inv_t = eng.split_planes(wt)
+    y, am = eng.conv3x3_f16s(x, wt2, inv_t, bias, r, relu, dil)
+    ref = _ref64(x, w, bias, r, relu, dil)
+    scale = float(ref.abs().max())
+    assert float((y.double() - ref).abs().max()) <= 4e-6 * scale
+    assert float(am.view(torch.float32)) == float(y.abs().max())
+
+
 def test_winograd_layers_inside_the_network(eng):
     """DRN-D-22 float32 with and without the Winograd / own-convolution paths: the map the pipeline pools (index 7)
     agrees to 2e-5 of its scale (north star: 1e-4), and the Winograd path really ran."""
@@ -92,9 +158,14 @@ def test_winograd_layers_inside_the_network(eng):
     x = synth.synth_batch([3, 4], 256, 512)
     E = drn._EPILOGUE
     saved = (E['winograd'], E['own_conv32'])
+    split_saved = E['split_gemm']
     try:
         E['own_conv32'] = True
         E['winograd'], E['wino_launches'] = 4, 0
+        E['split_gemm'], E['gemm16_launches'], E['gemm16n_launches'], E['conv16_launches'] = True, 0, 0, 0
+        _, a4s = m.batch_predict(x, need=[7])
+        assert E['wino_launches'] == 13 and E['gemm16_launches'] + E['gemm16n_launches'] == 13 and E['conv16_launches'] >= 3
+        E['split_gemm'], E['wino_launches'] = False, 0
         _, a4 = m.batch_predict(x, need=[7])
         assert E['wino_launches'] == 13                   # layers 4-8: both channel counts >= 128
         E['winograd'], E['wino_launches'] = 2, 0
@@ -106,15 +177,17 @@ def test_winograd_layers_inside_the_network(eng):
         _, c = m.batch_predict(x, need=[7])
     finally:
         E['winograd'], E['own_conv32'] = saved
+        E['split_gemm'] = split_saved
     # float64 network on the CPU: the yardstick for all four
     m64 = drn.create_drn('drn_d_22', device='cpu', dtype=torch.float64)
     _, r = m64.batch_predict(x, need=[7])
     r = r[7].cuda()
     scale = float(r.abs().max())
-    err = {k: float((v[7].double() - r).abs().max()) / scale for k, v in (('F(4x4,3x3)', a4), ('F(2x2,3x3)', a2), ('direct', b), ('MIOpen', c))}
+    err = {k: float((v[7].double() - r).abs().max()) / scale for k, v in (('F(4x4,3x3) two half-precision planes', a4s), ('F(4x4,3x3)', a4), ('F(2x2,3x3)', a2), ('direct', b), ('MIOpen', c))}
     print('map 7 vs the float64 network, of scale:', err)
     assert max(err.values()) <= 1e-5                      # north star: 1e-4
     assert err['F(4x4,3x3)'] <= 2.0 * err['MIOpen'] + 1e-6
+    assert err['F(4x4,3x3) two half-precision planes'] <= 2.0 * err['MIOpen'] + 1e-6
 
 
 @pytest.mark.parametrize('B,Cin,Cout,H,W,dil,res', [(2, 64, 256, 16, 40, 1, False), (1, 128, 256, 24, 300, 2, True), (2, 64, 64, 20, 300, 1, True)])
