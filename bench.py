@@ -106,11 +106,18 @@ LIMITERS = {
     'k_kmeans': 'latency: numpy-ordered float64 sums (one serial chain per cluster and column, ~10 cycles per member row) and '
                 'two grid barriers per Lloyd iteration',
     'k_rgb2lab': 'DP VALU: binary64 exp/log emulation of the float32 power and cube root (bit-defined transcendental)',
+    'k_gemm_f16x3<256, 256>': '16-bit MFMA pipe + its feed: the Winograd GEMMs with three half-precision products per float32 product.  Measured '
+                              'on the 512 -> 512 layer (30 images): 3.64 ms as is, 3.23 without the in-register split of the activations, '
+                              '2.89 with the global loads compiled out (LDS reads + conversions + MFMA: 1.2 PFLOP/s executed, the ceiling '
+                              'this part sustains on dense 16-bit MFMA before it lowers its clock) - i.e. 80 % of what the loop can deliver; '
+                              'the rest is the wait for the next K step (two LDS buffers of 64 KB: a third does not fit 160 KB)',
+    'k_conv3x3_f32<split>(all)': 'barrier and load latency, not the matrix pipe: 64 channels are two K steps per tap with 12 matrix '
+                                 'instructions per wave each; the layers move 2 GB per launch (1.1 TB/s)',
     'k_conv3x3_f32<0, 256, 1, 256>': 'float32 MFMA pipe.  K = Cin is 8-16 K steps per 256 x 256 tile against 144 in the 3x3 form, so the '
                                              'tile prologue and the store of the output tile weigh more (0.83 against 0.88 of the peak) although the '
                                              'workgroups are persistent and stage the next tile before their epilogue',
-    'k_wino_in': 'HBM: reads X, writes V = 4x X (position-major, dense rows)',
-    'k_wino_out': 'HBM: reads M = 4x Y (+ the residual), writes Y',
+    'k_wino_in': 'HBM: reads X, writes V = 2.25x X (position-major, dense rows); 5.3 TB/s on the 512-channel layers',
+    'k_wino_out': 'HBM: reads M = 2.25x Y (+ the residual), writes Y; 4.9 TB/s on the 512-channel layers',
     'k_conv3x3_f32<taps 9>(all)': 'float32 MFMA pipe: 0.88-0.89 of the 157.3 TFLOP/s peak on the 256/512-channel layers (MIOpen\'s hand-written '
                           'assembly reaches 0.88 on the same box, without the epilogue); the 64/128-channel layers (a sixth of the '
                           'launches\' time) run at 0.65-0.78: a K step is short there and its barrier + load wait shows',
@@ -419,7 +426,7 @@ def main():
     for name, (ms, n) in prof.items():
         avg = ms / n
         ent = {'launches_per_step': n / a.steps, 'avg_ms': round(avg, 4), 'ms_per_step': round(ms / a.steps, 3)}
-        if name.startswith('k_drn_stem_d') and a.dtype == 'fp32':
+        if name.startswith('k_drn_stem_d') and a.dtype == 'fp32' and not drn._EPILOGUE['split_gemm']:
             # the float32 network's fused stem is float32 MFMA arithmetic (the bf16 network's runs on the bf16
             # matrix cores and is priced against HBM like the other streaming kernels)
             tf = stem_flops(B, H, W) / (avg * 1e-3) / 1e12

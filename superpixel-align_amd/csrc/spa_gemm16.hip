@@ -35,7 +35,7 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 
 #define G16_THREADS 512
 
-template <int BM, int BN>
+template <int BM, int BN, int VARIANT = 0>
 __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3(const char *__restrict__ X, const char *__restrict__ Wt,
                                                             float *__restrict__ Y, int rows_per_z, int Cin, int Cout,
                                                             int ntiles, int total_tiles, int zcount, long long xz,
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3(const char *__restri
         __syncthreads();
         for (int t = 0; t < nk; ++t) {
             const int cur = (t + par) & 1;
-            if (t + 1 < nk) stage(t + 1, cur ^ 1);
+            if (t + 1 < nk) { if (VARIANT != 2) stage(t + 1, cur ^ 1); }
             else {
                 // last K step: the other buffers are free — stage the next tile's first K step under this step's matrix work
                 e_r0 = r0; e_n0 = n0; e_y = ybase;
@@ -159,8 +159,12 @@ __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3(const char *__restri
                 const f32x4 a = *(const f32x4 *)(lx + row * 128 + (((2 * fk) ^ (row & 7)) << 4));
                 const f32x4 b = *(const f32x4 *)(lx + row * 128 + (((2 * fk + 1) ^ (row & 7)) << 4));
                 const f32x8 v = (f32x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]} * sc;
-                ph[j] = __builtin_convertvector(v, f16x8);
-                pl[j] = __builtin_convertvector(v - __builtin_convertvector(ph[j], f32x8), f16x8);
+                if (VARIANT == 1) {          // development: no conversion (timing only)
+                    ph[j] = __builtin_bit_cast(f16x8, a); pl[j] = __builtin_bit_cast(f16x8, b);
+                } else {
+                    ph[j] = __builtin_convertvector(v, f16x8);
+                    pl[j] = __builtin_convertvector(v - __builtin_convertvector(ph[j], f32x8), f16x8);
+                }
             }
             // small terms first: they meet the accumulator while it is small
 #pragma unroll
@@ -211,6 +215,8 @@ int gemm_f16x3_raw(spa_ctx *ctx, const float *x, long long rows, int32_t Cin, co
     const size_t lds = 2 * (size_t)(bm + bn) * 128;
     if (!ctx->gemm16_attr_done) {
         SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3<256, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
+        SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3<256, 256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
+        SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3<256, 256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
         SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 128));
         ctx->gemm16_attr_done = 1;
     }
@@ -218,7 +224,14 @@ int gemm_f16x3_raw(spa_ctx *ctx, const float *x, long long rows, int32_t Cin, co
     const int per_cu = lds > 80 * 1024 ? 1 : 2;
     long long grid = (long long)ctx->n_cu * per_cu;
     if (grid > total * zcount) grid = total * zcount;
-    if (bm == 256)
+    static const int variant = getenv("SPA_GEMM16_VARIANT") ? atoi(getenv("SPA_GEMM16_VARIANT")) : 0;
+    if (bm == 256 && variant == 1)
+        hipLaunchKernelGGL((k_gemm_f16x3<256, 256, 1>), dim3((unsigned)grid), dim3(G16_THREADS), lds, s, (const char *)x, (const char *)wt, y,
+                           (int)rows, Cin, Cout, ntiles, (int)total, zcount, rows * Cin, (long long)Cout * Cin, rows * Cout, (const unsigned *)amax);
+    else if (bm == 256 && variant == 2)
+        hipLaunchKernelGGL((k_gemm_f16x3<256, 256, 2>), dim3((unsigned)grid), dim3(G16_THREADS), lds, s, (const char *)x, (const char *)wt, y,
+                           (int)rows, Cin, Cout, ntiles, (int)total, zcount, rows * Cin, (long long)Cout * Cin, rows * Cout, (const unsigned *)amax);
+    else if (bm == 256)
         hipLaunchKernelGGL((k_gemm_f16x3<256, 256>), dim3((unsigned)grid), dim3(G16_THREADS), lds, s, (const char *)x, (const char *)wt, y,
                            (int)rows, Cin, Cout, ntiles, (int)total, zcount, rows * Cin, (long long)Cout * Cin, rows * Cout, (const unsigned *)amax);
     else

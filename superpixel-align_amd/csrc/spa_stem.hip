@@ -400,6 +400,228 @@ __global__ __launch_bounds__(256) void k_drn_stem_d_bf16(const unsigned short *_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// float32 stem on the 16-bit matrix cores at float32 accuracy (round 3; the scheme of spa_gemm16.hip): every operand is
+// two half-precision planes h = rn(s x), l = rn(s x - h) of an exactly scaled value and every product three
+// v_mfma_f32_16x16x32_f16 (wl.xh + wh.xl + wh.xh, float32 accumulation) — 18 + 15 matrix instructions of 16 passes per
+// 16 pixels instead of 37 + 36 float32 ones of 32 passes.  Geometry, k orders, the two shifted patch copies and the
+// persistent tile loop are the bf16 kernel's above; the planes double the LDS (78 KB: two workgroups per CU).
+// Scales (powers of two, all static): the normalised image is below 4 in magnitude -> 2^12; layer0's output is bounded
+// by max_n (4 sum_k |w0[n][k]| + |b0[n]|) -> s1 = 2^(14 - ceil(log2 bound)); the weights by their largest magnitude
+// (k_stem_pack_f16 computes them and leaves the two unscale factors next to the fragments).
+// ---------------------------------------------------------------------------------------------------
+typedef _Float16 stem_h8 __attribute__((ext_vector_type(8)));
+#define SH_L0_PITCH 40                         // halfs per layer0 pixel in LDS: 16 h | 16 l | 8 pad (80 bytes: conflict-free b128)
+#define SH_IN_S0 4096.0f                       // 2^12: |normalised input| < 4
+
+__device__ __forceinline__ unsigned short stem_f16_bits(float f)
+{
+    const _Float16 h = (_Float16)f;
+    return __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ float stem_f16_val(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
+
+// wp: [22][64] x 8 halfs (layer0 h: steps 0-5, layer0 l: 6-11, layer1 h: 12-16, layer1 l: 17-21), then 4 floats:
+// unscale0 = 1 / (2^12 t0), s1, unscale1 = 1 / (s1 t1), -
+__global__ __launch_bounds__(256, 2) void k_drn_stem_d_f16x3(const float *__restrict__ xn, int B, int H, int W,   // normalised, (B,H,W,3)
+                                                             const unsigned short *__restrict__ wp,
+                                                             const float *__restrict__ b0, const float *__restrict__ b1,
+                                                             float *__restrict__ y)
+{
+    __shared__ __attribute__((aligned(16))) unsigned short in_h[2][SB_COPY], in_l[2][SB_COPY];
+    __shared__ __attribute__((aligned(16))) unsigned short l0_s[ST_LP * SH_L0_PITCH + 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int m = lane & 15, g = lane >> 4;
+    const long long npix = (long long)H * W;
+    const int tiles_x = (W + ST_TW - 1) / ST_TW, tiles_y = (H + ST_TH - 1) / ST_TH;
+    const int n_tiles = tiles_x * tiles_y * B;
+
+    stem_h8 w0h[6], w0l[6], w1h[5], w1l[5];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        w0h[s] = *(const stem_h8 *)(wp + ((size_t)s * 64 + lane) * 8);
+        w0l[s] = *(const stem_h8 *)(wp + ((size_t)(6 + s) * 64 + lane) * 8);
+    }
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        w1h[s] = *(const stem_h8 *)(wp + ((size_t)(12 + s) * 64 + lane) * 8);
+        w1l[s] = *(const stem_h8 *)(wp + ((size_t)(17 + s) * 64 + lane) * 8);
+    }
+    const float *sc = (const float *)(wp + (size_t)22 * 64 * 8);
+    const float unscale0 = sc[0], s1 = sc[1], unscale1 = sc[2];
+    const float4 bias0 = *(const float4 *)(b0 + 4 * g), bias1 = *(const float4 *)(b1 + 4 * g);
+    int goff[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const int grp = 4 * s + g;
+        const int ky = grp / 3, c = grp - ky * 3;
+        goff[s] = grp < 21 ? c * SB_PLANE + ky * SB_PW : 0;
+    }
+    int l1off[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        int tap = 2 * s + (g >> 1);
+        if (tap > 8) tap = 8;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        l1off[s] = (ky * ST_LW + kx) * SH_L0_PITCH + 8 * (g & 1);
+    }
+    constexpr int NE = 3 * ST_IH * ST_IW, NU = (NE + 255) / 256;
+    float raw[NU];
+    int eiy[NU], eix[NU], elds[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        int e = tid + u * 256;
+        const bool ok = e < NE;
+        if (!ok) e = NE - 1;
+        const int pix = e / 3, c = e - pix * 3;
+        eiy[u] = pix / ST_IW; eix[u] = pix - eiy[u] * ST_IW;
+        elds[u] = ok ? c * SB_PLANE + eiy[u] * SB_PW + eix[u] : -1;
+        eix[u] = eix[u] * 4 + c;
+    }
+    auto patch_load = [&](int tile) {
+        const int b = tile / (tiles_x * tiles_y), tr = tile - b * (tiles_x * tiles_y);
+        const int ty0 = (tr / tiles_x) * ST_TH, tx0 = (tr % tiles_x) * ST_TW;
+        const float *src = xn + (long long)b * npix * 3;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int gy = ty0 - 4 + eiy[u], gx = tx0 - 4 + (eix[u] >> 2);
+            const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+            raw[u] = src[(unsigned)((cy * W + cx) * 3 + (eix[u] & 3))];
+        }
+    };
+    for (int i = tid; i < SB_COPY; i += 256) { in_h[0][i] = 0; in_h[1][i] = 0; in_l[0][i] = 0; in_l[1][i] = 0; }
+    if ((int)blockIdx.x < n_tiles) patch_load(blockIdx.x);
+    __syncthreads();
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int b = tile / (tiles_x * tiles_y), tr = tile - b * (tiles_x * tiles_y);
+        const int ty0 = (tr / tiles_x) * ST_TH, tx0 = (tr % tiles_x) * ST_TW;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int ix = eix[u] >> 2;
+            const int gy = ty0 - 4 + eiy[u], gx = tx0 - 4 + ix;
+            const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            if (elds[u] >= 0) {
+                const float v = in ? raw[u] * SH_IN_S0 : 0.0f;
+                const unsigned short vh = stem_f16_bits(v);
+                const unsigned short vl = stem_f16_bits(v - stem_f16_val(vh));
+                in_h[0][elds[u]] = vh; in_l[0][elds[u]] = vl;
+                if (ix >= 1) { in_h[1][elds[u] - 1] = vh; in_l[1][elds[u] - 1] = vl; }
+            }
+        }
+        stem_lds_barrier();
+
+        // ---- layer0 on the 18 x 34 region
+        for (int t = wv; t < (ST_LP + 15) / 16; t += 4) {
+            int p = t * 16 + m;
+            if (p > ST_LP - 1) p = ST_LP - 1;
+            const int py = p / ST_LW, px = p - py * ST_LW;
+            const int boff = py * SB_PW + (px & ~1);
+            const unsigned short *bh = in_h[px & 1] + boff, *bl = in_l[px & 1] + boff;
+            stem_f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+                const uint32_t *qh = (const uint32_t *)(bh + goff[s]), *ql = (const uint32_t *)(bl + goff[s]);
+                union { uint32_t u[4]; stem_h8 v; } fh, fl;
+                fh.u[0] = qh[0]; fh.u[1] = qh[1]; fh.u[2] = qh[2]; fh.u[3] = qh[3];
+                fl.u[0] = ql[0]; fl.u[1] = ql[1]; fl.u[2] = ql[2]; fl.u[3] = ql[3];
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0l[s], fh.v, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0h[s], fl.v, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0h[s], fh.v, acc, 0, 0, 0);
+            }
+            const int q0 = t * 16 + m;
+            if (q0 < ST_LP) {
+                const int gy = ty0 - 1 + py, gx = tx0 - 1 + px;
+                const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                float v[4] = {acc[0] * unscale0 + bias0.x, acc[1] * unscale0 + bias0.y, acc[2] * unscale0 + bias0.z, acc[3] * unscale0 + bias0.w};
+                unsigned short vh[4], vl[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float r = in ? fmaxf(v[j], 0.0f) * s1 : 0.0f;
+                    vh[j] = stem_f16_bits(r);
+                    vl[j] = stem_f16_bits(r - stem_f16_val(vh[j]));
+                }
+                unsigned short *o = l0_s + q0 * SH_L0_PITCH + 4 * g;
+                *(uint2 *)o = make_uint2((unsigned)vh[0] | ((unsigned)vh[1] << 16), (unsigned)vh[2] | ((unsigned)vh[3] << 16));
+                *(uint2 *)(o + 16) = make_uint2((unsigned)vl[0] | ((unsigned)vl[1] << 16), (unsigned)vl[2] | ((unsigned)vl[3] << 16));
+            }
+        }
+        stem_lds_barrier();
+        if (tile + (int)gridDim.x < n_tiles) patch_load(tile + (int)gridDim.x);
+
+        // ---- layer1 on the 16 x 32 tile
+        for (int t = wv; t < 32; t += 4) {
+            const int row = t >> 1, col = (t & 1) * 16 + m;
+            stem_f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+            const unsigned short *lb = l0_s + (row * ST_LW + col) * SH_L0_PITCH;
+#pragma unroll
+            for (int s = 0; s < 5; ++s) {
+                const stem_h8 fh = *(const stem_h8 *)(lb + l1off[s]);
+                const stem_h8 fl = *(const stem_h8 *)(lb + l1off[s] + 16);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1l[s], fh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h[s], fl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h[s], fh, acc, 0, 0, 0);
+            }
+            const int gy = ty0 + row, gx = tx0 + col;
+            if (gy < H && gx < W)
+                *(float4 *)(y + ((((long long)b * H + gy) * W + gx) * 16 + 4 * g)) =
+                    make_float4(fmaxf(acc[0] * unscale1 + bias1.x, 0.0f), fmaxf(acc[1] * unscale1 + bias1.y, 0.0f),
+                                fmaxf(acc[2] * unscale1 + bias1.z, 0.0f), fmaxf(acc[3] * unscale1 + bias1.w, 0.0f));
+        }
+        stem_lds_barrier();
+    }
+}
+
+// weights -> scaled half-precision planes in MFMA A fragment order (one workgroup of 64 lanes per step, the k orders of
+// k_stem_pack_bf16), and the scale factors.  Every block recomputes the three maxima (2 352 + 2 304 weights: cheap).
+__global__ __launch_bounds__(64) void k_stem_pack_f16(const float *__restrict__ w0, const float *__restrict__ b0,
+                                                      const float *__restrict__ w1, unsigned short *__restrict__ wp)
+{
+    const int s = blockIdx.x, lane = threadIdx.x;
+    float m0 = 0.f, m1 = 0.f, bound = 0.f;
+    for (int i = lane; i < 16 * 147; i += 64) m0 = fmaxf(m0, fabsf(w0[i]));
+    for (int i = lane; i < 16 * 144; i += 64) m1 = fmaxf(m1, fabsf(w1[i]));
+    if (lane < 16) {
+        float a = 0.f;
+        for (int k = 0; k < 147; ++k) a += fabsf(w0[lane * 147 + k]);
+        bound = 4.0f * a + fabsf(b0[lane]);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        m0 = fmaxf(m0, __shfl_xor(m0, o)); m1 = fmaxf(m1, __shfl_xor(m1, o)); bound = fmaxf(bound, __shfl_xor(bound, o));
+    }
+    auto pow2_to_2_14 = [](float mx) {           // power of two t with t * mx in [2^14, 2^15)  (mx > 0)
+        const int e = (int)(__float_as_uint(mx) >> 23) - 127;
+        return __uint_as_float((unsigned)(127 + 14 - e) << 23);
+    };
+    const float t0 = pow2_to_2_14(fmaxf(m0, 1e-30f)), t1 = pow2_to_2_14(fmaxf(m1, 1e-30f));
+    const float s1 = 0.5f * pow2_to_2_14(fmaxf(bound, 1e-30f));       // bound < 2^(e+1): s1 * bound < 2^15
+    if (s == 22) {
+        if (lane == 0) {
+            float *sc = (float *)(wp + (size_t)22 * 64 * 8);
+            sc[0] = 1.0f / (SH_IN_S0 * t0); sc[1] = s1; sc[2] = 1.0f / (s1 * t1); sc[3] = 0.f;
+        }
+        return;
+    }
+    const int n = lane & 15, g = lane >> 4;
+    unsigned short *o = wp + ((size_t)s * 64 + lane) * 8;
+    const bool lo = (s >= 6 && s < 12) || s >= 17;
+    if (s < 12) {                                  // layer0: k = (ky*3 + c)*8 + kx
+        const int s0 = s % 6, grp = 4 * s0 + g, ky = grp / 3, c = grp - ky * 3;
+        for (int j = 0; j < 8; ++j) {
+            const float v = (grp < 21 && j < 7) ? w0[n * 147 + c * 49 + ky * 7 + j] * t0 : 0.f;
+            const unsigned short h = stem_f16_bits(v);
+            o[j] = lo ? stem_f16_bits(v - stem_f16_val(h)) : h;
+        }
+    } else {                                       // layer1: k = tap*16 + c
+        const int s1i = (s - 12) % 5, tap = 2 * s1i + (g >> 1), c0 = 8 * (g & 1);
+        for (int j = 0; j < 8; ++j) {
+            const float v = tap <= 8 ? w1[n * 144 + tap * 16 + c0 + j] * t1 : 0.f;
+            const unsigned short h = stem_f16_bits(v);
+            o[j] = lo ? stem_f16_bits(v - stem_f16_val(h)) : h;
+        }
+    }
+}
+
 // weights -> MFMA A fragments: [step][lane] x 8 bf16; lane = (channel n = lane & 15, k group g = lane >> 4)
 __global__ void k_stem_pack_bf16(const float *__restrict__ w0, const float *__restrict__ w1, unsigned short *__restrict__ wp)
 {
@@ -423,7 +645,7 @@ extern "C" int spa_drn_stem_d(spa_ctx *ctx, const float *x, int32_t B, int32_t H
                               float *xn_scratch, void *stream)
 {
     SPA_ARG(ctx && x && w0 && b0 && w1 && b1 && mean3_host && std3_host && y && B > 0 && H > 0 && W > 0);
-    SPA_ARG(out_dtype == 0 || out_dtype == 1);
+    SPA_ARG(out_dtype == 0 || out_dtype == 1 || out_dtype == 2);      // 2: float32 output, 16-bit matrix cores (two planes)
     // exact input normalisation (models/drn.py:319-321) into a channels-last workspace, then the stem
     SpaProfScope prof_(ctx, PROF_DRN_STEM, spa_stream(stream));
     int rc = SPA_OK;
@@ -452,6 +674,17 @@ extern "C" int spa_drn_stem_d(spa_ctx *ctx, const float *x, int32_t B, int32_t H
     if (rc != SPA_OK) return rc;
     rc = spa_drn_normalise(ctx, x, B, H, W, xn, 0, mean3_host, std3_host, stream);
     if (rc != SPA_OK) return rc;
+    if (out_dtype == 2) {
+        unsigned short *wp;
+        if ((rc = spa_ws_reserve(ctx, WS_STEM_WPACK, (size_t)22 * 64 * 8 * 2 + 16, (void **)&wp)) != SPA_OK) return rc;
+        hipLaunchKernelGGL(k_stem_pack_f16, dim3(23), dim3(64), 0, spa_stream(stream), w0, b0, w1, wp);
+        long long g2 = 2ll * ctx->n_cu;                    // two resident workgroups per CU (78 KB of LDS)
+        if (g2 > n_tiles) g2 = n_tiles;
+        hipLaunchKernelGGL(k_drn_stem_d_f16x3, dim3((unsigned)g2), dim3(256), 0, spa_stream(stream), (const float *)xn, B, H, W,
+                           (const unsigned short *)wp, b0, b1, (float *)y);
+        SPA_LAUNCH_CHECK();
+        return SPA_OK;
+    }
     hipLaunchKernelGGL(k_drn_stem_d, dim3((unsigned)grid), dim3(256), 0, spa_stream(stream), (const float *)xn, B, H, W,
                        w0, b0, w1, b1, y, (int)out_dtype);
     SPA_LAUNCH_CHECK();

@@ -379,7 +379,8 @@ class DRN(nn.Module):
         """One sub-batch: raw (b,3,H,W) float32 0..255 -> the 8 maps."""
         eng = _EPILOGUE['engine']
         if eng is not None and xc.is_cuda and getattr(self, '_stem', None) is not None and self.use_fused_stem:
-            l1 = eng.drn_stem_d(xc.float().contiguous(), *self._stem, dtype=self.compute_dtype)
+            l1 = eng.drn_stem_d(xc.float().contiguous(), *self._stem, dtype=self.compute_dtype,
+                                split=_EPILOGUE['split_gemm'] and self.compute_dtype == torch.float32)
             return self.forward_maps(None, layer1_out=l1)
         if eng is not None and xc.is_cuda:
             xi = eng.drn_normalise(xc.float().contiguous(), self.compute_dtype)

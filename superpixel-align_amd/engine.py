@@ -115,10 +115,11 @@ class Engine(object):
                                           0 if dtype == torch.float32 else 1, mean, std, self._s()))
         return out
 
-    def drn_stem_d(self, x, w0, b0, w1p, b1, dtype=torch.float32):
+    def drn_stem_d(self, x, w0, b0, w1p, b1, dtype=torch.float32, split=False):
         """DRN-D stem in one kernel: raw (B,3,H,W) float32 0..255 -> layer1 output (B,16,H,W) of
         `dtype` (float32 arithmetic) in channels-last storage.  w0 (16,147), w1p (16,144) in
-        (n, ky, kx, c) order."""
+        (n, ky, kx, c) order.  split (float32 only): the 16-bit matrix cores with two half-precision planes per operand
+        (float32 accuracy, csrc/spa_stem.hip) instead of the float32 matrix instructions."""
         x = _req(x, torch.float32, 'x')
         B, C, H, W = x.shape
         assert C == 3
@@ -132,7 +133,7 @@ class Engine(object):
         # on different streams (DRN.batch_predict(streams > 1)) never share the context-wide workspace
         scratch = torch.empty((B, H, W, 3), dtype=dtype, device=x.device)
         check(self._lib.spa_drn_stem_d(self._ctx, _ptr(x), B, H, W, _ptr(w0), _ptr(b0), _ptr(w1p), _ptr(b1),
-                                       mean, std, _ptr(out), 0 if dtype == torch.float32 else 1, _ptr(scratch),
+                                       mean, std, _ptr(out), (2 if split else 0) if dtype == torch.float32 else 1, _ptr(scratch),
                                        self._s()))
         return out
 

@@ -422,8 +422,9 @@ def test_host_stream_matches_device_resident_path(mods, synth):
     pipe.eng.raise_on_status()
 
 
+@pytest.mark.parametrize('split', [False, True])
 @pytest.mark.parametrize('shape', [(2, 64, 96), (1, 100, 75), (3, 33, 130)])
-def test_fused_drn_d_stem_matches_convolution_path(mods, shape):
+def test_fused_drn_d_stem_matches_convolution_path(mods, shape, split):
     """libspalign's float32-MFMA stem kernel (normalise + layer0 + layer1 of DRN-D) against the
     MIOpen convolutions + separate epilogues it replaces: float32 rounding-level agreement on
     layer1's output and on the final map, including image sizes that are not tile multiples."""
@@ -435,10 +436,24 @@ def test_fused_drn_d_stem_matches_convolution_path(mods, shape):
     _, ref = model.batch_predict(x)
     ref = [m.clone() for m in ref]
     model.use_fused_stem = True
-    _, got = model.batch_predict(x)
-    for i in (0, 1, 7):
-        scale = float(ref[i].abs().max())
-        assert float((got[i] - ref[i]).abs().max()) <= 2e-5 * scale
+    saved = mods.drn._EPILOGUE['split_gemm']
+    mods.drn._EPILOGUE['split_gemm'] = split        # the stem on the 16-bit matrix cores (two half-precision planes) or float32 MFMA
+    try:
+        _, got = model.batch_predict(x)
+        for i in (0, 1, 7):
+            scale = float(ref[i].abs().max())
+            assert float((got[i] - ref[i]).abs().max()) <= 2e-5 * scale
+        # layer1's output against float64 convolutions of the same normalised image: float32 rounding level either way
+        eng = mods.drn._EPILOGUE['engine']
+        l1 = eng.drn_stem_d(x.float().contiguous(), *model._stem, dtype=torch.float32, split=split)
+        xn = ((x.double() / 255.0) - torch.tensor([0.485, 0.456, 0.406], device='cuda', dtype=torch.float64).view(1, 3, 1, 1)) \
+            / torch.tensor([0.229, 0.224, 0.225], device='cuda', dtype=torch.float64).view(1, 3, 1, 1)
+        c0, c1 = model.layer0[0], model.layer1[0]
+        r = torch.relu(torch.nn.functional.conv2d(xn, c0.weight.double(), c0.bias.double(), 1, 3))
+        r = torch.relu(torch.nn.functional.conv2d(r, c1.weight.double(), c1.bias.double(), 1, 1))
+        assert float((l1.double() - r).abs().max()) <= 3e-6 * float(r.abs().max())
+    finally:
+        mods.drn._EPILOGUE['split_gemm'] = saved
 
 
 def test_fused_stem_in_bf16_mode(mods):
