@@ -177,6 +177,15 @@ int spa_conv1x1_f16s(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t
                      const void *wt2, float inv_t, int32_t Cout, const float *bias, const float *residual,
                      int32_t relu, const void *amax_in, void *amax_out, float *y, void *stream);
 
+/* the stride-2 3x3 convolution that opens layers 3 and 4 (models/drn.py:204-206; padding 1), on the 16-bit matrix cores at
+ * float32 accuracy, together with the block's 1x1 stride-2 projection (models/drn.py:195-203) as output channels
+ * [csplit, Cout) — wt2 rows csplit.. carry the projection's weights at the centre tap and zeros elsewhere — so the input is
+ * read once: y (B,Ho,Wo,csplit) = relu?(conv + bias), y2 (B,Ho,Wo,Cout-csplit) = projection + bias (or y2 NULL and
+ * csplit = Cout); Ho = (Hi+1)/2, Wo = (Wi+1)/2; amax_out tracks y.  Cout % 128 == 0, csplit % 64 == 0, Cin % 32 == 0. */
+int spa_conv3x3_s2_f16s(spa_ctx *ctx, const float *x, int32_t B, int32_t Hi, int32_t Wi, int32_t Cin,
+                        const void *wt2, float inv_t, int32_t Cout, int32_t csplit, const float *bias,
+                        int32_t relu, const void *amax_in, void *amax_out, float *y, float *y2, void *stream);
+
 /* ---- input stage ---------------------------------------------------------------------------
  * replaces the host resize of ResizeImageDataset.get_example (datasets/resize_image_dataset.py:31-34:
  * chainercv.transforms.resize(image, resize_shape, 3)) as Pillow computes it on an 8-bit image, channel by

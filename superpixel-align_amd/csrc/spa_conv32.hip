@@ -39,7 +39,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // bound on max |x|) and split in registers; three v_mfma_f32_16x16x32_f16 replace eight v_mfma_f32_16x16x4_f32 per
 // 32-channel step (5.3x less matrix time).  The epilogue multiplies by unscale = 2^(e - 14) / t before the bias and,
 // when amax_out is given, records the largest magnitude it stores (the next layer's scale).
-template <int HAS_RES, int BM, int TAPS, int BN, bool SPLIT = false>
+template <int HAS_RES, int BM, int TAPS, int BN, bool SPLIT = false, int S = 1>
 __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__restrict__ X, const float *__restrict__ Wt,
                                                              const float *__restrict__ bias,
                                                              const float *__restrict__ R, float *__restrict__ Y,
@@ -48,8 +48,14 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
                                                              int ntiles, int total_tiles, int zcount, long long xz,
                                                              long long wz, long long yz, int late_prefetch,
                                                              const unsigned *__restrict__ amax_in = nullptr,
-                                                             unsigned *__restrict__ amax_out = nullptr, float inv_t = 1.f)
+                                                             unsigned *__restrict__ amax_out = nullptr, float inv_t = 1.f,
+                                                             int Hi = 0, int Wi = 0, float *__restrict__ Y2 = nullptr, int csplit = 0)
 {
+    // S = 2 (round 3): stride 2, padding 1 (H, W = OUTPUT size, Hi, Wi = input size): the pixel segment of a K step is the
+    // 2 BN + 8 input pixels the tile's taps touch, fragments read every other row of it.  Y2 / csplit: two outputs from one
+    // pass over the input — output channels [0, csplit) go to Y with ReLU as asked, [csplit, Cout) to Y2 without (the 1x1
+    // stride-2 projection of a BasicBlock, models/drn.py:195-203, as extra channels whose only non-zero tap is the centre)
+    if (S == 1) { Hi = H; Wi = W; }
     extern __shared__ __attribute__((aligned(1024))) char lds32[];   // [2] weight tiles 32 KB | [2] pixel segments 33 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-aware tile order: consecutive workgroup ids go round-robin over the 8 XCDs; give every XCD a
@@ -78,14 +84,14 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
         y = row_id % H;
         x0 = xt * BN; n0 = nt * BM;
         wbase = (const char *)(Wt + (long long)z * wz + (long long)n0 * TAPS * Cin);
-        xbase = (const char *)(X + (long long)z * xz + (long long)row_id * W * Cin);      // input row y, pixel 0
+        xbase = (const char *)(X + (long long)z * xz + ((long long)(row_id / H) * Hi + (long long)y * S) * Wi * Cin);      // input row y * S, pixel 0
         ybase = Y + (long long)z * yz;
         rbase = R + (long long)z * yz;
     };
     constexpr int WN = BM == 64 ? 8 : 4;                 // waves along the pixels
     constexpr int MI = BM == 256 ? 8 : 4;                // 16-channel MFMA tiles per wave
     constexpr int NJ = BN / WN / 16;                     // 16-pixel MFMA tiles per wave
-    constexpr int XBLK = (BN + 2 * C32_HALO) / 8;        // 8-pixel row blocks of the pixel segment: 33 or 17
+    constexpr int XBLK = (S * BN + 2 * C32_HALO) / 8;    // 8-pixel row blocks of the pixel segment: 33 or 17
     constexpr int XTHIRD = (XBLK + 2) / 3;               // staged per K step: 11 or 6
     constexpr int XSEG = XBLK * 8 * 128;                 // bytes
     constexpr int WROWS = MI * 16;                       // channels per wave
@@ -116,9 +122,9 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
     // one third (11 of 33 row blocks) of the pixel segment of group g
     auto stage_x = [&](int g, int third) {
         const int dyi = TAPS == 9 ? g / ks : 1, kc = TAPS == 9 ? g - dyi * ks : g;
-        const int yy = y + (dyi - 1) * dil;
-        const bool yok = yy >= 0 && yy < H;
-        const char *xk = xbase + ((long long)(dyi - 1) * dil * W) * Cin * 4 + (long long)kc * C32_BK * 4 + chunk_byte;
+        const int yy = y * S + (dyi - 1) * dil;
+        const bool yok = yy >= 0 && yy < Hi;
+        const char *xk = xbase + ((long long)(dyi - 1) * dil * Wi) * Cin * 4 + (long long)kc * C32_BK * 4 + chunk_byte;
         char *dst = xbuf + ((g + px_par) & 1) * XSEG;
 #pragma unroll
         for (int r = 0; r < (XTHIRD + 7) / 8; ++r) {
@@ -126,8 +132,8 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
             if (i >= XTHIRD) break;
             const int blk = third * XTHIRD + i;
             if (blk >= XBLK) break;
-            const int px = x0 - C32_HALO + blk * 8 + sub;
-            const bool ok = yok && px >= 0 && px < W;
+            const int px = x0 * S - C32_HALO + blk * 8 + sub;
+            const bool ok = yok && px >= 0 && px < Wi;
             // a zero line for padding pixels (its 128 bytes are read at the chunk offset only)
             const char *src = ok ? xk + (long long)px * Cin * 4 : zero_line + chunk_byte;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
             }
         }
         const char *lw = wbuf + cur * (BM * 128), *lx = xbuf + ((g + px_par) & 1) * XSEG;
-        const int xshift = (TAPS == 9 ? C32_HALO + (dxi - 1) * dil : 0) + wn * (NJ * 16) + frow;      // segment row of fragment 0
+        const int xshift = (TAPS == 9 ? C32_HALO + (dxi - 1) * dil : 0) + S * (wn * (NJ * 16) + frow);      // segment row of fragment 0
         if constexpr (SPLIT) {
             f16x8 wh[MI], wl[MI], ph[NJ], pl[NJ];
 #pragma unroll
@@ -238,7 +244,7 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
             }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int row = xshift + j * 16;
+                const int row = xshift + S * j * 16;
                 const f32x4 a = *(const f32x4 *)(lx + row * 128 + (((2 * fk) ^ (row & 7)) << 4));
                 const f32x4 b = *(const f32x4 *)(lx + row * 128 + (((2 * fk + 1) ^ (row & 7)) << 4));
                 const f32x8 v = (f32x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]} * sc16;
@@ -271,7 +277,7 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
             }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int row = xshift + j * 16;
+                const int row = xshift + S * j * 16;
                 pf[j] = *(const f32x4 *)(lx + row * 128 + ((chunk ^ (row & 7)) << 4));
             }
 #pragma unroll
@@ -316,8 +322,14 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
                 const float4 rr = *(const float4 *)(e_r + pix * Cout + c);
                 v0 += rr.x; v1 += rr.y; v2 += rr.z; v3 += rr.w;
             }
-            if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-            *(float4 *)(e_y + pix * Cout + c) = make_float4(v0, v1, v2, v3);
+            if (S == 2 && Y2) {
+                if (c >= csplit) { *(float4 *)(Y2 + pix * (Cout - csplit) + (c - csplit)) = make_float4(v0, v1, v2, v3); continue; }
+                if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                *(float4 *)(e_y + pix * csplit + c) = make_float4(v0, v1, v2, v3);
+            } else {
+                if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                *(float4 *)(e_y + pix * Cout + c) = make_float4(v0, v1, v2, v3);
+            }
             if (SPLIT)
                 amx = max(max(amx, __float_as_uint(v0) & 0x7fffffffu), max(__float_as_uint(v1) & 0x7fffffffu,
                           max(__float_as_uint(v2) & 0x7fffffffu, __float_as_uint(v3) & 0x7fffffffu)));
@@ -450,6 +462,55 @@ extern "C" int spa_conv1x1_f16s(spa_ctx *ctx, const float *x, int32_t B, int32_t
     SPA_ARG(amax_in);
     return conv_f32_launch<1>(ctx, x, B, H, W, Cin, (const float *)wt2, Cout, bias, residual, relu, 1, y, stream, true, 1,
                               0, 0, 0, amax_in, amax_out, inv_t);
+}
+
+// 3x3 stride-2 padding-1 convolution (the first convolution of layers 3 and 4, models/drn.py:204-206) on the 16-bit matrix
+// cores at float32 accuracy, optionally together with the block's 1x1 stride-2 projection as output channels
+// [csplit, Cout) (wt2 rows csplit.. hold the projection's weights at the centre tap, zeros elsewhere): one pass over the
+// input, bias / ReLU fused, the output's maximum tracked.  x (B,Hi,Wi,Cin), y (B,Ho,Wo,csplit), y2 (B,Ho,Wo,Cout - csplit)
+// or NULL (then csplit = Cout), Ho = (Hi + 1) / 2, Wo = (Wi + 1) / 2; Cout % 128 == 0, csplit % 64 == 0.
+extern "C" int spa_conv3x3_s2_f16s(spa_ctx *ctx, const float *x, int32_t B, int32_t Hi, int32_t Wi, int32_t Cin,
+                                   const void *wt2, float inv_t, int32_t Cout, int32_t csplit, const float *bias,
+                                   int32_t relu, const void *amax_in, void *amax_out, float *y, float *y2, void *stream)
+{
+    SPA_ARG(ctx && x && wt2 && bias && y && amax_in && B > 0 && Hi > 0 && Wi > 0 && inv_t > 0.f);
+    SPA_ARG(Cin % C32_BK == 0 && Cout % 128 == 0 && csplit % 64 == 0 && csplit > 0 && csplit <= Cout && (y2 || csplit == Cout));
+    SPA_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)wt2 % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)y2 % 16) == 0 && ((uintptr_t)bias % 16) == 0);
+    hipStream_t s = spa_stream(stream);
+    char *zero;
+    int rc = spa_ws_reserve(ctx, WS_ZERO_LINE, 4096, (void **)&zero);
+    if (rc != SPA_OK) return rc;
+    if (!ctx->zero_line_ready) {
+        SPA_HIP(hipMemsetAsync(zero, 0, 4096, s));
+        ctx->zero_line_ready = 1;
+    }
+    if (amax_out) SPA_HIP(hipMemsetAsync(amax_out, 0, 4, s));
+    const int H = (Hi + 1) / 2, W = (Wi + 1) / 2;
+    // (64-pixel tiles, two workgroups per CU for the 128-row form, were measured: 2.06 vs 1.95 ms on the 32 -> 64+64 layer)
+    const int bm = Cout % 256 == 0 ? 256 : 128, bn = 128;
+    const int xtiles = (W + bn - 1) / bn, ntiles = Cout / bm;
+    const long long total = (long long)B * H * xtiles * ntiles;
+    SPA_ARG(total < (1ll << 31));
+    const size_t lds = 2 * (size_t)bm * 128 + 2 * (size_t)(2 * bn + 2 * C32_HALO) * 128;
+    if (!(ctx->conv32_attr_done & 4)) {
+        SPA_HIP(hipFuncSetAttribute((const void *)k_conv3x3_f32<0, 256, 9, 128, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 128 + 2 * (256 + 2 * C32_HALO) * 128));
+        SPA_HIP(hipFuncSetAttribute((const void *)k_conv3x3_f32<0, 128, 9, 128, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * 128 + 2 * (256 + 2 * C32_HALO) * 128));
+        ctx->conv32_attr_done |= 4;
+    }
+    SpaProfScope prof_(ctx, PROF_DRN_CONV16, s);
+    const int per_cu = lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3);
+    long long grid = (long long)ctx->n_cu * per_cu;
+    if (grid > total) grid = total;
+    if (bm == 256)
+        hipLaunchKernelGGL((k_conv3x3_f32<0, 256, 9, 128, true, 2>), dim3((unsigned)grid), dim3(C32_THREADS), lds, s, x, (const float *)wt2, bias,
+                           (const float *)nullptr, y, (const char *)zero, B, H, W, Cin, Cout, 1, relu, xtiles, ntiles, (int)total, 1, 0ll, 0ll, 0ll, 0,
+                           (const unsigned *)amax_in, (unsigned *)amax_out, inv_t, Hi, Wi, y2, csplit);
+    else
+        hipLaunchKernelGGL((k_conv3x3_f32<0, 128, 9, 128, true, 2>), dim3((unsigned)grid), dim3(C32_THREADS), lds, s, x, (const float *)wt2, bias,
+                           (const float *)nullptr, y, (const char *)zero, B, H, W, Cin, Cout, 1, relu, xtiles, ntiles, (int)total, 1, 0ll, 0ll, 0ll, 0,
+                           (const unsigned *)amax_in, (unsigned *)amax_out, inv_t, Hi, Wi, y2, csplit);
+    SPA_LAUNCH_CHECK();
+    return SPA_OK;
 }
 
 // plain GEMMs for the Winograd path (spa_wino.hip): y (rows, Cout) = x (rows, Cin) . wt^T, wt (Cout, Cin); rows is a

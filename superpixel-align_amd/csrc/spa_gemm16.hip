@@ -26,6 +26,12 @@
 // XCD-contiguous tile ranges) is the float32 kernel's (spa_conv32.hip), tile 256 x 256 (or 128 x 128 for 128 output
 // channels), 8 waves; a lane's fragment is one 16-byte chunk per plane, and the K step of 32 channels is 3 x MI x NJ
 // matrix instructions per wave.
+//
+// Measured on the 512 -> 512 layer, 30 images (36 x 61 440 x 512 x 512): 3.54-3.64 ms = 0.96-0.98 PFLOP/s executed.  The same
+// loop without the in-register split 3.23, with the global loads compiled out (LDS reads + split + MFMA) 2.89 = 1.2 PFLOP/s,
+// which is what dense 16-bit MFMA sustains on this part (the bf16 kernel's loop, spa_conv.hip, tops out at the same rate).
+// Touching the lines of K step t + 2 one step early (a 4-byte global_load_lds per lane into a dump area, counted vmcnt so
+// that it stays in flight) made it slower (3.70): the wait at the end of a K step is not HBM latency.
 #include "spa_common.h"
 #include <stdlib.h>
 
@@ -35,7 +41,7 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 
 #define G16_THREADS 512
 
-template <int BM, int BN, int VARIANT = 0>
+template <int BM, int BN>
 __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3(const char *__restrict__ X, const char *__restrict__ Wt,
                                                             float *__restrict__ Y, int rows_per_z, int Cin, int Cout,
                                                             int ntiles, int total_tiles, int zcount, long long xz,
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3(const char *__restri
         __syncthreads();
         for (int t = 0; t < nk; ++t) {
             const int cur = (t + par) & 1;
-            if (t + 1 < nk) { if (VARIANT != 2) stage(t + 1, cur ^ 1); }
+            if (t + 1 < nk) stage(t + 1, cur ^ 1);
             else {
                 // last K step: the other buffers are free — stage the next tile's first K step under this step's matrix work
                 e_r0 = r0; e_n0 = n0; e_y = ybase;
@@ -159,12 +165,8 @@ __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3(const char *__restri
                 const f32x4 a = *(const f32x4 *)(lx + row * 128 + (((2 * fk) ^ (row & 7)) << 4));
                 const f32x4 b = *(const f32x4 *)(lx + row * 128 + (((2 * fk + 1) ^ (row & 7)) << 4));
                 const f32x8 v = (f32x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]} * sc;
-                if (VARIANT == 1) {          // development: no conversion (timing only)
-                    ph[j] = __builtin_bit_cast(f16x8, a); pl[j] = __builtin_bit_cast(f16x8, b);
-                } else {
-                    ph[j] = __builtin_convertvector(v, f16x8);
-                    pl[j] = __builtin_convertvector(v - __builtin_convertvector(ph[j], f32x8), f16x8);
-                }
+                ph[j] = __builtin_convertvector(v, f16x8);
+                pl[j] = __builtin_convertvector(v - __builtin_convertvector(ph[j], f32x8), f16x8);
             }
             // small terms first: they meet the accumulator while it is small
 #pragma unroll
@@ -215,8 +217,6 @@ int gemm_f16x3_raw(spa_ctx *ctx, const float *x, long long rows, int32_t Cin, co
     const size_t lds = 2 * (size_t)(bm + bn) * 128;
     if (!ctx->gemm16_attr_done) {
         SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3<256, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
-        SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3<256, 256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
-        SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3<256, 256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
         SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 128));
         ctx->gemm16_attr_done = 1;
     }
@@ -224,14 +224,7 @@ int gemm_f16x3_raw(spa_ctx *ctx, const float *x, long long rows, int32_t Cin, co
     const int per_cu = lds > 80 * 1024 ? 1 : 2;
     long long grid = (long long)ctx->n_cu * per_cu;
     if (grid > total * zcount) grid = total * zcount;
-    static const int variant = getenv("SPA_GEMM16_VARIANT") ? atoi(getenv("SPA_GEMM16_VARIANT")) : 0;
-    if (bm == 256 && variant == 1)
-        hipLaunchKernelGGL((k_gemm_f16x3<256, 256, 1>), dim3((unsigned)grid), dim3(G16_THREADS), lds, s, (const char *)x, (const char *)wt, y,
-                           (int)rows, Cin, Cout, ntiles, (int)total, zcount, rows * Cin, (long long)Cout * Cin, rows * Cout, (const unsigned *)amax);
-    else if (bm == 256 && variant == 2)
-        hipLaunchKernelGGL((k_gemm_f16x3<256, 256, 2>), dim3((unsigned)grid), dim3(G16_THREADS), lds, s, (const char *)x, (const char *)wt, y,
-                           (int)rows, Cin, Cout, ntiles, (int)total, zcount, rows * Cin, (long long)Cout * Cin, rows * Cout, (const unsigned *)amax);
-    else if (bm == 256)
+    if (bm == 256)
         hipLaunchKernelGGL((k_gemm_f16x3<256, 256>), dim3((unsigned)grid), dim3(G16_THREADS), lds, s, (const char *)x, (const char *)wt, y,
                            (int)rows, Cin, Cout, ntiles, (int)total, zcount, rows * Cin, (long long)Cout * Cin, rows * Cout, (const unsigned *)amax);
     else

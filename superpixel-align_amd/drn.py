@@ -177,6 +177,17 @@ class BasicBlock(nn.Module):
         self.residual = residual
 
     def forward(self, x):
+        s2 = getattr(self, '_spa_s2', None)
+        eng = _EPILOGUE['engine']
+        if (s2 is not None and eng is not None and _EPILOGUE['split_gemm'] and _EPILOGUE['own_conv32'] and x.is_cuda
+                and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
+                and 128 * -(-((x.shape[3] + 1) // 2) // 128) <= 1.25 * ((x.shape[3] + 1) // 2)):
+            # the stride-2 opening convolution and the 1x1 stride-2 projection in ONE pass over x (csrc/spa_conv32.hip)
+            _EPILOGUE['conv16_flops'] += 2.0 * x.shape[0] * ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2) * s2[3] * 10 * x.shape[1]
+            _EPILOGUE['conv16_launches'] += 1
+            y, res, am = eng.conv3x3_s2_f16s(x, s2[0], s2[1], s2[2], s2[3], True, amax_in=getattr(x, '_spa_amax', None))
+            y._spa_amax = am
+            return conv_bias_act(self.conv2, self.bn2, y, res, True)
         y = conv_bias_act(self.conv1, self.bn1, x, None, True)
         res = None
         if self.residual:
@@ -326,6 +337,20 @@ class DRN(nn.Module):
                             and m.in_channels % 64 == 0 and m.out_channels % 64 == 0 and m.bias is not None):
                         wt = m.weight.detach().permute(0, 2, 3, 1).reshape(m.out_channels, 9, m.in_channels)
                         m._spa_packed = (wt.contiguous().to(torch.bfloat16), m.bias.detach().float().contiguous())
+            for blk in self.modules():
+                if isinstance(blk, BasicBlock):
+                    blk._spa_s2 = None
+                    c1, ds = blk.conv1, blk.downsample
+                    if (dtype == torch.float32 and self.folded and blk.residual and ds is not None and c1.stride == (2, 2)
+                            and c1.kernel_size == (3, 3) and c1.padding == (1, 1) and c1.dilation == (1, 1) and c1.bias is not None
+                            and ds[0].kernel_size == (1, 1) and ds[0].stride == (2, 2) and ds[0].bias is not None
+                            and c1.in_channels % 32 == 0 and c1.out_channels % 64 == 0):
+                        co, ci = c1.out_channels, c1.in_channels
+                        w = torch.zeros((2 * co, 9, ci), dtype=torch.float32, device=c1.weight.device)
+                        w[:co] = c1.weight.detach().float().permute(0, 2, 3, 1).reshape(co, 9, ci)
+                        w[co:, 4] = ds[0].weight.detach().float().reshape(co, ci)
+                        wt2, inv_t = Engine.split_planes(w)
+                        blk._spa_s2 = (wt2, inv_t, torch.cat([c1.bias.detach().float(), ds[0].bias.detach().float()]).contiguous(), co)
             if self.arch == 'D' and self.folded and dtype in (torch.float32, torch.bfloat16):
                 # operands of libspalign's fused stem kernel (normalise + layer0 + layer1)
                 c0, c1 = self.layer0[0], self.layer1[0]

@@ -203,6 +203,26 @@ class Engine(object):
                                              _ptr(y), self._s()))
         return y, amax_out
 
+    def conv3x3_s2_f16s(self, x, wt2, inv_t, bias, csplit, relu=True, amax_in=None):
+        """3x3 stride-2 padding-1 convolution (+ the block's 1x1 stride-2 projection as output channels csplit..) on the
+        16-bit matrix cores at float32 accuracy: one pass over x.  wt2 = split_planes of the (Cout,9,Cin) weights (the
+        projection's rows hold its weights at tap 4).  Returns (y, y2 or None, amax of y)."""
+        B, Cin, Hi, Wi = x.shape
+        Cout = wt2.shape[0]
+        assert x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
+        assert wt2.dtype == torch.float16 and wt2.is_contiguous() and tuple(wt2.shape) == (Cout, 9, Cin // 32, 2, 32)
+        assert bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == Cout
+        Ho, Wo = (Hi + 1) // 2, (Wi + 1) // 2
+        y = torch.empty((B, csplit, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        y2 = torch.empty((B, Cout - csplit, Ho, Wo), dtype=torch.float32, device=x.device,
+                         memory_format=torch.channels_last) if csplit < Cout else None
+        if amax_in is None:
+            amax_in = self.amax(x)
+        amax_out = torch.empty(1, dtype=torch.int32, device=x.device)
+        check(self._lib.spa_conv3x3_s2_f16s(self._ctx, _ptr(x), B, Hi, Wi, Cin, _ptr(wt2), ctypes.c_float(inv_t), Cout, int(csplit),
+                                            _ptr(bias), 1 if relu else 0, _ptr(amax_in), _ptr(amax_out), _ptr(y), _ptr(y2), self._s()))
+        return y, y2, amax_out
+
     @staticmethod
     def winograd_weights(weight, tile=2):
         """(Cout,Cin,3,3) -> (n*n,Cout,Cin) float32: G g G^T of F(tile x tile, 3x3), computed in float64, position-major.

@@ -149,6 +149,35 @@ def test_conv3x3_split_planes_direct_matches_float64(eng, B, Cin, Cout, H, W, di
     assert float(am.view(torch.float32)) == float(y.abs().max())
 
 
+@pytest.mark.parametrize('B,Cin,Cout,Hi,Wi', [(2, 32, 64, 37, 301), (1, 64, 128, 20, 270), (1, 64, 64, 9, 130), (2, 32, 128, 16, 256)])
+def test_conv3x3_stride2_with_projection_matches_float64(eng, B, Cin, Cout, Hi, Wi):
+    """the stride-2 opening convolution of layers 3/4 and the block's 1x1 stride-2 projection in one pass
+    (spa_conv3x3_s2_f16s): both outputs against float64 convolutions, odd input sizes included"""
+    g = torch.Generator(device='cuda').manual_seed(9)
+    x = (torch.relu(torch.randn((B, Cin, Hi, Wi), device='cuda', generator=g)) * 2.3).contiguous(memory_format=torch.channels_last)
+    w = torch.randn((Cout, Cin, 3, 3), device='cuda', generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    wd = torch.randn((Cout, Cin, 1, 1), device='cuda', generator=g) * (2.0 / Cin) ** 0.5
+    b = torch.randn((2 * Cout,), device='cuda', generator=g)
+    wc = torch.zeros((2 * Cout, 9, Cin), device='cuda')
+    wc[:Cout] = w.permute(0, 2, 3, 1).reshape(Cout, 9, Cin)
+    wc[Cout:, 4] = wd.reshape(Cout, Cin)
+    wt2, inv_t = eng.split_planes(wc)
+    y, y2, am = eng.conv3x3_s2_f16s(x, wt2, inv_t, b, Cout, True)
+    r1 = torch.relu(F.conv2d(x.double(), w.double(), b[:Cout].double(), 2, 1))
+    r2 = F.conv2d(x.double(), wd.double(), b[Cout:].double(), 2, 0)
+    assert y.shape == r1.shape and y2.shape == r2.shape
+    assert float((y.double() - r1).abs().max()) <= 4e-6 * float(r1.abs().max())
+    assert float((y2.double() - r2).abs().max()) <= 4e-6 * float(r2.abs().max())
+    assert float(am.view(torch.float32)) == float(y.abs().max())
+    # without the projection: csplit = Cout
+    if Cout % 128 == 0:
+        wt1, inv1 = eng.split_planes(wc[:Cout].contiguous())
+        y1, none, _ = eng.conv3x3_s2_f16s(x, wt1, inv1, b[:Cout].contiguous(), Cout, False)
+        assert none is None
+        r = F.conv2d(x.double(), w.double(), b[:Cout].double(), 2, 1)
+        assert float((y1.double() - r).abs().max()) <= 4e-6 * float(r.abs().max())
+
+
 def test_winograd_layers_inside_the_network(eng):
     """DRN-D-22 float32 with and without the Winograd / own-convolution paths: the map the pipeline pools (index 7)
     agrees to 2e-5 of its scale (north star: 1e-4), and the Winograd path really ran."""
