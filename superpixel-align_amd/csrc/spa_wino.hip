@@ -26,6 +26,8 @@ int conv1x1_f32_raw(spa_ctx *ctx, const float *x, long long rows, int32_t Cin, c
                     float *y, void *stream, int zcount);          // spa_conv32.hip
 
 struct WinoGeom { int B, H, W, d, th, tw; long long T; };
+typedef float wino_v4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 wino_nt_load(const float4 *p) { const wino_v4 v = __builtin_nontemporal_load((const wino_v4 *)p); return make_float4(v[0], v[1], v[2], v[3]); }
 
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
@@ -289,6 +291,7 @@ __global__ __launch_bounds__(256) void k_wino4_in(const float *__restrict__ X, f
         V o[6];
         wino4_bt(col, o);
 #pragma unroll
+        // (non-temporal stores of V were measured: 1.60 instead of 1.31 ms per 30 images of a 512-channel layer)
         for (int i = 0; i < 6; ++i) *(V *)(Vout + ((long long)(i * 6 + j) * Tpad + t) * C + c) = o[i];
     }
 }
@@ -401,7 +404,8 @@ __global__ __launch_bounds__(256, 2) void k_wino4_out_s(const float *__restrict_
             float4 col[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i)
-                col[i] = (cs.c[i * 6 + j] * inv) * *(const float4 *)(M + ((long long)(i * 6 + j) * Tpad + t) * K + k);
+                // M is read exactly once: non-temporal (1.66 instead of 1.70 ms per 30 images of a 512-channel layer)
+                col[i] = (cs.c[i * 6 + j] * inv) * wino_nt_load((const float4 *)(M + ((long long)(i * 6 + j) * Tpad + t) * K + k));
             float4 o[4];
             wino4_at(col, o);
 #pragma unroll
