@@ -7,7 +7,7 @@
 # then, in the build container:  python tools/write_profiles.py r3_final
 export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-rm -rf gpurun_out/final_stats gpurun_out/final_pmc_*
+rm -rf gpurun_out/final_stats gpurun_out/final_pmc_* gpurun_out/final_variant_*
 python3 bench.py > gpurun_out/final_bench_line.json 2> gpurun_out/final_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final_stats -- python3 bench.py --no_cpu_baseline > gpurun_out/final_stats_bench_line.json 2> gpurun_out/final_stats.err
 for P in FETCH_SIZE WRITE_SIZE; do
@@ -25,7 +25,8 @@ v anchor --pool_mode anchor
 v anchor_bf16 --pool_mode anchor --dtype bf16
 v anchor_bf16_device_rng --pool_mode anchor --dtype bf16 --device_rng
 v integer_images --integer_images
-v no_winograd --no_winograd
-v miopen_conv --miopen_conv
+v fp32_mfma_gemm --fp32_mfma_gemm
+v no_winograd --fp32_mfma_gemm --no_winograd
+v miopen_conv --miopen_conv --fp32_mfma_gemm
 v reference_operating_point --superpixel_method felzenszwalb --height 224 --width 224 --arch drn_c_26 --pool_mode anchor --n_clusters 4
 ls -la gpurun_out | tail -20

@@ -71,13 +71,17 @@ if a.wino:
     h, w = a.height // 8, a.width // 8
     x = torch.relu(torch.randn((a.batch, 512, h, w), device='cuda')).contiguous(memory_format=torch.channels_last)
     wt = torch.randn((512, 512, 3, 3), device='cuda') * (2.0 / (9 * 512)) ** 0.5
-    u, b = eng.winograd_weights(wt, 4), torch.randn((512,), device='cuda')        # F(4x4,3x3): the network's default
+    b = torch.randn((512,), device='cuda')
+    u2, cs = eng.winograd_weights_split(wt)         # F(4x4,3x3) with the GEMMs on the 16-bit matrix cores: the network's default
+    am = eng.amax(x)
     for _ in range(a.reps):
-        eng.conv3x3_wino_f32(x, u, b, None, True, 2)
+        eng.conv3x3_wino_f16s(x, u2, cs, b, None, True, 2, amax_in=am)
     x2 = torch.relu(torch.randn((a.batch, 128, h, w), device='cuda')).contiguous(memory_format=torch.channels_last)
     w2 = (torch.randn((128, 128, 3, 3), device='cuda') * (2.0 / (9 * 128)) ** 0.5).permute(0, 2, 3, 1).reshape(128, 9, 128).contiguous()
     b2 = torch.randn((128,), device='cuda')
+    w22, inv2 = eng.split_planes(w2)
+    am2 = eng.amax(x2)
     for _ in range(a.reps):
-        eng.conv3x3_f32(x2, w2, b2, None, True, 1)
+        eng.conv3x3_f16s(x2, w22, inv2, b2, None, True, 1, amax_in=am2)
     torch.cuda.synchronize()
     print('winograd 512 -> 512 dil 2 and direct 128 -> 128 at %dx%d, %d launches each' % (h, w, a.reps))

@@ -90,7 +90,7 @@ for k in sorted(fe):
     name = k.replace('void ', '')
     if not name.startswith('k_'):
         continue
-    is_wide = name in wide or name.startswith(('k_wino4_in<', 'k_wino4_out<'))
+    is_wide = name in wide or name.startswith(('k_wino4_in<', 'k_wino4_out<', 'k_wino4_out_s<', 'k_gemm_f16x3<', 'k_conv3x3_f32<'))
     f_mb = fe[k][1] * 1024 / 1e6 * (2 if is_wide else 1)
     w_mb = wr.get(k, (0, 0.0))[1] * 1024 / 1e6
     tot = f_mb + w_mb
@@ -124,6 +124,8 @@ if any(k.replace('void ', '').startswith('k_wino4_in') for k in fe):
     for kname, bench_name, built, what in (
             ('k_wino4_in<', 'k_wino_in', 3.25 * act, 'X read + V = 2.25 X written'),
             ('k_conv3x3_f32<0, 256, 1, 256>', 'k_conv3x3_f32<taps 1>(GEMM form, all)', 4.5 * act, 'V = 2.25 X read + M = 2.25 Y written'),
+            ('k_gemm_f16x3<256, 256', 'k_gemm_f16x3<256, 256>', 4.5 * act, 'V = 2.25 X read + M = 2.25 Y written'),
+            ('k_wino4_out_s<0', 'k_wino_out', 3.25 * act, 'M = 2.25 Y read + Y written'),
             ('k_wino4_out<0', 'k_wino_out', 3.25 * act, 'M = 2.25 Y read + Y written')):
         h = hbm_of(kname)
         if h:
@@ -151,3 +153,12 @@ json.dump({'note': 'HBM bytes per launch PER IMAGE (1024x2048) from the PMC pass
            'bytes_per_image_per_launch': traffic, 'ratio_to_algorithmic_bytes': ratio},
           open(os.path.join(prof, 'pmc_traffic.json'), 'w'), indent=1)
 print('\n'.join(lines[-40:]))
+
+# ---- 4. the other operating points (tools/make_profiles.sh: one bench line each)
+for src in sorted(glob.glob(os.path.join(go, 'final_variant_*.json'))):
+    txt = [l for l in open(src).read().splitlines() if l.startswith('{')]
+    if txt:
+        name = os.path.basename(src)[len('final_variant_'):-len('.json')]
+        open(os.path.join(prof, '%s_bench_%s.json' % (tag, name)), 'w').write(txt[-1] + '\n')
+        d = json.loads(txt[-1])
+        print('%-28s %9.2f %s  %8.2f ms/step' % (name, d['value'], d['unit'], d['ms_per_step']))
