@@ -91,6 +91,10 @@ int spa_drn_normalise(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_
                       int32_t out_dtype, const double *mean3_host, const double *std3_host, void *stream);
 int spa_bias_act(spa_ctx *ctx, void *y, int32_t dtype, int64_t rows, int32_t C, const void *bias,
                  const void *residual, int32_t relu, void *stream);
+/* float32 only: the same pass, and amax[0] (device word) = bit pattern of the largest magnitude stored — what spa_amax_f32
+ * would return for y, without the extra pass (the scale input of the split-plane convolutions below). */
+int spa_bias_act_amax(spa_ctx *ctx, float *y, int64_t rows, int32_t C, const float *bias,
+                      const float *residual, int32_t relu, void *amax, void *stream);
 
 /* The full-resolution stem of DRN-D as one float32-MFMA kernel: input normalisation
  * (models/drn.py:319-321), layer0 = conv7x7(3->16)+BN+ReLU and layer1 = conv3x3(16->16)+BN+ReLU

@@ -67,15 +67,19 @@ extern "C" int spa_drn_normalise(spa_ctx *ctx, const float *x, int32_t B, int32_
 template <bool POW2>
 __global__ __launch_bounds__(256) void k_bias_act_f32(float *__restrict__ y, const float *__restrict__ bias,
                                                       const float *__restrict__ res, unsigned n4, unsigned c4,
-                                                      int relu)
+                                                      int relu, unsigned *__restrict__ amax = nullptr)
 {
     const unsigned stride = gridDim.x * 256u;
+    unsigned mx = 0u;         // amax: largest magnitude stored (the scale input of the split-plane convolutions)
     const float4 *b4 = (const float4 *)bias;
     auto bidx = [&](unsigned i) -> unsigned { return POW2 ? (i & (c4 - 1u)) : (i % c4); };
     auto apply = [&](float4 v, const float4 bb, const float4 r) -> float4 {
         v.x = v.x + bb.x; v.y = v.y + bb.y; v.z = v.z + bb.z; v.w = v.w + bb.w;
         if (res) { v.x = v.x + r.x; v.y = v.y + r.y; v.z = v.z + r.z; v.w = v.w + r.w; }
         if (relu) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
+        if (amax)
+            mx = max(max(mx, __float_as_uint(v.x) & 0x7fffffffu), max(__float_as_uint(v.y) & 0x7fffffffu,
+                     max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu)));
         return v;
     };
     unsigned i = blockIdx.x * 256u + threadIdx.x;
@@ -92,6 +96,10 @@ __global__ __launch_bounds__(256) void k_bias_act_f32(float *__restrict__ y, con
     for (; i < n4; i += stride) {
         const float4 r = res ? ((const float4 *)res)[i] : zero;
         ((float4 *)y)[i] = apply(((const float4 *)y)[i], b4[bidx(i)], r);
+    }
+    if (amax) {
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+        if ((threadIdx.x & 63) == 0 && mx > *(volatile unsigned *)amax) atomicMax(amax, mx);
     }
 }
 
@@ -127,8 +135,27 @@ __global__ __launch_bounds__(256) void k_bias_act_bf16(unsigned short *__restric
     }
 }
 
+static int bias_act_impl(spa_ctx *ctx, void *y, int32_t dtype, int64_t rows, int32_t C, const void *bias,
+                         const void *residual, int32_t relu, void *amax, void *stream);
+
 extern "C" int spa_bias_act(spa_ctx *ctx, void *y, int32_t dtype, int64_t rows, int32_t C, const void *bias,
                             const void *residual, int32_t relu, void *stream)
+{
+    return bias_act_impl(ctx, y, dtype, rows, C, bias, residual, relu, nullptr, stream);
+}
+
+// float32 only: the same pass, and amax[0] = bit pattern of the largest magnitude it stored (spa_amax_f32's result for the
+// output, without the extra pass): the scale input of the split-plane convolution that reads y next
+extern "C" int spa_bias_act_amax(spa_ctx *ctx, float *y, int64_t rows, int32_t C, const float *bias,
+                                 const float *residual, int32_t relu, void *amax, void *stream)
+{
+    SPA_ARG(amax);
+    SPA_HIP(hipMemsetAsync(amax, 0, 4, spa_stream(stream)));
+    return bias_act_impl(ctx, y, 0, rows, C, bias, residual, relu, amax, stream);
+}
+
+static int bias_act_impl(spa_ctx *ctx, void *y, int32_t dtype, int64_t rows, int32_t C, const void *bias,
+                         const void *residual, int32_t relu, void *amax, void *stream)
 {
     SPA_ARG(ctx && y && bias && rows > 0 && C > 0);
     SPA_ARG(dtype == 0 || dtype == 1);
@@ -147,10 +174,10 @@ extern "C" int spa_bias_act(spa_ctx *ctx, void *y, int32_t dtype, int64_t rows, 
         if (g4 < 1) g4 = 1;
         if ((c4 & (c4 - 1u)) == 0u)
             hipLaunchKernelGGL(k_bias_act_f32<true>, dim3((unsigned)g4), dim3(256), 0, spa_stream(stream), (float *)y,
-                               (const float *)bias, (const float *)residual, (unsigned)n, c4, relu);
+                               (const float *)bias, (const float *)residual, (unsigned)n, c4, relu, (unsigned *)amax);
         else
             hipLaunchKernelGGL(k_bias_act_f32<false>, dim3((unsigned)g4), dim3(256), 0, spa_stream(stream), (float *)y,
-                               (const float *)bias, (const float *)residual, (unsigned)n, c4, relu);
+                               (const float *)bias, (const float *)residual, (unsigned)n, c4, relu, (unsigned *)amax);
     } else
         hipLaunchKernelGGL(k_bias_act_bf16, dim3((unsigned)gx), dim3(256), 0, spa_stream(stream),
                            (unsigned short *)y, (const unsigned short *)bias,

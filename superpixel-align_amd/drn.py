@@ -152,7 +152,7 @@ def conv_bias_act(conv, bn, x, residual=None, relu=True):
                 and (residual is None or residual.is_contiguous(memory_format=torch.channels_last))):
             _EPILOGUE['bytes'] += y.numel() * y.element_size() * (3 if residual is not None else 2)
             _EPILOGUE['launches'] += 1
-            return eng.bias_act_(y, conv.bias, residual, relu)
+            return eng.bias_act_(y, conv.bias, residual, relu, track_amax=_EPILOGUE['split_gemm'])
         y = y + conv.bias.view(1, -1, 1, 1)
     else:
         y = bn(conv(x))

@@ -137,9 +137,16 @@ class Engine(object):
                                        self._s()))
         return out
 
-    def bias_act_(self, y, bias, residual=None, relu=True):
-        """In place y = relu?(y + bias [+ residual]) on a channels-last (B,C,H,W) activation."""
+    def bias_act_(self, y, bias, residual=None, relu=True, track_amax=False):
+        """In place y = relu?(y + bias [+ residual]) on a channels-last (B,C,H,W) activation.  track_amax (float32): the
+        pass also records the largest magnitude it stores; the device word is attached to y as `_spa_amax`."""
         B, C, H, W = y.shape
+        if track_amax and y.dtype == torch.float32:
+            am = torch.empty(1, dtype=torch.int32, device=y.device)
+            check(self._lib.spa_bias_act_amax(self._ctx, _ptr(y), B * H * W, C, _ptr(bias), _ptr(residual), 1 if relu else 0,
+                                              _ptr(am), self._s()))
+            y._spa_amax = am
+            return y
         check(self._lib.spa_bias_act(self._ctx, _ptr(y), 0 if y.dtype == torch.float32 else 1, B * H * W, C,
                                      _ptr(bias), _ptr(residual), 1 if relu else 0, self._s()))
         return y

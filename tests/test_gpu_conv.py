@@ -178,6 +178,20 @@ def test_conv3x3_stride2_with_projection_matches_float64(eng, B, Cin, Cout, Hi, 
         assert float((y1.double() - r).abs().max()) <= 4e-6 * float(r.abs().max())
 
 
+def test_bias_act_tracks_the_maximum_it_stores(eng):
+    """spa_bias_act_amax: the epilogue pass behind a MIOpen convolution also hands the next (split-plane) convolution its scale"""
+    g = torch.Generator(device='cuda').manual_seed(13)
+    for relu, res in ((True, False), (False, True)):
+        y = torch.randn((2, 32, 37, 61), device='cuda', generator=g).contiguous(memory_format=torch.channels_last)
+        r = torch.randn_like(y) if res else None
+        b = torch.randn((32,), device='cuda', generator=g)
+        ref = y + b.view(1, -1, 1, 1) + (r if res else 0)
+        ref = torch.relu(ref) if relu else ref
+        out = eng.bias_act_(y, b, r, relu, track_amax=True)
+        assert torch.equal(out, ref)
+        assert float(out._spa_amax.view(torch.float32)) == float(ref.abs().max())
+
+
 def test_winograd_layers_inside_the_network(eng):
     """DRN-D-22 float32 with and without the Winograd / own-convolution paths: the map the pipeline pools (index 7)
     agrees to 2e-5 of its scale (north star: 1e-4), and the Winograd path really ran."""
