@@ -399,7 +399,9 @@ static int conv_f32_launch(spa_ctx *ctx, const float *x, int32_t B, int32_t H, i
     SpaProfScope prof_(ctx, prof ? (split ? PROF_DRN_CONV16 : (TAPS == 9 ? PROF_DRN_CONV32 : (bm == 256 && !residual ? PROF_DRN_GEMM32 : PROF_DRN_GEMM32_N))) : -1, s);
     // persistent workgroups: as many as are resident at once (LDS: one per CU for the wide tiles, two or three for the
     // 128-pixel ones), each looping over its share of the tiles
-    const int per_cu = lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3);
+    // (the split-plane form of the 64-channel tile is bound by its LDS reads — all eight waves read the same weight tile —
+    // not by load latency: 1.77 / 1.68 / 2.25 ms with 3 / 2 / 1 workgroups per CU on the 64 -> 64 layer of 30 images)
+    const int per_cu = lds > 80 * 1024 ? 1 : (lds > 53 * 1024 || (split && bm == 64) ? 2 : 3);
     const int late = getenv("SPA_CONV32_LATE_PREFETCH") ? 1 : 0;
     long long grid = (long long)ctx->n_cu * per_cu;
     if (grid > total * zcount) grid = total * zcount;
