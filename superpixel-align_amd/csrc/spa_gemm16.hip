@@ -31,7 +31,9 @@
 // loop without the in-register split 3.23, with the global loads compiled out (LDS reads + split + MFMA) 2.89 = 1.2 PFLOP/s,
 // which is what dense 16-bit MFMA sustains on this part (the bf16 kernel's loop, spa_conv.hip, tops out at the same rate).
 // Touching the lines of K step t + 2 one step early (a 4-byte global_load_lds per lane into a dump area, counted vmcnt so
-// that it stays in flight) made it slower (3.70): the wait at the end of a K step is not HBM latency.
+// that it stays in flight) made it slower (3.70): the wait at the end of a K step is not HBM latency.  Splitting the pixel
+// fragments one fragment ahead, a quarter fragment (6 vector instructions) after every 6 matrix instructions with the order
+// pinned by scheduling barriers, changed nothing (3.53): the two waves of a SIMD already overlap each other's phases.
 #include "spa_common.h"
 #include <stdlib.h>
 
