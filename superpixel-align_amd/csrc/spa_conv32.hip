@@ -371,7 +371,10 @@ static int conv_f32_launch(spa_ctx *ctx, const float *x, int32_t B, int32_t H, i
     // of a SIMD are never in the staging code together: 81 vs 121 TFLOP/s — the wave-dependent branch breaks the
     // straight-line schedule of the K step; without the output store the GEMM form runs 126: the store is 4 %)
     const int bm = Cout % 256 == 0 ? 256 : (Cout % 128 == 0 ? 128 : 64);
-    const int bn = bm == 256 || getenv("SPA_CONV32_BN256") ? 256 : 128;
+    // (split-plane form, 64 channels: every wave reads the whole weight tile from LDS, so 256 pixels per tile halve those reads
+    // per matrix instruction: 1.53 vs 1.69 ms on the 64 -> 64 layer of 30 images — where a row fills 256-pixel tiles to 80 %)
+    const bool wide64 = split && bm == 64 && (long long)((W + 255) / 256) * 256 * 4 <= 5ll * W;
+    const int bn = bm == 256 || wide64 || getenv("SPA_CONV32_BN256") ? 256 : 128;
     const int xtiles = (W + bn - 1) / bn, ntiles = Cout / bm;
     const long long total = (long long)B * H * xtiles * ntiles;
     SPA_ARG(total < (1ll << 31));
@@ -413,6 +416,17 @@ static int conv_f32_launch(spa_ctx *ctx, const float *x, int32_t B, int32_t H, i
                        (const char *)zero, B, H, W, Cin, Cout, dilation, relu, xtiles, ntiles, (int)total, zcount, xz, wz, yz, late, \
                        (const unsigned *)amax_in, (unsigned *)amax_out, inv_t)
     if (split) {
+        if (bm == 64 && bn == 256) {
+            static bool attr64 = false;
+            if (!attr64) {
+                SPA_HIP(hipFuncSetAttribute((const void *)k_conv3x3_f32<0, 64, TAPS, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 128 + 2 * (256 + 2 * C32_HALO) * 128));
+                SPA_HIP(hipFuncSetAttribute((const void *)k_conv3x3_f32<1, 64, TAPS, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 128 + 2 * (256 + 2 * C32_HALO) * 128));
+                attr64 = true;
+            }
+            if (residual) C32_LAUNCH_S(1, 64, 256); else C32_LAUNCH_S(0, 64, 256);
+            SPA_LAUNCH_CHECK();
+            return SPA_OK;
+        }
         SPA_ARG(bn == (bm == 256 ? 256 : 128));
         if (residual) { if (bm == 256) C32_LAUNCH_S(1, 256, 256); else if (bm == 128) C32_LAUNCH_S(1, 128, 128); else C32_LAUNCH_S(1, 64, 128); }
         else { if (bm == 256) C32_LAUNCH_S(0, 256, 256); else if (bm == 128) C32_LAUNCH_S(0, 128, 128); else C32_LAUNCH_S(0, 64, 128); }
