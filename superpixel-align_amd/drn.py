@@ -88,6 +88,13 @@ def conv_bias_act(conv, bn, x, residual=None, relu=True):
             return eng.conv3x3_bf16(x, packed[0], packed[1], residual, relu, conv.dilation[0])
         tile = _EPILOGUE['winograd']                   # 4 (default), 2 or 0/False
         wino = getattr(conv, '_spa_wino', {}).get(4 if tile == 4 else 2) if tile else None
+        # with the split-plane kernels the direct form wins below 256 input channels (30 x 128 x 256 pixels, ms Winograd /
+        # direct: 128 -> 128 1.10 / 0.99, 128 -> 256 1.85 / 1.61, 256 -> 256 2.65 / 3.09, 256 -> 512 4.28 / 5.35)
+        if (wino is not None and _EPILOGUE['split_gemm'] and conv.in_channels < int(os.environ.get('SPA_WINO_MIN_CIN', '256'))
+                and getattr(conv, '_spa_packed16', None) is not None):
+            bn_ = 256 if conv.out_channels % 256 == 0 else 128             # the direct kernel's pixel tile (rule below)
+            if -(-x.shape[3] // bn_) * bn_ <= 1.25 * x.shape[3]:
+                wino = None
         if (wino is not None and x.dtype == torch.float32 and _EPILOGUE['own_conv32']
                 and x.is_contiguous(memory_format=torch.channels_last)
                 and (residual is None or residual.is_contiguous(memory_format=torch.channels_last))):
