@@ -416,6 +416,7 @@ static int conv_f32_launch(spa_ctx *ctx, const float *x, int32_t B, int32_t H, i
                        (const char *)zero, B, H, W, Cin, Cout, dilation, relu, xtiles, ntiles, (int)total, zcount, xz, wz, yz, late, \
                        (const unsigned *)amax_in, (unsigned *)amax_out, inv_t)
     if (split) {
+        // (128 channels x 256 pixels, one workgroup per CU: 1.06 vs 1.04 ms — no gain, not kept)
         if (bm == 64 && bn == 256) {
             static bool attr64 = false;
             if (!attr64) {
