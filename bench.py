@@ -535,7 +535,7 @@ def main():
                                   'v_mfma_f32_16x16x32_f16 accumulated in float32 — the final map is as close to the float64 network as with '
                                   'float32 operands (DESIGN.md section 4); `achieved` = float32-equivalent FLOPs of the network per second, '
                                   'which the float32 matrix peak (157 TFLOP/s) no longer bounds.  ' if split16 else '') +
-                                 'float32: every stride-1 3x3 layer from 128 channels up runs as Winograd F(4x4,3x3) (input transform, 36 '
+                                 'float32: every stride-1 3x3 layer from 128 channels up (from 256 input channels up with the split planes; the layers below take the direct kernel) runs as Winograd F(4x4,3x3) (input transform, 36 '
                                  'GEMMs in one launch of the float32-MFMA kernel, output transform with the epilogue fused), the '
                                  '64-channel layers and the 1x1 projections on the same kernel directly, the stem on its own MFMA kernel; '
                                  'the five stride-2 layers are PyTorch-ROCm (MIOpen).  `achieved` counts the products actually '
