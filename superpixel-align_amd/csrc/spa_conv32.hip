@@ -207,7 +207,8 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
         const int cur = (t + pw_par) & 1;
         const int g = TAPS == 9 ? t / 3 : t, dxi = TAPS == 9 ? t - g * 3 : 1;
         // (the loads of the next K step go out in one burst: spreading them between the MFMA groups was
-        // measured 20 % slower — every global_load_lds re-programs M0 and breaks the MFMA stream)
+        // measured 20 % slower — every global_load_lds re-programs M0 and breaks the MFMA stream; issuing the next group's
+        // pixel thirds AFTER the step's wait, so that no wait covers an HBM load of the same step, was 4-6 % slower too)
         if (t + 1 < nk) stage_w(t + 1, cur ^ 1);
         if (g + 1 < ngroups) {
             if (TAPS == 9) stage_x(g + 1, dxi);
