@@ -57,7 +57,8 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
     // stride-2 projection of a BasicBlock, models/drn.py:195-203, as extra channels whose only non-zero tap is the centre)
     if (S == 1) { Hi = H; Wi = W; }
     extern __shared__ __attribute__((aligned(1024))) char lds32[];   // [2] weight tiles 32 KB | [2] pixel segments 33 KB
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // uniform: block and LDS addresses of the staging stay scalar
     // XCD-aware tile order: consecutive workgroup ids go round-robin over the 8 XCDs; give every XCD a
     // contiguous range of tiles (neighbouring rows of one image share two of their three input rows in L2)
     // PERSISTENT tile loop: a workgroup takes tiles vid = blockIdx.x, + gridDim.x, ... of zcount problems of
@@ -107,35 +108,39 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
     const int nk = TAPS * ks, ngroups = TAPS == 9 ? 3 * ks : ks;
 
     int pw_par = 0, px_par = 0;                  // buffer parities carried from tile to tile
-    auto stage_w = [&](int t, int buf) {
-        const int g = TAPS == 9 ? t / 3 : t, dxi = TAPS == 9 ? t - g * 3 : 0;
-        const int dyi = TAPS == 9 ? g / ks : 0, kc = g - dyi * ks;
-        const char *wk = wbase + ((long long)(dyi * 3 + dxi) * Cin + (long long)kc * C32_BK) * 4 + chunk_byte;
-        char *dst = wbuf + buf * (BM * 128);
+    // Index arithmetic of the staging (round 3, PMC: 5.5 scalar + 4.4 vector instructions per matrix instruction in the
+    // split-plane 64-channel layers, where a K step is only 12-24 matrix instructions per wave): the (dy, channel step, dx)
+    // of a K step are carried incrementally by the loop instead of being divided out of t, and everything of an address
+    // that does not change with the K step — the lane's row inside a tile, its swizzled chunk — is computed once.
+    const unsigned wlane = (unsigned)(wave * 8 + sub) * (unsigned)(TAPS * Cin * 4) + (unsigned)chunk_byte;   // + r * 64 rows
+    const unsigned wrstep = 64u * (unsigned)(TAPS * Cin * 4);
+    auto stage_w = [&](int tap, int kc, int buf) {               // tap = dy * 3 + dx (0 for the GEMM form)
+        const char *wk = wbase + ((long long)tap * Cin + (long long)kc * C32_BK) * 4;
+        char *dst = wbuf + buf * (BM * 128) + wave * 1024;
 #pragma unroll
-        for (int r = 0; r < BM / 64; ++r) {
-            const int blk = r * 8 + wave;                       // 8 rows = 1 KB per instruction
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wk + (long long)(blk * 8 + sub) * TAPS * Cin * 4),
-                                             (__attribute__((address_space(3))) void *)(dst + blk * 1024), 16, 0, 0);
-        }
+        for (int r = 0; r < BM / 64; ++r)                       // 8 rows = 1 KB per instruction
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wk + (wlane + r * wrstep)),
+                                             (__attribute__((address_space(3))) void *)(dst + r * 8192), 16, 0, 0);
     };
-    // one third (11 of 33 row blocks) of the pixel segment of group g
-    auto stage_x = [&](int g, int third) {
-        const int dyi = TAPS == 9 ? g / ks : 1, kc = TAPS == 9 ? g - dyi * ks : g;
+    // one third (11 of 33 row blocks) of the pixel segment of the group (dyi, kc) into segment buffer `xb`
+    int px0 = 0, xoff0 = 0;          // first pixel of this lane's staged rows (tile start - halo + sub) and its byte offset
+    const int pxstep = 8 * Cin * 4;  // bytes between two row blocks of 8 pixels (32-bit offsets inside one image row)
+    auto locate_x = [&]() { px0 = x0 * S - C32_HALO + sub; xoff0 = px0 * (Cin * 4); };
+    auto stage_x = [&](int dyi, int kc, int third, int xb) {
         const int yy = y * S + (dyi - 1) * dil;
         const bool yok = yy >= 0 && yy < Hi;
         const char *xk = xbase + ((long long)(dyi - 1) * dil * Wi) * Cin * 4 + (long long)kc * C32_BK * 4 + chunk_byte;
-        char *dst = xbuf + ((g + px_par) & 1) * XSEG;
+        char *dst = xbuf + xb * XSEG;
 #pragma unroll
         for (int r = 0; r < (XTHIRD + 7) / 8; ++r) {
             const int i = r * 8 + wave;
             if (i >= XTHIRD) break;
             const int blk = third * XTHIRD + i;
             if (blk >= XBLK) break;
-            const int px = x0 * S - C32_HALO + blk * 8 + sub;
-            const bool ok = yok && px >= 0 && px < Wi;
+            const int px = px0 + blk * 8;
+            const bool ok = yok && (unsigned)px < (unsigned)Wi;
             // a zero line for padding pixels (its 128 bytes are read at the chunk offset only)
-            const char *src = ok ? xk + (long long)px * Cin * 4 : zero_line + chunk_byte;
+            const char *src = ok ? xk + (xoff0 + blk * pxstep) : zero_line + chunk_byte;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(dst + blk * 1024), 16, 0, 0);
         }
@@ -153,8 +158,8 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
             xrow[r] = xbase + (long long)px * Cin * 4 + chunk_byte;
         }
     };
-    auto stage_x1 = [&](int g) {
-        char *dst = xbuf + ((g + px_par) & 1) * XSEG;
+    auto stage_x1 = [&](int g, int xb) {
+        char *dst = xbuf + xb * XSEG;
 #pragma unroll
         for (int r = 0; r < BN / 64; ++r)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xrow[r] + (long long)g * C32_BK * 4),
@@ -169,9 +174,9 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
     bool first_tile = true;
     const bool counted_wait = (W % BN) == 0;          // every lane of every epilogue store is live
     locate(vid);
-    stage_w(0, 0);
-    if (TAPS == 1) { locate_rows(); stage_x1(0); }
-    else { stage_x(0, 0); stage_x(0, 1); stage_x(0, 2); }
+    stage_w(0, 0, 0);
+    if (TAPS == 1) { locate_rows(); stage_x1(0, 0); }
+    else { locate_x(); stage_x(0, 0, 0, 0); stage_x(0, 0, 1, 0); stage_x(0, 0, 2, 0); }
     float sc16 = 1.f, unscale = 1.f;
     unsigned amx = 0;
     if (SPLIT) {
@@ -203,16 +208,24 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
     }
     first_tile = false;
     __syncthreads();
+    // (dxi, kc, dyi) of step t and the segment buffer of its group, carried incrementally
+    int dxi = TAPS == 9 ? 0 : 1, kc = 0, dyi = TAPS == 9 ? 0 : 1, g = 0, xcur = px_par;
     for (int t = 0; t < nk; ++t) {
         const int cur = (t + pw_par) & 1;
-        const int g = TAPS == 9 ? t / 3 : t, dxi = TAPS == 9 ? t - g * 3 : 1;
+        // step t + 1 and group g + 1
+        int ndxi = dxi, nkc = kc, ndyi = dyi, gkc = kc + 1, gdyi = dyi;
+        if (TAPS == 9) {
+            ndxi = dxi + 1;
+            if (ndxi == 3) { ndxi = 0; nkc = kc + 1; if (nkc == ks) { nkc = 0; ndyi = dyi + 1; } }
+            if (gkc == ks) { gkc = 0; gdyi = dyi + 1; }
+        } else nkc = kc + 1;
         // (the loads of the next K step go out in one burst: spreading them between the MFMA groups was
         // measured 20 % slower — every global_load_lds re-programs M0 and breaks the MFMA stream; issuing the next group's
         // pixel thirds AFTER the step's wait, so that no wait covers an HBM load of the same step, was 4-6 % slower too)
-        if (t + 1 < nk) stage_w(t + 1, cur ^ 1);
+        if (t + 1 < nk) stage_w(TAPS == 9 ? ndyi * 3 + ndxi : 0, nkc, cur ^ 1);
         if (g + 1 < ngroups) {
-            if (TAPS == 9) stage_x(g + 1, dxi);
-            else stage_x1(g + 1);
+            if (TAPS == 9) stage_x(gdyi, gkc, dxi, xcur ^ 1);
+            else stage_x1(g + 1, xcur ^ 1);
         }
         if (t + 1 == nk && !late_prefetch) {
             // LAST K step of the tile: nothing of this tile is left to load and the other buffer of each pair is
@@ -226,14 +239,13 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
                 const int npw = (pw_par + nk) & 1, npx = (px_par + ngroups) & 1;
                 const int spw = pw_par, spx = px_par;
                 locate(vid);
-                pw_par = npw; px_par = npx;             // the staging lambdas address the next tile's buffers
-                stage_w(0, npw);
-                if (TAPS == 1) { locate_rows(); stage_x1(0); }
-                else { stage_x(0, 0); stage_x(0, 1); stage_x(0, 2); }
-                pw_par = spw; px_par = spx;             // this step still reads this tile's
+                (void)spw; (void)spx;
+                stage_w(0, 0, npw);
+                if (TAPS == 1) { locate_rows(); stage_x1(0, npx); }
+                else { locate_x(); stage_x(0, 0, 0, npx); stage_x(0, 0, 1, npx); stage_x(0, 0, 2, npx); }
             }
         }
-        const char *lw = wbuf + cur * (BM * 128), *lx = xbuf + ((g + px_par) & 1) * XSEG;
+        const char *lw = wbuf + cur * (BM * 128), *lx = xbuf + xcur * XSEG;
         const int xshift = (TAPS == 9 ? C32_HALO + (dxi - 1) * dil : 0) + S * (wn * (NJ * 16) + frow);      // segment row of fragment 0
         if constexpr (SPLIT) {
             f16x8 wh[MI], wl[MI], ph[NJ], pl[NJ];
@@ -291,6 +303,9 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (TAPS == 9) { if (ndxi == 0) { ++g; xcur ^= 1; } }
+        else { ++g; xcur ^= 1; }
+        dxi = ndxi; kc = nkc; dyi = ndyi;
     }
 
     pw_par = (pw_par + nk) & 1;
@@ -301,9 +316,9 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
         more = vid < all_tiles;
         if (more) {
             locate(vid);
-            stage_w(0, pw_par);
-            if (TAPS == 1) { locate_rows(); stage_x1(0); }
-            else { stage_x(0, 0); stage_x(0, 1); stage_x(0, 2); }
+            stage_w(0, 0, pw_par);
+            if (TAPS == 1) { locate_rows(); stage_x1(0, px_par); }
+            else { locate_x(); stage_x(0, 0, 0, px_par); stage_x(0, 0, 1, px_par); stage_x(0, 0, 2, px_par); }
         }
     }
     // ---- epilogue: lane holds channels c..c+3 (c = tile channel base + (lane>>4)*4) of pixel (lane & 15)
@@ -379,6 +394,7 @@ static int conv_f32_launch(spa_ctx *ctx, const float *x, int32_t B, int32_t H, i
     const int xtiles = (W + bn - 1) / bn, ntiles = Cout / bm;
     const long long total = (long long)B * H * xtiles * ntiles;
     SPA_ARG(total < (1ll << 31));
+    SPA_ARG((long long)(2 * W + 1024) * Cin * 4 < (1ll << 31));            // 32-bit byte offsets inside an image row
     const size_t lds = 2 * (size_t)bm * 128 + 2 * (size_t)(bn + 2 * C32_HALO) * 128;
     if (split) {
         SPA_ARG(bias && zcount == 1 && inv_t > 0.f);
@@ -509,6 +525,7 @@ extern "C" int spa_conv3x3_s2_f16s(spa_ctx *ctx, const float *x, int32_t B, int3
     const int xtiles = (W + bn - 1) / bn, ntiles = Cout / bm;
     const long long total = (long long)B * H * xtiles * ntiles;
     SPA_ARG(total < (1ll << 31));
+    SPA_ARG((long long)(2 * W + 1024) * Cin * 4 < (1ll << 31));            // 32-bit byte offsets inside an image row
     const size_t lds = 2 * (size_t)bm * 128 + 2 * (size_t)(2 * bn + 2 * C32_HALO) * 128;
     if (!(ctx->conv32_attr_done & 4)) {
         SPA_HIP(hipFuncSetAttribute((const void *)k_conv3x3_f32<0, 256, 9, 128, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 128 + 2 * (256 + 2 * C32_HALO) * 128));

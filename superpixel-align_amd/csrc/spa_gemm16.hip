@@ -50,7 +50,8 @@ __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3(const char *__restri
                                                             long long wz, long long yz, const unsigned *__restrict__ amax)
 {
     extern __shared__ __attribute__((aligned(1024))) char lds16[];   // [2] weight tiles | [2] row tiles, 128 bytes per row
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // uniform: the staging's block and LDS addresses stay scalar
     const long long all_tiles = (long long)zcount * total_tiles;
     const int nwg = total_tiles;
     int r0, n0;
