@@ -111,8 +111,12 @@ LIMITERS = {
                               '2.89 with the global loads compiled out (LDS reads + conversions + MFMA: 1.2 PFLOP/s executed, the ceiling '
                               'this part sustains on dense 16-bit MFMA before it lowers its clock) - i.e. 80 % of what the loop can deliver; '
                               'the rest is the wait for the next K step (two LDS buffers of 64 KB: a third does not fit 160 KB)',
-    'k_conv3x3_f32<split>(all)': 'barrier and load latency, not the matrix pipe: 64 channels are two K steps per tap with 12 matrix '
-                                 'instructions per wave each; the layers move 2 GB per launch (1.1 TB/s)',
+    'k_conv3x3_f32<split>(all)': 'instruction issue, not the matrix pipe (SQ counters, profiles/r3_sq_counters_drn_split.txt): a K step of these '
+                                 'narrow layers is 12-24 matrix instructions per wave next to 4-5 other vector and ~5 scalar instructions per '
+                                 'matrix instruction (split of the pixels, staging addresses, scalar state spilled to vector lanes); matrix pipe busy '
+                                 '20-37 % of the cycles, waves 40 % waiting; measured around it: 3 / 2 / 1 workgroups per CU 1.77 / 1.68 / 2.25 ms '
+                                 '(64 -> 64), 256-pixel tiles 1.53, delayed pixel staging +5 %, K loop unrolled by the three taps -5 % on 64 '
+                                 'channels but +25 % on the 256-channel tile (code size)',
     'k_conv3x3_f32<0, 256, 1, 256>': 'float32 MFMA pipe.  K = Cin is 8-16 K steps per 256 x 256 tile against 144 in the 3x3 form, so the '
                                              'tile prologue and the store of the output tile weigh more (0.83 against 0.88 of the peak) although the '
                                              'workgroups are persistent and stage the next tile before their epilogue',
