@@ -190,6 +190,17 @@ int spa_conv3x3_s2_f16s(spa_ctx *ctx, const float *x, int32_t B, int32_t Hi, int
                         const void *wt2, float inv_t, int32_t Cout, int32_t csplit, const float *bias,
                         int32_t relu, const void *amax_in, void *amax_out, float *y, float *y2, void *stream);
 
+/* spa_drn_stem_d with out_dtype 2 that also records the largest value it stores (device word amax_out), and layer 2 of
+ * DRN-D (models/drn.py:134-145: conv3x3 16 -> 32, stride 2, padding 1, BN folded, ReLU) on the 16-bit matrix cores at float32
+ * accuracy: x (B,H,W,16) float32 channels-last -> y (B,(H+1)/2,(W+1)/2,32); wp = the A fragments of the two planes of t * w,
+ * [2 channel tiles][2 planes][5 steps][64 lanes] x 8 half-precision numbers (Engine.layer2_planes), inv_t = 1 / t. */
+int spa_drn_stem_d_amax(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W,
+                        const float *w0, const float *b0, const float *w1, const float *b1,
+                        const double *mean3_host, const double *std3_host, float *y,
+                        float *xn_scratch, void *amax_out, void *stream);
+int spa_drn_layer2_f16s(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W, const void *wp, float inv_t,
+                        const float *bias, const void *amax_in, void *amax_out, float *y, void *stream);
+
 /* ---- input stage ---------------------------------------------------------------------------
  * replaces the host resize of ResizeImageDataset.get_example (datasets/resize_image_dataset.py:31-34:
  * chainercv.transforms.resize(image, resize_shape, 3)) as Pillow computes it on an 8-bit image, channel by

@@ -426,9 +426,10 @@ __device__ __forceinline__ float stem_f16_val(unsigned short b) { return (float)
 __global__ __launch_bounds__(256, 2) void k_drn_stem_d_f16x3(const float *__restrict__ xn, int B, int H, int W,   // normalised, (B,H,W,3)
                                                              const unsigned short *__restrict__ wp,
                                                              const float *__restrict__ b0, const float *__restrict__ b1,
-                                                             float *__restrict__ y)
+                                                             float *__restrict__ y, unsigned *__restrict__ amax_out)
 {
     __shared__ __attribute__((aligned(16))) unsigned short in_h[2][SB_COPY], in_l[2][SB_COPY];
+    unsigned amx = 0;                            // largest value stored (the scale of the layer that reads y)
     __shared__ __attribute__((aligned(16))) unsigned short l0_s[ST_LP * SH_L0_PITCH + 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int m = lane & 15, g = lane >> 4;
@@ -563,13 +564,172 @@ __global__ __launch_bounds__(256, 2) void k_drn_stem_d_f16x3(const float *__rest
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h[s], fh, acc, 0, 0, 0);
             }
             const int gy = ty0 + row, gx = tx0 + col;
-            if (gy < H && gx < W)
-                *(float4 *)(y + ((((long long)b * H + gy) * W + gx) * 16 + 4 * g)) =
-                    make_float4(fmaxf(acc[0] * unscale1 + bias1.x, 0.0f), fmaxf(acc[1] * unscale1 + bias1.y, 0.0f),
-                                fmaxf(acc[2] * unscale1 + bias1.z, 0.0f), fmaxf(acc[3] * unscale1 + bias1.w, 0.0f));
+            if (gy < H && gx < W) {
+                const float4 o = make_float4(fmaxf(acc[0] * unscale1 + bias1.x, 0.0f), fmaxf(acc[1] * unscale1 + bias1.y, 0.0f),
+                                             fmaxf(acc[2] * unscale1 + bias1.z, 0.0f), fmaxf(acc[3] * unscale1 + bias1.w, 0.0f));
+                *(float4 *)(y + ((((long long)b * H + gy) * W + gx) * 16 + 4 * g)) = o;
+                amx = max(amx, max(max(__float_as_uint(o.x), __float_as_uint(o.y)), max(__float_as_uint(o.z), __float_as_uint(o.w))));
+            }
         }
         stem_lds_barrier();
     }
+    if (amax_out) {
+        for (int o = 32; o > 0; o >>= 1) amx = max(amx, (unsigned)__shfl_xor((int)amx, o));
+        if (lane == 0 && amx > *(volatile unsigned *)amax_out) atomicMax(amax_out, amx);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Layer 2 of DRN-D (models/drn.py:134-145 `_make_conv_layers`: conv3x3(16 -> 32, stride 2, padding 1) + BN + ReLU at half
+// resolution) on the 16-bit matrix cores at float32 accuracy — the last convolution that ran on MIOpen (its 16 input
+// channels do not fit the 32-channel K steps of k_conv3x3_f32): ~2.3 ms + a 0.85 ms epilogue pass per 30 images.  Built
+// like the stem's layer 1: a workgroup stages the 9 x 65 input pixels of its 4 x 32 output tile in LDS as two
+// half-precision planes (80-byte pixels: conflict-free 16-byte fragment reads at the stride-2 pixel step), K = 9 taps x
+// 16 channels = 144 padded to 160 (five steps of two taps), two 16-channel tiles of output channels, three matrix
+// instructions per product; bias, ReLU, the largest stored magnitude (the next layer's scale) in the epilogue.  The input
+// patch of the next tile is loaded while this tile computes.  HBM: the input once (9/8 of it), the output once.
+// ---------------------------------------------------------------------------------------------------
+#define L2_TH 4
+#define L2_TW 32
+#define L2_PH (2 * L2_TH + 1)
+#define L2_PW (2 * L2_TW + 1)
+#define L2_PITCH 40                            // halfs per staged pixel: 16 h | 16 l | 8 pad
+
+// wp: [2 channel tiles][2 planes][5 steps][64 lanes] x 8 halfs (A fragments of t * w); x (B,H,W,16) float32; y (B,Ho,Wo,32)
+__global__ __launch_bounds__(256, 2) void k_drn_layer2_f16x3(const float *__restrict__ x, int B, int H, int W, int Ho, int Wo,
+                                                             const unsigned short *__restrict__ wp, const float *__restrict__ bias,
+                                                             float inv_t, const unsigned *__restrict__ amax_in,
+                                                             unsigned *__restrict__ amax_out, float *__restrict__ y)
+{
+    __shared__ __attribute__((aligned(16))) unsigned short patch[L2_PH * L2_PW * L2_PITCH + 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int m = lane & 15, g = lane >> 4;
+    const int tiles_x = (Wo + L2_TW - 1) / L2_TW, tiles_y = (Ho + L2_TH - 1) / L2_TH;
+    const int n_tiles = tiles_x * tiles_y * B;
+    stem_h8 wh[2][5], wl[2][5];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            wh[ct][s] = *(const stem_h8 *)(wp + ((size_t)((ct * 2 + 0) * 5 + s) * 64 + lane) * 8);
+            wl[ct][s] = *(const stem_h8 *)(wp + ((size_t)((ct * 2 + 1) * 5 + s) * 64 + lane) * 8);
+        }
+    float sc, unscale;
+    {
+        const unsigned bits = *amax_in;
+        int e = (int)(bits >> 23) - 127;
+        e = bits == 0u ? 0 : (e < -100 ? -100 : (e > 100 ? 100 : e));
+        sc = __uint_as_float((unsigned)(127 + 14 - e) << 23);
+        unscale = __uint_as_float((unsigned)(127 - 14 + e) << 23) * inv_t;
+    }
+    const float4 bias_lo = *(const float4 *)(bias + 4 * g), bias_hi = *(const float4 *)(bias + 16 + 4 * g);
+    int toff[5];                                   // patch offset (halfs) of k group (step s, g): tap = 2s + g/2, channels 8 (g & 1)
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        int tap = 2 * s + (g >> 1);
+        if (tap > 8) tap = 8;                      // zero-weight pad: any valid address
+        toff[s] = ((tap / 3) * L2_PW + tap % 3) * L2_PITCH + 8 * (g & 1);
+    }
+    constexpr int NE = L2_PH * L2_PW * 4, NU = (NE + 255) / 256;           // float4 elements of a patch
+    float4 raw[NU];
+    int epix[NU], eq[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        int e = tid + u * 256;
+        if (e >= NE) e = -1;
+        epix[u] = e < 0 ? -1 : e >> 2;
+        eq[u] = e & 3;
+    }
+    auto patch_load = [&](int tile) {
+        const int b = tile / (tiles_x * tiles_y), tr = tile - b * (tiles_x * tiles_y);
+        const int ty0 = (tr / tiles_x) * L2_TH, tx0 = (tr % tiles_x) * L2_TW;
+        const float *src = x + (long long)b * H * W * 16;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int pix = epix[u] < 0 ? 0 : epix[u];
+            const int iy = pix / L2_PW, ix = pix - iy * L2_PW;
+            const int gy = 2 * ty0 - 1 + iy, gx = 2 * tx0 - 1 + ix;
+            const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+            raw[u] = *(const float4 *)(src + ((long long)cy * W + cx) * 16 + 4 * eq[u]);
+        }
+    };
+    unsigned amx = 0;
+    if ((int)blockIdx.x < n_tiles) patch_load(blockIdx.x);
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int b = tile / (tiles_x * tiles_y), tr = tile - b * (tiles_x * tiles_y);
+        const int ty0 = (tr / tiles_x) * L2_TH, tx0 = (tr % tiles_x) * L2_TW;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            if (epix[u] < 0) continue;
+            const int iy = epix[u] / L2_PW, ix = epix[u] - iy * L2_PW;
+            const int gy = 2 * ty0 - 1 + iy, gx = 2 * tx0 - 1 + ix;
+            const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            const float v[4] = {in ? raw[u].x * sc : 0.f, in ? raw[u].y * sc : 0.f, in ? raw[u].z * sc : 0.f, in ? raw[u].w * sc : 0.f};
+            unsigned short vh[4], vl[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { vh[j] = stem_f16_bits(v[j]); vl[j] = stem_f16_bits(v[j] - stem_f16_val(vh[j])); }
+            unsigned short *o = patch + epix[u] * L2_PITCH + 4 * eq[u];
+            *(uint2 *)o = make_uint2((unsigned)vh[0] | ((unsigned)vh[1] << 16), (unsigned)vh[2] | ((unsigned)vh[3] << 16));
+            *(uint2 *)(o + 16) = make_uint2((unsigned)vl[0] | ((unsigned)vl[1] << 16), (unsigned)vl[2] | ((unsigned)vl[3] << 16));
+        }
+        stem_lds_barrier();
+        if (tile + (int)gridDim.x < n_tiles) patch_load(tile + (int)gridDim.x);     // next tile's input travels under the matrix work
+        // 8 pixel tiles of 16 (row t >> 1 of the output tile, columns (t & 1) * 16 ..): two per wave
+        for (int t = wv; t < (L2_TH * L2_TW) / 16; t += 4) {
+            const int row = t >> 1, col = (t & 1) * 16 + m;
+            const unsigned short *pb = patch + ((2 * row) * L2_PW + 2 * col) * L2_PITCH;
+            stem_f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 5; ++s) {
+                const stem_h8 fh = *(const stem_h8 *)(pb + toff[s]);
+                const stem_h8 fl = *(const stem_h8 *)(pb + toff[s] + 16);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[0][s], fh, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[1][s], fh, a1, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[0][s], fl, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[1][s], fl, a1, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[0][s], fh, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[1][s], fh, a1, 0, 0, 0);
+            }
+            const int gy = ty0 + row, gx = tx0 + col;
+            if (gy < Ho && gx < Wo) {
+                const float4 o0 = make_float4(fmaxf(a0[0] * unscale + bias_lo.x, 0.f), fmaxf(a0[1] * unscale + bias_lo.y, 0.f),
+                                              fmaxf(a0[2] * unscale + bias_lo.z, 0.f), fmaxf(a0[3] * unscale + bias_lo.w, 0.f));
+                const float4 o1 = make_float4(fmaxf(a1[0] * unscale + bias_hi.x, 0.f), fmaxf(a1[1] * unscale + bias_hi.y, 0.f),
+                                              fmaxf(a1[2] * unscale + bias_hi.z, 0.f), fmaxf(a1[3] * unscale + bias_hi.w, 0.f));
+                float *o = y + (((long long)b * Ho + gy) * Wo + gx) * 32 + 4 * g;
+                *(float4 *)o = o0;
+                *(float4 *)(o + 16) = o1;
+                amx = max(amx, max(max(__float_as_uint(o0.x), __float_as_uint(o0.y)), max(__float_as_uint(o0.z), __float_as_uint(o0.w))));
+                amx = max(amx, max(max(__float_as_uint(o1.x), __float_as_uint(o1.y)), max(__float_as_uint(o1.z), __float_as_uint(o1.w))));
+            }
+        }
+        stem_lds_barrier();
+    }
+    if (amax_out) {
+        for (int o = 32; o > 0; o >>= 1) amx = max(amx, (unsigned)__shfl_xor((int)amx, o));
+        if (lane == 0 && amx > *(volatile unsigned *)amax_out) atomicMax(amax_out, amx);
+    }
+}
+
+// x (B,H,W,16) float32 channels-last -> y (B,(H+1)/2,(W+1)/2,32) = relu(conv3x3 stride 2 padding 1 + bias); wp = the packed
+// planes of t * w (layout above), inv_t = 1 / t; amax_in / amax_out as in spa_conv3x3_wino4_f16s
+extern "C" int spa_drn_layer2_f16s(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W, const void *wp, float inv_t,
+                                   const float *bias, const void *amax_in, void *amax_out, float *y, void *stream)
+{
+    SPA_ARG(ctx && x && wp && bias && amax_in && y && B > 0 && H > 0 && W > 0 && inv_t > 0.f);
+    SPA_ARG((((uintptr_t)x | (uintptr_t)wp | (uintptr_t)bias | (uintptr_t)y) & 15) == 0);
+    hipStream_t s = spa_stream(stream);
+    if (amax_out) SPA_HIP(hipMemsetAsync(amax_out, 0, 4, s));
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const long long n_tiles = (long long)((Wo + L2_TW - 1) / L2_TW) * ((Ho + L2_TH - 1) / L2_TH) * B;
+    SPA_ARG(n_tiles < (1ll << 31));
+    SpaProfScope prof_(ctx, PROF_DRN_CONV16, s);
+    long long grid = 3ll * ctx->n_cu;
+    if (grid > n_tiles) grid = n_tiles;
+    hipLaunchKernelGGL(k_drn_layer2_f16x3, dim3((unsigned)grid), dim3(256), 0, s, x, B, H, W, Ho, Wo, (const unsigned short *)wp, bias,
+                       inv_t, (const unsigned *)amax_in, (unsigned *)amax_out, y);
+    SPA_LAUNCH_CHECK();
+    return SPA_OK;
 }
 
 // weights -> scaled half-precision planes in MFMA A fragment order (one workgroup of 64 lanes per step, the k orders of
@@ -639,10 +799,34 @@ __global__ void k_stem_pack_bf16(const float *__restrict__ w0, const float *__re
     }
 }
 
+static int stem_impl(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W,
+                     const float *w0, const float *b0, const float *w1, const float *b1,
+                     const double *mean3_host, const double *std3_host, void *y, int32_t out_dtype,
+                     float *xn_scratch, void *amax_out, void *stream);
+
 extern "C" int spa_drn_stem_d(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W,
                               const float *w0, const float *b0, const float *w1, const float *b1,
                               const double *mean3_host, const double *std3_host, void *y, int32_t out_dtype,
                               float *xn_scratch, void *stream)
+{
+    return stem_impl(ctx, x, B, H, W, w0, b0, w1, b1, mean3_host, std3_host, y, out_dtype, xn_scratch, nullptr, stream);
+}
+
+// out_dtype 2 (float32 output on the 16-bit matrix cores) and amax_out[0] = bit pattern of the largest value stored: the
+// scale input of spa_drn_layer2_f16s
+extern "C" int spa_drn_stem_d_amax(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W,
+                                   const float *w0, const float *b0, const float *w1, const float *b1,
+                                   const double *mean3_host, const double *std3_host, float *y,
+                                   float *xn_scratch, void *amax_out, void *stream)
+{
+    SPA_ARG(amax_out);
+    return stem_impl(ctx, x, B, H, W, w0, b0, w1, b1, mean3_host, std3_host, y, 2, xn_scratch, amax_out, stream);
+}
+
+static int stem_impl(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W,
+                     const float *w0, const float *b0, const float *w1, const float *b1,
+                     const double *mean3_host, const double *std3_host, void *y, int32_t out_dtype,
+                     float *xn_scratch, void *amax_out, void *stream)
 {
     SPA_ARG(ctx && x && w0 && b0 && w1 && b1 && mean3_host && std3_host && y && B > 0 && H > 0 && W > 0);
     SPA_ARG(out_dtype == 0 || out_dtype == 1 || out_dtype == 2);      // 2: float32 output, 16-bit matrix cores (two planes)
@@ -675,13 +859,14 @@ extern "C" int spa_drn_stem_d(spa_ctx *ctx, const float *x, int32_t B, int32_t H
     rc = spa_drn_normalise(ctx, x, B, H, W, xn, 0, mean3_host, std3_host, stream);
     if (rc != SPA_OK) return rc;
     if (out_dtype == 2) {
+        if (amax_out) SPA_HIP(hipMemsetAsync(amax_out, 0, 4, spa_stream(stream)));
         unsigned short *wp;
         if ((rc = spa_ws_reserve(ctx, WS_STEM_WPACK, (size_t)22 * 64 * 8 * 2 + 16, (void **)&wp)) != SPA_OK) return rc;
         hipLaunchKernelGGL(k_stem_pack_f16, dim3(23), dim3(64), 0, spa_stream(stream), w0, b0, w1, wp);
         long long g2 = 2ll * ctx->n_cu;                    // two resident workgroups per CU (78 KB of LDS)
         if (g2 > n_tiles) g2 = n_tiles;
         hipLaunchKernelGGL(k_drn_stem_d_f16x3, dim3((unsigned)g2), dim3(256), 0, spa_stream(stream), (const float *)xn, B, H, W,
-                           (const unsigned short *)wp, b0, b1, (float *)y);
+                           (const unsigned short *)wp, b0, b1, (float *)y, (unsigned *)amax_out);
         SPA_LAUNCH_CHECK();
         return SPA_OK;
     }

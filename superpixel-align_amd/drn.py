@@ -153,6 +153,13 @@ def conv_bias_act(conv, bn, x, residual=None, relu=True):
             else:
                 _EPILOGUE['conv_flops'] += fl
             return eng.conv3x3_f32(x, packed32[0], packed32[1], residual, relu, conv.dilation[0])
+        l2 = getattr(conv, '_spa_layer2', None)
+        if (l2 is not None and _EPILOGUE['split_gemm'] and _EPILOGUE['own_conv32'] and x.dtype == torch.float32 and relu
+                and residual is None and x.is_contiguous(memory_format=torch.channels_last)):
+            # layer 2 of arch D (16 -> 32 channels, stride 2): its own kernel on the 16-bit matrix cores
+            _EPILOGUE['conv16_flops'] += 2.0 * x.shape[0] * ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2) * 32 * 9 * 16
+            _EPILOGUE['conv16_launches'] += 1
+            return eng.drn_layer2_f16s(x, l2[0], l2[1], l2[2], amax_in=getattr(x, '_spa_amax', None))
         y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation)
         vec = 4 if y.dtype == torch.float32 else 8
         if (y.is_contiguous(memory_format=torch.channels_last) and y.shape[1] % vec == 0
@@ -307,6 +314,11 @@ class DRN(nn.Module):
                     m._spa_packed = None
                     m._spa_packed32 = None
                     m._spa_packed16 = None
+                    m._spa_layer2 = None
+                    if (dtype == torch.float32 and self.folded and m.kernel_size == (3, 3) and m.stride == (2, 2)
+                            and m.padding == (1, 1) and m.dilation == (1, 1) and m.groups == 1 and m.in_channels == 16
+                            and m.out_channels == 32 and m.bias is not None):
+                        m._spa_layer2 = Engine.layer2_planes(m.weight) + (m.bias.detach().float().contiguous(),)
                     m._spa_wino = {}
                     # Winograd where it wins (measured, 30 x 128 x 256 pixels, ms direct / F(2x2) / F(4x4)):
                     #   512 -> 512  33.2 / 19.8 / 11.9     256 -> 512  16.8 / 11.6 / 7.0     256 -> 256  8.5 / 6.6 / 4.2

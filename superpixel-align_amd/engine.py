@@ -132,10 +132,55 @@ class Engine(object):
         # normalised channels-last copy of the image (float32, or bfloat16 for the bf16 kernel): per call, so calls
         # on different streams (DRN.batch_predict(streams > 1)) never share the context-wide workspace
         scratch = torch.empty((B, H, W, 3), dtype=dtype, device=x.device)
+        if split and dtype == torch.float32:
+            am = torch.empty(1, dtype=torch.int32, device=x.device)      # the largest value stored: layer 2's scale
+            check(self._lib.spa_drn_stem_d_amax(self._ctx, _ptr(x), B, H, W, _ptr(w0), _ptr(b0), _ptr(w1p), _ptr(b1),
+                                                mean, std, _ptr(out), _ptr(scratch), _ptr(am), self._s()))
+            out._spa_amax = am
+            return out
         check(self._lib.spa_drn_stem_d(self._ctx, _ptr(x), B, H, W, _ptr(w0), _ptr(b0), _ptr(w1p), _ptr(b1),
-                                       mean, std, _ptr(out), (2 if split else 0) if dtype == torch.float32 else 1, _ptr(scratch),
+                                       mean, std, _ptr(out), 0 if dtype == torch.float32 else 1, _ptr(scratch),
                                        self._s()))
         return out
+
+    @staticmethod
+    def layer2_planes(weight):
+        """(32,16,3,3) -> (wp, inv_t) for drn_layer2_f16s: the MFMA A fragments of the two half-precision planes of t * w,
+        [2 channel tiles][2 planes][5 steps][64 lanes][8]: lane = (channel n = lane & 15, k group g = lane >> 4), k group
+        (step s, g) = tap 2s + g // 2 (tap 9: zero pad), input channels 8 (g & 1) .. + 7 (csrc/spa_stem.hip)."""
+        assert tuple(weight.shape) == (32, 16, 3, 3)
+        w = weight.detach().float()
+        amax = float(w.abs().max().clamp_min(1e-30))
+        t = 2.0 ** (14 - int(np.floor(np.log2(amax))))
+        ws = (w.double() * t).float().reshape(32, 16, 9)                      # (n, c, tap)
+        frag = torch.zeros((2, 5, 64, 8), dtype=torch.float32, device=w.device)
+        for s_ in range(5):
+            for g in range(4):
+                tap = 2 * s_ + g // 2
+                if tap > 8:
+                    continue
+                c0 = 8 * (g & 1)
+                for ct in range(2):
+                    frag[ct, s_, g * 16:(g + 1) * 16, :] = ws[ct * 16:(ct + 1) * 16, c0:c0 + 8, tap]
+        h = frag.half()
+        l = (frag - h.float()).half()
+        return torch.stack([h, l], dim=1).contiguous(), float(1.0 / t)        # (2, 2, 5, 64, 8)
+
+    def drn_layer2_f16s(self, x, wp, inv_t, bias, amax_in=None):
+        """relu(conv3x3(x; 16 -> 32 channels, stride 2, padding 1) + bias) on the 16-bit matrix cores at float32 accuracy.
+        Returns y with the device word of its largest value attached as `_spa_amax`."""
+        B, C, H, W = x.shape
+        assert C == 16 and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
+        assert wp.dtype == torch.float16 and tuple(wp.shape) == (2, 2, 5, 64, 8) and wp.is_contiguous()
+        assert bias.dtype == torch.float32 and bias.numel() == 32 and bias.is_contiguous()
+        if amax_in is None:
+            amax_in = self.amax(x)
+        y = torch.empty((B, 32, (H + 1) // 2, (W + 1) // 2), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        am = torch.empty(1, dtype=torch.int32, device=x.device)
+        check(self._lib.spa_drn_layer2_f16s(self._ctx, _ptr(x), B, H, W, _ptr(wp), ctypes.c_float(inv_t), _ptr(bias), _ptr(amax_in),
+                                            _ptr(am), _ptr(y), self._s()))
+        y._spa_amax = am
+        return y
 
     def bias_act_(self, y, bias, residual=None, relu=True, track_amax=False):
         """In place y = relu?(y + bias [+ residual]) on a channels-last (B,C,H,W) activation.  track_amax (float32): the

@@ -178,6 +178,22 @@ def test_conv3x3_stride2_with_projection_matches_float64(eng, B, Cin, Cout, Hi, 
         assert float((y1.double() - r).abs().max()) <= 4e-6 * float(r.abs().max())
 
 
+@pytest.mark.parametrize('B,H,W', [(2, 37, 61), (1, 64, 130), (1, 9, 257), (3, 8, 32)])
+def test_drn_layer2_split_planes_matches_float64(eng, B, H, W):
+    """layer 2 of DRN-D (conv3x3 16 -> 32, stride 2, padding 1, ReLU) on the 16-bit matrix cores: spa_drn_layer2_f16s against
+    a float64 convolution, odd sizes and partial tiles included; the tracked maximum is the output's"""
+    g = torch.Generator(device='cuda').manual_seed(21)
+    x = (torch.relu(torch.randn((B, 16, H, W), device='cuda', generator=g)) * 1.7).contiguous(memory_format=torch.channels_last)
+    w = torch.randn((32, 16, 3, 3), device='cuda', generator=g) * (2.0 / 144) ** 0.5
+    b = torch.randn((32,), device='cuda', generator=g)
+    wp, inv_t = eng.layer2_planes(w)
+    y = eng.drn_layer2_f16s(x, wp, inv_t, b)
+    ref = torch.relu(F.conv2d(x.double(), w.double(), b.double(), 2, 1))
+    assert y.shape == ref.shape
+    assert float((y.double() - ref).abs().max()) <= 3e-6 * float(ref.abs().max())
+    assert float(y._spa_amax.view(torch.float32)) == float(y.abs().max())
+
+
 def test_bias_act_tracks_the_maximum_it_stores(eng):
     """spa_bias_act_amax: the epilogue pass behind a MIOpen convolution also hands the next (split-plane) convolution its scale"""
     g = torch.Generator(device='cuda').manual_seed(13)
