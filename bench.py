@@ -541,13 +541,13 @@ def main():
                                   'which the float32 matrix peak (157 TFLOP/s) no longer bounds.  ' if split16 else '') +
                                  'float32: every stride-1 3x3 layer from 128 channels up (from 256 input channels up with the split planes; the layers below take the direct kernel) runs as Winograd F(4x4,3x3) (input transform, 36 '
                                  'GEMMs in one launch of the float32-MFMA kernel, output transform with the epilogue fused), the '
-                                 '64-channel layers and the 1x1 projections on the same kernel directly, the stem on its own MFMA kernel; '
+                                 '64-channel layers and the 1x1 projections on the same kernel directly, the stem on its own MFMA kernel; ' +
                                  ('the stride-2 layers (layer 2, the openers of layers 3 / 4 with their projections) have their own split-plane kernels: no MIOpen convolution is left.  ' if split16 else 'the five stride-2 layers are PyTorch-ROCm (MIOpen).  ') + '`achieved` counts the products actually '
                                  'executed, `effective_TFLOPs_direct_equivalent` what a direct convolution would have to sustain'
                                  if a.dtype == 'fp32' else
                                  'bf16: the stride-1 3x3 layers from 64 channels up are libspalign\'s bf16 implicit-GEMM convolution with '
                                  'the epilogue fused (k_conv3x3_bf16), the stem its bf16-MFMA kernel; the light layers are MIOpen')
-                         if conv_flops > 0 else
+                         if (conv_flops > 0 or split16 or wino_direct > 0) else
                          'the big convolutions are PyTorch-ROCm (MIOpen); libspalign adds the fused float32-MFMA stem '
                          'of DRN-D (normalise + layer0 + layer1, k_drn_stem_d) and the bias/residual/ReLU epilogues')},
         'stage_ms_per_step': dict({k: round(v / a.steps, 3) for k, v in stage.items()},
