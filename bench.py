@@ -527,7 +527,12 @@ def main():
                                % (a.arch, a.dtype, 'SLIC(%d)' % a.n_slic_segments if a.superpixel_method == 'slic'
                                   else 'felzenszwalb(300,0.8,20)', a.pool_mode, a.n_clusters, H, W, B, NB),
                    'images_per_step_per_gpu': B, 'sharding': 'images (no data-path collective), '
-                   'one all_gather of score records'},
+                   'one all_gather of score records',
+                   'drn_arithmetic': ('float32 tensors; matrix products as three v_mfma_f32_16x16x32_f16 per float32 product on two '
+                                      'half-precision planes per operand (22 significand bits after an exact power-of-two scaling), float32 '
+                                      'accumulation: the final map is as close to the float64 network as with float32 matrix instructions '
+                                      '(--fp32_mfma_gemm selects those)') if split16 else
+                                     ('float32 matrix instructions' if a.dtype == 'fp32' else 'bf16 operands, float32 accumulation')},
         'roofline': roof,
         'host_to_host': h2h,
         'drn': {'bound': 'mfma' if not split16 else 'mixed: 16-bit mfma (GEMMs) + hbm (Winograd transforms)',
