@@ -237,9 +237,7 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
             more = vid < all_tiles;
             if (more) {
                 const int npw = (pw_par + nk) & 1, npx = (px_par + ngroups) & 1;
-                const int spw = pw_par, spx = px_par;
                 locate(vid);
-                (void)spw; (void)spx;
                 stage_w(0, 0, npw);
                 if (TAPS == 1) { locate_rows(); stage_x1(0, npx); }
                 else { locate_x(); stage_x(0, 0, 0, npx); stage_x(0, 0, 1, npx); stage_x(0, 0, 2, npx); }
