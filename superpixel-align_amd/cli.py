@@ -60,6 +60,7 @@ _COMMON_FLAGS = [
     ('--decode_procs', dict(type=int, default=0)),       # > 0: decode PNGs in this many worker processes (shared-memory slabs)
     ('--strict_retry', dict(action='store_true', default=False)),     # k = 2: die with RecursionError where the reference does
     ('--host_resize', dict(action='store_true', default=False)),      # resize with Pillow on the host threads instead
+    ('--resize_backend', dict(type=str, default='pil', choices=['pil', 'cv2'])),   # cv2: OpenCV's INTER_CUBIC algorithm (not pinned)
 ]
 
 
@@ -126,9 +127,50 @@ def _decode(fp_or_path):
         return np.asarray(f, dtype=np.uint8)
 
 
+RESIZE_BACKEND = ['pil']         # --resize_backend: 'pil' (pinned against Pillow) or 'cv2' (OpenCV's algorithm, not pinned)
+
+
+def _cv_cubic_taps(n_src, n_dst):
+    """OpenCV INTER_CUBIC along one axis: (clamped source indices (n_dst, 4), float32 coefficients (n_dst, 4))."""
+    scale = float(n_src) / float(n_dst)
+    d = np.arange(n_dst, dtype=np.float64)
+    f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    x = (f - s.astype(np.float32)).astype(np.float32)
+    A = np.float32(-0.75)
+    one = np.float32(1)
+    c0 = ((A * (x + one) - np.float32(5) * A) * (x + one) + np.float32(8) * A) * (x + one) - np.float32(4) * A
+    c1 = ((A + np.float32(2)) * x - (A + np.float32(3))) * x * x + one
+    c2 = ((A + np.float32(2)) * (one - x) - (A + np.float32(3))) * (one - x) * (one - x) + one
+    c3 = one - c0 - c1 - c2
+    idx = np.clip(s[:, None] - 1 + np.arange(4)[None, :], 0, n_src - 1)
+    return idx, np.stack([c0, c1, c2, c3], 1).astype(np.float32)
+
+
+def resize_cvcubic_chw(img_chw, shape):
+    """cv2.resize(img.transpose(1, 2, 0), (w, h), interpolation=cv2.INTER_CUBIC).transpose(2, 0, 1) on a float32 image, as
+    OpenCV's scalar float path computes it (float32 horizontal sums, then a float32 vertical sum, left to right; border
+    replication; no clipping): the host form of spa_resize_cvcubic_u8, same bits.  Not pinned against cv2 itself."""
+    a = np.asarray(img_chw, dtype=np.float32)
+    C, H, W = a.shape
+    h, w = int(shape[0]), int(shape[1])
+    xi, xc = _cv_cubic_taps(W, w)
+    yi, yc = _cv_cubic_taps(H, h)
+    r = a[:, :, xi[:, 0]] * xc[:, 0]
+    for k in (1, 2, 3):
+        r = r + a[:, :, xi[:, k]] * xc[:, k]                   # (C, H, w) float32, left to right
+    o = r[:, yi[:, 0], :] * yc[:, 0][None, :, None]
+    for k in (1, 2, 3):
+        o = o + r[:, yi[:, k], :] * yc[:, k][None, :, None]
+    return o.astype(np.float32)
+
+
 def resize_bicubic_chw(img_chw, shape):
-    """datasets/resize_image_dataset.py:31-34 (chainercv.transforms.resize(img, size, 3)).
-    PIL bicubic here; OpenCV INTER_CUBIC bit-parity is a later row."""
+    """datasets/resize_image_dataset.py:31-34 (chainercv.transforms.resize(img, size, 3)): Pillow's 8-bit bicubic
+    (pinned), or with --resize_backend cv2 OpenCV's float INTER_CUBIC (the branch the reference environment ran; its
+    algorithm restated, not pinned: no cv2 here)."""
+    if RESIZE_BACKEND[0] == 'cv2':
+        return resize_cvcubic_chw(img_chw, shape)
     from PIL import Image
     h, w = shape
     out = [np.asarray(Image.fromarray(c).resize((w, h), Image.BICUBIC)) for c in img_chw]
@@ -306,7 +348,7 @@ class ImageList(object):
             ring = self._ring
         u8 = ring.upload(raw, engine.device, pool)
         shape = tuple(self._shape) if self._shape is not None else raw[0].shape[:2]
-        return engine.resize_bicubic_u8(u8, shape)
+        return engine.resize_u8(u8, shape, RESIZE_BACKEND[0])
 
     def batch(self, lo, hi, pool=None):
         """dataset[lo:hi] stacked (python slice semantics, like concat_examples(dataset[i:end_i]));
@@ -465,6 +507,7 @@ def main_labelled(argv=None, get=None, make_pipe=None, originals=False, make_mod
     pipeline also wants the undecimated uint8 images of the batch (superpixel_overlaps.py:322);
     `make_model`: factory replacing create_model (tests of the host logic inject a stub)."""
     args = (get or get_args)(argv)
+    RESIZE_BACKEND[0] = getattr(args, 'resize_backend', 'pil')
     rank, ws, local = spdist.init()
     if ws > 1:
         args.gpu = local
@@ -569,7 +612,7 @@ def main_labelled(argv=None, get=None, make_pipe=None, originals=False, make_mod
                         if got is not None:
                             u8, gt_dev, gts = got
                             shape = tuple(imgs_ds._shape) if imgs_ds._shape is not None else tuple(u8.shape[1:3])
-                            t = tls.eng.resize_bicubic_u8(u8, shape)
+                            t = tls.eng.resize_u8(u8, shape, RESIZE_BACKEND[0])
                             ev = torch.cuda.Event()
                             ev.record(tls.stream)
                             return t, ev, gts, gt_dev
@@ -774,6 +817,7 @@ def main_overlaps(argv=None):
 def main_labelfree(argv=None):
     args = get_args_labelfree(argv)
     args.resize_shape = tuple(args.resize_shape)
+    RESIZE_BACKEND[0] = getattr(args, 'resize_backend', 'pil')
     model = ops.create_model(args)
     pipe = LabelPipeline(args, model, ops.engine())
     img_fns = sorted(fn.strip() for fn in open(args.img_list_fn) if fn.strip())

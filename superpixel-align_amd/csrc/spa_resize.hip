@@ -159,3 +159,76 @@ extern "C" int spa_resize_bicubic_u8(spa_ctx *ctx, const uint8_t *src, int32_t B
     SPA_LAUNCH_CHECK();
     return SPA_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------
+// The OpenCV branch of the reference's input resize (datasets/resize_image_dataset.py:31-34: chainercv.transforms.resize(
+// image, shape, 3) with cv2 importable = cv2.resize(float32 HWC image, (w, h), interpolation=cv2.INTER_CUBIC)) — what the
+// reference environment ran.  NOT PINNED: there is no cv2 in the build image and no fixture in the reference; the kernel
+// follows OpenCV's published scalar algorithm (modules/imgproc/src/resize.cpp: resizeGeneric_ with HResizeCubic /
+// VResizeCubic for float; coefficients interpolateCubic with A = -0.75f, source position (float)((d + 0.5) * scale - 0.5),
+// border replication, float32 horizontal sums then a float32 vertical sum, no clipping) and is bit-identical to the
+// restatement oracle/resize_oracle.c:orc_resize_cvcubic_f32 (tests/test_gpu_parity.py).  One thread = one destination
+// pixel (all channels): the four horizontal sums of its four source rows, then the vertical sum — the same float32
+// operations in the same order as the two-pass form.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cv_cubic_coeffs(float x, float (&c)[4])
+{
+    const float A = -0.75f;
+    c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+    c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+    c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+    c[3] = 1.f - c[0] - c[1] - c[2];
+}
+
+__global__ __launch_bounds__(256) void k_resize_cvcubic(const uint8_t *__restrict__ src, int H, int W, int C, int h, int w,
+                                                        double sx, double sy, float *__restrict__ out)
+{
+    const int b = blockIdx.z, dy = blockIdx.y;
+    const int dx = blockIdx.x * 256 + threadIdx.x;
+    if (dx >= w) return;
+    float fx = (float)((dx + 0.5) * sx - 0.5), fy = (float)((dy + 0.5) * sy - 0.5);
+    const int x0 = (int)floorf(fx), y0 = (int)floorf(fy);
+    fx -= (float)x0; fy -= (float)y0;
+    float a[4], bb[4];
+    cv_cubic_coeffs(fx, a);
+    cv_cubic_coeffs(fy, bb);
+    int xs[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int v = x0 - 1 + k; xs[k] = v < 0 ? 0 : (v >= W ? W - 1 : v); }
+    const uint8_t *img = src + (long long)b * H * W * C;
+    for (int c = 0; c < C; ++c) {
+        float r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int yy = y0 - 1 + k;
+            yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+            const uint8_t *S = img + (long long)yy * W * C + c;
+            r[k] = (float)S[xs[0] * C] * a[0] + (float)S[xs[1] * C] * a[1] + (float)S[xs[2] * C] * a[2] + (float)S[xs[3] * C] * a[3];
+        }
+        out[(((long long)b * C + c) * h + dy) * w + dx] = r[0] * bb[0] + r[1] * bb[1] + r[2] * bb[2] + r[3] * bb[3];
+    }
+}
+
+// src (B,H,W,C) uint8 interleaved (a decoded PNG: the float32 image the reference resizes holds exactly these values) ->
+// out (B,C,dst_h,dst_w) float32 planar, not clipped.  With dst == src size only the layout/dtype change is made (the
+// reference resizes only when the shapes differ).
+extern "C" int spa_resize_cvcubic_u8(spa_ctx *ctx, const uint8_t *src, int32_t B, int32_t H, int32_t W, int32_t C,
+                                     int32_t dst_h, int32_t dst_w, float *out, void *stream)
+{
+    SPA_ARG(ctx && src && out && B > 0 && H > 0 && W > 0 && C > 0 && C <= 4 && dst_h > 0 && dst_w > 0);
+    SPA_ARG(dst_h < 65536 && B < 65536);
+    hipStream_t s = spa_stream(stream);
+    if (dst_h == H && dst_w == W) {
+        const long long npix = (long long)H * W;
+        int g = (int)((npix + 255) / 256);
+        if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(k_u8_to_planar, dim3(g, B), dim3(256), 0, s, src, npix, C, out);
+        SPA_LAUNCH_CHECK();
+        return SPA_OK;
+    }
+    hipLaunchKernelGGL(k_resize_cvcubic, dim3((dst_w + 255) / 256, dst_h, B), dim3(256), 0, s, src, H, W, C, dst_h, dst_w,
+                       (double)W / (double)dst_w, (double)H / (double)dst_h, out);
+    SPA_LAUNCH_CHECK();
+    return SPA_OK;
+}

@@ -386,6 +386,19 @@ class Engine(object):
         check(self._lib.spa_resize_bicubic_u8(self._ctx, _ptr(src), B, H, W, C, h, w, _ptr(out), self._s()))
         return out
 
+    def resize_cvcubic_u8(self, src, shape):
+        """Decoded 8-bit images (B,H,W,C) uint8 -> (B,C,h,w) float32 by OpenCV's float INTER_CUBIC (the cv2 branch of
+        chainercv.transforms.resize: what the reference environment ran; not pinned, see include/spalign.h)."""
+        src = _req(src, torch.uint8, 'src')
+        B, H, W, C = src.shape
+        h, w = int(shape[0]), int(shape[1])
+        out = torch.empty((B, C, h, w), dtype=torch.float32, device=src.device)
+        check(self._lib.spa_resize_cvcubic_u8(self._ctx, _ptr(src), B, H, W, C, h, w, _ptr(out), self._s()))
+        return out
+
+    def resize_u8(self, src, shape, backend='pil'):
+        return self.resize_cvcubic_u8(src, shape) if backend == 'cv2' else self.resize_bicubic_u8(src, shape)
+
     # ------------------------------------------------------------------ SLIC
     def rgb2lab(self, rgb, ratio=0.1):
         rgb = _req(rgb, torch.float32, 'rgb')

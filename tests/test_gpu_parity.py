@@ -481,6 +481,26 @@ def test_resize_bicubic_bit_exact(eng, orc):
     assert np.array_equal(same, big[0, :64, :96].transpose(2, 0, 1).astype(np.float32))
 
 
+def test_resize_opencv_cubic_follows_the_restatement(eng, orc):
+    """spa_resize_cvcubic_u8 — the OpenCV branch of the reference's resize (cv2.resize(float32 HWC, INTER_CUBIC)), which cannot be
+    pinned here (no cv2, no fixture): the kernel is bit-identical to the restatement of OpenCV's published scalar algorithm
+    (oracle/resize_oracle.c: orc_resize_cvcubic_f32) on down- and up-scaling, odd sizes and the 1024x2048 -> 224x224 operating
+    point, and to the host form the driver falls back to."""
+    import importlib
+    cli = importlib.import_module('superpixel-align_amd.cli')
+    rs = np.random.RandomState(8)
+    for (H, W, h, w) in ((37, 53, 16, 24), (64, 100, 224, 224), (30, 30, 30, 61), (9, 7, 20, 3), (1024, 2048, 224, 224)):
+        img = rs.randint(0, 256, (2, H, W, 3)).astype(np.uint8)
+        out = eng.resize_cvcubic_u8(dev(img), (h, w)).cpu().numpy()
+        assert out.dtype == np.float32 and out.shape == (2, 3, h, w)
+        for b in range(2):
+            ref = orc.resize_cvcubic_f32(img[b].transpose(2, 0, 1).astype(np.float32), (h, w))
+            assert np.array_equal(out[b], ref), (H, W, h, w)
+        assert np.array_equal(out[0], cli.resize_cvcubic_chw(img[0].transpose(2, 0, 1), (h, w)))
+    same = eng.resize_cvcubic_u8(dev(img[:1, :64, :96]), (64, 96))[0].cpu().numpy()      # layout / dtype change only
+    assert np.array_equal(same, img[0, :64, :96].transpose(2, 0, 1).astype(np.float32))
+
+
 def test_kmeans_near_ties(eng):
     """Inputs bisected onto the reference's decision boundary (tests/golden/kmeans_tie.npz): the
     kernel's sums must round exactly like numpy's (sequential axis-0 centre sums, pairwise
