@@ -274,21 +274,26 @@ def test_driver_gpu_input_stage_equals_host_resize(mods, synth, tmp_path):
     (tmp_path / 'imgs.txt').write_text('\n'.join(img_fns) + '\n')
     (tmp_path / 'labs.txt').write_text('\n'.join(lab_fns) + '\n')
     outs = []
-    for extra in ([], ['--host_resize']):
+    # ... and the same for the OpenCV branch of the resize (--resize_backend cv2): device kernel vs the host form
+    for extra in ([], ['--host_resize'], ['--resize_backend', 'cv2'], ['--resize_backend', 'cv2', '--host_resize']):
         out = tmp_path / ('out' + str(len(outs)))
         argv = ['--superpixel_method', 'slic', '--n_slic_segments', '20', '--n_clusters', '2',
                 '--resize_shape', '64', '80', '--batchsize', '2', '--out_dir', str(out),
                 '--img_file_list', str(tmp_path / 'imgs.txt'), '--label_file_list', str(tmp_path / 'labs.txt'),
                 '--arch', 'drn_d_22', '--pool_mode', 'mean', '--no_figure'] + extra
-        assert mods.cli.main_labelled(argv) == 0
+        try:
+            assert mods.cli.main_labelled(argv) == 0
+        finally:
+            mods.cli.RESIZE_BACKEND[0] = 'pil'
         outs.append(out)
-    for fn in img_fns:
-        base = os.path.splitext(os.path.basename(fn))[0]
-        for suffix in ('.npy', '_all_cluster.npy'):
-            assert np.array_equal(np.load(outs[0] / (base + suffix)), np.load(outs[1] / (base + suffix))), base
-    a = [json.loads(l) for l in open(outs[0] / 'result.json')]
-    b = [json.loads(l) for l in open(outs[1] / 'result.json')]
-    assert [(x['TP'], x['FP'], x['FN']) for x in a] == [(x['TP'], x['FP'], x['FN']) for x in b]
+    for p, q in ((0, 1), (2, 3)):
+        for fn in img_fns:
+            base = os.path.splitext(os.path.basename(fn))[0]
+            for suffix in ('.npy', '_all_cluster.npy'):
+                assert np.array_equal(np.load(outs[p] / (base + suffix)), np.load(outs[q] / (base + suffix))), base
+        a = [json.loads(l) for l in open(outs[p] / 'result.json')]
+        b = [json.loads(l) for l in open(outs[q] / 'result.json')]
+        assert [(x['TP'], x['FP'], x['FN']) for x in a] == [(x['TP'], x['FP'], x['FN']) for x in b]
 
 
 def test_driver_process_decode_equals_thread_decode(mods, synth, tmp_path):
