@@ -349,7 +349,7 @@ def main():
     drn._EPILOGUE['bytes'] = 0
     drn._EPILOGUE['launches'] = 0
     drn._EPILOGUE['conv_flops'] = 0.0
-    for key in ('conv16_flops', 'conv16_launches', 'gemm16_flops', 'gemm16_launches', 'gemm16_bytes', 'gemm16n_flops', 'gemm16n_launches', 'gemm16n_bytes',
+    for key in ('conv16_flops', 'conv16_launches', 'conv16_bytes', 'gemm16_flops', 'gemm16_launches', 'gemm16_bytes', 'gemm16n_flops', 'gemm16n_launches', 'gemm16n_bytes',
                 'gemm_flops', 'gemm_launches', 'gemm_bytes', 'gemmn_flops', 'gemmn_launches', 'gemmn_bytes', 'wino_direct_flops', 'wino_saved_flops', 'wino_in_bytes', 'wino_out_bytes', 'wino_launches'):
         drn._EPILOGUE[key] = 0
 
@@ -455,7 +455,10 @@ def main():
             tf = fl / a.steps / (ms / a.steps * 1e-3) / 1e12
             ent.update(bound='mfma', achieved=round(3 * tf, 1), peak=BF16_MATRIX_PEAK_TF, unit='TFLOP/s',
                        frac=round(3 * tf / BF16_MATRIX_PEAK_TF, 4), float32_equivalent_tflops=round(tf, 1),
-                       flops_per_step=3 * fl / a.steps, flops_per_launch=3 * fl / nl)
+                       flops_per_step=3 * fl / a.steps, flops_per_launch=3 * fl / nl,
+                       hbm_bytes_per_launch_by_construction=int(E['conv16_bytes'] / nl),
+                       achieved_hbm_GBs=round(E['conv16_bytes'] / a.steps / (ms / a.steps * 1e-3) / 1e9, 1),
+                       hbm_frac=round(E['conv16_bytes'] / a.steps / (ms / a.steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
         elif name.startswith('k_gemm_f16x3'):
             # the Winograd GEMMs on the 16-bit matrix cores at float32 accuracy: every product of the float32 GEMM is three
             # half-precision matrix products (csrc/spa_gemm16.hip).  achieved = EXECUTED half-precision FLOPs (3 x the

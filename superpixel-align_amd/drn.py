@@ -67,7 +67,7 @@ _EPILOGUE = {'engine': None, 'bytes': 0, 'launches': 0, 'own_conv': True, 'own_c
              # products: csrc/spa_gemm16.hip); SPA_SPLIT_GEMM=0 keeps the float32 matrix instructions
              'split_gemm': os.environ.get('SPA_SPLIT_GEMM', '1') != '0',
              'gemm16_flops': 0.0, 'gemm16_launches': 0, 'gemm16_bytes': 0.0,
-             'gemm16n_flops': 0.0, 'gemm16n_launches': 0, 'gemm16n_bytes': 0.0, 'conv16_flops': 0.0, 'conv16_launches': 0}
+             'gemm16n_flops': 0.0, 'gemm16n_launches': 0, 'gemm16n_bytes': 0.0, 'conv16_flops': 0.0, 'conv16_launches': 0, 'conv16_bytes': 0.0}
 
 
 def conv_bias_act(conv, bn, x, residual=None, relu=True):
@@ -140,6 +140,7 @@ def conv_bias_act(conv, bn, x, residual=None, relu=True):
             if p16 is not None and _EPILOGUE['split_gemm']:
                 # ... on the 16-bit matrix cores at float32 accuracy (two half-precision planes per operand)
                 _EPILOGUE['conv16_flops'] += fl
+                _EPILOGUE['conv16_bytes'] += 4.0 * x.shape[0] * x.shape[2] * x.shape[3] * (conv.in_channels + conv.out_channels * (2 if residual is not None else 1))
                 _EPILOGUE['conv16_launches'] += 1
                 y, am = eng.conv3x3_f16s(x, p16[0], p16[1], packed32[1], residual, relu, conv.dilation[0],
                                          amax_in=getattr(x, '_spa_amax', None))
@@ -158,6 +159,7 @@ def conv_bias_act(conv, bn, x, residual=None, relu=True):
                 and residual is None and x.is_contiguous(memory_format=torch.channels_last)):
             # layer 2 of arch D (16 -> 32 channels, stride 2): its own kernel on the 16-bit matrix cores
             _EPILOGUE['conv16_flops'] += 2.0 * x.shape[0] * ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2) * 32 * 9 * 16
+            _EPILOGUE['conv16_bytes'] += 4.0 * x.shape[0] * (x.shape[2] * x.shape[3] * 16 + ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2) * 32)
             _EPILOGUE['conv16_launches'] += 1
             return eng.drn_layer2_f16s(x, l2[0], l2[1], l2[2], amax_in=getattr(x, '_spa_amax', None))
         y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation)
@@ -198,6 +200,7 @@ class BasicBlock(nn.Module):
                 and 128 * -(-((x.shape[3] + 1) // 2) // 128) <= 1.25 * ((x.shape[3] + 1) // 2)):
             # the stride-2 opening convolution and the 1x1 stride-2 projection in ONE pass over x (csrc/spa_conv32.hip)
             _EPILOGUE['conv16_flops'] += 2.0 * x.shape[0] * ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2) * s2[3] * 10 * x.shape[1]
+            _EPILOGUE['conv16_bytes'] += 4.0 * x.shape[0] * (x.shape[2] * x.shape[3] * x.shape[1] + ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2) * 2 * s2[3])
             _EPILOGUE['conv16_launches'] += 1
             y, res, am = eng.conv3x3_s2_f16s(x, s2[0], s2[1], s2[2], s2[3], True, amax_in=getattr(x, '_spa_amax', None))
             y._spa_amax = am
