@@ -5,21 +5,21 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one batch of synthetic 1024x2048 RGB images that is
-already resident in HBM: DRN features (PyTorch-ROCm/MIOpen) -> HIP SLIC -> per-superpixel pooling
--> location prior -> weighted k-means -> painted road masks -> per-image confusion counts
-(BASELINE.json configs[1]: DRN-D-22 fp32, SLIC 200 superpixels, k = 2).  Three distinct batches
-rotate through the steps.  With N > 1 every rank labels its own batches (images shard with no
+One "step" = one pass of the hot path over one batch of synthetic 1024x2048 RGB images: DRN features
+(libspalign's own MFMA kernels) -> HIP SLIC -> per-superpixel pooling -> location prior -> weighted
+k-means -> painted road masks -> per-image confusion counts (BASELINE.json configs[1]: DRN-D-22 fp32,
+SLIC 200 superpixels, k = 2).  Three distinct batches rotate through the steps.  With N > 1 every rank labels its own batches (images shard with no
 data-path collective; weak scaling) and the per-image score records are exchanged by one RCCL
 all_gather at the end of the timed region, the native replacement of the reference's shared
 result.json append.
 
-Prints ONE JSON line on rank 0 (see README/DESIGN for the fields).  `value` is the device-resident
-rate (inputs in HBM when the timed region starts).  `host_to_host` is SURVEY.md 8d's region, timed
-in a second loop of the same length: batches in pinned host memory -> masks in pinned host memory
-through pipeline.HostStream (uploads and downloads double buffered on copy streams under the
-kernels).  `kernels` holds one roofline-shaped entry per hand-written kernel family of libspalign
-(HIP events on the launch stream, recorded during the timed region): HBM-bound ones against 8 TB/s
+Prints ONE JSON line on rank 0 (see README/DESIGN for the fields).  `value` / `ms_per_step` are SURVEY.md
+8d's region — the reference's own step (batch_spalign_kmeans.py:427-458: H->D at :431, D->H at :355-357):
+batches of decoded 8-bit images in pinned host memory -> cluster + road masks in pinned host memory
+through pipeline.HostStream (uploads and downloads double buffered on copy streams under the kernels).
+`device_resident_value` / `device_resident_ms_per_step` time the same K steps with the batches already in
+HBM (a loop of its own, run first).  `kernels` holds one roofline-shaped entry per hand-written kernel
+family of libspalign (HIP events on the launch stream, recorded during the headline loop): HBM-bound ones against 8 TB/s
 with their algorithmic bytes, the float32-MFMA stem against the fp32 matrix peak; `roofline` is the
 family with the most time per step, whichever it is.  `drn` reports the MFMA side of the step (the
 big convolutions are PyTorch-ROCm / MIOpen).  `cpu_baseline` times, on the host cores, the C
@@ -77,8 +77,10 @@ def parse():
     p.add_argument('--no_host_loop', action='store_true', help='skip the pinned-host to pinned-host loop')
     p.add_argument('--n_batches', type=int, default=3, help='distinct batches rotating through the steps')
     p.add_argument('--no_prof', action='store_true', help='do not record per-kernel events')
-    p.add_argument('--integer_images', action='store_true',
-                   help='integer-valued synthetic images (what decoded 8-bit PNGs are): k_rgb2lab takes its 256-entry sRGB table path')
+    p.add_argument('--integer_images', action='store_true', help='(default since round 4; kept for old command lines)')
+    p.add_argument('--float_images', action='store_true',
+                   help='non-integer synthetic float32 images (SURVEY 8d\'s generator before quantisation) instead of 8-bit-valued '
+                        'ones (what a decoded PNG is): the host loop then uploads float32 planes, 12 bytes per pixel instead of 3')
     p.add_argument('--device_rng', action='store_true', help='anchor mode: draw the anchors on the device (spa_anchor_ranks_dev)')
     p.add_argument('--miopen_conv', action='store_true', help='leave the stride-1 3x3 layers to MIOpen (A/B against spa_conv3x3_bf16 / spa_conv3x3_f32)')
     p.add_argument('--winograd', type=int, default=4, choices=[2, 4], help='float32: F(4x4,3x3) (default) or F(2x2,3x3) tiles')
@@ -120,6 +122,10 @@ LIMITERS = {
     'k_conv3x3_f32<0, 256, 1, 256>': 'float32 MFMA pipe.  K = Cin is 8-16 K steps per 256 x 256 tile against 144 in the 3x3 form, so the '
                                              'tile prologue and the store of the output tile weigh more (0.83 against 0.88 of the peak) although the '
                                              'workgroups are persistent and stage the next tile before their epilogue',
+    'k_wino4_fused': 'both at once, by design: the layer is cut into work items (input-transform slices, 256 x 256 GEMM tiles, output-transform '
+                     'slices) popped from per-XCD lists, so the transforms\' HBM streaming (X -> V = 2.25 X, M = 2.25 Y -> Y) runs on a few '
+                     'compute units while the others are inside GEMM tiles; the launch is bound by the 16-bit matrix pipe + its feed for the '
+                     'tiles (the loop of k_gemm_f16x3) and by HBM for the bytes (see achieved_hbm_GBs), whichever is longer for the layer',
     'k_wino_in': 'HBM: reads X, writes V = 2.25x X (position-major, dense rows); 5.3 TB/s on the 512-channel layers',
     'k_wino_out': 'HBM: reads M = 2.25x Y (+ the residual), writes Y; 4.9 TB/s on the 512-channel layers',
     'k_conv3x3_f32<taps 9>(all)': 'float32 MFMA pipe: 0.88-0.89 of the 157.3 TFLOP/s peak on the 256/512-channel layers (MIOpen\'s hand-written '
@@ -317,15 +323,21 @@ def main():
 
     B, H, W = a.batch, a.height, a.width
     NB = max(1, a.n_batches)
-    # distinct batches in pinned host memory (the host loop's source) and their device copies
-    host, gts = [], []
+    # distinct batches in pinned host memory (the host loop's source) and their device copies.  Default: 8-bit-valued
+    # images, held on the host as a PNG decoder leaves them — (B,H,W,3) uint8 — like the drivers of cli.py hold them
+    integer = not a.float_images
+    host, gts, dev = [], [], []
     for nb in range(NB):
         pin = torch.empty((B, 3, H, W), dtype=torch.float32).pin_memory()
         _, g = make_batch(spa.synth, B, H, W, scene=(a.superpixel_method == 'felzenszwalb'),
-                          seed0=1000 * rank + 4 * nb, out=pin.numpy(), integer=a.integer_images)
+                          seed0=1000 * rank + 4 * nb, out=pin.numpy(), integer=integer)
+        dev.append(pin.cuda())
+        if integer:
+            u8 = torch.empty((B, H, W, 3), dtype=torch.uint8).pin_memory()
+            u8.copy_(pin.permute(0, 2, 3, 1))
+            pin = u8
         host.append(pin)
         gts.append(torch.from_numpy(g).cuda())
-    dev = [h.cuda() for h in host]
     conf_total = torch.zeros((B, 4), dtype=torch.int64, device='cuda')
     cur = [0]
 
@@ -342,44 +354,92 @@ def main():
         res = step(s)
     eng.raise_on_status()
     torch.cuda.synchronize()
-    conf_total.zero_()
-    if not a.no_prof:
-        eng.prof_enable(True)
-    stage = {'time_feature_maps': 0.0, 'time_superpixel': 0.0, 'time_roialign': 0.0, 'time_kmeans': 0.0}
-    drn._EPILOGUE['bytes'] = 0
-    drn._EPILOGUE['launches'] = 0
-    drn._EPILOGUE['conv_flops'] = 0.0
-    for key in ('conv16_flops', 'conv16_launches', 'conv16_bytes', 'gemm16_flops', 'gemm16_launches', 'gemm16_bytes', 'gemm16n_flops', 'gemm16n_launches', 'gemm16n_bytes',
-                'gemm_flops', 'gemm_launches', 'gemm_bytes', 'gemmn_flops', 'gemmn_launches', 'gemmn_bytes', 'wino_direct_flops', 'wino_saved_flops', 'wino_in_bytes', 'wino_out_bytes', 'wino_launches'):
-        drn._EPILOGUE[key] = 0
+    COUNTERS = ('bytes', 'launches', 'conv_flops', 'conv16_flops', 'conv16_launches', 'conv16_bytes', 'gemm16_flops', 'gemm16_launches',
+                'gemm16_bytes', 'gemm16n_flops', 'gemm16n_launches', 'gemm16n_bytes', 'gemm_flops', 'gemm_launches', 'gemm_bytes',
+                'gemmn_flops', 'gemmn_launches', 'gemmn_bytes', 'wino_direct_flops', 'wino_saved_flops', 'wino_in_bytes',
+                'wino_out_bytes', 'wino_launches', 'winof_launches', 'winof_flops', 'winof_bytes')
 
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    evs = []
-    for s in range(a.steps):
-        res = step(a.warmup + s)
-        evs.append(dict(pipe._ev))             # device events, read after the timed region
-    # the result.json reduction: one all_gather of per-image records
-    info = res.info.cpu().numpy()
-    conf = conf_total.cpu().numpy()
-    n_sp = res.n_labels.cpu().numpy()
-    rec = np.zeros((B, dist.RECORD_WIDTH), np.int64)
-    rec[:, 0] = rank * B + np.arange(B)
-    rec[:, 1:5] = conf
-    rec[:, 5] = n_sp
-    rec[:, 6], rec[:, 7] = info[0], info[1]
-    allrec = dist.gather_records(rec)
-    dist.barrier()
-    torch.cuda.synchronize()
-    dt = dist.max_over_ranks(time.perf_counter() - t0)
-    eng.raise_on_status()
+    def gather(res):
+        """the result.json reduction: one all_gather of per-image records (inside the timed region)"""
+        info = res.info.cpu().numpy()
+        conf = conf_total.cpu().numpy()
+        n_sp = res.n_labels.cpu().numpy()
+        rec = np.zeros((B, dist.RECORD_WIDTH), np.int64)
+        rec[:, 0] = rank * B + np.arange(B)
+        rec[:, 1:5] = conf
+        rec[:, 5] = n_sp
+        rec[:, 6], rec[:, 7] = info[0], info[1]
+        return dist.gather_records(rec), info, n_sp
+
+    def loop_device(headline):
+        """K steps on batches already resident in HBM"""
+        evs = []
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in range(a.steps):
+            res = step(a.warmup + s)
+            evs.append(dict(pipe._ev))             # device events, read after the timed region
+        g = gather(res) if headline else None
+        dist.barrier()
+        torch.cuda.synchronize()
+        dt = dist.max_over_ranks(time.perf_counter() - t0)
+        eng.raise_on_status()
+        return dt, res, evs, g
+
+    def loop_host(headline):
+        """SURVEY.md 8d's region, K steps: batches in pinned host memory -> masks in pinned host memory, double buffered"""
+        first = [a.warmup]
+        evs = []
+
+        def after(r, s):
+            conf_total.add_(eng.confusion(r.road, gts[(first[0] + s) % NB]))
+            evs.append(dict(pipe._ev))
+        hs = pipeline.HostStream(pipe, B, H, W, after=after, u8_hwc=integer)
+        order = [host[(a.warmup + s) % NB] for s in range(a.steps + 1)]
+        for _ in hs.process(iter(order[:1])):   # warm the copy streams and buffers (not timed, not profiled)
+            pass
+        torch.cuda.synchronize()
+        del evs[:]
+        conf_total.zero_()
+        if headline and not a.no_prof:
+            eng.prof_enable(True)
+        for key in COUNTERS:
+            drn._EPILOGUE[key] = 0
+        first[0] = a.warmup + 1
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n_out = 0
+        for cluster_h, road_h, res in hs.process(iter(order[1:])):
+            n_out += int(road_h.shape[0])
+        g = gather(res) if headline else None
+        dist.barrier()
+        torch.cuda.synchronize()
+        dt = dist.max_over_ranks(time.perf_counter() - t1)
+        eng.raise_on_status()
+        assert n_out == B * a.steps
+        return dt, res, evs, g
+
+    # the device-resident loop first (plain), then the headline loop with the per-kernel events
+    host_headline = not a.no_host_loop
+    conf_total.zero_()
+    for key in COUNTERS:
+        drn._EPILOGUE[key] = 0
+    if not host_headline and not a.no_prof:
+        eng.prof_enable(True)
+    dt_dev, res, evs, g = loop_device(headline=not host_headline)
+    dt_h = None
+    if host_headline:
+        dt_h, res, evs, g = loop_host(headline=True)
+    allrec, info, n_sp = g
+    dt = dt_h if host_headline else dt_dev
+    stage = {'time_feature_maps': 0.0, 'time_superpixel': 0.0, 'time_roialign': 0.0, 'time_kmeans': 0.0}
     bias_bytes, bias_launches = drn._EPILOGUE['bytes'], drn._EPILOGUE['launches']
     conv_flops = drn._EPILOGUE['conv_flops']
-    E = dict(drn._EPILOGUE)                 # snapshot: the host-to-host loop below keeps counting
+    E = dict(drn._EPILOGUE)
     wino_direct = E['wino_direct_flops']
     wino_saved = E['wino_saved_flops']                             # multiplications Winograd does not execute
-
     for e in evs:
         pipe._ev = e
         for k2, v2 in pipe.stage_ms().items():
@@ -387,34 +447,13 @@ def main():
                 stage[k2] += v2
     prof = eng.prof_read() if not a.no_prof else {}
     eng.prof_enable(False)
-
-    # ---- SURVEY.md 8d's region: pinned host memory -> masks in pinned host memory, double buffered
+    px_bytes = 3 if integer else 12
     h2h = None
-    if not a.no_host_loop:
-        first = [a.warmup]
-        hs = pipeline.HostStream(pipe, B, H, W,
-                                 after=lambda r, s: conf_total.add_(eng.confusion(r.road, gts[(first[0] + s) % NB])))
-        order = [host[(a.warmup + s) % NB] for s in range(a.steps + 1)]
-
-        def feed(seq):
-            for hb in seq:
-                yield hb
-        for _ in hs.process(feed(order[:1])):   # warm the copy streams and buffers
-            pass
-        first[0] = a.warmup + 1
-        dist.barrier()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        n_out = 0
-        for cluster_h, road_h, _r in hs.process(feed(order[1:])):
-            n_out += int(road_h.shape[0])
-        dist.barrier()
-        torch.cuda.synchronize()
-        dt_h = dist.max_over_ranks(time.perf_counter() - t1)
-        eng.raise_on_status()
+    if host_headline:
         h2h = {'value': round(ws * B * a.steps / dt_h, 3), 'unit': 'images/sec',
-               'ms_per_step': round(dt_h / a.steps * 1e3, 3), 'images_downloaded': n_out * ws,
-               'pcie_bytes_per_step': B * (3 * H * W * 4 + 2 * H * W),
+               'ms_per_step': round(dt_h / a.steps * 1e3, 3), 'images_downloaded': B * a.steps * ws,
+               'pcie_bytes_per_step': B * (px_bytes * H * W + 2 * H * W),
+               'host_batch': '(B,H,W,3) uint8, a decoded PNG\'s layout' if integer else '(B,3,H,W) float32',
                'region': 'batches in pinned host memory -> cluster + road masks in pinned host memory; uploads '
                          '(h2d stream) and downloads (d2h stream) double buffered under the kernels'}
 
@@ -471,6 +510,17 @@ def main():
                        flops_per_step=3 * fl / a.steps, flops_per_launch=3 * fl / nl,
                        hbm_bytes_per_launch_by_construction=int(by / nl),
                        traffic=pmc_traffic(name, B, H, W, by / nl))
+        elif name == 'k_wino4_fused':
+            # a whole Winograd layer per launch (csrc/spa_winof.hip): executed half-precision FLOPs of its 36 GEMMs against the dense
+            # 16-bit peak, and the HBM bytes its transforms + GEMM operands move by construction against the HBM peak
+            fl, nl, by = E['winof_flops'], max(1, E['winof_launches']), E['winof_bytes']
+            tf = fl / a.steps / (ms / a.steps * 1e-3) / 1e12
+            gbs = by / a.steps / (ms / a.steps * 1e-3) / 1e9
+            ent.update(bound='mfma', achieved=round(3 * tf, 1), peak=BF16_MATRIX_PEAK_TF, unit='TFLOP/s',
+                       frac=round(3 * tf / BF16_MATRIX_PEAK_TF, 4), float32_equivalent_tflops=round(tf, 1),
+                       flops_per_step=3 * fl / a.steps, flops_per_launch=3 * fl / nl,
+                       hbm_bytes_per_launch_by_construction=int(by / nl), achieved_hbm_GBs=round(gbs, 1),
+                       hbm_frac=round(gbs / HBM_PEAK_GBS, 4), traffic=pmc_traffic(name, B, H, W, by / nl))
         elif name in ('k_wino_in', 'k_wino_out'):
             ab = (E['wino_in_bytes'] if name == 'k_wino_in' else E['wino_out_bytes']) / max(1, E['wino_launches'])
             gbs = ab / (avg * 1e-3) / 1e9
@@ -522,13 +572,19 @@ def main():
                   else 'images/sec superpixel-align labelling (%dx%d)' % (H, W),
         'value': round(total_images / dt, 3), 'unit': 'images/sec', 'n_gpus': ws, 'steps': a.steps,
         'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if a.dtype == 'fp32' else 'bf16',
+        'scaling': 'weak', 'vs_baseline': None,
+        'dtype': ('f32 as 2 x f16 planes, f32 accumulate' if split16 else 'f32') if a.dtype == 'fp32' else 'bf16',
         'data': 'synthetic',
+        'timed_region': ('host to host (SURVEY.md 8d; reference batch_spalign_kmeans.py:427-458): decoded batches in pinned host '
+                         'memory -> masks in pinned host memory' if host_headline else
+                         'device resident (--no_host_loop): batches already in HBM -> masks in HBM'),
+        'device_resident_value': round(total_images / dt_dev, 3),
+        'device_resident_ms_per_step': round(dt_dev / a.steps * 1e3, 3),
         'config': {'workload': 'BASELINE configs[1] x batch: %s %s features + HIP %s/%s-pool/'
                                'prior/k-means(k=%d)/paint, %dx%d, %d images per step per GPU, '
-                               '%d distinct batches rotating, random-init weights'
+                               '%d distinct batches rotating, %s images, random-init weights'
                                % (a.arch, a.dtype, 'SLIC(%d)' % a.n_slic_segments if a.superpixel_method == 'slic'
-                                  else 'felzenszwalb(300,0.8,20)', a.pool_mode, a.n_clusters, H, W, B, NB),
+                                  else 'felzenszwalb(300,0.8,20)', a.pool_mode, a.n_clusters, H, W, B, NB, '8-bit-valued' if integer else 'float-valued'),
                    'images_per_step_per_gpu': B, 'sharding': 'images (no data-path collective), '
                    'one all_gather of score records',
                    'drn_arithmetic': ('float32 tensors; matrix products as three v_mfma_f32_16x16x32_f16 per float32 product on two '

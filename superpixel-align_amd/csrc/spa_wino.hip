@@ -20,14 +20,12 @@
 // HBM traffic per layer: X once, V written and read (4x X), M written and read (4x Y), Y once — 38 GB per 30
 // images of a 512 -> 512 layer, ~5 ms of streaming next to a GEMM of 16 ms, against 33 ms of direct convolution.
 #include "spa_common.h"
+#include "spa_wino_dev.h"
 #include <stdlib.h>
 
 int conv1x1_f32_raw(spa_ctx *ctx, const float *x, long long rows, int32_t Cin, const float *wt, int32_t Cout,
                     float *y, void *stream, int zcount);          // spa_conv32.hip
 
-struct WinoGeom { int B, H, W, d, th, tw; long long T; };
-typedef float wino_v4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 wino_nt_load(const float4 *p) { const wino_v4 v = __builtin_nontemporal_load((const wino_v4 *)p); return make_float4(v[0], v[1], v[2], v[3]); }
 
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
@@ -41,15 +39,6 @@ __device__ __forceinline__ long long wino_block()
     return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
 }
 
-// tile id -> (image, sub-grid, tile row, tile column)
-__device__ __forceinline__ void wino_tile(const WinoGeom &g, long long t, int &b, int &sy, int &sx, int &ty, int &tx)
-{
-    tx = (int)(t % g.tw); t /= g.tw;
-    ty = (int)(t % g.th); t /= g.th;
-    sx = (int)(t % g.d); t /= g.d;
-    sy = (int)(t % g.d);
-    b = (int)(t / g.d);
-}
 
 // one thread = one tile x 4 channels: 16 float4 loads, B^T d B, 16 float4 stores
 __global__ __launch_bounds__(256) void k_wino_in(const float *__restrict__ X, float *__restrict__ V, WinoGeom g, int C,
@@ -214,50 +203,10 @@ extern "C" int spa_conv3x3_wino_f32(spa_ctx *ctx, const float *x, int32_t B, int
 // (row 3 of B^T is the generated row / 16 and row 3 of G x 16: powers of two, no rounding.)
 // A thread owns one tile x 2 channels (float2): 36 values in flight.
 // =========================================================================================================
-__device__ __forceinline__ float2 operator+(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 operator-(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 operator*(float s, float2 a) { return make_float2(s * a.x, s * a.y); }
-__device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ __forceinline__ float4 operator-(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
-__device__ __forceinline__ float4 operator*(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
-template <typename V> __device__ __forceinline__ V wino_zero();
-template <> __device__ __forceinline__ float2 wino_zero<float2>() { return make_float2(0.f, 0.f); }
-template <> __device__ __forceinline__ float4 wino_zero<float4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
-__device__ __forceinline__ float2 wino_relu(float2 v) { return make_float2(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f)); }
-__device__ __forceinline__ float4 wino_relu(float4 v) { return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)); }
-
-// y = B^T x for a 6-vector of float2
-template <typename V>
-__device__ __forceinline__ void wino4_bt(const V (&x)[6], V (&y)[6])
-{
-    y[0] = 2.0f * (x[0] + x[4]) + 3.0f * (x[3] - x[1]) - 4.0f * x[2];
-    y[1] = 2.0f * (x[4] - x[1]) + x[2] + 5.0f * x[3];
-    y[2] = 5.0f * x[2] - 2.0f * (x[1] + x[4]) - x[3];
-    y[3] = 2.0f * (x[1] - x[3]) + x[2] - x[4];
-    y[4] = (x[1] - x[3]) + 2.0f * (x[4] - x[2]);
-    y[5] = 2.0f * (x[1] + x[5]) + 3.0f * (x[4] - x[2]) - 4.0f * x[3];
-}
-
-// y = A^T x: 4 outputs from 6
-template <typename V>
-__device__ __forceinline__ void wino4_at(const V (&x)[6], V (&y)[4])
-{
-    y[0] = ((x[0] + x[1]) + x[2]) + (x[3] + x[4]);
-    y[1] = (x[1] - x[2]) + (0.5f * x[3] - 2.0f * x[4]);
-    y[2] = (x[1] + x[2]) + (0.25f * x[3] + 4.0f * x[4]);
-    y[3] = ((x[1] - x[2]) + (0.125f * x[3] - 8.0f * x[4])) + x[5];
-}
 
 // (numbering the F(4x4) tiles in blocks of 4 x 4 tiles, so that consecutive workgroups transform tiles whose 6 x 6
 // input patches overlap in both directions, was measured: no change — the overlap is served by L2 / MALL anyway —
 // and it padded small sub-grids to multiples of 4 tiles: 4x the work on a 7 x 7 sub-grid.  Row-major it is.)
-static void wino4_geom(int B, int H, int W, int d, WinoGeom *g)
-{
-    g->B = B; g->H = H; g->W = W; g->d = d;
-    const int hs = (H + d - 1) / d, ws = (W + d - 1) / d;
-    g->th = (hs + 3) / 4; g->tw = (ws + 3) / 4;
-    g->T = (long long)B * d * d * g->th * g->tw;
-}
 
 template <typename V>
 __global__ __launch_bounds__(256) void k_wino4_in(const float *__restrict__ X, float *__restrict__ Vout, WinoGeom g, int C,
@@ -353,15 +302,6 @@ __global__ __launch_bounds__(256) void k_wino4_out(const float *__restrict__ M, 
 // the weights' planes carry a static per-position scale t_ij, and k_wino4_out undoes both (cs[i][j] = 2^(p_i+p_j) / t_ij
 // from the host, 2^(e - 14) from amax) while it reads M.
 // =========================================================================================================
-struct WinoScale { float c[36]; };
-
-__device__ __forceinline__ int wino_amax_exp(unsigned bits)
-{
-    int e = (int)(bits >> 23) - 127;
-    e = e < -100 ? -100 : (e > 100 ? 100 : e);
-    return bits == 0u ? 0 : e;
-}
-__device__ __forceinline__ float wino_pow2(int k) { return __uint_as_float((unsigned)(127 + k) << 23); }
 
 // amax[0] = bits of max |x| (as unsigned: non-negative floats order like their bit patterns)
 __global__ __launch_bounds__(256) void k_amax(const float4 *__restrict__ x, long long n4, unsigned *__restrict__ amax)

@@ -67,7 +67,11 @@ _EPILOGUE = {'engine': None, 'bytes': 0, 'launches': 0, 'own_conv': True, 'own_c
              # products: csrc/spa_gemm16.hip); SPA_SPLIT_GEMM=0 keeps the float32 matrix instructions
              'split_gemm': os.environ.get('SPA_SPLIT_GEMM', '1') != '0',
              'gemm16_flops': 0.0, 'gemm16_launches': 0, 'gemm16_bytes': 0.0,
-             'gemm16n_flops': 0.0, 'gemm16n_launches': 0, 'gemm16n_bytes': 0.0, 'conv16_flops': 0.0, 'conv16_launches': 0, 'conv16_bytes': 0.0}
+             'gemm16n_flops': 0.0, 'gemm16n_launches': 0, 'gemm16n_bytes': 0.0, 'conv16_flops': 0.0, 'conv16_launches': 0, 'conv16_bytes': 0.0,
+             # a Winograd layer as ONE persistent launch (transforms streamed under the GEMM tiles, csrc/spa_winof.hip);
+             # SPA_WINO_FUSED=0 keeps the three launches
+             'wino_fused': os.environ.get('SPA_WINO_FUSED', '1') != '0',
+             'winof_flops': 0.0, 'winof_launches': 0, 'winof_bytes': 0.0}
 
 
 def conv_bias_act(conv, bn, x, residual=None, relu=True):
@@ -106,15 +110,26 @@ def conv_bias_act(conv, bn, x, residual=None, relu=True):
             _EPILOGUE['wino_saved_flops'] += direct * (1.0 - frac)
             px = x.shape[0] * x.shape[2] * x.shape[3]
             split = wino[0].shape[0] == 36 and _EPILOGUE['split_gemm'] and conv._spa_wino.get('4s')
+            fused = bool(split) and _EPILOGUE['wino_fused'] and conv.out_channels % 256 == 0
+            in_bytes = 4.0 * px * (1 + expand) * conv.in_channels            # k_wino_in reads X and writes V
+            mm_bytes = 4.0 * px * expand * (conv.in_channels + conv.out_channels)     # V read, M written
+            out_bytes = 4.0 * px * ((2 if residual is not None else 1) + expand) * conv.out_channels   # M [+ R] read, Y written
+            if fused:
+                _EPILOGUE['winof_flops'] += direct * frac
+                _EPILOGUE['winof_launches'] += 1
+                _EPILOGUE['winof_bytes'] += in_bytes + mm_bytes + out_bytes
+                y, am = eng.conv3x3_wino_f16s(x, split[0], split[1], split[2], residual, relu, conv.dilation[0],
+                                              amax_in=getattr(x, '_spa_amax', None), fused=True)
+                y._spa_amax = am
+                return y
             key = 'gemm' if conv.out_channels % 256 == 0 else 'gemmn'       # the 256 x 256 instance / the narrow tiles
             if split:
                 key = key.replace('gemm', 'gemm16')
             _EPILOGUE[key + '_flops'] += direct * frac
             _EPILOGUE[key + '_launches'] += 1
-            _EPILOGUE[key + '_bytes'] += 4.0 * px * expand * (conv.in_channels + conv.out_channels)     # V read, M written
-            # HBM bytes by construction: k_wino_in reads X and writes V; k_wino_out reads M [+ R] and writes Y
-            _EPILOGUE['wino_in_bytes'] += 4.0 * px * (1 + expand) * conv.in_channels
-            _EPILOGUE['wino_out_bytes'] += 4.0 * px * ((2 if residual is not None else 1) + expand) * conv.out_channels
+            _EPILOGUE[key + '_bytes'] += mm_bytes
+            _EPILOGUE['wino_in_bytes'] += in_bytes
+            _EPILOGUE['wino_out_bytes'] += out_bytes
             _EPILOGUE['wino_launches'] += 1
             if split:
                 # the bound on max |x| that scales V travels with the tensor object from the call that produced it

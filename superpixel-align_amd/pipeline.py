@@ -309,11 +309,17 @@ class HostStream(object):
     `after(res, s)` may enqueue extra device work on the compute stream for the s-th batch of the
     call (bench: confusion counts)."""
 
-    def __init__(self, pipe, B, H, W, after=None):
-        self.pipe, self.after = pipe, after
+    def __init__(self, pipe, B, H, W, after=None, u8_hwc=False):
+        """u8_hwc: the batches are decoded 8-bit images, (B,H,W,3) uint8 as a PNG decoder leaves them (what the drivers
+        of cli.py hand over): 3 bytes per pixel cross PCIe instead of 12, and the planar float32 batch the kernels
+        take is made on the device (spa_resize_bicubic_u8 at unchanged size = layout and type change only)."""
+        self.pipe, self.after, self.u8_hwc = pipe, after, bool(u8_hwc)
         dev = pipe.eng.device
         self.dev = dev
-        self.inp = [torch.empty((B, 3, H, W), dtype=torch.float32, device=dev) for _ in range(2)]
+        if self.u8_hwc:
+            self.inp = [torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+        else:
+            self.inp = [torch.empty((B, 3, H, W), dtype=torch.float32, device=dev) for _ in range(2)]
         self.out = [(torch.empty((B, H, W), dtype=torch.uint8).pin_memory(),
                      torch.empty((B, H, W), dtype=torch.uint8).pin_memory()) for _ in range(2)]
         self.h2d = torch.cuda.Stream(device=dev)
@@ -326,7 +332,7 @@ class HostStream(object):
     def pinned_batch(self, B=None):
         """A pinned (B,3,H,W) float32 array for the decode workers to fill in place."""
         shape = tuple(self.inp[0].shape) if B is None else (B,) + tuple(self.inp[0].shape[1:])
-        return torch.empty(shape, dtype=torch.float32).pin_memory()
+        return torch.empty(shape, dtype=self.inp[0].dtype).pin_memory()
 
     def _upload(self, slot, batch):
         t = torch.as_tensor(batch)
@@ -334,7 +340,7 @@ class HostStream(object):
             # pageable memory: stage through a pinned buffer (a host memcpy; the drivers decode straight
             # into pinned_batch() arrays instead)
             if self.staging is None or self.staging.shape != t.shape:
-                self.staging = torch.empty(t.shape, dtype=torch.float32).pin_memory()
+                self.staging = torch.empty(t.shape, dtype=self.inp[0].dtype).pin_memory()
             self.h2d.synchronize()
             self.staging.copy_(t)
             t = self.staging
@@ -362,7 +368,10 @@ class HostStream(object):
             if nxt is not None:
                 nb = self._upload(slot ^ 1, nxt)      # under this batch's kernels
             main.wait_event(self.up_done[slot])
-            res = self.pipe.run(self.inp[slot][:cur_n], check_status=False)
+            src = self.inp[slot][:cur_n]
+            if self.u8_hwc:
+                src = self.pipe.eng.resize_u8(src, (src.shape[1], src.shape[2]))       # same size: (B,3,H,W) float32 planar
+            res = self.pipe.run(src, check_status=False)
             if self.after is not None:
                 self.after(res, s)
             self.in_free[slot].record(main)
