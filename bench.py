@@ -397,7 +397,7 @@ def main():
             evs.append(dict(pipe._ev))
         hs = pipeline.HostStream(pipe, B, H, W, after=after, u8_hwc=integer)
         order = [host[(a.warmup + s) % NB] for s in range(a.steps + 1)]
-        for _ in hs.process(iter(order[:1])):   # warm the copy streams and buffers (not timed, not profiled)
+        for _ in hs.process(iter([order[0]] * 3)):   # warm the copy streams, buffers and the allocator's pools (not timed)
             pass
         torch.cuda.synchronize()
         del evs[:]
@@ -407,6 +407,7 @@ def main():
         for key in COUNTERS:
             drn._EPILOGUE[key] = 0
         first[0] = a.warmup + 1
+        del evs[:]
         dist.barrier()
         torch.cuda.synchronize()
         t1 = time.perf_counter()

@@ -120,6 +120,7 @@ struct spa_ctx {
 #define SPA_WF_LISTS 8
     struct { int key[4]; unsigned *d; } wf_lists[SPA_WF_LISTS];
     int wf_n;
+    unsigned long long *wf_dbg;
     int rng_seeded;
     int rs_key[4], rs_ks[2];       // bicubic tables held in WS_RESIZE_TAB: (H, W, h, w) and tap counts
 };

@@ -54,6 +54,8 @@ struct WfParams {
     unsigned *sync;               // [0..7] heads, [16..51] the 36 scale constants (float), [64 ..] in_cnt[NRB], then mm_cnt[NRB * NCB]
     int NRB;
     uint32_t *status;
+    int vec2;                     // bit 0: input transform on 2 channels per lane, bit 1: output transform (else 4)
+    unsigned long long *dbg;      // development aid (SPA_WF_TIMING=1): per item kind {ticks of the 100 MHz clock, count}, [6] pop ticks
 };
 
 __device__ __forceinline__ int wf_xcc_id()
@@ -67,6 +69,8 @@ __device__ __forceinline__ int wf_xcc_id()
 // was tried first and stored stale registers: the hazard recogniser does not look inside inline asm (a VALU result read as
 // the data of a 16-byte store, a v_readfirstlane'd base read as its address, need wait states).  aux 17 = sc0 | sc1.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// (plain stores instead — aux 0 — were measured: the 512 -> 512 layer then differs from the three-launch result, i.e. a
+// consumer did read stale bytes; the write-through form costs nothing measurable)
 __device__ __forceinline__ void wf_store_wt(float *base, unsigned off, f32x4 v)
 {
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0x7fffffff, 0x00020000);
@@ -94,13 +98,15 @@ __device__ __forceinline__ void wf_st(float *base, unsigned off, float4 v) { wf_
 __device__ __forceinline__ unsigned wf_ld_u32(const unsigned *q) { return *WF_G(const unsigned, q); }
 
 // lane 0 of the workgroup: wait until *cnt >= want (sc1 poll), bounded
-__device__ __forceinline__ void wf_wait(const unsigned *cnt, unsigned want, uint32_t *status)
+__device__ __forceinline__ void wf_wait(const unsigned *cnt, unsigned want, uint32_t *status, unsigned long long *dbg, int slot)
 {
     unsigned spins = 0;
+    const unsigned long long c0 = dbg ? wall_clock64() : 0ull;
     while (__hip_atomic_load(WF_G(const unsigned, cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
         __builtin_amdgcn_s_sleep(8);
         if (++spins > (1u << 21)) { __hip_atomic_fetch_or(WF_G(uint32_t, status), SPA_ST_WINO_SYNC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
     }
+    if (dbg) atomicAdd(&dbg[slot], wall_clock64() - c0);
 }
 
 // a uniform view of the parameter block inside a non-inlined function
@@ -132,50 +138,110 @@ template <typename T> __device__ __forceinline__ T *wf_uni(T *q)
 }
 
 // the three item bodies are separate (not inlined) functions: each gets the register file to itself
+// vector-typed global accesses of 2 or 4 floats at (uniform base, 32-bit byte offset)
+template <typename V> struct WfVec;
+template <> struct WfVec<float2> {
+    typedef float raw __attribute__((ext_vector_type(2)));
+    typedef unsigned uraw __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ float2 make(raw v) { return make_float2(v[0], v[1]); }
+    static __device__ __forceinline__ raw unmake(float2 v) { return (raw){v.x, v.y}; }
+    static __device__ __forceinline__ void store_wt(float *base, unsigned off, float2 v)
+    {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0x7fffffff, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uraw, unmake(v)), r, (int)off, 0, 17);
+    }
+    static __device__ __forceinline__ unsigned amax(float2 v) { return max(__float_as_uint(v.x) & 0x7fffffffu, __float_as_uint(v.y) & 0x7fffffffu); }
+};
+template <> struct WfVec<float4> {
+    typedef float raw __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ float4 make(raw v) { return make_float4(v[0], v[1], v[2], v[3]); }
+    static __device__ __forceinline__ raw unmake(float4 v) { return (raw){v.x, v.y, v.z, v.w}; }
+    static __device__ __forceinline__ void store_wt(float *base, unsigned off, float4 v) { wf_store_wt(base, off, v); }
+    static __device__ __forceinline__ unsigned amax(float4 v)
+    {
+        return max(max(__float_as_uint(v.x) & 0x7fffffffu, __float_as_uint(v.y) & 0x7fffffffu),
+                   max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu));
+    }
+};
+template <typename V> __device__ __forceinline__ V wf_ldv(const float *base, unsigned off)
+{
+    return WfVec<V>::make(*WF_G(const typename WfVec<V>::raw, (const char *)base + off));
+}
+template <typename V> __device__ __forceinline__ V wf_ldv_nt(const float *base, unsigned off)
+{
+    return WfVec<V>::make(__builtin_nontemporal_load(WF_G(const typename WfVec<V>::raw, (const char *)base + off)));
+}
+template <typename V> __device__ __forceinline__ void wf_stv(float *base, unsigned off, V v)
+{
+    *WF_G(typename WfVec<V>::raw, (char *)base + off) = WfVec<V>::unmake(v);
+}
+
+// Both transform bodies are written for EIGHT waves per compute unit (the GEMM tiles need the whole register file, so nothing
+// else is resident): a lane issues all the loads of its unit before it touches any of them — straight-line code, clamped
+// addresses and selects instead of branches around loads (a branch makes the compiler drain the loads in flight) — because at
+// this occupancy the bytes a lane keeps in flight are the streaming rate.  V = float2 or float4 channels per lane.
+template <typename V>
 __device__ __noinline__ void wf_item_in(const WfParams &pr, int rb, int zp)
 {
     WF_UNIFORM_PARAMS
     rb = wf_uni(rb); zp = wf_uni(zp);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int BM = 256, BN = 256;
-    const int Cin = p.Cin, Cout = p.Cout;
-    unsigned *const in_cnt = p.sync + 64, *const mm_cnt = p.sync + 64 + p.NRB;
-    (void)lane; (void)wave; (void)Cout; (void)in_cnt; (void)mm_cnt; (void)BM;
-    // ---------------- input transform of tiles [t0, t1) of row block rb: one lane = one tile x 4 channels
+    constexpr int VN = sizeof(V) / 4;
+    const int tid = threadIdx.x;
+    constexpr int BN = 256;
+    const int Cin = p.Cin;
+    unsigned *const in_cnt = p.sync + 64;
+    // ---------------- input transform of tiles [t0, t1) of row block rb: one lane = one tile x VN channels
     const int per = BN / p.PI;
-    const long long t0 = (long long)rb * BN + (long long)zp * per;
-    long long t1 = t0 + per;
-    if (t1 > p.g.T) t1 = p.g.T;
-    const int c4 = Cin >> 2;
-    const int n = t1 > t0 ? (int)(t1 - t0) * c4 : 0;
+    const int t0 = rb * BN + zp * per;
+    int t1 = t0 + per;
+    if (t1 > (int)p.g.T) t1 = (int)p.g.T;
+    const int cv = Cin / VN;
+    const int n = t1 > t0 ? (t1 - t0) * cv : 0;
+    const unsigned plane_b = (unsigned)wf_uni((int)(p.Tpad * Cin * 4));          // bytes of one position of V
+    float *vb[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) vb[i] = wf_uni(p.V + (long long)(i * 6) * p.Tpad * Cin);
+    const int H = p.g.H, W = p.g.W, d = p.g.d;
     for (int u = tid; u < n; u += WF_THREADS) {
-        const long long t = t0 + u / c4;
-        const int c = (u % c4) << 2;
+        const int t = t0 + u / cv;
+        const int c = (u % cv) * VN;
         int b, sy, sx, ty, tx;
-        wino_tile(p.g, t, b, sy, sx, ty, tx);
-        const long long plane = p.Tpad * Cin;                    // floats of one position of V
-        const unsigned voff = (unsigned)((int)t * Cin + c) * 4u;
-        float4 r[6][6];
+        wino_tile(p.g, (long long)t, b, sy, sx, ty, tx);
+        const unsigned voff = (unsigned)(t * Cin + c) * 4u;
+        // all 36 loads first (rows / columns outside the image: a clamped address, the value replaced by zero)
+        V dv[6][6];
+        unsigned okx = 0, oky = 0;
+        int xo[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int x = sx + (4 * tx - 1 + j) * d;
+            okx |= (x >= 0 && x < W) ? (1u << j) : 0u;
+            xo[j] = min(max(x, 0), W - 1);
+        }
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
-            const int y = sy + (4 * ty - 1 + a) * p.g.d;
-            float4 dv[6];
+            const int y = sy + (4 * ty - 1 + a) * d;
+            oky |= (y >= 0 && y < H) ? (1u << a) : 0u;
+            const int row = (b * H + min(max(y, 0), H - 1)) * W;
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const int x = sx + (4 * tx - 1 + j) * p.g.d;
-                const bool ok = y >= 0 && y < p.g.H && x >= 0 && x < p.g.W;
-                dv[j] = ok ? wf_ld(p.X, (unsigned)(((b * p.g.H + y) * p.g.W + x) * Cin + c) * 4u) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            wino4_bt(dv, r[a]);
+            for (int j = 0; j < 6; ++j) dv[a][j] = wf_ldv<V>(p.X, (unsigned)((row + xo[j]) * Cin + c) * 4u);
+        }
+        if (VN == 2) __builtin_amdgcn_sched_barrier(0);          // (two channels per lane: all 36 loads fit in flight)
+        V r[6][6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                if (!((oky >> a) & (okx >> j) & 1u)) dv[a][j] = wino_zero<V>();
+            wino4_bt(dv[a], r[a]);
         }
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-            const float4 col[6] = {r[0][j], r[1][j], r[2][j], r[3][j], r[4][j], r[5][j]};
-            float4 o[6];
+            const V col[6] = {r[0][j], r[1][j], r[2][j], r[3][j], r[4][j], r[5][j]};
+            V o[6];
             wino4_bt(col, o);
 #pragma unroll
-            for (int i = 0; i < 6; ++i) wf_store_wt(p.V + (long long)(i * 6) * plane, voff + (unsigned)j * (unsigned)(plane * 4), o[i]);
+            for (int i = 0; i < 6; ++i) WfVec<V>::store_wt(vb[i], voff + (unsigned)j * plane_b, o[i]);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -183,16 +249,43 @@ __device__ __noinline__ void wf_item_in(const WfParams &pr, int rb, int zp)
     if (tid == 0) __hip_atomic_fetch_add(WF_G(unsigned, &in_cnt[rb]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ __noinline__ void wf_item_mm(const WfParams &pr, int rb, int cb, int zp)
+
+// workgroup-shared scratch words of the dispatcher: [0] broadcast item, [1] queue of lane 0's pops, [2] queues tried, [3] flag
+__shared__ unsigned wf_s[8];
+
+// lane 0 of the workgroup: pop the next item of this workgroup's list (an empty list: steal from the next XCD's)
+__device__ __forceinline__ unsigned wf_pop(const unsigned *items, unsigned *heads)
+{
+    int qsel = (int)wf_s[1], tried = (int)wf_s[2];
+    unsigned it = WF_NONE;
+    while (tried < 8) {
+        const unsigned lo = WF_G(const unsigned, items)[qsel], hi = WF_G(const unsigned, items)[qsel + 1];
+        const unsigned idx = __hip_atomic_fetch_add(WF_G(unsigned, &heads[qsel]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (idx < hi - lo) { it = WF_G(const unsigned, items)[16 + lo + idx]; break; }
+        qsel = (qsel + 1) & 7;
+        ++tried;
+    }
+    wf_s[1] = (unsigned)qsel; wf_s[2] = (unsigned)tried;
+    return it;
+}
+
+// A RUN of GEMM tiles: item `it` and every GEMM item this workgroup pops right behind it whose input is ready, as one
+// software-pipelined loop (the structure of k_gemm_f16x3): the next tile's first K step is staged during this tile's last K
+// step, the epilogue's write-through stores drain under the next tile's first K step (its mm_cnt is signalled after that
+// step's drain), and the pop of the next item is spread over four earlier K steps — step nk-5: the queue head's atomic is
+// issued (its latency sits under that step's matrix work, the end-of-step vmcnt(0) collects it), nk-4: the item word is
+// loaded, nk-3: its row block's in_cnt, nk-2: verdict to LDS + agent acquire, nk-1: staging.  Returns the first item that is
+// not part of the run (popped, not started), or WF_NONE.
+__device__ __noinline__ unsigned wf_run_mm(const WfParams &pr, unsigned it_arg)
 {
     WF_UNIFORM_PARAMS
-    rb = wf_uni(rb); cb = wf_uni(cb); zp = wf_uni(zp);
+    unsigned it = (unsigned)wf_uni((int)it_arg);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int BM = 256, BN = 256;
     const int Cin = p.Cin, Cout = p.Cout;
-    unsigned *const in_cnt = p.sync + 64, *const mm_cnt = p.sync + 64 + p.NRB;
-    (void)lane; (void)wave; (void)Cout; (void)in_cnt; (void)mm_cnt; (void)BM;
+    unsigned *const heads = p.sync, *const in_cnt = p.sync + 64, *const mm_cnt = p.sync + 64 + p.NRB;
+    const unsigned *const items = wf_uni(pr.items);
     extern __shared__ __attribute__((aligned(1024))) char lds16[];   // [2] weight tiles | [2] row tiles, 128 bytes per row
     constexpr int WN = 4, MI = 8, NJ = 4, WROWS = MI * 16;
     const float sb = wino_pow2(14 - wf_uni(wino_amax_exp(wf_ld_u32(p.amax_in))));
@@ -202,23 +295,21 @@ __device__ __noinline__ void wf_item_mm(const WfParams &pr, int rb, int cb, int 
     const int nk = Cin / 32;
     const int wm = wave / WN, wn = wave % WN;
     const int frow = lane & 15, fk = lane >> 4;
-    // ---------------- one GEMM tile: rows of rb x channels of cb at position z = zp
-    if (wave == 0) {
-        if (lane == 0) wf_wait(&in_cnt[rb], (unsigned)p.PI, p.status);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    const int z = zp, r0 = rb * BN, n0 = cb * BM;
-    const char *wbase = p.U2 + ((long long)z * Cout + n0) * Cin * 4;
-    const char *xbase = (const char *)p.V + ((long long)z * p.Tpad + r0) * Cin * 4;
-    float *ybase = p.M + (long long)z * p.Tpad * Cout;
-    float sc;
-    {
+
+    int r0, n0, pair;
+    const char *wbase, *xbase;
+    float *ybase;
+    float sc_next;
+    auto locate = [&](unsigned item) {
+        const int cb = (int)((item >> 2) & 3u), z = (int)((item >> 4) & 63u), rb = (int)(item >> 10);
+        r0 = rb * BN; n0 = cb * BM; pair = rb * p.NCB + cb;
+        wbase = p.U2 + ((long long)z * Cout + n0) * Cin * 4;
+        xbase = (const char *)p.V + ((long long)z * p.Tpad + r0) * Cin * 4;
+        ybase = p.M + (long long)z * p.Tpad * Cout;
         const int zi = z / 6, zj = z - zi * 6;
         const int psum = ((0x433444 >> (4 * zi)) & 15) + ((0x433444 >> (4 * zj)) & 15);
-        sc = sb * wino_pow2(-psum);
-    }
+        sc_next = sb * wino_pow2(-psum);
+    };
     auto stage = [&](int t, int buf) {
         const char *wk = wbase + (long long)t * 128 + chunk_byte;
         char *dw = wbuf + buf * (BM * 128);
@@ -237,136 +328,244 @@ __device__ __noinline__ void wf_item_mm(const WfParams &pr, int rb, int cb, int 
                                              (__attribute__((address_space(3))) void *)(dx + blk * 1024), 16, 0, 0);
         }
     };
-    f32x4 acc[MI][NJ];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // the first tile of the run: wait for its input (blocking), acquire, stage
+    if (wave == 0) {
+        if (lane == 0) wf_wait(&in_cnt[it >> 10], (unsigned)p.PI, p.status, pr.dbg, 8);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
-    for (int t = 0; t < nk; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nk) stage(t + 1, cur ^ 1);
-        const char *lw = wbuf + cur * (BM * 128), *lx = xbuf + cur * (BN * 128);
-        f16x8 wh[MI], wl[MI], ph[NJ], pl[NJ];
+    locate(it);
+    stage(0, 0);
+    float sc = sc_next;
+    bool first = true;
+    int par = 0, pending = -1;                 // pending: pair index of the tile whose stores are still draining
+    unsigned nxt = WF_NONE;                    // what the run hands back
+    // lane 0's look-ahead state
+    unsigned pf_idx = 0, pf_item = WF_NONE, pf_cnt = 0, pf_lo = 0, pf_n = 0;
+    for (;;) {
+        f32x4 acc[MI][NJ];
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int row = wm * WROWS + i * 16 + frow;
-            wh[i] = *(const f16x8 *)(lw + row * 128 + ((fk ^ (row & 7)) << 4));
-            wl[i] = *(const f16x8 *)(lw + row * 128 + (((4 + fk) ^ (row & 7)) << 4));
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // this tile's first K step was staged BEFORE the previous tile's MI * NJ epilogue stores per wave (vmcnt counts both,
+        // in order): waiting until that many operations remain lets the stores drain under this tile's matrix work
+        if (!first) {
+            static_assert(MI * NJ <= 63, "vmcnt range");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MI * NJ) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        first = false;
+        __syncthreads();
+        int e_r0 = 0, e_n0 = 0, e_pair = 0;
+        float *e_y = nullptr;
+        bool more = false;
+        for (int t = 0; t < nk; ++t) {
+            const int cur = (t + par) & 1;
+            // ---- the look-ahead of lane 0 (wave 0), one dependent memory operation per K step
+            if (wave == 0) {
+                if (t == nk - 5) {
+                    if (lane == 0) {
+                        const int qsel = (int)wf_s[1];
+                        pf_lo = WF_G(const unsigned, items)[qsel];
+                        pf_n = WF_G(const unsigned, items)[qsel + 1] - pf_lo;
+                        pf_idx = wf_s[2] < 8u ? __hip_atomic_fetch_add(WF_G(unsigned, &heads[qsel]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+                    }
+                } else if (t == nk - 4) {
+                    if (lane == 0) pf_item = pf_idx < pf_n ? WF_G(const unsigned, items)[16 + pf_lo + pf_idx] : WF_NONE;
+                } else if (t == nk - 3) {
+                    if (lane == 0 && pf_item != WF_NONE && (pf_item & 3u) == WF_MM)
+                        pf_cnt = __hip_atomic_load(WF_G(const unsigned, &in_cnt[pf_item >> 10]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else if (t == nk - 2) {
+                    if (lane == 0) {
+                        // (a list that ran dry: the steal is left to the blocking pop after the run)
+                        wf_s[0] = pf_item;
+                        wf_s[3] = (pf_item != WF_NONE && (pf_item & 3u) == WF_MM && pf_cnt >= (unsigned)p.PI) ? 1u : 0u;
+                        wf_s[4] = pf_idx < pf_n ? 1u : 0u;                       // 0: the list was empty, nothing was popped
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // before the next tile's operands are touched
+                }
+            }
+            if (t + 1 < nk) stage(t + 1, cur ^ 1);
+            else {
+                // last K step: the other buffers are free — stage the next tile's first K step under this step's matrix work
+                e_r0 = r0; e_n0 = n0; e_y = ybase; e_pair = pair;
+                more = wf_s[3] != 0u;
+                if (more) { locate(wf_s[0]); stage(0, cur ^ 1); }
+            }
+            const char *lw = wbuf + cur * (BM * 128), *lx = xbuf + cur * (BN * 128);
+            const float scl = sc;
+            if (t + 1 == nk) sc = sc_next;          // (locate() above has moved on to the next tile)
+            f16x8 wh[MI], wl[MI], ph[NJ], pl[NJ];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int row = wm * WROWS + i * 16 + frow;
+                wh[i] = *(const f16x8 *)(lw + row * 128 + ((fk ^ (row & 7)) << 4));
+                wl[i] = *(const f16x8 *)(lw + row * 128 + (((4 + fk) ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int row = wn * (NJ * 16) + j * 16 + frow;
+                const f32x4 a = *(const f32x4 *)(lx + row * 128 + (((2 * fk) ^ (row & 7)) << 4));
+                const f32x4 b = *(const f32x4 *)(lx + row * 128 + (((2 * fk + 1) ^ (row & 7)) << 4));
+                const f32x8 v = (f32x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]} * scl;
+                ph[j] = __builtin_convertvector(v, f16x8);
+                pl[j] = __builtin_convertvector(v - __builtin_convertvector(ph[j], f32x8), f16x8);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], ph[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], pl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], ph[j], acc[i][j], 0, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            // the previous tile's stores were drained by every wave's wait above: its 36-counter may move
+            if (t == 0 && pending >= 0) {
+                if (tid == 0) __hip_atomic_fetch_add(WF_G(unsigned, &mm_cnt[pending]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pending = -1;
+            }
+        }
+        par = (par + nk) & 1;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int row = wn * (NJ * 16) + j * 16 + frow;
-            const f32x4 a = *(const f32x4 *)(lx + row * 128 + (((2 * fk) ^ (row & 7)) << 4));
-            const f32x4 b = *(const f32x4 *)(lx + row * 128 + (((2 * fk + 1) ^ (row & 7)) << 4));
-            const f32x8 v = (f32x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]} * sc;
-            ph[j] = __builtin_convertvector(v, f16x8);
-            pl[j] = __builtin_convertvector(v - __builtin_convertvector(ph[j], f32x8), f16x8);
+            const int row = e_r0 + wn * (NJ * 16) + j * 16 + (lane & 15);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int c = e_n0 + wm * WROWS + i * 16 + (lane >> 4) * 4;
+                wf_store_wt(e_y, (unsigned)(row * Cout + c) * 4u, acc[i][j]);
+            }
         }
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], ph[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], pl[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], ph[j], acc[i][j], 0, 0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        pending = e_pair;
+        if (!more) break;
     }
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int row = r0 + wn * (NJ * 16) + j * 16 + (lane & 15);
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int c = n0 + wm * WROWS + i * 16 + (lane >> 4) * 4;
-            wf_store_wt(ybase, (unsigned)(row * Cout + c) * 4u, acc[i][j]);
-        }
-    }
+    // the run ends: drain the last tile's stores, signal, and hand back what the look-ahead popped (or pop, blocking)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(WF_G(unsigned, &mm_cnt[rb * p.NCB + cb]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+        __hip_atomic_fetch_add(WF_G(unsigned, &mm_cnt[pending]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned h = wf_s[0];
+        if (wf_s[4] == 0u) {                   // the look-ahead found its list empty: move on to the next list
+            wf_s[1] = (wf_s[1] + 1u) & 7u; wf_s[2] = wf_s[2] + 1u;
+            h = wf_pop(items, heads);
+        }
+        wf_s[0] = h;
+    }
+    __syncthreads();
+    nxt = wf_s[0];
+    __syncthreads();
+    return nxt;
 }
 
+template <typename V>
 __device__ __noinline__ void wf_item_out(const WfParams &pr, int rb, int cb, int zp)
 {
     WF_UNIFORM_PARAMS
     rb = wf_uni(rb); cb = wf_uni(cb); zp = wf_uni(zp);
+    constexpr int VN = sizeof(V) / 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int BM = 256, BN = 256;
-    const int Cin = p.Cin, Cout = p.Cout;
-    unsigned *const in_cnt = p.sync + 64, *const mm_cnt = p.sync + 64 + p.NRB;
-    (void)lane; (void)wave; (void)Cout; (void)in_cnt; (void)mm_cnt; (void)BM;
+    const int Cout = p.Cout;
+    unsigned *const mm_cnt = p.sync + 64 + p.NRB;
     const float inv = wino_pow2(wf_uni(wino_amax_exp(wf_ld_u32(p.amax_in))) - 14);
     float csv[36];
 #pragma unroll
     for (int i = 0; i < 36; ++i) csv[i] = *(const __attribute__((address_space(4))) float *)(p.cs + i);
-    // ---------------- output transform of tiles [t0, t1) of (rb, cb): one lane = one tile x 4 output channels
+    // ---------------- output transform of tiles [t0, t1) of (rb, cb): one lane = one tile x VN output channels
     if (wave == 0) {
-        if (lane == 0) wf_wait(&mm_cnt[rb * p.NCB + cb], 36u, p.status);
+        if (lane == 0) wf_wait(&mm_cnt[rb * p.NCB + cb], 36u, p.status, pr.dbg, 9);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
     const int per = BN / p.PO;
-    const long long t0 = (long long)rb * BN + (long long)zp * per;
-    long long t1 = t0 + per;
-    if (t1 > p.g.T) t1 = p.g.T;
-    constexpr int k4 = BM >> 2;
-    const int n = t1 > t0 ? (int)(t1 - t0) * k4 : 0;
+    const int t0 = rb * BN + zp * per;
+    int t1 = t0 + per;
+    if (t1 > (int)p.g.T) t1 = (int)p.g.T;
+    constexpr int kv = BM / VN;
+    const int n = t1 > t0 ? (t1 - t0) * kv : 0;
     unsigned mx = 0;
     const unsigned plane_b = (unsigned)wf_uni((int)(p.Tpad * Cout * 4));          // bytes of one position of M
     const float *mb[6];                                                          // row i of the 6 x 6 positions: scalar bases
 #pragma unroll
     for (int i = 0; i < 6; ++i) mb[i] = wf_uni(p.M + (long long)(i * 6) * p.Tpad * Cout);
+    const int H = p.g.H, W = p.g.W, d = p.g.d;
+    const bool has_res = p.R != nullptr;
     for (int u = tid; u < n; u += WF_THREADS) {
-        const long long t = t0 + u / k4;
-        const int k = cb * BM + ((u % k4) << 2);
+        const int t = t0 + u / kv;
+        const int k = cb * BM + (u % kv) * VN;
         int b, sy, sx, ty, tx;
-        wino_tile(p.g, t, b, sy, sx, ty, tx);
-        float4 s[4][6];
-        const unsigned moff = (unsigned)((int)t * Cout + k) * 4u;
-        // two halves of 18 loads: all 36 in flight next to s[][] would not fit the register file
+        wino_tile(p.g, (long long)t, b, sy, sx, ty, tx);
+        const unsigned moff = (unsigned)(t * Cout + k) * 4u;
+        // all 36 loads of M first (M is read exactly once: non-temporal), then the residual's 16 (clamped addresses)
+        V m[6][6];
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int j = 0; j < 6; ++j)
 #pragma unroll
-            for (int j = 3 * half; j < 3 * half + 3; ++j) {
-                float4 col[6];
+            for (int i = 0; i < 6; ++i) m[i][j] = wf_ldv_nt<V>(mb[i], moff + (unsigned)j * plane_b);
+        unsigned yoff[4], okm = 0;
+        int xo[4];
 #pragma unroll
-                for (int i = 0; i < 6; ++i)
-                    col[i] = inv * (csv[i * 6 + j] * wf_ld_nt(mb[i], moff + (unsigned)j * plane_b));      // both powers of two: exact
-                float4 o[4];
-                wino4_at(col, o);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) s[i][j] = o[i];
-            }
-            __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < 4; ++j) {
+            const int x = sx + (4 * tx + j) * d;
+            okm |= (x < W) ? (1u << j) : 0u;
+            xo[j] = min(x, W - 1);
         }
-        const float4 bv = wf_ld(p.bias + k);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int y = sy + (4 * ty + i) * p.g.d;
-            float4 o[4];
+            const int y = sy + (4 * ty + i) * d;
+            okm |= (y < H) ? (16u << i) : 0u;
+            yoff[i] = (unsigned)((b * H + min(y, H - 1)) * W);
+        }
+        V res[4][4];
+        if (VN == 2 && has_res) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) res[i][j] = wf_ldv<V>(p.R, ((yoff[i] + (unsigned)xo[j]) * (unsigned)Cout + (unsigned)k) * 4u);
+        }
+        V s[4][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            V col[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) col[i] = inv * (csv[i * 6 + j] * m[i][j]);      // both powers of two: exact
+            V o[4];
+            wino4_at(col, o);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s[i][j] = o[i];
+        }
+        if (VN == 4 && has_res) {
+            // (four channels per lane: the residual's 64 registers only fit once M's are free)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) res[i][j] = wf_ldv<V>(p.R, ((yoff[i] + (unsigned)xo[j]) * (unsigned)Cout + (unsigned)k) * 4u);
+        }
+        const V bv = wf_ldv<V>(p.bias, (unsigned)k * 4u);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            V o[4];
             wino4_at(s[i], o);
-            if (y >= p.g.H) continue;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int x = sx + (4 * tx + j) * p.g.d;
-                if (x >= p.g.W) continue;
-                float4 v = o[j] + bv;
-                const unsigned off = (unsigned)(((b * p.g.H + y) * p.g.W + x) * Cout + k) * 4u;
-                if (p.R) v = v + wf_ld(p.R, off);
+                V v = o[j] + bv;
+                if (has_res) v = v + res[i][j];
                 if (p.relu) v = wino_relu(v);
-                wf_st(p.Y, off, v);
-                mx = max(max(mx, __float_as_uint(v.x) & 0x7fffffffu), max(__float_as_uint(v.y) & 0x7fffffffu,
-                         max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu)));
+                if ((okm >> j) & (okm >> (4 + i)) & 1u) {
+                    wf_stv<V>(p.Y, ((yoff[i] + (unsigned)xo[j]) * (unsigned)Cout + (unsigned)k) * 4u, v);
+                    mx = max(mx, WfVec<V>::amax(v));
+                }
             }
         }
     }
@@ -376,35 +575,42 @@ __device__ __noinline__ void wf_item_out(const WfParams &pr, int rb, int cb, int
     }
 }
 
+
 __global__ __launch_bounds__(WF_THREADS) void k_wino4_fused(WfParams p)
 {
-    __shared__ unsigned s_item;
     const int tid = threadIdx.x;
-    unsigned *const heads = p.sync;
-    const unsigned *const lists = p.items + 16;
-    int qsel = wf_xcc_id(), tried = 0;
-    for (;;) {
-        if (tid == 0) {
-            unsigned it = WF_NONE;
-            while (tried < 8) {
-                const unsigned lo = p.items[qsel], hi = p.items[qsel + 1];
-                const unsigned idx = __hip_atomic_fetch_add(&heads[qsel], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (idx < hi - lo) { it = lists[lo + idx]; break; }
-                qsel = (qsel + 1) & 7;
-                ++tried;
-            }
-            s_item = it;
-        }
-        __syncthreads();
-        const unsigned it = s_item;
-        __syncthreads();
-        if (it == WF_NONE) break;
+    const unsigned long long cstart = p.dbg ? wall_clock64() : 0ull;
+    if (tid == 0) {
+        wf_s[1] = (unsigned)wf_xcc_id(); wf_s[2] = 0u; wf_s[3] = 0u; wf_s[4] = 1u;
+        wf_s[0] = wf_pop(p.items, p.sync);
+    }
+    __syncthreads();
+    unsigned it = wf_s[0];
+    __syncthreads();
+    while (it != WF_NONE) {
         const unsigned type = it & 3u;
         const int cb = (int)((it >> 2) & 3u), zp = (int)((it >> 4) & 63u), rb = (int)(it >> 10);
-        if (type == WF_IN) wf_item_in(p, rb, zp);
-        else if (type == WF_MM) wf_item_mm(p, rb, cb, zp);
-        else wf_item_out(p, rb, cb, zp);
+        const unsigned long long c0 = p.dbg ? wall_clock64() : 0ull;
+        if (type == WF_MM) {
+            it = wf_run_mm(p, it);             // a run of GEMM tiles; returns the item behind it
+        } else {
+            // the next item's pop runs on lane 0 while the other waves are already at work
+            if (tid == 0) wf_s[0] = wf_pop(p.items, p.sync);
+            if (type == WF_IN) {
+                if (p.vec2 & 1) wf_item_in<float2>(p, rb, zp); else wf_item_in<float4>(p, rb, zp);
+            } else {
+                if (p.vec2 & 2) wf_item_out<float2>(p, rb, cb, zp); else wf_item_out<float4>(p, rb, cb, zp);
+            }
+            __syncthreads();
+            it = wf_s[0];
+            __syncthreads();
+        }
+        if (p.dbg && tid == 0) {
+            atomicAdd(&p.dbg[2 * type], wall_clock64() - c0);
+            atomicAdd(&p.dbg[2 * type + 1], 1ull);
+        }
     }
+    if (p.dbg && tid == 0) atomicAdd(&p.dbg[7], wall_clock64() - cstart);
 }
 
 // queue heads and counters to zero, the layer's 36 output scales into their slots, the tracked maximum to zero
@@ -536,7 +742,7 @@ extern "C" int spa_conv3x3_wino4_fused(spa_ctx *ctx, const float *x, int32_t B, 
                                        void *amax_out, void *v_scratch, float *m_scratch, void *scratch, float *y, void *stream)
 {
     SPA_ARG(ctx && x && u2 && cs && bias && y && v_scratch && m_scratch && scratch && amax_in && B > 0 && H > 0 && W > 0 && dilation >= 1);
-    SPA_ARG(Cin % 32 == 0 && Cout % 256 == 0 && Cout / 256 <= 4);
+    SPA_ARG(Cin % 32 == 0 && Cin >= 160 && Cout % 256 == 0 && Cout / 256 <= 4);      // (>= 5 K steps: the look-ahead pipeline)
     SPA_ARG((((uintptr_t)x | (uintptr_t)u2 | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)residual | (uintptr_t)v_scratch |
               (uintptr_t)m_scratch | (uintptr_t)scratch) % 16) == 0);
     hipStream_t s = spa_stream(stream);
@@ -557,6 +763,12 @@ extern "C" int spa_conv3x3_wino4_fused(spa_ctx *ctx, const float *x, int32_t B, 
     for (int i = 0; i < 36; ++i) sc.c[i] = cs[i];
     p.amax_in = (const unsigned *)amax_in; p.amax_out = (unsigned *)amax_out;
     p.status = ctx->d_status;
+    p.dbg = nullptr;
+    if (getenv("SPA_WF_TIMING")) {
+        if (!ctx->wf_dbg) SPA_HIP(hipMalloc((void **)&ctx->wf_dbg, 16 * 8));
+        SPA_HIP(hipMemsetAsync(ctx->wf_dbg, 0, 16 * 8, s));
+        p.dbg = ctx->wf_dbg;
+    }
 
     // the lists of this (NRB, NCB): built once per context, kept in device memory (read-only: shared by calls on any stream)
     int hit = -1;
@@ -584,5 +796,14 @@ extern "C" int spa_conv3x3_wino4_fused(spa_ctx *ctx, const float *x, int32_t B, 
     hipLaunchKernelGGL(k_wf_reset, dim3((unsigned)((n_sync + 255) / 256)), dim3(256), 0, s, d_sync, n_sync, (unsigned *)amax_out, sc);
     hipLaunchKernelGGL(k_wino4_fused, dim3((unsigned)ctx->n_cu), dim3(WF_THREADS), 2 * 512 * 128, s, p);
     SPA_LAUNCH_CHECK();
+    if (p.dbg) {
+        unsigned long long h[16];
+        SPA_HIP(hipMemcpy(h, p.dbg, sizeof h, hipMemcpyDeviceToHost));
+        const double us = 0.01;       // 100 MHz
+        fprintf(stderr, "wf timing: IN %llu items %.1f us each | MM %llu items %.1f us each | OUT %llu items %.1f us each | pop %.1f us per item | "
+                "waits IN->MM %.0f us OUT %.0f us total | workgroup lifetime %.0f us avg\n",
+                h[1], h[1] ? h[0] * us / h[1] : 0., h[3], h[3] ? h[2] * us / h[3] : 0., h[5], h[5] ? h[4] * us / h[5] : 0.,
+                (h[1] + h[3] + h[5]) ? h[6] * us / (h[1] + h[3] + h[5]) : 0., h[8] * us, h[9] * us, h[7] * us / ctx->n_cu);
+    }
     return SPA_OK;
 }

@@ -357,7 +357,7 @@ class Engine(object):
         m = torch.empty((36, T, Cout), dtype=torch.float32, device=x.device)
         if _keep is not None:                    # tools / tests: look at the transformed operands
             _keep['v'], _keep['m'] = v, m
-        if fused and Cout % 256 == 0:
+        if fused and Cout % 256 == 0 and Cin >= 160:
             # the layer as ONE persistent launch: transforms streamed under the GEMM tiles (csrc/spa_winof.hip)
             sync = torch.empty((int(self._lib.spa_wino4_fused_scratch_words(T, Cout)),), dtype=torch.int32, device=x.device)
             check(self._lib.spa_conv3x3_wino4_fused(self._ctx, _ptr(x), B, H, W, Cin, _ptr(u2), cs.ctypes.data, Cout, _ptr(bias),

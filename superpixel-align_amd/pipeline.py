@@ -314,6 +314,7 @@ class HostStream(object):
         of cli.py hand over): 3 bytes per pixel cross PCIe instead of 12, and the planar float32 batch the kernels
         take is made on the device (spa_resize_bicubic_u8 at unchanged size = layout and type change only)."""
         self.pipe, self.after, self.u8_hwc = pipe, after, bool(u8_hwc)
+        self.upload_after = os.environ.get('SPA_UPLOAD_AFTER', '') or None      # a pipe._ev key to delay the next upload to; default: at once
         dev = pipe.eng.device
         self.dev = dev
         if self.u8_hwc:
@@ -334,7 +335,12 @@ class HostStream(object):
         shape = tuple(self.inp[0].shape) if B is None else (B,) + tuple(self.inp[0].shape[1:])
         return torch.empty(shape, dtype=self.inp[0].dtype).pin_memory()
 
-    def _upload(self, slot, batch):
+    def _upload(self, slot, batch, after=None):
+        """after: an event of the compute stream the copy waits for (SPA_UPLOAD_AFTER=features|superpixel|joined delays the
+        next batch's upload to that point of the current batch).  Measured (tools/h2h_probe2.py, 30 x 1024x2048, 8-bit
+        uploads of 189 MB = 3.85 ms of DMA): the loop costs 80-82 ms per batch wherever the upload is placed and with 4, 8
+        or 16 hardware queues, 77.8 without uploads, 76 device resident — every kernel of the batch runs a few per cent
+        slower while host traffic is in flight, so the default stays 'at once'."""
         t = torch.as_tensor(batch)
         if not t.is_pinned():
             # pageable memory: stage through a pinned buffer (a host memcpy; the drivers decode straight
@@ -346,6 +352,8 @@ class HostStream(object):
             t = self.staging
         with torch.cuda.stream(self.h2d):
             self.h2d.wait_event(self.in_free[slot])
+            if after is not None:
+                self.h2d.wait_event(after)
             self.inp[slot][:t.shape[0]].copy_(t, non_blocking=True)
             self.up_done[slot].record(self.h2d)
         return t.shape[0]
@@ -365,16 +373,19 @@ class HostStream(object):
             slot = s & 1
             cur_n = nb
             nxt = next(it, None)
-            if nxt is not None:
-                nb = self._upload(slot ^ 1, nxt)      # under this batch's kernels
             main.wait_event(self.up_done[slot])
             src = self.inp[slot][:cur_n]
             if self.u8_hwc:
                 src = self.pipe.eng.resize_u8(src, (src.shape[1], src.shape[2]))       # same size: (B,3,H,W) float32 planar
+                self.in_free[slot].record(main)        # the 8-bit buffer is free as soon as it has been widened
             res = self.pipe.run(src, check_status=False)
             if self.after is not None:
                 self.after(res, s)
-            self.in_free[slot].record(main)
+            if not self.u8_hwc:
+                self.in_free[slot].record(main)
+            if nxt is not None:
+                # under this batch's kernels (optionally behind one of its stage events, see _upload)
+                nb = self._upload(slot ^ 1, nxt, after=self.pipe._ev.get(self.upload_after) if self.upload_after else None)
             done = torch.cuda.Event()
             done.record(main)
             with torch.cuda.stream(self.d2h):

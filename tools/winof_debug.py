@@ -35,3 +35,26 @@ for name in ('v', 'm'):
         print('    rows with differences: %d, first %s last %s' % (rows.numel(), rows[:5].tolist(), rows[-5:].tolist()))
 ne = y1 != y3
 print('y differing', int(ne.sum()), 'of', y1.numel())
+if os.environ.get('WF_NET'):
+    # layer by layer inside the network: the same input through both forms
+    drn = importlib.import_module('superpixel-align_amd.drn')
+    synth = importlib.import_module('superpixel-align_amd.synth')
+    m = drn.create_drn('drn_d_22', device='cuda', dtype=torch.float32)
+    xs = synth.synth_batch([3, 4], 256, 512)
+    orig = eng.conv3x3_wino_f16s
+    n = [0]
+    def both(x, u2, cs, bias, residual=None, relu=True, dilation=1, amax_in=None, track_amax=True, fused=False, _keep=None):
+        y3, a3 = orig(x, u2, cs, bias, residual, relu, dilation, amax_in, track_amax, False)
+        if u2.shape[1] % 256 == 0 and x.shape[1] >= 160:
+            for rep in range(3):
+                y1, a1 = orig(x, u2, cs, bias, residual, relu, dilation, amax_in, track_amax, True)
+                ne = int((y1 != y3).sum())
+                print('layer %d: %s -> %d dil %d res %s | differing %d | amax %d %d' % (n[0], tuple(x.shape), u2.shape[1], dilation, residual is not None, ne, int(a1), int(a3)))
+                if ne:
+                    idx = (y1 != y3).nonzero()
+                    print('   first', idx[0].tolist(), float(y1[tuple(idx[0])]), float(y3[tuple(idx[0])]), 'last', idx[-1].tolist())
+        n[0] += 1
+        return y3, a3
+    drn._EPILOGUE['engine'].conv3x3_wino_f16s = both
+    m.batch_predict(xs, need=[7])
+    print('status 0x%x' % eng.status())
