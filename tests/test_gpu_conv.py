@@ -233,8 +233,8 @@ def test_winograd_layers_inside_the_network(eng):
         assert E['wino_launches'] == 13 and E['gemm16_launches'] + E['gemm16n_launches'] == 13 and E['conv16_launches'] >= 3
         # the fused launches are the three-launch arithmetic, bit for bit — checked where every convolution of the forward is
         # libspalign's (at this 256 x 512 size the stride-2 openers of layers 3 / 4 are MIOpen's, whose results differ in the
-        # last bit from run to run): 64 x 1024 pixels fill the stride-2 kernel's 128-pixel tiles
-        xw = synth.synth_batch([5, 6], 64, 1024)
+        # last bit from run to run, and so are the 1x1 projections on maps narrower than 205 pixels): 64 x 2048 pixels fill every kernel's pixel tiles
+        xw = synth.synth_batch([5, 6], 64, 2048)
         E['wino_fused'] = True
         _, wf = m.batch_predict(xw, need=[7])
         E['wino_fused'] = False
