@@ -228,10 +228,13 @@ int spa_drn_layer2_f16s(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int3
  * With dst == src size only the layout/dtype change is made. */
 int spa_resize_bicubic_u8(spa_ctx *ctx, const uint8_t *src, int32_t B, int32_t H, int32_t W, int32_t C,
                           int32_t dst_h, int32_t dst_w, float *out, void *stream);
-/* the OpenCV branch of the same resize (chainercv.transforms.resize with cv2 importable: cv2.resize(float32 HWC image, (w, h),
- * interpolation=cv2.INTER_CUBIC)), which is what the reference environment ran — NOT PINNED (no cv2 in the build image, no
- * fixture in the reference): OpenCV's published scalar float algorithm (A = -0.75, border replication, no clipping), bit-identical
- * to the restatement oracle/resize_oracle.c:orc_resize_cvcubic_f32.  Same arguments as spa_resize_bicubic_u8. */
+/* the OpenCV branch of the same resize (chainercv.transforms.resize with cv2 importable: cv2.resize(uint8 HWC image, (w, h),
+ * interpolation=cv2.INTER_CUBIC) — the datasets resize the decoded uint8 image and convert to float32 afterwards,
+ * datasets/resize_image_dataset.py:20-36, datasets/zipped_cityscapes_road_dataset.py:78-85), which is what the reference
+ * environment ran — NOT PINNED (no cv2 in the build image, no fixture in the reference): OpenCV's published 8-bit scalar
+ * algorithm (A = -0.75 taps as shorts of 1/2048, int32 sums, (v + 2^21) >> 22 saturated to 0..255, border replication),
+ * bit-identical to the restatement oracle/resize_oracle.c:orc_resize_cvcubic_u8.  out holds the resized bytes as float32.
+ * Same arguments as spa_resize_bicubic_u8. */
 int spa_resize_cvcubic_u8(spa_ctx *ctx, const uint8_t *src, int32_t B, int32_t H, int32_t W, int32_t C,
                           int32_t dst_h, int32_t dst_w, float *out, void *stream);
 

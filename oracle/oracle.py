@@ -587,16 +587,17 @@ def resize_bicubic_u8(img_chw_u8, shape):
     return out
 
 
-def resize_cvcubic_f32(img_chw, shape):
+def resize_cvcubic_u8(img_chw, shape):
     """PARITY UNPINNED: cv2.resize(img.transpose(1, 2, 0), (w, h), interpolation=cv2.INTER_CUBIC).transpose(2, 0, 1) on a
-    float32 CHW image — the OpenCV branch of chainercv.transforms.resize(img, shape, 3) (datasets/resize_image_dataset.py:
-    31-34), restated from OpenCV's published algorithm (resize_oracle.c)."""
-    a = np.ascontiguousarray(np.asarray(img_chw, dtype=np.float32).transpose(1, 2, 0))
+    UINT8 CHW image — the OpenCV branch of chainercv.transforms.resize(img, shape, 3) as the reference's datasets call it
+    (datasets/resize_image_dataset.py:20-36: resize first, astype(float32) after), OpenCV's 8-bit fixed-point path restated
+    from its published algorithm (resize_oracle.c).  Returns uint8 CHW."""
+    a = np.ascontiguousarray(np.asarray(img_chw, dtype=np.uint8).transpose(1, 2, 0))
     H, W, C = a.shape
     h, w = int(shape[0]), int(shape[1])
-    out = np.empty((h, w, C), np.float32)
+    out = np.empty((h, w, C), np.uint8)
     L = lib()
-    L.orc_resize_cvcubic_f32.restype = None
-    L.orc_resize_cvcubic_f32.argtypes = [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, ctypes.c_int, ctypes.c_int]
-    L.orc_resize_cvcubic_f32(a.ctypes.data, H, W, C, out.ctypes.data, h, w)
+    L.orc_resize_cvcubic_u8.restype = None
+    L.orc_resize_cvcubic_u8.argtypes = [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, ctypes.c_int, ctypes.c_int]
+    L.orc_resize_cvcubic_u8(a.ctypes.data, H, W, C, out.ctypes.data, h, w)
     return np.ascontiguousarray(out.transpose(2, 0, 1))

@@ -114,65 +114,77 @@ void orc_resize_bicubic_u8(const uint8_t *src, int H, int W, uint8_t *dst, int h
 
 
 /*
- * orc_resize_cvcubic_f32 — PARITY UNPINNED (no cv2 in this image, no fixture in the reference): the OpenCV branch of
- *   datasets/resize_image_dataset.py:31-34  chainercv.transforms.resize(image, shape, 3)
- * i.e. cv2.resize(img.transpose(1, 2, 0), dsize=(w, h), interpolation=cv2.INTER_CUBIC) on the float32 image the
- * reference holds (chainercv 0.7 `_resize`, cv2 importable), which is what the reference environment ran (header above).
+ * orc_resize_cvcubic_u8 — PARITY UNPINNED (no cv2 in this image, no fixture in the reference): the OpenCV branch of
+ *   datasets/resize_image_dataset.py:20-36, datasets/zipped_cityscapes_road_dataset.py:78-85
+ * which decode to uint8, call chainercv.transforms.resize(image, shape, 3) / cv.resize ON THE UINT8 IMAGE (cv2 importable:
+ * cv2.resize(img.transpose(1, 2, 0), dsize=(w, h), interpolation=cv2.INTER_CUBIC)) and only then .astype(float32): OpenCV's
+ * 8-bit path.  (Round 3 restated the float32 path, which the reference never takes — ADVICE r3.)
  * Restated from the published algorithm of OpenCV's modules/imgproc/src/resize.cpp [3p] — cv::resize ->
- * resizeGeneric_<HResizeCubic<float,float,float>, VResizeCubic<float,float,float,Cast<float,float>,...>>, scalar form:
+ * resizeGeneric_<HResizeCubic<uchar,int,short>, VResizeCubic<uchar,int,short,FixedPtCast<int,uchar,22>,...>>, scalar form:
  *   scale = src / dst (double);  per destination index d:  f = (float)((d + 0.5) * scale - 0.5);  s = floor(f);  f -= s;
  *   interpolateCubic(f):  A = -0.75f;
  *       c0 = ((A*(f+1) - 5*A)*(f+1) + 8*A)*(f+1) - 4*A;   c1 = ((A+2)*f - (A+3))*f*f + 1;
  *       c2 = ((A+2)*(1-f) - (A+3))*(1-f)*(1-f) + 1;        c3 = 1 - c0 - c1 - c2          (float32 operations, this order)
- *   horizontal pass per source row: D = S[s-1]*c0 + S[s]*c1 + S[s+1]*c2 + S[s+2]*c3, left to right, indices clamped to the
- *   row (border replication), float32 intermediate; vertical pass: D = R0*b0 + R1*b1 + R2*b2 + R3*b3 on rows
- *   clip(s - 1 + k, 0, H - 1).  No clipping of the result (cubic overshoot stays).  OpenCV builds with AVX2/FMA vector paths
- *   may differ from this scalar form in the last bit: one more reason the variant is stated, not pinned.
- * src, dst: interleaved (H, W, C) / (h, w, C) float32.
+ *   taps  t_k = saturate_cast<short>(c_k * INTER_RESIZE_COEF_SCALE),  INTER_RESIZE_COEF_SCALE = 2048, cvRound (half to even);
+ *   horizontal pass per source row (int32): D = S[s-1]*t0 + S[s]*t1 + S[s+1]*t2 + S[s+2]*t3, indices clamped to the row
+ *   (border replication);  vertical pass (int32) on rows clip(s - 1 + k, 0, H - 1): v = R0*b0 + R1*b1 + R2*b2 + R3*b3,
+ *   dst = saturate_cast<uchar>((v + (1 << 21)) >> 22).
+ * OpenCV's vector form of the vertical pass (VResizeCubicVec_32s8u: the int rows converted to float, products with
+ * b_k / 2^22 summed in float, round to nearest even) can differ from this fixed-point form in the last bit of rare pixels:
+ * one more reason the variant is stated, not pinned.
+ * src, dst: interleaved (H, W, C) / (h, w, C) uint8.
  */
-static void cv_cubic_coeffs(float x, float c[4])
+static void cv_cubic_taps_s16(float x, int t[4])
 {
     const float A = -0.75f;
+    float c[4];
     c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
     c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
     c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
     c[3] = 1.f - c[0] - c[1] - c[2];
+    for (int k = 0; k < 4; ++k) {
+        const int r = (int)rintf(c[k] * 2048.f);
+        t[k] = r < -32768 ? -32768 : (r > 32767 ? 32767 : r);
+    }
 }
 
 static int cv_clip(int v, int n) { return v < 0 ? 0 : (v >= n ? n - 1 : v); }
 
-void orc_resize_cvcubic_f32(const float *src, int H, int W, int C, float *dst, int h, int w)
+void orc_resize_cvcubic_u8(const unsigned char *src, int H, int W, int C, unsigned char *dst, int h, int w)
 {
     const double sx = (double)W / (double)w, sy = (double)H / (double)h;
     int *xo = (int *)malloc((size_t)w * sizeof(int));
-    float *xa = (float *)malloc((size_t)w * 4 * sizeof(float));
-    float *rows = (float *)malloc((size_t)4 * w * C * sizeof(float));
+    int *xa = (int *)malloc((size_t)w * 4 * sizeof(int));
+    int *rows = (int *)malloc((size_t)4 * w * C * sizeof(int));
     for (int d = 0; d < w; ++d) {
         float f = (float)((d + 0.5) * sx - 0.5);
         const int s = (int)floorf(f);
         f -= (float)s;
         xo[d] = s;
-        cv_cubic_coeffs(f, xa + 4 * d);
+        cv_cubic_taps_s16(f, xa + 4 * d);
     }
     for (int dy = 0; dy < h; ++dy) {
         float f = (float)((dy + 0.5) * sy - 0.5);
         const int s = (int)floorf(f);
         f -= (float)s;
-        float b[4];
-        cv_cubic_coeffs(f, b);
+        int b[4];
+        cv_cubic_taps_s16(f, b);
         for (int k = 0; k < 4; ++k) {
-            const float *S = src + (size_t)cv_clip(s - 1 + k, H) * W * C;
-            float *R = rows + (size_t)k * w * C;
+            const unsigned char *S = src + (size_t)cv_clip(s - 1 + k, H) * W * C;
+            int *R = rows + (size_t)k * w * C;
             for (int d = 0; d < w; ++d)
                 for (int c = 0; c < C; ++c) {
-                    const float *a = xa + 4 * d;
+                    const int *a = xa + 4 * d;
                     R[d * C + c] = S[cv_clip(xo[d] - 1, W) * C + c] * a[0] + S[cv_clip(xo[d], W) * C + c] * a[1] +
                                    S[cv_clip(xo[d] + 1, W) * C + c] * a[2] + S[cv_clip(xo[d] + 2, W) * C + c] * a[3];
                 }
         }
-        float *D = dst + (size_t)dy * w * C;
-        for (int i = 0; i < w * C; ++i)
-            D[i] = rows[i] * b[0] + rows[(size_t)w * C + i] * b[1] + rows[(size_t)2 * w * C + i] * b[2] + rows[(size_t)3 * w * C + i] * b[3];
+        unsigned char *D = dst + (size_t)dy * w * C;
+        for (int i = 0; i < w * C; ++i) {
+            int v = rows[i] * b[0] + rows[(size_t)w * C + i] * b[1] + rows[(size_t)2 * w * C + i] * b[2] + rows[(size_t)3 * w * C + i] * b[3];
+            v = (v + (1 << 21)) >> 22;
+            D[i] = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
     }
     free(xo); free(xa); free(rows);
 }

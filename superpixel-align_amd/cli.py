@@ -131,7 +131,8 @@ RESIZE_BACKEND = ['pil']         # --resize_backend: 'pil' (pinned against Pillo
 
 
 def _cv_cubic_taps(n_src, n_dst):
-    """OpenCV INTER_CUBIC along one axis: (clamped source indices (n_dst, 4), float32 coefficients (n_dst, 4))."""
+    """OpenCV INTER_CUBIC along one axis, 8-bit path: (clamped source indices (n_dst, 4), int32 taps (n_dst, 4)) — the
+    float32 coefficients of interpolateCubic (A = -0.75) as saturate_cast<short>(c * 2048), cvRound = round half to even."""
     scale = float(n_src) / float(n_dst)
     d = np.arange(n_dst, dtype=np.float64)
     f = ((d + 0.5) * scale - 0.5).astype(np.float32)
@@ -144,30 +145,35 @@ def _cv_cubic_taps(n_src, n_dst):
     c2 = ((A + np.float32(2)) * (one - x) - (A + np.float32(3))) * (one - x) * (one - x) + one
     c3 = one - c0 - c1 - c2
     idx = np.clip(s[:, None] - 1 + np.arange(4)[None, :], 0, n_src - 1)
-    return idx, np.stack([c0, c1, c2, c3], 1).astype(np.float32)
+    taps = np.rint(np.stack([c0, c1, c2, c3], 1).astype(np.float32) * np.float32(2048)).astype(np.int64)
+    return idx, np.clip(taps, -32768, 32767).astype(np.int32)
 
 
 def resize_cvcubic_chw(img_chw, shape):
-    """cv2.resize(img.transpose(1, 2, 0), (w, h), interpolation=cv2.INTER_CUBIC).transpose(2, 0, 1) on a float32 image, as
-    OpenCV's scalar float path computes it (float32 horizontal sums, then a float32 vertical sum, left to right; border
-    replication; no clipping): the host form of spa_resize_cvcubic_u8, same bits.  Not pinned against cv2 itself."""
-    a = np.asarray(img_chw, dtype=np.float32)
+    """cv2.resize(img.transpose(1, 2, 0), (w, h), interpolation=cv2.INTER_CUBIC).transpose(2, 0, 1) on a UINT8 image, as
+    OpenCV's scalar 8-bit path computes it (int32 horizontal sums of byte x tap, int32 vertical sum, (v + 2^21) >> 22,
+    saturated to 0..255; border replication): what the reference's datasets do before .astype(float32)
+    (datasets/resize_image_dataset.py:20-36).  The host form of spa_resize_cvcubic_u8, same bytes.  Not pinned against cv2."""
+    a = np.asarray(img_chw)
+    if a.dtype != np.uint8:
+        raise ValueError('resize_cvcubic_chw: the reference resizes the decoded uint8 image (got %s)' % a.dtype)
     C, H, W = a.shape
     h, w = int(shape[0]), int(shape[1])
     xi, xc = _cv_cubic_taps(W, w)
     yi, yc = _cv_cubic_taps(H, h)
-    r = a[:, :, xi[:, 0]] * xc[:, 0]
+    ai = a.astype(np.int32)
+    r = ai[:, :, xi[:, 0]] * xc[:, 0]
     for k in (1, 2, 3):
-        r = r + a[:, :, xi[:, k]] * xc[:, k]                   # (C, H, w) float32, left to right
+        r = r + ai[:, :, xi[:, k]] * xc[:, k]                  # (C, H, w) int32
     o = r[:, yi[:, 0], :] * yc[:, 0][None, :, None]
     for k in (1, 2, 3):
         o = o + r[:, yi[:, k], :] * yc[:, k][None, :, None]
-    return o.astype(np.float32)
+    return np.clip((o + (1 << 21)) >> 22, 0, 255).astype(np.uint8)
 
 
 def resize_bicubic_chw(img_chw, shape):
     """datasets/resize_image_dataset.py:31-34 (chainercv.transforms.resize(img, size, 3)): Pillow's 8-bit bicubic
-    (pinned), or with --resize_backend cv2 OpenCV's float INTER_CUBIC (the branch the reference environment ran; its
+    (pinned), or with --resize_backend cv2 OpenCV's 8-bit INTER_CUBIC (the branch the reference environment ran; its
     algorithm restated, not pinned: no cv2 here)."""
     if RESIZE_BACKEND[0] == 'cv2':
         return resize_cvcubic_chw(img_chw, shape)

@@ -162,23 +162,35 @@ extern "C" int spa_resize_bicubic_u8(spa_ctx *ctx, const uint8_t *src, int32_t B
 
 
 // ---------------------------------------------------------------------------------------------------
-// The OpenCV branch of the reference's input resize (datasets/resize_image_dataset.py:31-34: chainercv.transforms.resize(
-// image, shape, 3) with cv2 importable = cv2.resize(float32 HWC image, (w, h), interpolation=cv2.INTER_CUBIC)) — what the
-// reference environment ran.  NOT PINNED: there is no cv2 in the build image and no fixture in the reference; the kernel
-// follows OpenCV's published scalar algorithm (modules/imgproc/src/resize.cpp: resizeGeneric_ with HResizeCubic /
-// VResizeCubic for float; coefficients interpolateCubic with A = -0.75f, source position (float)((d + 0.5) * scale - 0.5),
-// border replication, float32 horizontal sums then a float32 vertical sum, no clipping) and is bit-identical to the
-// restatement oracle/resize_oracle.c:orc_resize_cvcubic_f32 (tests/test_gpu_parity.py).  One thread = one destination
-// pixel (all channels): the four horizontal sums of its four source rows, then the vertical sum — the same float32
-// operations in the same order as the two-pass form.
+// The OpenCV branch of the reference's input resize: datasets/resize_image_dataset.py:20-36 and
+// datasets/zipped_cityscapes_road_dataset.py:78-85 decode to uint8, resize THE UINT8 IMAGE (chainercv.transforms.resize(img,
+// shape, 3) with cv2 importable = cv2.resize(uint8 HWC, (w, h), interpolation=cv2.INTER_CUBIC)) and only then .astype(float32):
+// OpenCV's 8-bit path, integer-valued results in 0..255.  (Round 3 restated the float32 path here; the reference never holds a
+// float32 image at that point — ADVICE r3.)  NOT PINNED: there is no cv2 in the build image and no fixture in the reference;
+// the kernel follows OpenCV's published scalar algorithm (modules/imgproc/src/resize.cpp: resizeGeneric_<HResizeCubic<uchar,
+// int, short>, VResizeCubic<uchar, int, short, FixedPtCast<int, uchar, 22>>>):
+//   per destination index d:  f = (float)((d + 0.5) * scale - 0.5);  s = floor(f);  f -= s;  interpolateCubic(f), A = -0.75f,
+//   float32; the four taps as saturate_cast<short>(c * 2048) (cvRound = round half to even);
+//   horizontal: int32 sums of byte x tap over s-1 .. s+2, indices clamped to the row (border replication);
+//   vertical: int32 sum of the four rows clip(s - 1 + k, 0, H - 1) x tap, then (v + 2^21) >> 22 saturated to 0..255.
+// and is bit-identical to the restatement oracle/resize_oracle.c:orc_resize_cvcubic_u8 (tests/test_gpu_parity.py).  OpenCV's
+// vector form of the vertical pass (VResizeCubicVec_32s8u: float products, round to nearest even) can differ from the scalar
+// fixed-point form above in the last bit of rare pixels: one more reason this branch is stated, not pinned.
+// One thread = one destination pixel (all channels).
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void cv_cubic_coeffs(float x, float (&c)[4])
+__device__ __forceinline__ void cv_cubic_taps_s16(float x, int (&t)[4])
 {
     const float A = -0.75f;
+    float c[4];
     c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
     c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
     c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
     c[3] = 1.f - c[0] - c[1] - c[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = (int)rintf(c[k] * 2048.f);                  // saturate_cast<short>(float): cvRound, then the range
+        t[k] = r < -32768 ? -32768 : (r > 32767 ? 32767 : r);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_resize_cvcubic(const uint8_t *__restrict__ src, int H, int W, int C, int h, int w,
@@ -190,28 +202,29 @@ __global__ __launch_bounds__(256) void k_resize_cvcubic(const uint8_t *__restric
     float fx = (float)((dx + 0.5) * sx - 0.5), fy = (float)((dy + 0.5) * sy - 0.5);
     const int x0 = (int)floorf(fx), y0 = (int)floorf(fy);
     fx -= (float)x0; fy -= (float)y0;
-    float a[4], bb[4];
-    cv_cubic_coeffs(fx, a);
-    cv_cubic_coeffs(fy, bb);
+    int a[4], bb[4];
+    cv_cubic_taps_s16(fx, a);
+    cv_cubic_taps_s16(fy, bb);
     int xs[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { const int v = x0 - 1 + k; xs[k] = v < 0 ? 0 : (v >= W ? W - 1 : v); }
     const uint8_t *img = src + (long long)b * H * W * C;
     for (int c = 0; c < C; ++c) {
-        float r[4];
+        int v = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             int yy = y0 - 1 + k;
             yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
             const uint8_t *S = img + (long long)yy * W * C + c;
-            r[k] = (float)S[xs[0] * C] * a[0] + (float)S[xs[1] * C] * a[1] + (float)S[xs[2] * C] * a[2] + (float)S[xs[3] * C] * a[3];
+            v += ((int)S[xs[0] * C] * a[0] + (int)S[xs[1] * C] * a[1] + (int)S[xs[2] * C] * a[2] + (int)S[xs[3] * C] * a[3]) * bb[k];
         }
-        out[(((long long)b * C + c) * h + dy) * w + dx] = r[0] * bb[0] + r[1] * bb[1] + r[2] * bb[2] + r[3] * bb[3];
+        v = (v + (1 << 21)) >> 22;
+        out[(((long long)b * C + c) * h + dy) * w + dx] = (float)(v < 0 ? 0 : (v > 255 ? 255 : v));
     }
 }
 
-// src (B,H,W,C) uint8 interleaved (a decoded PNG: the float32 image the reference resizes holds exactly these values) ->
-// out (B,C,dst_h,dst_w) float32 planar, not clipped.  With dst == src size only the layout/dtype change is made (the
+// src (B,H,W,C) uint8 interleaved (a decoded PNG) -> out (B,C,dst_h,dst_w) float32 planar holding the resized BYTES (what
+// the reference's .astype(float32) of the resized uint8 image holds).  With dst == src size only the layout/dtype change is made (the
 // reference resizes only when the shapes differ).
 extern "C" int spa_resize_cvcubic_u8(spa_ctx *ctx, const uint8_t *src, int32_t B, int32_t H, int32_t W, int32_t C,
                                      int32_t dst_h, int32_t dst_w, float *out, void *stream)

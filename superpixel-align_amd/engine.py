@@ -396,8 +396,9 @@ class Engine(object):
         return out
 
     def resize_cvcubic_u8(self, src, shape):
-        """Decoded 8-bit images (B,H,W,C) uint8 -> (B,C,h,w) float32 by OpenCV's float INTER_CUBIC (the cv2 branch of
-        chainercv.transforms.resize: what the reference environment ran; not pinned, see include/spalign.h)."""
+        """Decoded 8-bit images (B,H,W,C) uint8 -> (B,C,h,w) float32 holding the bytes of OpenCV's 8-bit INTER_CUBIC resize
+        (the cv2 branch of chainercv.transforms.resize on the uint8 image: what the reference environment ran; not pinned,
+        see include/spalign.h)."""
         src = _req(src, torch.uint8, 'src')
         B, H, W, C = src.shape
         h, w = int(shape[0]), int(shape[1])

@@ -121,3 +121,39 @@ def test_fused_winograd_plan_orders_producers_before_consumers():
                 else:
                     assert t == 2 and zp < PO and mms.get((rb, cb), 0) == 36
         assert len(seen) == n_items
+
+
+def test_host_rng_vector_and_scalar_forms_agree():
+    """spa_pyrandom_shuffle_select_host has an AVX-512 form (16 generator outputs per step of the rejection sampling; the
+    anchors' places traced backwards through the swaps with vector compares) chosen at run time and a scalar form
+    (SPA_RNG_SCALAR=1): the same ranks on sizes around every boundary of the vector code — lists of 0..40 elements, the 16-lane
+    block, the bit-length bands (2^k - 1, 2^k, 2^k + 1), a 200 000-element list — with the stream carried across lists."""
+    import hashlib
+    import subprocess
+    import sys
+    code = r'''
+import importlib, hashlib, numpy as np
+engine = importlib.import_module('superpixel-align_amd.engine')
+sizes = list(range(0, 41)) + [63, 64, 65, 127, 128, 129, 255, 256, 257, 1023, 1024, 1025, 4095, 4096, 4097, 10007, 32767, 32768, 32769, 200000]
+r = engine.PyRandom(1111)
+h = hashlib.sha256()
+for rep in range(2):
+    for A in (10, 16, 3):
+        ranks, nv = r.shuffle_select(np.array(sizes, np.int32), A)
+        assert all(nv[i] == min(max(s, 0), A) for i, s in enumerate(sizes))
+        for i, s in enumerate(sizes):
+            assert len(set(ranks[i, :nv[i]].tolist())) == nv[i] and (nv[i] == 0 or ranks[i, :nv[i]].max() < s)
+        h.update(ranks.tobytes()); h.update(nv.tobytes())
+print(h.hexdigest())
+'''
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for scalar in ('', '1'):
+        env = dict(os.environ, PYTHONPATH=root)
+        if scalar:
+            env['SPA_RNG_SCALAR'] = '1'
+        else:
+            env.pop('SPA_RNG_SCALAR', None)
+        outs.append(subprocess.check_output([sys.executable, '-c', code], env=env, cwd=root).decode().strip())
+    assert outs[0] == outs[1] and len(outs[0]) == 64

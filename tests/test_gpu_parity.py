@@ -482,10 +482,11 @@ def test_resize_bicubic_bit_exact(eng, orc):
 
 
 def test_resize_opencv_cubic_follows_the_restatement(eng, orc):
-    """spa_resize_cvcubic_u8 — the OpenCV branch of the reference's resize (cv2.resize(float32 HWC, INTER_CUBIC)), which cannot be
-    pinned here (no cv2, no fixture): the kernel is bit-identical to the restatement of OpenCV's published scalar algorithm
-    (oracle/resize_oracle.c: orc_resize_cvcubic_f32) on down- and up-scaling, odd sizes and the 1024x2048 -> 224x224 operating
-    point, and to the host form the driver falls back to."""
+    """spa_resize_cvcubic_u8 — the OpenCV branch of the reference's resize (cv2.resize(uint8 HWC, INTER_CUBIC), then
+    .astype(float32): datasets/resize_image_dataset.py:20-36), which cannot be pinned here (no cv2, no fixture): the kernel is
+    bit-identical to the restatement of OpenCV's published 8-bit scalar algorithm (oracle/resize_oracle.c:
+    orc_resize_cvcubic_u8) on down- and up-scaling, odd sizes and the 1024x2048 -> 224x224 operating point, and to the host
+    form the driver falls back to; its values are bytes."""
     import importlib
     cli = importlib.import_module('superpixel-align_amd.cli')
     rs = np.random.RandomState(8)
@@ -494,9 +495,10 @@ def test_resize_opencv_cubic_follows_the_restatement(eng, orc):
         out = eng.resize_cvcubic_u8(dev(img), (h, w)).cpu().numpy()
         assert out.dtype == np.float32 and out.shape == (2, 3, h, w)
         for b in range(2):
-            ref = orc.resize_cvcubic_f32(img[b].transpose(2, 0, 1).astype(np.float32), (h, w))
-            assert np.array_equal(out[b], ref), (H, W, h, w)
-        assert np.array_equal(out[0], cli.resize_cvcubic_chw(img[0].transpose(2, 0, 1), (h, w)))
+            ref = orc.resize_cvcubic_u8(img[b].transpose(2, 0, 1), (h, w))
+            assert np.array_equal(out[b], ref.astype(np.float32)), (H, W, h, w)
+        assert np.array_equal(out[0], cli.resize_cvcubic_chw(img[0].transpose(2, 0, 1), (h, w)).astype(np.float32))
+        assert np.array_equal(out, np.rint(out)) and out.min() >= 0 and out.max() <= 255
     same = eng.resize_cvcubic_u8(dev(img[:1, :64, :96]), (64, 96))[0].cpu().numpy()      # layout / dtype change only
     assert np.array_equal(same, img[0, :64, :96].transpose(2, 0, 1).astype(np.float32))
 
