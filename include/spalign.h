@@ -70,6 +70,10 @@ int spa_status(spa_ctx *ctx, uint32_t *status_host, void *stream);
    the caller reads the word once an event recorded behind the call has completed.  (The reference has no
    counterpart: its per-image exceptions surface synchronously, batch_spalign_kmeans.py:538-548.) */
 int spa_status_peek_async(spa_ctx *ctx, uint32_t *status_pinned, void *stream);
+/* the same copy followed, in stream order, by the clear of the latch: the word then holds the bits raised since the previous
+   take — what a batch loop wants (an error is reported once, by the batch that raised it; informational bits of one batch
+   do not stick to the next). */
+int spa_status_take_async(spa_ctx *ctx, uint32_t *status_pinned, void *stream);
 
 /* Per-kernel timing for the roofline report (bench.py): when enabled, HIP events are recorded on
    the launch stream around each kernel family; spa_prof_read synchronises the device and

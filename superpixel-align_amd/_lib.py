@@ -54,6 +54,7 @@ PROTOTYPES = {
     'spa_ctx_destroy': (None, [c_p]),
     'spa_status': (ctypes.c_int, [c_p, ctypes.POINTER(ctypes.c_uint32), c_p]),
     'spa_status_peek_async': (ctypes.c_int, [c_p, c_p, c_p]),
+    'spa_status_take_async': (ctypes.c_int, [c_p, c_p, c_p]),
     'spa_prof_enable': (ctypes.c_int, [c_p, ctypes.c_int]),
     'spa_prof_slots': (ctypes.c_int, []),
     'spa_prof_name': (ctypes.c_char_p, [ctypes.c_int]),

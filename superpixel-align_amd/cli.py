@@ -223,6 +223,10 @@ class PinnedRing(object):
         return t
 
 
+class ShmTooSmall(RuntimeError):
+    """/dev/shm cannot hold the decode slabs: the caller falls back to the decode threads."""
+
+
 class ProcessDecoder(object):
     """Batches of PNGs decoded by worker processes into shared-memory slabs that are registered as pinned host memory
     (decode_worker.py).  take(idx) -> (images uint8 (B,H,W,3) device tensor, labels uint8 (B,H,W) device tensor, list of
@@ -243,20 +247,35 @@ class ProcessDecoder(object):
         self.ibytes = int(np.prod(self.ishape))
         self.gbytes = int(np.prod(self.gshape))
         slab = batch * (self.ibytes + self.gbytes)
+        # the slabs live in /dev/shm: on a tmpfs smaller than they are (a container's default is 64 MB; 30 full-size frames
+        # need 3 x 250 MB) SharedMemory(create=True) still succeeds and the workers die with SIGBUS on their first write
+        try:
+            st = os.statvfs('/dev/shm')
+            free = st.f_bavail * st.f_frsize
+        except OSError:
+            free = None
+        if free is not None and free < depth * slab + (16 << 20):
+            raise ShmTooSmall('/dev/shm has %d MB free, the decode slabs need %d MB' % (free >> 20, (depth * slab) >> 20))
         self.slots = []
-        for _ in range(depth):
-            shm = shared_memory.SharedMemory(create=True, size=slab)
-            t = torch.frombuffer(shm.buf, dtype=torch.uint8)
-            try:
-                rc = torch.cuda.cudart().cudaHostRegister(t.data_ptr(), slab, 0)
-                pinned = rc is None or int(rc) == 0
-            except Exception:
-                pinned = False                      # pageable slab: the upload is staged, still correct
-            self.slots.append(dict(shm=shm, t=t, pinned=pinned, ev=None))
-        self.k = 0
-        # spawn, not fork: this process has initialised the GPU
-        self.pool = ProcessPoolExecutor(max_workers=n_procs, mp_context=mp.get_context('spawn'))
-        list(self.pool.map(decode_worker.warm, range(n_procs)))
+        self.pool = None
+        try:
+            for _ in range(depth):
+                shm = shared_memory.SharedMemory(create=True, size=slab)
+                slot = dict(shm=shm, t=None, pinned=False, ev=None)
+                self.slots.append(slot)
+                slot['t'] = t = torch.frombuffer(shm.buf, dtype=torch.uint8)
+                try:
+                    rc = torch.cuda.cudart().cudaHostRegister(t.data_ptr(), slab, 0)
+                    slot['pinned'] = rc is None or int(rc) == 0
+                except Exception:
+                    slot['pinned'] = False                  # pageable slab: the upload is staged, still correct
+            self.k = 0
+            # spawn, not fork: this process has initialised the GPU
+            self.pool = ProcessPoolExecutor(max_workers=n_procs, mp_context=mp.get_context('spawn'))
+            list(self.pool.map(decode_worker.warm, range(n_procs)))
+        except BaseException:
+            self.close()                                # unregister and unlink what exists so far
+            raise
 
     def _src(self, ds, i):
         p = ds._paths[i]
@@ -288,15 +307,22 @@ class ProcessDecoder(object):
         return img_d, gt_d, [np.array(gt_h[j].numpy()) if self.host_labels else None for j in range(n)]
 
     def close(self):
-        self.pool.shutdown(wait=True, cancel_futures=True)
+        if self.pool is not None:
+            self.pool.shutdown(wait=True, cancel_futures=True)
+            self.pool = None
         for s in self.slots:
+            if s.get('t') is not None:
+                if s.get('pinned'):
+                    try:
+                        torch.cuda.cudart().cudaHostUnregister(s['t'].data_ptr())
+                    except Exception:
+                        pass
+                s['t'] = None
             try:
-                torch.cuda.cudart().cudaHostUnregister(s['t'].data_ptr())
+                s['shm'].close()
+                s['shm'].unlink()
             except Exception:
                 pass
-            del s['t']
-            s['shm'].close()
-            s['shm'].unlink()
         self.slots = []
 
 
@@ -543,8 +569,6 @@ def main_labelled(argv=None, get=None, make_pipe=None, originals=False, make_mod
         the ground truth's size (the asynchronous loop); otherwise decode, resize and count here."""
         img_fn, label_fn = imgs_ds._paths[i], labels_ds._paths[i]
         if conf is not None:
-            if isinstance(st_all, float) and st_all < 0:            # -seconds of device time of the batch
-                st_all = time.time() + st_all
             save_npy(args, img_fn, rm, cl)
             gt = None
             if not args.no_figure:
@@ -647,8 +671,11 @@ def main_labelled(argv=None, get=None, make_pipe=None, originals=False, make_mod
 
         decoder_lock = threading.Lock()
         if use_async and have_gpu and getattr(args, 'decode_procs', 0) > 0 and not args.host_resize and ranges:
-            decoder = ProcessDecoder(imgs_ds, labels_ds, args.batchsize, args.decode_procs, ops.engine().device,
-                                     host_labels=not args.no_figure)
+            try:
+                decoder = ProcessDecoder(imgs_ds, labels_ds, args.batchsize, args.decode_procs, ops.engine().device,
+                                         host_labels=not args.no_figure)
+            except ShmTooSmall as exc:
+                print('--decode_procs: %s; decoding on the %d io threads instead' % (exc, args.io_threads), file=sys.stderr)
         depth = 2 if use_async else 1
         queue = [loader.submit(load, lo, hi) for lo, hi in ranges[:depth]]
         if use_async:
@@ -677,7 +704,9 @@ def main_labelled(argv=None, get=None, make_pipe=None, originals=False, make_mod
                 if st['fail_h'] is not None:
                     st['res'].check_retry(st['fail_h'])
                 times = pipe.elapsed_times(st['events'])
-                t_dev = st['events']['start'].elapsed_time(st['done']) / 1000.0
+                # `elapsed_time` stays what the reference reports (:420: wall clock since the batch was started, which in this
+                # loop includes the batches in flight ahead of it); the batch's own device time goes under its own key
+                times['time_device'] = st['events']['start'].elapsed_time(st['done']) / 1000.0
                 info, n_sp = st['info_h'].numpy(), st['nsp_h'].numpy()
                 conf = st['conf_h'].numpy() if st['conf_h'] is not None else None
                 # a re-labelled image (last batch shifted back, :539-542) must overwrite its earlier files:
@@ -686,7 +715,7 @@ def main_labelled(argv=None, get=None, make_pipe=None, originals=False, make_mod
                 keep.append(st)
                 for j, i in enumerate(st['idx']):
                     pending.append(workers.submit(finish, i, st['road_h'][j].numpy(), st['cl_h'][j].numpy(), int(n_sp[j]),
-                                                  info, times, -t_dev if conf is not None else st['st_all'],
+                                                  info, times, st['st_all'],
                                                   None if conf is None else conf[j],
                                                   None if st['gts'] is None else st['gts'][j]))
 
@@ -711,7 +740,7 @@ def main_labelled(argv=None, get=None, make_pipe=None, originals=False, make_mod
                     road_d, cl_d = to_gt_size(res.road, gt_dev.shape[1:]), to_gt_size(res.cluster, gt_dev.shape[1:])
                     gtm = torch.where(gt_dev <= 6, -1, torch.where(gt_dev == 7, 1, 0)).to(torch.int32)   # :279-296
                     conf_d = eng.confusion(road_d.contiguous(), gtm)
-                status_h = eng.status_peek_async()
+                status_h = eng.status_take_async()          # this batch's bits (copy, then clear, in stream order)
                 computed = torch.cuda.Event()
                 computed.record(main)
                 with torch.cuda.stream(d2h):

@@ -99,6 +99,16 @@ extern "C" int spa_status_peek_async(spa_ctx *ctx, uint32_t *status_pinned, void
     return SPA_OK;
 }
 
+// the same copy followed, in stream order, by the clear: every batch of an asynchronous loop reads ITS bits (an error
+// once, by the batch that raised it; informational bits do not stick to later batches)
+extern "C" int spa_status_take_async(spa_ctx *ctx, uint32_t *status_pinned, void *stream)
+{
+    SPA_ARG(ctx && status_pinned);
+    SPA_HIP(hipMemcpyAsync(status_pinned, ctx->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, spa_stream(stream)));
+    SPA_HIP(hipMemsetAsync(ctx->d_status, 0, sizeof(uint32_t), spa_stream(stream)));
+    return SPA_OK;
+}
+
 // ---------------------------------------------------------------------------------------
 // skimage.util.regular_grid((1, H, W), n) — host integer/double logic of slic()
 // (skimage/util/_regular_grid.py:61-83; call sites slic_superpixels.py:91 and inside the

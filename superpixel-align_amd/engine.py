@@ -69,6 +69,14 @@ class Engine(object):
         check(self._lib.spa_status_peek_async(self._ctx, ctypes.c_void_p(word.data_ptr()), self._s()))
         return word
 
+    def status_take_async(self, word=None):
+        """status_peek_async followed, in stream order, by the clear of the latch: the word holds the bits of the work
+        enqueued since the previous take (per batch in the drivers' asynchronous loop)."""
+        if word is None:
+            word = torch.zeros(1, dtype=torch.int32).pin_memory()
+        check(self._lib.spa_status_take_async(self._ctx, ctypes.c_void_p(word.data_ptr()), self._s()))
+        return word
+
     def raise_on_word(self, word, ignore=_lib.INFO_BITS):
         st = int(word.item()) & 0xffffffff
         self.last_info = st & _lib.INFO_BITS

@@ -82,7 +82,12 @@ def create_model(args):
     """DRN feature extractor. The reference hard-codes drn_c_26 + models/drn_c_26.npz; here the
     architecture (--arch), precision (--dtype) and weight file (--drn_weights, .npz or .pth)
     are flags and the default weights are random (no checkpoint ships with the repository)."""
-    if args.gpu is not None and args.gpu >= 0 and torch.cuda.is_available():
+    if args.gpu is not None and args.gpu < 0:
+        # the reference's --gpu -1 selects its NumPy path (batch_spalign_kmeans.py:349-354); this build has none
+        from ._lib import SpalignError
+        raise SpalignError('--gpu %d: this build has no CPU path (the hot path runs on an MI355X only); pass --gpu 0 '
+                           '(the device HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES exposes)' % args.gpu)
+    if args.gpu is not None and torch.cuda.is_available():
         torch.cuda.set_device(args.gpu)
     dtype = {'fp32': torch.float32, 'bf16': torch.bfloat16}[getattr(args, 'dtype', 'fp32')]
     return create_drn(getattr(args, 'arch', 'drn_c_26'), getattr(args, 'drn_weights', None),

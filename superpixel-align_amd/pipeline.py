@@ -193,7 +193,13 @@ class LabelPipeline(object):
         The reference's weighted_kmeans re-runs itself, result discarded, for every image that ends without a
         cluster-0 pixel (:201-205).  k > 2: each run shuffles the initial assignment with numpy's global
         generator, so the retries (a tree: a retry can fail and recurse) are executed here for their effect on
-        the stream later batches draw from.  k = 2: see BatchResult.check_retry."""
+        the stream later batches draw from.  k = 2: see BatchResult.check_retry.
+
+        k > 2 synchronises the host with the batch (the drivers' asynchronous loop then overlaps only the decode and the
+        writers, not the enqueue): the length of the vector numpy shuffles is the number of superpixels at or below the
+        median weight — known only once the prior is on the host (:141-149) — and a failed image's retry must advance the
+        generator before the NEXT batch draws from it, so the flags are read here, not at the end of the batch.  Both are
+        the reference's data dependences, not this implementation's; k = 2 (BASELINE configs 1-5) has neither."""
         a, eng = self.args, self.eng
         B = labels.shape[0]
         init_other = None

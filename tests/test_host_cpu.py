@@ -403,3 +403,43 @@ def test_result_lines_from_concurrent_processes_do_not_interleave(tmp_path):
     assert [p.wait(timeout=120) for p in procs] == [0] * 4
     rows = [json.loads(l) for l in open(path)]                     # any torn line fails to parse
     assert len(rows) == 800 and sorted((r['p'], r['i']) for r in rows) == [(p, i) for p in range(4) for i in range(200)]
+
+
+def test_eight_ranks_label_the_full_training_split(tmp_path):
+    """BASELINE configs[3] as far as a box without GPUs can run it: cli.main_labelled on EIGHT gloo ranks over
+    n_data = 2975 (the Cityscapes train split; the files are links to one small image) with the reference batch size 30.
+    Every rank labels the range the reference launcher gives its GPU — step = 2975 // 8 + 1 = 372
+    (utils/create_random300_labels.sh:37-51) — the per-image records cross ranks in one all_gather and rank 0 writes
+    result.json in index order, the shifted-back last batch of every range included (batch_spalign_kmeans.py:538-544)."""
+    from PIL import Image
+    n, ws = 2975, 8
+    rs = np.random.RandomState(3)
+    src_i, src_l = tmp_path / 'src_img.png', tmp_path / 'src_lab.png'
+    Image.fromarray(rs.randint(0, 256, size=(16, 24, 3)).astype(np.uint8)).save(str(src_i))
+    Image.fromarray(rs.randint(0, 12, size=(16, 24)).astype(np.uint8)).save(str(src_l))
+    data = tmp_path / 'data'
+    data.mkdir()
+    imgs, labs = [], []
+    for i in range(n):
+        fn, ln = data / ('city_%06d_000019_leftImg8bit.png' % i), data / ('city_%06d_000019_gtFine_labelIds.png' % i)
+        os.symlink(str(src_i), str(fn)); os.symlink(str(src_l), str(ln))
+        imgs.append(str(fn)); labs.append(str(ln))
+    (tmp_path / 'imgs.txt').write_text('\n'.join(imgs) + '\n')
+    (tmp_path / 'labels.txt').write_text('\n'.join(labs) + '\n')
+    rcs, lines, out, err = _run_cli_ranks(tmp_path, ws, ['--batchsize', '30'], 29641)
+    assert rcs == [0] * ws, err
+    shards = [dist.shard_range(n, ws, r) for r in range(ws)]
+    assert shards == [(372 * r, min(372 * (r + 1), n)) for r in range(ws)] and shards[-1] == (2604, 2975)
+    expect = []
+    for s, e in shards:
+        for lo, hi in dist.batch_ranges(s, e, 30):
+            expect += list(range(lo, hi))
+    pos = {fn: i for i, fn in enumerate(imgs)}
+    idx = [pos[l['img_fn']] for l in lines]
+    assert idx == sorted(idx) and idx == sorted(expect) and set(idx) == set(range(n))
+    assert len(idx) > n                                            # 372 = 12 x 30 + 12: every range re-labels 18 images
+    owner = {i: r for r, (s, e) in enumerate(shards) for i in range(s, e)}
+    assert all(l['gpu'] == owner[pos[l['img_fn']]] for l in lines)
+    keys = set(lines[0])
+    assert all(set(l) == keys for l in lines)
+    assert len(list(out.glob('*_leftImg8bit.npy'))) == n
