@@ -9,6 +9,8 @@
 // Both are MT19937; what differs is seeding and how bounded integers are drawn.
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
+#include <atomic>
 #include <chrono>
 #include <stdio.h>
 #include <thread>
@@ -45,7 +47,8 @@ struct MT {
         idx = 624;
     }
     uint32_t out[624];
-    void refill()
+    void refill() { refill_to(out); idx = 0; }
+    void refill_to(uint32_t *dst)
     {
         // the classic three-segment regeneration (no modulo in the loops), then tempering of
         // the whole block: both loops vectorise
@@ -66,9 +69,8 @@ struct MT {
             t ^= (t << 7) & 0x9d2c5680u;
             t ^= (t << 15) & 0xefc60000u;
             t ^= (t >> 18);
-            out[i] = t;
+            dst[i] = t;
         }
-        idx = 0;
     }
     inline uint32_t next()
     {
@@ -78,7 +80,52 @@ struct MT {
 };
 }  // namespace
 
-struct spa_pyrandom { MT g; };
+static bool pyrandom_have_avx512();
+
+// The CPython stream as a ring of generated blocks filled by a background thread: MT19937's regeneration + tempering is as
+// much work per output as the rejection sampling that consumes it, and it does not depend on it — so it runs ahead (a 2 MB
+// ring: a larger one was measured memory bound, the outputs of a batch are 320 MB) and the consumer reads finished blocks.  Blocks are
+// (26 generator refills = 16 224 outputs, a multiple of the 16 lanes the vector consumer loads).
+struct spa_pyrandom {
+    MT g;
+    static const int BS = 624 * 26, NB = 32;            // 32 blocks of 63 KB = 2 MB: producer and consumer meet in the cache, not in DRAM
+    std::vector<uint32_t> ring;
+    std::atomic<uint64_t> produced{0}, consumed{0};    // blocks
+    std::atomic<bool> stop{false};
+    std::thread producer;
+    // consumer position inside block `consumed`
+    const uint32_t *cur = nullptr;
+    int avail = 0;
+    bool vec = false;
+    double waited = 0;                                  // seconds the consumer spent waiting for the producer (timing aid)
+    void fill_block(uint32_t *dst);
+    void run()
+    {
+        while (!stop.load(std::memory_order_relaxed)) {
+            const uint64_t p = produced.load(std::memory_order_relaxed);
+            if (p - consumed.load(std::memory_order_acquire) < (uint64_t)NB) {
+                fill_block(ring.data() + (size_t)(p % NB) * BS);
+                produced.store(p + 1, std::memory_order_release);
+            } else {
+                std::this_thread::sleep_for(std::chrono::microseconds(50));
+            }
+        }
+    }
+    // the consumer: make `cur` / `avail` describe unread outputs (waits for the producer when it has caught up)
+    inline void need()
+    {
+        if (avail > 0) return;
+        if (cur) consumed.fetch_add(1, std::memory_order_release);          // the block just finished is free again
+        const uint64_t c = consumed.load(std::memory_order_relaxed);
+        if (produced.load(std::memory_order_acquire) <= c) {
+            const auto t0 = std::chrono::steady_clock::now();
+            while (produced.load(std::memory_order_acquire) <= c) std::this_thread::yield();
+            waited += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        }
+        cur = ring.data() + (size_t)(c % NB) * BS;
+        avail = BS;
+    }
+};
 struct spa_nprandom { MT g; };
 
 extern "C" int spa_pyrandom_create(uint64_t seed, spa_pyrandom **out)
@@ -88,10 +135,19 @@ extern "C" int spa_pyrandom_create(uint64_t seed, spa_pyrandom **out)
     // random.seed(int): init_by_array over the 32-bit digits of abs(seed)
     uint32_t key[2] = {(uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32)};
     r->g.init_by_array(key, key[1] ? 2 : 1);
+    r->ring.resize((size_t)spa_pyrandom::BS * spa_pyrandom::NB);
+    r->vec = pyrandom_have_avx512();
+    r->producer = std::thread([r]() { r->run(); });
     *out = r;
     return SPA_OK;
 }
-extern "C" void spa_pyrandom_destroy(spa_pyrandom *r) { delete r; }
+extern "C" void spa_pyrandom_destroy(spa_pyrandom *r)
+{
+    if (!r) return;
+    r->stop.store(true);
+    if (r->producer.joinable()) r->producer.join();
+    delete r;
+}
 
 // Two phases so that only the generator itself is sequential:
 //   phase 1 (this thread, in stream order): the accepted draws j of every swap of every superpixel, stored in DRAW order —
@@ -191,7 +247,7 @@ static void replay_group(const int32_t *count, const int32_t *draws, const int64
 
 // ---- phase 1 ------------------------------------------------------------------------------------------------------
 // the draws of one shuffle of n elements, in draw order, into jd[0 .. n-2]
-static void draws_scalar(MT &g, int32_t n, int32_t *jd)
+static void draws_scalar(spa_pyrandom &q, int32_t n, int32_t *jd)
 {
     // randbelow(i + 1) for i = n-1 .. 1: top bit_length(i+1) bits of a 32-bit output, redrawn while >= i+1.  Branch-free over
     // the generator's output block: every candidate is stored at the current slot (a rejected one is overwritten by the next
@@ -203,9 +259,9 @@ static void draws_scalar(MT &g, int32_t n, int32_t *jd)
         const int32_t band_lo = (int32_t)(0x80000000u >> sh) - 1;  // bit_length(i + 1) stays k while i >= 2^(k-1) - 1
         const int32_t stop = band_lo > 1 ? band_lo : 1;
         while (i >= stop) {
-            if (g.idx >= 624) g.refill();
-            const uint32_t *o = g.out + g.idx;
-            const int avail = 624 - g.idx;
+            q.need();
+            const uint32_t *o = q.cur;
+            const int avail = q.avail;
             int used = 0;
             while (used < avail && i >= stop) {
                 const uint32_t v = o[used++] >> sh;
@@ -214,7 +270,7 @@ static void draws_scalar(MT &g, int32_t n, int32_t *jd)
                 w += acc;
                 i -= acc;
             }
-            g.idx += used;
+            q.cur += used; q.avail -= used;
         }
     }
 }
@@ -232,7 +288,7 @@ __attribute__((target("avx512f"))) static inline void twist16(uint32_t *mt, int 
     _mm512_storeu_si512((void *)(mt + k), r);
 }
 
-__attribute__((target("avx512f"))) static void refill_avx512(MT &g)
+__attribute__((target("avx512f"))) static void refill_avx512(MT &g, uint32_t *dst)
 {
     // the same three-segment regeneration and tempering, 16 lanes at a time (the segments' dependences are 227 and 397
     // elements apart; the read of mt[k + 1] precedes the write of mt[k .. k + 15] inside an iteration)
@@ -254,12 +310,11 @@ __attribute__((target("avx512f"))) static void refill_avx512(MT &g)
         t = _mm512_xor_si512(t, _mm512_and_si512(_mm512_slli_epi32(t, 7), m7));
         t = _mm512_xor_si512(t, _mm512_and_si512(_mm512_slli_epi32(t, 15), m15));
         t = _mm512_xor_si512(t, _mm512_srli_epi32(t, 18));
-        _mm512_storeu_si512((void *)(g.out + i), t);
+        _mm512_storeu_si512((void *)(dst + i), t);
     }
-    g.idx = 0;
 }
 
-__attribute__((target("avx512f,popcnt"))) static void draws_avx512(MT &g, int32_t n, int32_t *jd)
+__attribute__((target("avx512f,popcnt"))) static void draws_avx512(spa_pyrandom &q, int32_t n, int32_t *jd)
 {
     int32_t i = n - 1;
     int32_t *w = jd;
@@ -270,12 +325,12 @@ __attribute__((target("avx512f,popcnt"))) static void draws_avx512(MT &g, int32_
         const int32_t stop = band_lo > 1 ? band_lo : 1;
         const __m128i shc = _mm_cvtsi32_si128(sh);
         while (i >= stop) {
-            if (g.idx >= 624) refill_avx512(g);
+            q.need();
             // 16 outputs at a time while all 16 could be accepted inside the band.  Output k is accepted iff
             // v_k <= i - (accepted before k): surely when v_k <= i - k, surely not when v_k > i; a block with an output in
             // between (probability ~ 16 * 8 / 2^bits) is taken one output at a time
-            while (g.idx + 16 <= 624 && i - 16 >= stop) {
-                const __m512i v = _mm512_srl_epi32(_mm512_loadu_si512((const void *)(g.out + g.idx)), shc);
+            while (q.avail >= 16 && i - 16 >= stop) {
+                const __m512i v = _mm512_srl_epi32(_mm512_loadu_si512((const void *)q.cur), shc);
                 const __m512i iv = _mm512_set1_epi32(i);
                 const __mmask16 yes = _mm512_cmple_epu32_mask(v, _mm512_sub_epi32(iv, lane));
                 const __mmask16 no = _mm512_cmpgt_epu32_mask(v, iv);
@@ -284,11 +339,12 @@ __attribute__((target("avx512f,popcnt"))) static void draws_avx512(MT &g, int32_
                 // several x86 cores; the 16 lanes stored beyond the accepted ones are overwritten by the next block)
                 _mm512_storeu_si512((void *)w, _mm512_maskz_compress_epi32(yes, v));
                 const int c = __builtin_popcount((unsigned)yes);
-                w += c; i -= c; g.idx += 16;
+                w += c; i -= c; q.cur += 16; q.avail -= 16;
             }
             // one block's worth (or the band's / generator block's tail) output by output
-            const uint32_t *o = g.out + g.idx;
-            const int avail = 624 - g.idx < 16 ? 624 - g.idx : 16;
+            if (q.avail == 0) continue;
+            const uint32_t *o = q.cur;
+            const int avail = q.avail < 16 ? q.avail : 16;
             int used = 0;
             while (used < avail && i >= stop) {
                 const uint32_t v = o[used++] >> sh;
@@ -297,12 +353,24 @@ __attribute__((target("avx512f,popcnt"))) static void draws_avx512(MT &g, int32_
                 w += acc;
                 i -= acc;
             }
-            g.idx += used;
+            q.cur += used; q.avail -= used;
         }
     }
 }
 #endif
 }  // namespace
+
+static bool pyrandom_have_avx512() { return have_avx512(); }
+
+void spa_pyrandom::fill_block(uint32_t *dst)
+{
+    for (int k = 0; k < BS / 624; ++k, dst += 624) {
+#ifdef SPA_RNG_X86
+        if (vec) refill_avx512(g, dst); else
+#endif
+            g.refill_to(dst);
+    }
+}
 
 extern "C" int spa_pyrandom_shuffle_select_host(spa_pyrandom *r, const int32_t *count, int32_t N,
                                                 int32_t A, int32_t *ranks, int32_t *n_valid)
@@ -311,7 +379,7 @@ extern "C" int spa_pyrandom_shuffle_select_host(spa_pyrandom *r, const int32_t *
     unsigned hw = std::thread::hardware_concurrency();
     int nthreads = hw >= 16 ? 8 : (hw >= 4 ? (int)hw / 2 : 1);
     if (getenv("SPA_RNG_THREADS")) nthreads = atoi(getenv("SPA_RNG_THREADS")) > 0 ? atoi(getenv("SPA_RNG_THREADS")) : 1;
-    const int64_t group_draws = 2 << 20;
+    const int64_t group_draws = getenv("SPA_RNG_GROUP") ? atoll(getenv("SPA_RNG_GROUP")) : (512 << 10);      // 2 MB of draws per group: L2-sized
     const bool vec = have_avx512();
     std::vector<int32_t> buf[2];
     std::vector<int64_t> doff[2];
@@ -343,9 +411,9 @@ extern "C" int spa_pyrandom_shuffle_select_host(spa_pyrandom *r, const int32_t *
             if (n <= 1) continue;                               // (a list of one element: no draw; its rank 0 is already there)
             int32_t *jd = d.data() + off[t - s];
 #ifdef SPA_RNG_X86
-            if (vec) { draws_avx512(r->g, n, jd); continue; }
+            if (vec) { draws_avx512(*r, n, jd); continue; }
 #endif
-            draws_scalar(r->g, n, jd);
+            draws_scalar(*r, n, jd);
         }
         // ---- phase 2 of the previous group must be done before its buffers are reused next time
         const double t1 = timing ? now() : 0;
@@ -365,8 +433,11 @@ extern "C" int spa_pyrandom_shuffle_select_host(spa_pyrandom *r, const int32_t *
     }
     const double t2 = timing ? now() : 0;
     for (auto &w : workers) w.join();
-    if (timing) fprintf(stderr, "shuffle_select: draws %.1f ms, waiting for the traces %.1f ms (+ %.1f at the end), %d trace threads\n",
-                        t_draw * 1e3, t_join * 1e3, (now() - t2) * 1e3, nthreads);
+    if (timing) {
+        fprintf(stderr, "shuffle_select: draws %.1f ms (of which %.1f waiting for the generator thread), waiting for the traces %.1f ms "
+                "(+ %.1f at the end), %d trace threads\n", t_draw * 1e3, r->waited * 1e3, t_join * 1e3, (now() - t2) * 1e3, nthreads);
+        r->waited = 0;
+    }
     return SPA_OK;
 }
 
