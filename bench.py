@@ -156,8 +156,12 @@ def algorithmic_bytes(kernel, B, H, W, C, fh, fw, n_seg, feat_bytes):
     px = H * W
     per_image = {
         'k_rgb2lab': px * (12 + 12),                      # f32 RGB in, f32 Lab out
-        'k_slic_assign': px * (12 + 4),                   # Lab in, i32 label out (centres on chip)
-        'k_slic_update': px * (4 + 12),                   # labels + Lab of every pixel once
+        # SURVEY.md 8d prices a SLIC iteration at 16 B/pixel (Lab in, label out, centre sums on chip).  This build needs a
+        # second pass per iteration for scikit-image's raster-order float32 sums (a serial chain per segment: no tile-partial
+        # sums reproduce its bits), so an iteration is two launches: the 16 bytes are split between them, 8 each, and the two
+        # fractions ADD UP to the iteration's share of the roofline instead of each claiming the whole budget
+        'k_slic_assign': px * 8,
+        'k_slic_update': px * 8,
         'connectivity(all)': px * (4 + 4),
         'segment_stats(all)': px * 4,
         'k_cell_weights': px * 4,
@@ -517,6 +521,8 @@ def main():
             fl, nl, by = E['winof_flops'], max(1, E['winof_launches']), E['winof_bytes']
             tf = fl / a.steps / (ms / a.steps * 1e-3) / 1e12
             gbs = by / a.steps / (ms / a.steps * 1e-3) / 1e9
+            # (the launch also streams the layer's transforms: hbm_frac is that side; the matrix side is the roofline entry, as for
+            # every other convolution of the DRN — SURVEY.md 8d)
             ent.update(bound='mfma', achieved=round(3 * tf, 1), peak=BF16_MATRIX_PEAK_TF, unit='TFLOP/s',
                        frac=round(3 * tf / BF16_MATRIX_PEAK_TF, 4), float32_equivalent_tflops=round(tf, 1),
                        flops_per_step=3 * fl / a.steps, flops_per_launch=3 * fl / nl,

@@ -51,7 +51,7 @@ struct WfParams {
     long long Tpad;
     const unsigned *amax_in; unsigned *amax_out;
     const unsigned *items;        // [0..8]: offsets of the 8 lists (in items, relative to items + 16), then the lists
-    unsigned *sync;               // [0..7] heads, [16..51] the 36 scale constants (float), [64 ..] in_cnt[NRB], then mm_cnt[NRB * NCB]
+    unsigned *sync;               // [0..7] heads, [8] abort word, [16..51] the 36 scale constants (float), [64 ..] in_cnt[NRB], then mm_cnt[NRB * NCB]
     int NRB;
     uint32_t *status;
     int vec2;                     // bit 0: input transform on 2 channels per lane, bit 1: output transform (else 4)
@@ -97,14 +97,22 @@ __device__ __forceinline__ float4 wf_ld_nt(const float *base, unsigned off) { re
 __device__ __forceinline__ void wf_st(float *base, unsigned off, float4 v) { wf_st((float *)((char *)base + off), v); }
 __device__ __forceinline__ unsigned wf_ld_u32(const unsigned *q) { return *WF_G(const unsigned, q); }
 
-// lane 0 of the workgroup: wait until *cnt >= want (sc1 poll), bounded
-__device__ __forceinline__ void wf_wait(const unsigned *cnt, unsigned want, uint32_t *status, unsigned long long *dbg, int slot)
+// lane 0 of the workgroup: wait until *cnt >= want (sc1 poll).  Bounded: ~0.3 s without progress latches SPA_ST_WINO_SYNC and
+// raises the launch's abort word (sync[8]), which ends every other wait at once — a broken launch returns in well under a
+// second with the status bit set instead of timing its waits out one after the other
+__device__ __forceinline__ void wf_wait(const unsigned *cnt, unsigned want, uint32_t *status, unsigned long long *dbg, int slot,
+                                        unsigned *abort_word)
 {
     unsigned spins = 0;
     const unsigned long long c0 = dbg ? wall_clock64() : 0ull;
     while (__hip_atomic_load(WF_G(const unsigned, cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
         __builtin_amdgcn_s_sleep(8);
-        if (++spins > (1u << 21)) { __hip_atomic_fetch_or(WF_G(uint32_t, status), SPA_ST_WINO_SYNC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        if ((++spins & 63u) == 0u && __hip_atomic_load(WF_G(const unsigned, abort_word), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        if (spins > (1u << 18)) {
+            __hip_atomic_fetch_or(WF_G(uint32_t, status), SPA_ST_WINO_SYNC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(WF_G(unsigned, abort_word), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
     }
     if (dbg) atomicAdd(&dbg[slot], wall_clock64() - c0);
 }
@@ -331,7 +339,7 @@ __device__ __noinline__ unsigned wf_run_mm(const WfParams &pr, unsigned it_arg)
 
     // the first tile of the run: wait for its input (blocking), acquire, stage
     if (wave == 0) {
-        if (lane == 0) wf_wait(&in_cnt[it >> 10], (unsigned)p.PI, p.status, pr.dbg, 8);
+        if (lane == 0) wf_wait(&in_cnt[it >> 10], (unsigned)p.PI, p.status, pr.dbg, 8, p.sync + 8);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -483,7 +491,7 @@ __device__ __noinline__ void wf_item_out(const WfParams &pr, int rb, int cb, int
     for (int i = 0; i < 36; ++i) csv[i] = *(const __attribute__((address_space(4))) float *)(p.cs + i);
     // ---------------- output transform of tiles [t0, t1) of (rb, cb): one lane = one tile x VN output channels
     if (wave == 0) {
-        if (lane == 0) wf_wait(&mm_cnt[rb * p.NCB + cb], 36u, p.status, pr.dbg, 9);
+        if (lane == 0) wf_wait(&mm_cnt[rb * p.NCB + cb], 36u, p.status, pr.dbg, 9, p.sync + 8);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
