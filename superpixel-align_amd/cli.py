@@ -699,6 +699,23 @@ def main_labelled(argv=None, get=None, make_pipe=None, originals=False, make_mod
                 return m.index_select(1, ys).index_select(2, xs)
 
             def finalize(st):
+                res = st['res']
+                road_d, cl_d, conf_d = st.pop('dev')
+                st['computed'].synchronize()
+                with torch.cuda.stream(d2h):
+                    st.update(road_h=torch.empty(road_d.shape, dtype=torch.uint8, pin_memory=True),
+                              cl_h=torch.empty(cl_d.shape, dtype=torch.uint8, pin_memory=True),
+                              info_h=torch.empty(res.info.shape, dtype=res.info.dtype, pin_memory=True),
+                              nsp_h=torch.empty(res.n_labels.shape, dtype=res.n_labels.dtype, pin_memory=True),
+                              conf_h=None if conf_d is None else torch.empty(conf_d.shape, dtype=conf_d.dtype, pin_memory=True),
+                              fail_h=None if res.retry_fail is None else torch.empty(res.retry_fail.shape, dtype=torch.bool, pin_memory=True))
+                    for h, d in ((st['road_h'], road_d), (st['cl_h'], cl_d), (st['info_h'], res.info),
+                                 (st['nsp_h'], res.n_labels), (st['conf_h'], conf_d), (st['fail_h'], res.retry_fail)):
+                        if h is not None:
+                            h.copy_(d, non_blocking=True)
+                            d.record_stream(d2h)
+                    st['done'] = torch.cuda.Event()
+                    st['done'].record(d2h)
                 st['done'].synchronize()
                 eng.raise_on_word(st['status_h'])
                 if st['fail_h'] is not None:
@@ -706,7 +723,7 @@ def main_labelled(argv=None, get=None, make_pipe=None, originals=False, make_mod
                 times = pipe.elapsed_times(st['events'])
                 # `elapsed_time` stays what the reference reports (:420: wall clock since the batch was started, which in this
                 # loop includes the batches in flight ahead of it); the batch's own device time goes under its own key
-                times['time_device'] = st['events']['start'].elapsed_time(st['done']) / 1000.0
+                times['time_device'] = st['events']['start'].elapsed_time(st['computed']) / 1000.0
                 info, n_sp = st['info_h'].numpy(), st['nsp_h'].numpy()
                 conf = st['conf_h'].numpy() if st['conf_h'] is not None else None
                 # a re-labelled image (last batch shifted back, :539-542) must overwrite its earlier files:
@@ -741,25 +758,13 @@ def main_labelled(argv=None, get=None, make_pipe=None, originals=False, make_mod
                     gtm = torch.where(gt_dev <= 6, -1, torch.where(gt_dev == 7, 1, 0)).to(torch.int32)   # :279-296
                     conf_d = eng.confusion(road_d.contiguous(), gtm)
                 status_h = eng.status_take_async()          # this batch's bits (copy, then clear, in stream order)
-                computed = torch.cuda.Event()
+                computed = torch.cuda.Event(enable_timing=True)
                 computed.record(main)
-                with torch.cuda.stream(d2h):
-                    d2h.wait_event(computed)
-                    st = dict(idx=list(range(len(imgs_ds)))[lo:hi], res=res, events=events, gts=gts, st_all=st_all,
-                              status_h=status_h,
-                              road_h=torch.empty(road_d.shape, dtype=torch.uint8, pin_memory=True),
-                              cl_h=torch.empty(cl_d.shape, dtype=torch.uint8, pin_memory=True),
-                              info_h=torch.empty(res.info.shape, dtype=res.info.dtype, pin_memory=True),
-                              nsp_h=torch.empty(res.n_labels.shape, dtype=res.n_labels.dtype, pin_memory=True),
-                              conf_h=None if conf_d is None else torch.empty(conf_d.shape, dtype=conf_d.dtype, pin_memory=True),
-                              fail_h=None if res.retry_fail is None else torch.empty(res.retry_fail.shape, dtype=torch.bool, pin_memory=True))
-                    for h, d in ((st['road_h'], road_d), (st['cl_h'], cl_d), (st['info_h'], res.info),
-                                 (st['nsp_h'], res.n_labels), (st['conf_h'], conf_d), (st['fail_h'], res.retry_fail)):
-                        if h is not None:
-                            h.copy_(d, non_blocking=True)
-                            d.record_stream(d2h)
-                    st['done'] = torch.cuda.Event(enable_timing=True)
-                    st['done'].record(d2h)
+                # the downloads are enqueued by finalize(), once the batch HAS been computed (the host waits, the copy stream does
+                # not): a copy queue whose head is a barrier waiting a batch's time for the compute stream slows every dispatch of
+                # that batch (measured: 82 -> 77.6 ms per batch of 30 in pipeline.HostStream, tools/h2h_probe2.py)
+                st = dict(idx=list(range(len(imgs_ds)))[lo:hi], res=res, events=events, gts=gts, st_all=st_all,
+                          status_h=status_h, computed=computed, dev=(road_d, cl_d, conf_d))
                 t_enq = time.time()
                 if prev is not None:
                     finalize(prev)
@@ -768,7 +773,7 @@ def main_labelled(argv=None, get=None, make_pipe=None, originals=False, make_mod
                               'done(prev)->start %.1f ms, device batch(prev) %.1f ms'
                               % (bi, (t_loaded - st_all) * 1e3, (t_enq - t_loaded) * 1e3, (time.time() - t_enq) * 1e3,
                                  prev['done'].elapsed_time(events['start']) if False else -1.0,
-                                 prev['events']['start'].elapsed_time(prev['done'])), file=sys.stderr)
+                                 prev['events']['start'].elapsed_time(prev['computed'])), file=sys.stderr)
                 prev = st
             if prev is not None:
                 finalize(prev)

@@ -76,6 +76,8 @@ class LabelPipeline(object):
         # their state carries over from batch to batch
         self.pyrandom = PyRandom(getattr(args, 'seed', 1111))
         self.nprandom = NpRandom(getattr(args, 'seed', 1111))
+        if os.environ.get('SPA_PIPE_OVERLAP') in ('0', '1'):
+            overlap = os.environ['SPA_PIPE_OVERLAP'] == '1'
         self.aux = torch.cuda.Stream(device=self.eng.device) if overlap else None
         self._ev = {}
         # anchor mode, device_rng: the CPython `random` stream lives on the device (seeded like the reference's
@@ -320,6 +322,7 @@ class HostStream(object):
         of cli.py hand over): 3 bytes per pixel cross PCIe instead of 12, and the planar float32 batch the kernels
         take is made on the device (spa_resize_bicubic_u8 at unchanged size = layout and type change only)."""
         self.pipe, self.after, self.u8_hwc = pipe, after, bool(u8_hwc)
+        self.late_download = os.environ.get('SPA_LATE_DOWNLOAD', '1') != '0'
         self.upload_after = os.environ.get('SPA_UPLOAD_AFTER', '') or None      # a pipe._ev key to delay the next upload to; default: at once
         dev = pipe.eng.device
         self.dev = dev
@@ -364,6 +367,17 @@ class HostStream(object):
             self.up_done[slot].record(self.h2d)
         return t.shape[0]
 
+    def _download(self, slot, res, n, after):
+        with torch.cuda.stream(self.d2h):
+            if after is not None:
+                self.d2h.wait_event(after)
+            oc, orr = self.out[slot]
+            oc[:n].copy_(res.cluster, non_blocking=True)
+            orr[:n].copy_(res.road, non_blocking=True)
+            res.cluster.record_stream(self.d2h)
+            res.road.record_stream(self.d2h)
+            self.down_done[slot].record(self.d2h)
+
     def process(self, batches):
         main = torch.cuda.current_stream(self.dev)
         it = iter(batches)
@@ -394,20 +408,23 @@ class HostStream(object):
                 nb = self._upload(slot ^ 1, nxt, after=self.pipe._ev.get(self.upload_after) if self.upload_after else None)
             done = torch.cuda.Event()
             done.record(main)
-            with torch.cuda.stream(self.d2h):
-                self.d2h.wait_event(done)
-                oc, orr = self.out[slot]
-                oc[:cur_n].copy_(res.cluster, non_blocking=True)
-                orr[:cur_n].copy_(res.road, non_blocking=True)
-                res.cluster.record_stream(self.d2h)
-                res.road.record_stream(self.d2h)
-                self.down_done[slot].record(self.d2h)
+            if not self.late_download:
+                self._download(slot, res, cur_n, done)
             if prev is not None:
-                pslot, pres, pn = prev
+                pslot, pres, pn, pdone = prev
+                if self.late_download:
+                    # the download is enqueued only once the batch HAS finished (the host waits, the copy stream does not):
+                    # a copy queue whose head is a barrier waiting ~a batch's time for the compute stream was measured to
+                    # slow every dispatch of that batch (tools/h2h_probe2.py)
+                    pdone.synchronize()
+                    self._download(pslot, pres, pn, None)
                 self.down_done[pslot].synchronize()
                 yield self.out[pslot][0][:pn].numpy(), self.out[pslot][1][:pn].numpy(), pres
-            prev = (slot, res, cur_n)
+            prev = (slot, res, cur_n, done)
             s += 1
-        pslot, pres, pn = prev
+        pslot, pres, pn, pdone = prev
+        if self.late_download:
+            pdone.synchronize()
+            self._download(pslot, pres, pn, None)
         self.down_done[pslot].synchronize()
         yield self.out[pslot][0][:pn].numpy(), self.out[pslot][1][:pn].numpy(), pres
