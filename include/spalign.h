@@ -221,6 +221,24 @@ int spa_drn_stem_d_amax(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int3
                         const float *w0, const float *b0, const float *w1, const float *b1,
                         const double *mean3_host, const double *std3_host, float *y,
                         float *xn_scratch, void *amax_out, void *stream);
+/* DRN-C's stem (models/drn.py:134-170, 230-237): spa_drn_stem_d_amax that also stores layer0's output y0 (B,H,W,16) — the
+ * residual of layer1's BasicBlock, whose first convolution is the kernel's second stage. */
+int spa_drn_stem_c_amax(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W,
+                        const float *w0, const float *b0, const float *w1, const float *b1,
+                        const double *mean3_host, const double *std3_host, float *y, float *y0,
+                        float *xn_scratch, void *amax_out, void *stream);
+/* the thin 3x3 convolutions at the top of DRN-C (layer1's second convolution 16 -> 16, layer2's BasicBlock 16 -> 32 stride 2
+ * with its 1x1 stride-2 projection, 32 -> 32) on the 16-bit matrix cores at float32 accuracy (csrc/spa_convs.hip):
+ * x (B,H,W,Cin) float32 channels-last, Cin 16 or 32 -> y (B,Ho,Wo,Cout) = relu?(conv3x3(x; stride, padding 1) + bias [+ residual]),
+ * Cout 16 or 32, stride 1 or 2, Ho = (H + stride - 1) / stride.  n_proj 0 or 32 (stride 2, Cin 16, Cout 32): the block's 1x1
+ * stride-2 projection as y2 (B,Ho,Wo,32) = its convolution + bias[Cout ..], no ReLU — one pass over x, two outputs.
+ * wp: the A fragments of the two planes of t * w, [Cout/16][2 planes][steps][64 lanes] x 8 half-precision numbers (steps = 5 of
+ * two taps x 16 channels, or 9 of one tap x 32 channels), then [n_proj/16][2][64] x 8 for the projection (Engine.small_planes);
+ * inv_t = 1 / t; bias Cout + n_proj floats; amax_in / amax_out as in spa_conv3x3_wino4_f16s (amax_out tracks y). */
+int spa_conv_small_f16s(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W, int32_t Cin, const void *wp,
+                        float inv_t, int32_t Cout, int32_t stride, int32_t n_proj, const float *bias,
+                        const float *residual, int32_t relu, const void *amax_in, void *amax_out, float *y, float *y2,
+                        void *stream);
 int spa_drn_layer2_f16s(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W, const void *wp, float inv_t,
                         const float *bias, const void *amax_in, void *amax_out, float *y, void *stream);
 

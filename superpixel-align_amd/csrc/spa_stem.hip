@@ -426,8 +426,11 @@ __device__ __forceinline__ float stem_f16_val(unsigned short b) { return (float)
 __global__ __launch_bounds__(256, 2) void k_drn_stem_d_f16x3(const float *__restrict__ xn, int B, int H, int W,   // normalised, (B,H,W,3)
                                                              const unsigned short *__restrict__ wp,
                                                              const float *__restrict__ b0, const float *__restrict__ b1,
-                                                             float *__restrict__ y, unsigned *__restrict__ amax_out)
+                                                             float *__restrict__ y, unsigned *__restrict__ amax_out,
+                                                             float *__restrict__ y0)
 {
+    // y0 (DRN-C, models/drn.py:134-170): layer0's output relu(conv7x7 + bias) as a tensor of its own — the residual of the
+    // BasicBlock whose first convolution is this kernel's second stage
     __shared__ __attribute__((aligned(16))) unsigned short in_h[2][SB_COPY], in_l[2][SB_COPY];
     unsigned amx = 0;                            // largest value stored (the scale of the layer that reads y)
     __shared__ __attribute__((aligned(16))) unsigned short l0_s[ST_LP * SH_L0_PITCH + 64];
@@ -542,6 +545,9 @@ __global__ __launch_bounds__(256, 2) void k_drn_stem_d_f16x3(const float *__rest
                     vh[j] = stem_f16_bits(r);
                     vl[j] = stem_f16_bits(r - stem_f16_val(vh[j]));
                 }
+                if (y0 && in && py >= 1 && py <= ST_TH && px >= 1 && px <= ST_TW)       // the tile's own pixels (not its halo)
+                    *(float4 *)(y0 + ((((long long)b * H + gy) * W + gx) * 16 + 4 * g)) =
+                        make_float4(fmaxf(v[0], 0.0f), fmaxf(v[1], 0.0f), fmaxf(v[2], 0.0f), fmaxf(v[3], 0.0f));
                 unsigned short *o = l0_s + q0 * SH_L0_PITCH + 4 * g;
                 *(uint2 *)o = make_uint2((unsigned)vh[0] | ((unsigned)vh[1] << 16), (unsigned)vh[2] | ((unsigned)vh[3] << 16));
                 *(uint2 *)(o + 16) = make_uint2((unsigned)vl[0] | ((unsigned)vl[1] << 16), (unsigned)vl[2] | ((unsigned)vl[3] << 16));
@@ -802,7 +808,7 @@ __global__ void k_stem_pack_bf16(const float *__restrict__ w0, const float *__re
 static int stem_impl(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W,
                      const float *w0, const float *b0, const float *w1, const float *b1,
                      const double *mean3_host, const double *std3_host, void *y, int32_t out_dtype,
-                     float *xn_scratch, void *amax_out, void *stream);
+                     float *xn_scratch, void *amax_out, void *stream, float *y0 = nullptr);
 
 extern "C" int spa_drn_stem_d(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W,
                               const float *w0, const float *b0, const float *w1, const float *b1,
@@ -823,12 +829,24 @@ extern "C" int spa_drn_stem_d_amax(spa_ctx *ctx, const float *x, int32_t B, int3
     return stem_impl(ctx, x, B, H, W, w0, b0, w1, b1, mean3_host, std3_host, y, 2, xn_scratch, amax_out, stream);
 }
 
+// the same for DRN-C (models/drn.py:134-170, 230-237): conv1 + bn1 + relu (= layer0) and the first convolution of layer1's
+// BasicBlock (+ bn + relu) in one pass; y0 (B,H,W,16) also receives layer0's output, the block's residual
+extern "C" int spa_drn_stem_c_amax(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W,
+                                   const float *w0, const float *b0, const float *w1, const float *b1,
+                                   const double *mean3_host, const double *std3_host, float *y, float *y0,
+                                   float *xn_scratch, void *amax_out, void *stream)
+{
+    SPA_ARG(amax_out && y0 && ((uintptr_t)y0 & 15) == 0);
+    return stem_impl(ctx, x, B, H, W, w0, b0, w1, b1, mean3_host, std3_host, y, 2, xn_scratch, amax_out, stream, y0);
+}
+
 static int stem_impl(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W,
                      const float *w0, const float *b0, const float *w1, const float *b1,
                      const double *mean3_host, const double *std3_host, void *y, int32_t out_dtype,
-                     float *xn_scratch, void *amax_out, void *stream)
+                     float *xn_scratch, void *amax_out, void *stream, float *y0)
 {
     SPA_ARG(ctx && x && w0 && b0 && w1 && b1 && mean3_host && std3_host && y && B > 0 && H > 0 && W > 0);
+    SPA_ARG(!y0 || out_dtype == 2);
     SPA_ARG(out_dtype == 0 || out_dtype == 1 || out_dtype == 2);      // 2: float32 output, 16-bit matrix cores (two planes)
     // exact input normalisation (models/drn.py:319-321) into a channels-last workspace, then the stem
     SpaProfScope prof_(ctx, PROF_DRN_STEM, spa_stream(stream));
@@ -866,7 +884,7 @@ static int stem_impl(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t
         long long g2 = 2ll * ctx->n_cu;                    // two resident workgroups per CU (78 KB of LDS)
         if (g2 > n_tiles) g2 = n_tiles;
         hipLaunchKernelGGL(k_drn_stem_d_f16x3, dim3((unsigned)g2), dim3(256), 0, spa_stream(stream), (const float *)xn, B, H, W,
-                           (const unsigned short *)wp, b0, b1, (float *)y, (unsigned *)amax_out);
+                           (const unsigned short *)wp, b0, b1, (float *)y, (unsigned *)amax_out, y0);
         SPA_LAUNCH_CHECK();
         return SPA_OK;
     }

@@ -391,6 +391,24 @@ class DRN(nn.Module):
                         w[co:, 4] = ds[0].weight.detach().float().reshape(co, ci)
                         wt2, inv_t = Engine.split_planes(w)
                         blk._spa_s2 = (wt2, inv_t, torch.cat([c1.bias.detach().float(), ds[0].bias.detach().float()]).contiguous(), co)
+            self._front_c = None
+            if self.arch == 'C' and self.folded and dtype == torch.float32:
+                # DRN-C's full-resolution front on libspalign's own kernels (csrc/spa_stem.hip, spa_convs.hip): conv1 + layer1's first
+                # convolution as the fused stem (which also stores conv1's output, the block's residual), layer1's second convolution,
+                # layer2's stride-2 opener together with its 1x1 projection, layer2's second convolution
+                c0, b1, b2 = self.conv1, self.layer1[0], self.layer2[0]
+                ok = (len(self.layer1) == 1 and len(self.layer2) == 1 and b1.residual and b1.downsample is None and b2.residual
+                      and b2.downsample is not None and b2.conv1.stride == (2, 2) and b2.downsample[0].stride == (2, 2)
+                      and all(c.bias is not None for c in (c0, b1.conv1, b1.conv2, b2.conv1, b2.conv2, b2.downsample[0])))
+                if ok:
+                    f32 = lambda t: t.detach().float().contiguous()
+                    self._front_c = dict(
+                        stem=(f32(c0.weight).reshape(16, 147).contiguous(), f32(c0.bias),
+                              f32(b1.conv1.weight).permute(0, 2, 3, 1).reshape(16, 144).contiguous(), f32(b1.conv1.bias)),
+                        l1c2=Engine.small_planes(b1.conv2.weight) + (f32(b1.conv2.bias),),
+                        l2c1=Engine.small_planes(b2.conv1.weight, b2.downsample[0].weight)
+                        + (torch.cat([f32(b2.conv1.bias), f32(b2.downsample[0].bias)]).contiguous(),),
+                        l2c2=Engine.small_planes(b2.conv2.weight) + (f32(b2.conv2.bias),))
             if self.arch == 'D' and self.folded and dtype in (torch.float32, torch.bfloat16):
                 # operands of libspalign's fused stem kernel (normalise + layer0 + layer1)
                 c0, c1 = self.layer0[0], self.layer1[0]
@@ -401,9 +419,9 @@ class DRN(nn.Module):
         return self
 
     # -- forward ---------------------------------------------------------------------------------
-    def forward_maps(self, x, layer1_out=None):
-        """x: normalised (B,3,H,W) (or None with `layer1_out`, the fused stem's output).
-        Returns the 8 maps of the Chainer convention."""
+    def forward_maps(self, x, layer1_out=None, front_maps=None):
+        """x: normalised (B,3,H,W) (or None with `layer1_out`, the fused stem's output, or `front_maps`, the outputs of the
+        first len(front_maps) layers computed by libspalign's front kernels).  Returns the 8 maps of the Chainer convention."""
         def plain(seq, t):
             mods = list(seq.children())            # (conv, bn | Identity, relu) triples
             for i in range(0, len(mods), 3):
@@ -412,7 +430,11 @@ class DRN(nn.Module):
 
         first = 1
         maps = []
-        if layer1_out is not None:             # the fused stem already produced layer1's output
+        if front_maps is not None:
+            maps = list(front_maps)
+            x = maps[-1]
+            first = len(maps) + 1
+        elif layer1_out is not None:           # the fused stem already produced layer1's output
             x = layer1_out
             maps.append(x)
             first = 2
@@ -443,6 +465,21 @@ class DRN(nn.Module):
     def _forward_chunk(self, xc):
         """One sub-batch: raw (b,3,H,W) float32 0..255 -> the 8 maps."""
         eng = _EPILOGUE['engine']
+        fc = getattr(self, '_front_c', None)
+        if (eng is not None and xc.is_cuda and fc is not None and self.use_fused_stem and _EPILOGUE['split_gemm']
+                and _EPILOGUE['own_conv32'] and self.compute_dtype == torch.float32):
+            # DRN-C: conv1 .. layer2 on libspalign's kernels (no MIOpen convolution, no separate epilogue pass)
+            E = _EPILOGUE
+            B, _, H, W = xc.shape
+            a1, y0 = eng.drn_stem_d(xc.float().contiguous(), *fc['stem'], dtype=torch.float32, split=True, want_layer0=True)
+            l1, _ = eng.conv_small_f16s(a1, fc['l1c2'][0], fc['l1c2'][1], fc['l1c2'][2], 16, 1, 0, y0, True, amax_in=a1._spa_amax)
+            a2, proj = eng.conv_small_f16s(l1, fc['l2c1'][0], fc['l2c1'][1], fc['l2c1'][2], 32, 2, 32, None, True, amax_in=l1._spa_amax)
+            l2, _ = eng.conv_small_f16s(a2, fc['l2c2'][0], fc['l2c2'][1], fc['l2c2'][2], 32, 1, 0, proj, True, amax_in=a2._spa_amax)
+            Ho, Wo = a2.shape[2], a2.shape[3]
+            E['conv16_flops'] += 2.0 * B * (H * W * 16 * 9 * 16 + Ho * Wo * (32 * 9 * 16 + 32 * 16 + 32 * 9 * 32))
+            E['conv16_bytes'] += 4.0 * B * (H * W * (16 + 16 + 16) + H * W * 16 + Ho * Wo * (32 + 32) + Ho * Wo * (32 + 32 + 32))
+            E['conv16_launches'] += 3
+            return self.forward_maps(None, front_maps=[l1, l2])
         if eng is not None and xc.is_cuda and getattr(self, '_stem', None) is not None and self.use_fused_stem:
             l1 = eng.drn_stem_d(xc.float().contiguous(), *self._stem, dtype=self.compute_dtype,
                                 split=_EPILOGUE['split_gemm'] and self.compute_dtype == torch.float32)

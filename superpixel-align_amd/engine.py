@@ -123,7 +123,7 @@ class Engine(object):
                                           0 if dtype == torch.float32 else 1, mean, std, self._s()))
         return out
 
-    def drn_stem_d(self, x, w0, b0, w1p, b1, dtype=torch.float32, split=False):
+    def drn_stem_d(self, x, w0, b0, w1p, b1, dtype=torch.float32, split=False, want_layer0=False):
         """DRN-D stem in one kernel: raw (B,3,H,W) float32 0..255 -> layer1 output (B,16,H,W) of
         `dtype` (float32 arithmetic) in channels-last storage.  w0 (16,147), w1p (16,144) in
         (n, ky, kx, c) order.  split (float32 only): the 16-bit matrix cores with two half-precision planes per operand
@@ -142,6 +142,13 @@ class Engine(object):
         scratch = torch.empty((B, H, W, 3), dtype=dtype, device=x.device)
         if split and dtype == torch.float32:
             am = torch.empty(1, dtype=torch.int32, device=x.device)      # the largest value stored: layer 2's scale
+            if want_layer0:
+                # DRN-C: layer0's output as well (the residual of layer1's BasicBlock)
+                out0 = torch.empty((B, 16, H, W), dtype=dtype, device=x.device, memory_format=torch.channels_last)
+                check(self._lib.spa_drn_stem_c_amax(self._ctx, _ptr(x), B, H, W, _ptr(w0), _ptr(b0), _ptr(w1p), _ptr(b1),
+                                                    mean, std, _ptr(out), _ptr(out0), _ptr(scratch), _ptr(am), self._s()))
+                out._spa_amax = am
+                return out, out0
             check(self._lib.spa_drn_stem_d_amax(self._ctx, _ptr(x), B, H, W, _ptr(w0), _ptr(b0), _ptr(w1p), _ptr(b1),
                                                 mean, std, _ptr(out), _ptr(scratch), _ptr(am), self._s()))
             out._spa_amax = am
@@ -189,6 +196,65 @@ class Engine(object):
                                             _ptr(am), _ptr(y), self._s()))
         y._spa_amax = am
         return y
+
+    @staticmethod
+    def small_planes(weight, proj_weight=None):
+        """(Cout,Cin,3,3) [+ the block's 1x1 projection (Cp,Cin,1,1)] -> (wp, inv_t) for conv_small_f16s: the MFMA A fragments of
+        the two half-precision planes of t * w.  Main tiles [Cout/16][2 planes][steps][64 lanes][8]: lane = (channel n = lane & 15
+        of the tile, k group g = lane >> 4); Cin 16: 5 steps, k group (s, g) = tap 2s + g // 2 (tap 9: zero pad), input channels
+        8 (g & 1) .. + 7; Cin 32: 9 steps, k group (s, g) = tap s, channels 8 g .. + 7.  Projection tiles [Cp/16][2][64][8]: the
+        fragment of the step holding the centre tap (csrc/spa_convs.hip)."""
+        Cout, Cin = int(weight.shape[0]), int(weight.shape[1])
+        assert tuple(weight.shape[2:]) == (3, 3) and Cin in (16, 32) and Cout % 16 == 0
+        w = weight.detach().float()
+        amax = float(w.abs().max())
+        if proj_weight is not None:
+            assert tuple(proj_weight.shape[1:]) == (Cin, 1, 1) and proj_weight.shape[0] % 16 == 0 and Cin == 16
+            amax = max(amax, float(proj_weight.detach().float().abs().max()))
+        t = 2.0 ** (14 - int(np.floor(np.log2(max(amax, 1e-30)))))
+        ws = (w.double() * t).float().reshape(Cout, Cin, 9)
+        steps = 5 if Cin == 16 else 9
+        frag = torch.zeros((Cout // 16, steps, 64, 8), dtype=torch.float32, device=w.device)
+        for s_ in range(steps):
+            for g in range(4):
+                tap, c0 = (2 * s_ + g // 2, 8 * (g & 1)) if Cin == 16 else (s_, 8 * g)
+                if tap > 8:
+                    continue
+                for ct in range(Cout // 16):
+                    frag[ct, s_, g * 16:(g + 1) * 16, :] = ws[ct * 16:(ct + 1) * 16, c0:c0 + 8, tap]
+        h = frag.half()
+        parts = [torch.stack([h, (frag - h.float()).half()], dim=1).reshape(-1)]          # (tiles, 2, steps, 64, 8)
+        if proj_weight is not None:
+            Cp = int(proj_weight.shape[0])
+            ps = (proj_weight.detach().double() * t).float().reshape(Cp, Cin)
+            pf = torch.zeros((Cp // 16, 64, 8), dtype=torch.float32, device=w.device)
+            for g in range(2):                                                            # tap 4 = step 2, k groups 0 and 1
+                for pt in range(Cp // 16):
+                    pf[pt, g * 16:(g + 1) * 16, :] = ps[pt * 16:(pt + 1) * 16, 8 * g:8 * g + 8]
+            ph = pf.half()
+            parts.append(torch.stack([ph, (pf - ph.float()).half()], dim=1).reshape(-1))  # (tiles, 2, 64, 8)
+        return torch.cat(parts).contiguous(), float(1.0 / t)
+
+    def conv_small_f16s(self, x, wp, inv_t, bias, cout, stride=1, n_proj=0, residual=None, relu=True, amax_in=None):
+        """relu?(conv3x3(x; Cin 16 | 32 -> cout 16 | 32, stride 1 | 2, padding 1) + bias [+ residual]) on the 16-bit matrix cores
+        at float32 accuracy, optionally with the block's 1x1 stride-2 projection as a second output (n_proj = 32).
+        -> (y, y2 or None); y carries the device word of its largest value as `_spa_amax`."""
+        B, Cin, H, W = x.shape
+        assert x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
+        assert wp.dtype == torch.float16 and wp.is_contiguous() and bias.dtype == torch.float32 and bias.numel() == cout + n_proj
+        Ho, Wo = (H + stride - 1) // stride, (W + stride - 1) // stride
+        if amax_in is None:
+            amax_in = self.amax(x)
+        y = torch.empty((B, cout, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        y2 = torch.empty((B, n_proj, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last) if n_proj else None
+        if residual is not None:
+            assert residual.dtype == torch.float32 and residual.shape == y.shape and residual.is_contiguous(memory_format=torch.channels_last)
+        am = torch.empty(1, dtype=torch.int32, device=x.device)
+        check(self._lib.spa_conv_small_f16s(self._ctx, _ptr(x), B, H, W, Cin, _ptr(wp), ctypes.c_float(inv_t), int(cout), int(stride),
+                                            int(n_proj), _ptr(bias), _ptr(residual), 1 if relu else 0, _ptr(amax_in), _ptr(am),
+                                            _ptr(y), _ptr(y2), self._s()))
+        y._spa_amax = am
+        return y, y2
 
     def bias_act_(self, y, bias, residual=None, relu=True, track_amax=False):
         """In place y = relu?(y + bias [+ residual]) on a channels-last (B,C,H,W) activation.  track_amax (float32): the

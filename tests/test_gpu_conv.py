@@ -304,3 +304,67 @@ def test_conv3x3_winograd_fused_launch_is_the_three_launch_result(eng, B, Cin, C
     eng.raise_on_status()
     ref = _ref64(x, w, bias, r, relu, dil)
     assert float((y1.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize('Cin,Cout,stride,proj,res,relu,B,H,W', [(16, 16, 1, False, True, True, 2, 37, 61), (16, 16, 1, False, False, False, 1, 8, 32),
+                                                                 (16, 32, 2, True, False, True, 2, 37, 61), (16, 32, 2, False, False, True, 1, 64, 130),
+                                                                 (32, 32, 1, False, True, True, 2, 19, 67), (16, 32, 1, False, False, True, 1, 9, 33)])
+def test_thin_convolutions_of_drn_c_match_float64(eng, Cin, Cout, stride, proj, res, relu, B, H, W):
+    """spa_conv_small_f16s (csrc/spa_convs.hip): the 16- and 32-channel 3x3 convolutions at the top of DRN-C
+    (models/drn.py:134-170: layer1's BasicBlock, layer2's stride-2 BasicBlock with its 1x1 projection) on the 16-bit matrix cores
+    with two half-precision planes per operand, against float64 convolutions — odd sizes, partial tiles, both outputs of the
+    opener + projection form, the tracked maximum."""
+    g = torch.Generator(device='cuda').manual_seed(17)
+    x = (torch.relu(torch.randn((B, Cin, H, W), device='cuda', generator=g)) * 1.9).contiguous(memory_format=torch.channels_last)
+    w = torch.randn((Cout, Cin, 3, 3), device='cuda', generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    wd = torch.randn((32, Cin, 1, 1), device='cuda', generator=g) * (2.0 / Cin) ** 0.5 if proj else None
+    bias = torch.randn((Cout + (32 if proj else 0),), device='cuda', generator=g)
+    Ho, Wo = (H + stride - 1) // stride, (W + stride - 1) // stride
+    r = torch.randn((B, Cout, Ho, Wo), device='cuda', generator=g).contiguous(memory_format=torch.channels_last) if res else None
+    wp, inv_t = eng.small_planes(w, wd)
+    y, y2 = eng.conv_small_f16s(x, wp, inv_t, bias, Cout, stride, 32 if proj else 0, r, relu)
+    ref = F.conv2d(x.double(), w.double(), bias[:Cout].double(), stride, 1)
+    if res:
+        ref = ref + r.double()
+    if relu:
+        ref = torch.relu(ref)
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+    assert float((y.double() - ref).abs().max()) <= 3e-6 * float(ref.abs().max())
+    assert float(y._spa_amax.view(torch.float32)) == float(y.abs().max())
+    if proj:
+        ref2 = F.conv2d(x.double(), wd.double(), bias[Cout:].double(), stride, 0)
+        assert y2.shape == ref2.shape
+        assert float((y2.double() - ref2).abs().max()) <= 3e-6 * float(ref2.abs().max())
+    else:
+        assert y2 is None
+
+
+def test_drn_c_front_runs_on_own_kernels(eng):
+    """DRN-C-26, the reference's default backbone (batch_spalign_kmeans.py:524-526): with the fused stem that also stores conv1's
+    output and the thin convolutions above, NO convolution of the float32 forward is MIOpen's at a size that fills the kernels'
+    pixel tiles, maps 0, 1 and 7 agree with the float64 network, and the forward is reproducible bit for bit."""
+    drn = importlib.import_module('superpixel-align_amd.drn')
+    synth = importlib.import_module('superpixel-align_amd.synth')
+    m = drn.create_drn('drn_c_26', device='cuda', dtype=torch.float32)
+    assert m._front_c is not None
+    x = synth.synth_batch([7, 8], 64, 2048)
+    calls = [0]
+    orig = drn.F.conv2d
+
+    def counting(*a, **k):
+        calls[0] += 1
+        return orig(*a, **k)
+    drn.F.conv2d = counting
+    try:
+        _, a = m.batch_predict(x, need=[0, 1, 7])
+        _, b = m.batch_predict(x, need=[0, 1, 7])
+    finally:
+        drn.F.conv2d = orig
+    assert calls[0] == 0
+    assert all(torch.equal(a[i], b[i]) for i in (0, 1, 7))
+    m64 = drn.create_drn('drn_c_26', device='cpu', dtype=torch.float64)
+    _, r = m64.batch_predict(x, need=[0, 1, 7])
+    for i in (0, 1, 7):
+        ref = r[i].cuda()
+        err = float((a[i].double() - ref).abs().max()) / float(ref.abs().max())
+        assert err <= 1e-5, (i, err)
