@@ -379,7 +379,7 @@ extern "C" int spa_pyrandom_shuffle_select_host(spa_pyrandom *r, const int32_t *
     unsigned hw = std::thread::hardware_concurrency();
     int nthreads = hw >= 16 ? 8 : (hw >= 4 ? (int)hw / 2 : 1);
     if (getenv("SPA_RNG_THREADS")) nthreads = atoi(getenv("SPA_RNG_THREADS")) > 0 ? atoi(getenv("SPA_RNG_THREADS")) : 1;
-    const int64_t group_draws = getenv("SPA_RNG_GROUP") ? atoll(getenv("SPA_RNG_GROUP")) : (512 << 10);      // 2 MB of draws per group: L2-sized
+    const int64_t group_draws = getenv("SPA_RNG_GROUP") ? atoll(getenv("SPA_RNG_GROUP")) : (2 << 20);       // 8 MB of draws per group (smaller groups were measured no faster and start more threads)
     const bool vec = have_avx512();
     std::vector<int32_t> buf[2];
     std::vector<int64_t> doff[2];

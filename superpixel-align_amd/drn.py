@@ -113,7 +113,10 @@ def conv_bias_act(conv, bn, x, residual=None, relu=True):
             # the one-launch form wins where a GEMM tile is long (K = 512: 6.37-6.44 against 6.54-6.72 ms per 30 images; at
             # K = 256 its transform slices weigh more: 2.80-2.88 against 2.60-2.66, tools/winof_bench.py), SPA_WINO_FUSED_MIN_CIN
             fused = (bool(split) and _EPILOGUE['wino_fused'] and conv.out_channels % 256 == 0
-                     and conv.in_channels >= int(os.environ.get('SPA_WINO_FUSED_MIN_CIN', '512')))
+                     and conv.in_channels >= int(os.environ.get('SPA_WINO_FUSED_MIN_CIN', '512'))
+                     # ... and where the launch has work to spread: from 64 row blocks of 256 tiles up (30 images of 224 x 224: six
+                     # row blocks, the lists' prologue and epilogue dominate — 6.6 against 5.7 ms for that forward)
+                     and px >= int(os.environ.get('SPA_WINO_FUSED_MIN_PX', '262144')))
             in_bytes = 4.0 * px * (1 + expand) * conv.in_channels            # k_wino_in reads X and writes V
             mm_bytes = 4.0 * px * expand * (conv.in_channels + conv.out_channels)     # V read, M written
             out_bytes = 4.0 * px * ((2 if residual is not None else 1) + expand) * conv.out_channels   # M [+ R] read, Y written

@@ -225,6 +225,7 @@ def test_winograd_layers_inside_the_network(eng):
         E['split_gemm'], E['gemm16_launches'], E['gemm16n_launches'], E['conv16_launches'] = True, 0, 0, 0
         fused_saved, E['wino_fused'], E['winof_launches'] = E['wino_fused'], True, 0
         os.environ['SPA_WINO_FUSED_MIN_CIN'] = '256'
+        os.environ['SPA_WINO_FUSED_MIN_PX'] = '1'
         _, a4f = m.batch_predict(x, need=[7])
         # 13 Winograd layers: the 9 from 256 input channels up as ONE launch each, the 128-channel ones as three
         assert E['winof_launches'] == 9 and E['wino_launches'] == 4 and E['conv16_launches'] >= 3
@@ -241,6 +242,7 @@ def test_winograd_layers_inside_the_network(eng):
         _, ws = m.batch_predict(xw, need=[7])
         _, ws2 = m.batch_predict(xw, need=[7])
         del os.environ['SPA_WINO_FUSED_MIN_CIN']
+        del os.environ['SPA_WINO_FUSED_MIN_PX']
         E['wino_fused'] = fused_saved
         assert torch.equal(ws[7], ws2[7]) and torch.equal(wf[7], ws[7])
         a4f = None
