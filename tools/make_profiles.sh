@@ -4,7 +4,7 @@
 #   2. rocprofv3 --kernel-trace --stats of the default bench    -> gpurun_out/final_stats/
 #   3. HBM traffic PMC passes (FETCH_SIZE, WRITE_SIZE; separate passes) over tools/prof_stages.py
 #   4. the other operating points (one JSON line each)          -> gpurun_out/final_variant_*.json
-# then, in the build container:  python tools/write_profiles.py r3_final
+# then, in the build container:  python tools/write_profiles.py r4_final
 export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/final_stats gpurun_out/final_pmc_* gpurun_out/final_variant_*
@@ -24,9 +24,15 @@ v overlap --overlap
 v anchor --pool_mode anchor
 v anchor_bf16 --pool_mode anchor --dtype bf16
 v anchor_bf16_device_rng --pool_mode anchor --dtype bf16 --device_rng
-v integer_images --integer_images
+v float_images --float_images
 v fp32_mfma_gemm --fp32_mfma_gemm
-v no_winograd --fp32_mfma_gemm --no_winograd
-v miopen_conv --miopen_conv --fp32_mfma_gemm
+v drn_c_26 --arch drn_c_26
+v drn_c_26_bf16 --arch drn_c_26 --dtype bf16
 v reference_operating_point --superpixel_method felzenszwalb --height 224 --width 224 --arch drn_c_26 --pool_mode anchor --n_clusters 4
+SPA_WINO_FUSED=0 python3 bench.py --no_cpu_baseline 2> gpurun_out/final_variant_three_launch_winograd.err | tail -1 > gpurun_out/final_variant_three_launch_winograd.json
+python3 tools/winof_bench.py --reps 5 > gpurun_out/final_winof_bench.txt 2>&1
+python3 tools/h2h_probe2.py --steps 10 2>&1 | grep -E "device resident|host loop" > gpurun_out/final_h2h_probe.txt
+SPA_LATE_DOWNLOAD=0 python3 tools/h2h_probe2.py --steps 10 2>&1 | grep -E "device resident|host loop" | sed "s/^/[downloads enqueued at once, behind an event] /" >> gpurun_out/final_h2h_probe.txt
+python3 -m pytest tests/test_gpu_hostile.py -q -s 2>&1 | grep -E "hostile|per-channel|bulk error|passed|failed" > gpurun_out/final_hostile.txt
+python3 tools/driver300.py --n 600 --decode_procs 32 2>/dev/null | tail -1 > gpurun_out/final_driver600_procs32.json
 ls -la gpurun_out | tail -20
