@@ -8,15 +8,15 @@
 export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/final_stats gpurun_out/final_pmc_* gpurun_out/final_variant_*
-python3 bench.py > gpurun_out/final_bench_line.json 2> gpurun_out/final_bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final_stats -- python3 bench.py --no_cpu_baseline > gpurun_out/final_stats_bench_line.json 2> gpurun_out/final_stats.err
+python3 bench.py --steps 20 --warmup 5 > gpurun_out/final_bench_line.json 2> gpurun_out/final_bench.err      # the step counts the round driver uses
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final_stats -- python3 bench.py --no_cpu_baseline --steps 20 --warmup 5 > gpurun_out/final_stats_bench_line.json 2> gpurun_out/final_stats.err
 for P in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $P --kernel-trace --output-format csv -d gpurun_out/final_pmc_$P -- python3 tools/prof_stages.py --batch 8 --reps 2 --bias_act --wino > gpurun_out/final_pmc_$P.log 2>&1
 done
 python3 tools/pmc_summary.py gpurun_out/final_pmc_FETCH_SIZE > gpurun_out/final_pmc_fetch.txt
 python3 tools/pmc_summary.py gpurun_out/final_pmc_WRITE_SIZE > gpurun_out/final_pmc_write.txt
 rm -rf gpurun_out/final_pmc_FETCH_SIZE gpurun_out/final_pmc_WRITE_SIZE          # raw counter dumps: tens of MB
-v() { name=$1; shift; python3 bench.py --no_cpu_baseline "$@" 2> gpurun_out/final_variant_$name.err | tail -1 > gpurun_out/final_variant_$name.json; }
+v() { name=$1; shift; python3 bench.py --no_cpu_baseline --steps 20 --warmup 5 "$@" 2> gpurun_out/final_variant_$name.err | tail -1 > gpurun_out/final_variant_$name.json; }
 v bf16 --dtype bf16
 v cfg5 --dtype bf16 --n_slic_segments 400
 v cfg5_overlap --dtype bf16 --n_slic_segments 400 --overlap
@@ -29,7 +29,7 @@ v fp32_mfma_gemm --fp32_mfma_gemm
 v drn_c_26 --arch drn_c_26
 v drn_c_26_bf16 --arch drn_c_26 --dtype bf16
 v reference_operating_point --superpixel_method felzenszwalb --height 224 --width 224 --arch drn_c_26 --pool_mode anchor --n_clusters 4
-SPA_WINO_FUSED=0 python3 bench.py --no_cpu_baseline 2> gpurun_out/final_variant_three_launch_winograd.err | tail -1 > gpurun_out/final_variant_three_launch_winograd.json
+SPA_WINO_FUSED=0 python3 bench.py --no_cpu_baseline --steps 20 --warmup 5 2> gpurun_out/final_variant_three_launch_winograd.err | tail -1 > gpurun_out/final_variant_three_launch_winograd.json
 python3 tools/winof_bench.py --reps 5 > gpurun_out/final_winof_bench.txt 2>&1
 python3 tools/h2h_probe2.py --steps 10 2>&1 | grep -E "device resident|host loop" > gpurun_out/final_h2h_probe.txt
 SPA_LATE_DOWNLOAD=0 python3 tools/h2h_probe2.py --steps 10 2>&1 | grep -E "device resident|host loop" | sed "s/^/[downloads enqueued at once, behind an event] /" >> gpurun_out/final_h2h_probe.txt

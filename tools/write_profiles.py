@@ -24,8 +24,8 @@ for r in ours:
     r['short'] = re.sub(r'^void ', '', r['Name']).split('(')[0]
 ours.sort(key=lambda r: -float(r['TotalDurationNs']))
 lines = ['# %s: rocprofv3 --kernel-trace --stats of the default bench' % tag,
-         'command: rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no_cpu_baseline',
-         '(2 warm-up + 6 device-resident + 3 host-loop warm-up + 6 host-loop (the headline) steps of 30 images, 1024x2048, DRN-D-22 fp32, SLIC 200, '
+         'command: rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no_cpu_baseline --steps 20 --warmup 5',
+         '(5 warm-up + 20 device-resident + 3 host-loop warm-up + 20 host-loop (the headline) steps of 30 images, 1024x2048, DRN-D-22 fp32, SLIC 200, '
          'mean pooling, k=2)', '',
          '## libspalign kernels (hand-written HIP)', '',
          '| kernel | calls | total ms | avg us | min us | max us |', '|---|---|---|---|---|---|']
@@ -90,7 +90,7 @@ for k in sorted(fe):
     name = k.replace('void ', '')
     if not name.startswith('k_'):
         continue
-    is_wide = name in wide or name.startswith(('k_wino4_in<', 'k_wino4_out<', 'k_wino4_out_s<', 'k_gemm_f16x3<', 'k_conv3x3_f32<', 'k_wino4_fused'))
+    is_wide = name in wide or name.startswith(('k_wino4_in<', 'k_wino4_out<', 'k_wino4_out_s<', 'k_gemm_f16x3<', 'k_conv3x3_f32<'))
     f_mb = fe[k][1] * 1024 / 1e6 * (2 if is_wide else 1)
     w_mb = wr.get(k, (0, 0.0))[1] * 1024 / 1e6
     tot = f_mb + w_mb
@@ -118,7 +118,10 @@ if bkey:
 # transform, each against the bytes it moves by construction (bench.py scales these ratios to its launches' mix)
 def hbm_of(kname):
     key = [k for k in fe if k.replace('void ', '').startswith(kname)]           # (pmc_summary truncates long template names)
-    return (fe[key[0]][1] * 1024 * 2 + wr.get(key[0], (0, 0.0))[1] * 1024) if key else None
+    # the fused layer kernel mixes 8-byte loads (output transform), 16-byte loads and LDS-DMA: FETCH_SIZE is uncalibrated for
+    # that mix (MI355X_MICROARCH.md) and is taken as it stands — it then equals the bytes read by construction to 1 %
+    fx = 1 if kname.startswith('k_wino4_fused') else 2
+    return (fe[key[0]][1] * 1024 * fx + wr.get(key[0], (0, 0.0))[1] * 1024) if key else None
 if any(k.replace('void ', '').startswith('k_wino4_in') for k in fe):
     act = 4.0 * B * (1024 // 8) * (2048 // 8) * 512           # one 512-channel activation at 1/8 resolution
     for kname, bench_name, built, what in (
