@@ -82,47 +82,24 @@ struct MT {
 
 static bool pyrandom_have_avx512();
 
-// The CPython stream as a ring of generated blocks filled by a background thread: MT19937's regeneration + tempering is as
-// much work per output as the rejection sampling that consumes it, and it does not depend on it — so it runs ahead (a 2 MB
-// ring: a larger one was measured memory bound, the outputs of a batch are 320 MB) and the consumer reads finished blocks.  Blocks are
-// (26 generator refills = 16 224 outputs, a multiple of the 16 lanes the vector consumer loads).
+// The CPython stream for the anchors: the generator's tempered outputs in a small buffer of the object (four refills = 10 KB,
+// L1 resident) that the rejection sampling reads with 16-lane loads.  (Round 4 also tried MT19937 on a background thread
+// through a ring: with a 66 MB ring the consumer was memory bound, with a 2 MB one the blocks crossed between two cores'
+// caches at 4-6 GB/s — the consumer waited 26-35 of 73 ms for the producer; generating in place costs ~0.15 ns per output.)
 struct spa_pyrandom {
     MT g;
-    static const int BS = 624 * 26, NB = 32;            // 32 blocks of 63 KB = 2 MB: producer and consumer meet in the cache, not in DRAM
-    std::vector<uint32_t> ring;
-    std::atomic<uint64_t> produced{0}, consumed{0};    // blocks
-    std::atomic<bool> stop{false};
-    std::thread producer;
-    // consumer position inside block `consumed`
+    static const int BS = 624 * 4;
+    uint32_t buf[BS + 16];
     const uint32_t *cur = nullptr;
     int avail = 0;
     bool vec = false;
-    double waited = 0;                                  // seconds the consumer spent waiting for the producer (timing aid)
-    void fill_block(uint32_t *dst);
-    void run()
-    {
-        while (!stop.load(std::memory_order_relaxed)) {
-            const uint64_t p = produced.load(std::memory_order_relaxed);
-            if (p - consumed.load(std::memory_order_acquire) < (uint64_t)NB) {
-                fill_block(ring.data() + (size_t)(p % NB) * BS);
-                produced.store(p + 1, std::memory_order_release);
-            } else {
-                std::this_thread::sleep_for(std::chrono::microseconds(50));
-            }
-        }
-    }
-    // the consumer: make `cur` / `avail` describe unread outputs (waits for the producer when it has caught up)
+    double waited = 0;                                  // (timing aid of the ring experiment: stays 0)
+    void fill();
     inline void need()
     {
         if (avail > 0) return;
-        if (cur) consumed.fetch_add(1, std::memory_order_release);          // the block just finished is free again
-        const uint64_t c = consumed.load(std::memory_order_relaxed);
-        if (produced.load(std::memory_order_acquire) <= c) {
-            const auto t0 = std::chrono::steady_clock::now();
-            while (produced.load(std::memory_order_acquire) <= c) std::this_thread::yield();
-            waited += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        }
-        cur = ring.data() + (size_t)(c % NB) * BS;
+        fill();
+        cur = buf;
         avail = BS;
     }
 };
@@ -135,17 +112,12 @@ extern "C" int spa_pyrandom_create(uint64_t seed, spa_pyrandom **out)
     // random.seed(int): init_by_array over the 32-bit digits of abs(seed)
     uint32_t key[2] = {(uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32)};
     r->g.init_by_array(key, key[1] ? 2 : 1);
-    r->ring.resize((size_t)spa_pyrandom::BS * spa_pyrandom::NB);
     r->vec = pyrandom_have_avx512();
-    r->producer = std::thread([r]() { r->run(); });
     *out = r;
     return SPA_OK;
 }
 extern "C" void spa_pyrandom_destroy(spa_pyrandom *r)
 {
-    if (!r) return;
-    r->stop.store(true);
-    if (r->producer.joinable()) r->producer.join();
     delete r;
 }
 
@@ -329,8 +301,12 @@ __attribute__((target("avx512f,popcnt"))) static void draws_avx512(spa_pyrandom 
             // 16 outputs at a time while all 16 could be accepted inside the band.  Output k is accepted iff
             // v_k <= i - (accepted before k): surely when v_k <= i - k, surely not when v_k > i; a block with an output in
             // between (probability ~ 16 * 8 / 2^bits) is taken one output at a time
-            while (q.avail >= 16 && i - 16 >= stop) {
-                const __m512i v = _mm512_srl_epi32(_mm512_loadu_si512((const void *)q.cur), shc);
+            // (cursor and count live in locals: `avail` is an int like the draws stored through w, so as members the compiler
+            // had to reload them after every store)
+            const uint32_t *cur = q.cur;
+            int avail16 = q.avail;
+            while (avail16 >= 16 && i - 16 >= stop) {
+                const __m512i v = _mm512_srl_epi32(_mm512_loadu_si512((const void *)cur), shc);
                 const __m512i iv = _mm512_set1_epi32(i);
                 const __mmask16 yes = _mm512_cmple_epu32_mask(v, _mm512_sub_epi32(iv, lane));
                 const __mmask16 no = _mm512_cmpgt_epu32_mask(v, iv);
@@ -339,8 +315,9 @@ __attribute__((target("avx512f,popcnt"))) static void draws_avx512(spa_pyrandom 
                 // several x86 cores; the 16 lanes stored beyond the accepted ones are overwritten by the next block)
                 _mm512_storeu_si512((void *)w, _mm512_maskz_compress_epi32(yes, v));
                 const int c = __builtin_popcount((unsigned)yes);
-                w += c; i -= c; q.cur += 16; q.avail -= 16;
+                w += c; i -= c; cur += 16; avail16 -= 16;
             }
+            q.cur = cur; q.avail = avail16;
             // one block's worth (or the band's / generator block's tail) output by output
             if (q.avail == 0) continue;
             const uint32_t *o = q.cur;
@@ -362,8 +339,9 @@ __attribute__((target("avx512f,popcnt"))) static void draws_avx512(spa_pyrandom 
 
 static bool pyrandom_have_avx512() { return have_avx512(); }
 
-void spa_pyrandom::fill_block(uint32_t *dst)
+void spa_pyrandom::fill()
 {
+    uint32_t *dst = buf;
     for (int k = 0; k < BS / 624; ++k, dst += 624) {
 #ifdef SPA_RNG_X86
         if (vec) refill_avx512(g, dst); else
@@ -434,8 +412,8 @@ extern "C" int spa_pyrandom_shuffle_select_host(spa_pyrandom *r, const int32_t *
     const double t2 = timing ? now() : 0;
     for (auto &w : workers) w.join();
     if (timing) {
-        fprintf(stderr, "shuffle_select: draws %.1f ms (of which %.1f waiting for the generator thread), waiting for the traces %.1f ms "
-                "(+ %.1f at the end), %d trace threads\n", t_draw * 1e3, r->waited * 1e3, t_join * 1e3, (now() - t2) * 1e3, nthreads);
+        fprintf(stderr, "shuffle_select: draws %.1f ms, waiting for the traces %.1f ms (+ %.1f at the end), %d trace threads\n",
+                t_draw * 1e3, t_join * 1e3, (now() - t2) * 1e3, nthreads);
         r->waited = 0;
     }
     return SPA_OK;
