@@ -122,6 +122,10 @@ class LabelPipeline(object):
         """Everything of batch_superpixel_align (:316-330) + batch_create_prior (:333-344) that
         needs only the label maps: offsets, sizes, centres of mass, prior, and in anchor mode the
         anchor pixels (random.shuffle stream of the reference, :231-234)."""
+        return self.segments_anchors(imgs_shape, labels, self.segments_stats(imgs_shape, labels, n_labels))
+
+    def segments_stats(self, imgs_shape, labels, n_labels):
+        """the part of `segments` that only enqueues: offsets, sizes, centres of mass, prior"""
         a, eng = self.args, self.eng
         B, _, H, W = imgs_shape
         ncap = self.capacity(B, H, W, n_labels)
@@ -129,6 +133,14 @@ class LabelPipeline(object):
         count, centroid, prior = eng.segment_stats(
             labels, off, ncap, (a.y_rel_pos, a.x_rel_pos, a.y_rel_sigma, a.x_rel_sigma),
             want_centroid=True)
+        return dict(ncap=ncap, off=off, count=count, centroid=centroid, prior=prior, anchors=None, nvalid=None)
+
+    def segments_anchors(self, imgs_shape, labels, seg):
+        """the anchor pixels of `segments` (anchor mode; with the host generator the calling thread waits for the sizes and
+        draws: ~47 ms per 30 full-size images)"""
+        a, eng = self.args, self.eng
+        B, _, H, W = imgs_shape
+        ncap, off, count = seg['ncap'], seg['off'], seg['count']
         anchors = nvalid = None
         if self.pool_mode == 'anchor' and self.device_rng and int(1.7 * B * H * W) + (1 << 21) > (1 << 27) - 4096:
             # the shuffles of one batch consume ~1.4-1.5 generator outputs per pixel; the device ring holds 2^27.
@@ -175,8 +187,8 @@ class LabelPipeline(object):
             anchors = eng.select_anchor_pixels(labels, off, ncap, ranks, nvalid)
         elif self.pool_mode != 'mean':
             raise ValueError('pool_mode must be anchor or mean')
-        return dict(ncap=ncap, off=off, count=count, centroid=centroid, prior=prior,
-                    anchors=anchors, nvalid=nvalid)
+        seg['anchors'], seg['nvalid'] = anchors, nvalid
+        return seg
 
     def pool(self, imgs_shape, labels, seg, fmap):
         """The part of batch_superpixel_align that reads the feature map -> X (Ncap, D)."""
@@ -240,7 +252,30 @@ class LabelPipeline(object):
             imgs_dev = imgs_dev.to(self.eng.device, non_blocking=True)
         imgs_dev = imgs_dev.float().contiguous()
         self._tick('start')
-        if self.aux is not None:
+        if self.aux is not None and self.pool_mode == 'anchor' and not self.device_rng:
+            # anchor mode with the host generator: the superpixels and their statistics run FIRST, on the main stream, the DRN
+            # forward behind them; the host then waits for the sizes (14 ms in), draws the anchors (~47 ms) while the forward
+            # (~65 ms) runs, and sends them back on the auxiliary stream.  (Superpixels BESIDE the forward on a second stream —
+            # the layout below — cost 27.6 + 77.6 ms instead of 14 + 65: the forward's persistent kernels and the SLIC sweeps
+            # take the compute units from each other, and the draws started 14 ms later.)
+            self._tick('sp_start')
+            labels, n_labels = self.superpixels(imgs_dev)
+            self._tick('superpixel')
+            seg = self.segments_stats(imgs_dev.shape, labels, n_labels)
+            sizes = torch.cuda.Event()
+            sizes.record(main)
+            fmap = self.features(imgs_dev)
+            self._tick('features')
+            self.aux.wait_event(sizes)
+            with torch.cuda.stream(self.aux):
+                for t in [labels, n_labels] + [v for v in seg.values() if isinstance(v, torch.Tensor)]:
+                    t.record_stream(self.aux)
+                seg = self.segments_anchors(imgs_dev.shape, labels, seg)
+                self._tick('segments')
+            main.wait_stream(self.aux)
+            for t in [v for v in seg.values() if isinstance(v, torch.Tensor)]:
+                t.record_stream(main)
+        elif self.aux is not None:
             # superpixel branch on the auxiliary stream; it also waits for the previous batch's
             # consumers of the shared workspaces, which ran on the main stream
             self.aux.wait_stream(main)
