@@ -32,6 +32,7 @@
 #define FZ_THREADS 1024
 #define FZ_EPT 1                 // edges per thread per window (1: a window of 1 024 sorted edges; larger windows only add serial work per round — measured 11.6 / 14.1 / 19.0 / 41 ms per 30 images of 224x224 for 1 / 2 / 4 / 8)
 
+#define FZ_MAXB 256               // images per launch (one resident workgroup each)
 struct FzImg {
     unsigned barrier;            // monotonic arrival counter of this image's workgroup group
     int cnt[4];                  // ring of group-wide counters (see fz_group_sum)
@@ -209,7 +210,7 @@ __global__ void k_fz_init(int *__restrict__ parent, int *__restrict__ size, doub
         for (int i = 0; i < 4; ++i) st[threadIdx.x].cnt[i] = 0;
         for (int i = 0; i < 3; ++i) st[threadIdx.x].pad[i] = 0;
     }
-    if (blockIdx.x == 0 && threadIdx.x < 16) ((int *)((char *)st + 64 * sizeof(FzImg)))[64 + threadIdx.x] = 0;    // pass diagnostics
+    if (blockIdx.x == 0 && threadIdx.x < 16) ((int *)((char *)st + FZ_MAXB * sizeof(FzImg)))[FZ_MAXB + threadIdx.x] = 0;    // pass diagnostics
 }
 
 __device__ __forceinline__ void fz_group_sync(unsigned *ctr, unsigned G, unsigned &epoch, uint32_t *status)
@@ -960,7 +961,10 @@ static int fz_run(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t 
     SPA_ARG((long long)H * W < (1ll << 28));
     {
         // the persistent passes need every workgroup resident: at most n_cu images per launch
-        const int maxB = ctx->n_cu < 64 ? ctx->n_cu : 64;
+        // (one workgroup per image: 256 full-size images in one launch keep every CU busy — 64 per launch measured
+        // 12.6 ms per image amortised; SPA_FZ_MAXB for experiments)
+        int maxB = ctx->n_cu < FZ_MAXB ? ctx->n_cu : FZ_MAXB;
+        if (const char *e = getenv("SPA_FZ_MAXB")) { const int v = atoi(e); if (v > 0 && v < maxB) maxB = v; }
         if (B > maxB) {
             const long long px = (long long)H * W;
             for (int b0 = 0; b0 < B; b0 += maxB) {
@@ -1005,7 +1009,7 @@ static int fz_run(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t 
     if ((rc = spa_ws_reserve(ctx, WS_FZ_STATE, (size_t)B * npix * 16, (void **)&cint)) != SPA_OK) return rc;
     mark = (unsigned long long *)(cint + (size_t)B * npix);
     if ((rc = spa_ws_reserve(ctx, WS_BLK, (size_t)B * 2 * nblk * 4, (void **)&blk)) != SPA_OK) return rc;
-    if ((rc = spa_ws_reserve(ctx, WS_CONNMISC, 64 * sizeof(FzImg) + 128 * sizeof(int), (void **)&st)) != SPA_OK) return rc;
+    if ((rc = spa_ws_reserve(ctx, WS_CONNMISC, FZ_MAXB * sizeof(FzImg) + (FZ_MAXB + 64) * sizeof(int), (void **)&st)) != SPA_OK) return rc;
     size_t tmp_bytes = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys0, keys1, vals0, vals1, (int)g.nE, 0, 64, s);
     tmp_bytes = (tmp_bytes + 255) & ~(size_t)255;
@@ -1041,7 +1045,7 @@ static int fz_run(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t 
         SPA_HIP(hipStreamWaitEvent(s, ctx->ev_join[1], 0));
     }
     hipLaunchKernelGGL(k_fz_init, dim3(1024), dim3(256), 0, s, parent, size, cint, mark, (long long)B * npix, st, B);
-    int *zcount = (int *)((char *)st + 64 * sizeof(FzImg));
+    int *zcount = (int *)((char *)st + FZ_MAXB * sizeof(FzImg));
     hipLaunchKernelGGL(k_fz_zero_count, dim3(B), dim3(64), 0, s, (const unsigned long long *)keys1, g.nE, zcount);
     hipLaunchKernelGGL(k_fz_zero_union, dim3(256, B), dim3(256), 0, s, (const unsigned *)vals1, g,
                        (const int *)zcount, parent);
@@ -1084,7 +1088,7 @@ static int fz_run(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t 
         SPA_HIP(hipFuncSetAttribute((const void *)k_fz_pass_tab<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
         ctx->fz_attr_done |= 2;
     }
-    int *diag = zcount + 64;              // windows, chunks, rounds of the batch (diagnostics, spa_debug_peek)
+    int *diag = zcount + FZ_MAXB;              // windows, chunks, rounds of the batch (diagnostics, spa_debug_peek)
     for (int mode = 0; mode < 2; ++mode) {
         const unsigned r0 = mode ? 0x40000000u : 0u;
         if (tab && lpar)

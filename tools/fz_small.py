@@ -18,6 +18,6 @@ lib_mod = importlib.import_module('superpixel-align_amd._lib')
 src = open(os.path.join(os.path.dirname(lib_mod.__file__), 'csrc', 'spa_common.h')).read()
 names = re.findall(r'^\s*(WS_[A-Z_0-9]+)\s*(?:=\s*0)?,', src, re.M)
 host = (ctypes.c_int32 * 9)()
-lib_mod.check(lib_mod.lib().spa_debug_peek(eng._ctx, names.index('WS_CONNMISC'), 64 * 32 + 64 * 4, 36, host))
+lib_mod.check(lib_mod.lib().spa_debug_peek(eng._ctx, names.index('WS_CONNMISC'), 256 * 32 + 256 * 4, 36, host))
 print('per image and both passes: %.0f windows, %.0f chunks of 1024 sorted edges, %.0f full rounds, %.0f tail rounds' % tuple(v / 30.0 for v in host[:4]))
 print('kilo-cycles per image: flatten %.0f | collect %.0f | window set-up + write-back %.0f | full rounds %.0f | tail %.0f' % tuple(v / 30.0 for v in host[4:9]))
