@@ -212,7 +212,8 @@ int gemm_f16x3_raw(spa_ctx *ctx, const float *x, long long rows, int32_t Cin, co
     SPA_ARG(Cin % 32 == 0 && Cout % 128 == 0);
     SPA_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)wt % 16) == 0 && ((uintptr_t)y % 16) == 0);
     hipStream_t s = spa_stream(stream);
-    const int bm = Cout % 256 == 0 ? 256 : 128;
+    static const int force_tile = getenv("SPA_GEMM16_TILE") ? atoi(getenv("SPA_GEMM16_TILE")) : 0;      // experiments: 128
+    const int bm = (Cout % 256 == 0 && force_tile != 128) ? 256 : 128;
     const int bn = bm == 256 ? 256 : 128;
     const int ntiles = Cout / bm;
     const long long total = rows / bn * ntiles;
@@ -224,7 +225,8 @@ int gemm_f16x3_raw(spa_ctx *ctx, const float *x, long long rows, int32_t Cin, co
         ctx->gemm16_attr_done = 1;
     }
     SpaProfScope prof_(ctx, bm == 256 ? PROF_DRN_GEMM16 : PROF_DRN_GEMM16_N, s);
-    const int per_cu = lds > 80 * 1024 ? 1 : 2;
+    static const int force_per_cu = getenv("SPA_GEMM16_PER_CU") ? atoi(getenv("SPA_GEMM16_PER_CU")) : 0;
+    const int per_cu = force_per_cu > 0 ? force_per_cu : (lds > 80 * 1024 ? 1 : 2);
     long long grid = (long long)ctx->n_cu * per_cu;
     if (grid > total * zcount) grid = total * zcount;
     if (bm == 256)
