@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libspalign.so')
+LIB_PATH = os.environ.get('SPA_LIB_PATH') or os.path.join(_HERE, 'libspalign.so')      # SPA_LIB_PATH: A/B runs of two builds on one box
 _LIB = None
 
 SPA_OK = 0

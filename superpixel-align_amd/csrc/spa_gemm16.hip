@@ -93,6 +93,10 @@ __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3(const char *__restri
     char *wbuf = lds16, *xbuf = lds16 + 2 * (BM * 128);
     const int sub = lane >> 3, cs = lane & 7;
     const int chunk_byte = (cs ^ sub) << 4;        // staged row = block * 8 + sub: (row & 7) = sub for every block
+    // (round 4: the two 16-byte reads of a fragment row are served with 2-way bank conflicts by this image — SQ_LDS_BANK_CONFLICT
+    // 1.33 x SQ_ACTIVE_INST_LDS.  The conflict-free image of spa_conv32.hip's pixel segment, c ^ g(r & 7) with g = 0 0 1 1 4 4 5 5,
+    // was built here too, counted 0 conflicts, and ran 1.3-2 % SLOWER in same-box A/B runs (512 -> 512: 6.96 vs 6.86 ms, 256 ->
+    // 256: 2.69 vs 2.63): the LDS is not what this loop waits for, so the X tile keeps the weights' image)
     const int nk = Cin / 32;
     int par = 0;                                   // buffer parity carried from tile to tile
     auto stage = [&](int t, int buf) {
