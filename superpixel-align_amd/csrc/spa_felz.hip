@@ -389,6 +389,10 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass(const unsigned long long
         bool pend[FZ_EPT];
         int ea[FZ_EPT], eb[FZ_EPT];
         double cost[FZ_EPT];
+        // roots carried from round to round (round 4): a root of the last round is either still a root (one read) or has
+        // been linked to its new root by this window's merges (two or three reads) — the walk from the pixel through the
+        // forest of the last flattening is paid once per window, not once per round.  ea/eb hold the pixel, then the roots.
+        int ra[FZ_EPT], rb[FZ_EPT];
 #pragma unroll
         for (int u = 0; u < FZ_EPT; ++u) {
             const long long e = lo + tg + (long long)u * T;     // sorted position
@@ -397,21 +401,23 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass(const unsigned long long
                 fz_endpoints(g, (long long)V[e], ea[u], eb[u]);
                 cost[u] = __longlong_as_double((long long)K[e]);
             }
+            ra[u] = ea[u]; rb[u] = eb[u];
         }
         for (;;) {
             ++round;
             if (tg == 0) me->pad[0] += 1;                       // diagnostics: rounds
             const unsigned long long tag = (unsigned long long)(~round) << 32;
-            int ra[FZ_EPT], rb[FZ_EPT];
             bool want[FZ_EPT], resv[FZ_EPT];
+            unsigned hold_a[FZ_EPT], hold_b[FZ_EPT];            // earliest reservation of either component, as last read
             // ---- phase 1: roots and the merge test against the current state; edges that want
             // to merge reserve both components with their position in the window
 #pragma unroll
             for (int u = 0; u < FZ_EPT; ++u) {
                 want[u] = false; resv[u] = false;
+                hold_a[u] = hold_b[u] = 0xFFFFFFFFu;
                 if (!pend[u]) continue;
-                ra[u] = find(ea[u]);
-                rb[u] = find(eb[u]);
+                ra[u] = find(ra[u]);
+                rb[u] = find(rb[u]);
                 if (ra[u] == rb[u]) { pend[u] = false; continue; }      // same component for ever
                 if (mode == 0) {
                     const float t0 = (float)(CI[ra[u]] + scale / (double)S[ra[u]]);
@@ -431,16 +437,20 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass(const unsigned long long
             // ---- propagation: an edge that does not want to merge NOW may want to once an earlier
             // reserved edge has changed one of its components, so while it waits it must hold its
             // components too (later edges must not be decided against a state it might still change)
+            // (every pending edge reads the two reservation words in every step, also the ones that hold already: the step
+            // that changes nothing leaves the values the decision below needs — one dependent round trip less per round)
             for (;;) {
                 int changed = 0;
 #pragma unroll
                 for (int u = 0; u < FZ_EPT; ++u) {
-                    if (!pend[u] || resv[u]) continue;
+                    if (!pend[u]) continue;
                     const unsigned pos = (unsigned)(tg + (long long)u * T);
                     const unsigned long long ma = __hip_atomic_load(M + ra[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const unsigned long long mb = __hip_atomic_load(M + rb[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const unsigned pa = (ma >> 32) == (tag >> 32) ? (unsigned)ma : 0xFFFFFFFFu;
                     const unsigned pb = (mb >> 32) == (tag >> 32) ? (unsigned)mb : 0xFFFFFFFFu;
+                    hold_a[u] = pa; hold_b[u] = pb;
+                    if (resv[u]) continue;
                     if (pa < pos || pb < pos) {
                         const unsigned long long key = tag | (unsigned long long)pos;
                         atomicMin(M + ra[u], key);
@@ -458,10 +468,7 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass(const unsigned long long
             for (int u = 0; u < FZ_EPT; ++u) {
                 if (!pend[u]) continue;
                 const unsigned pos = (unsigned)(tg + (long long)u * T);
-                const unsigned long long ma = __hip_atomic_load(M + ra[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned long long mb = __hip_atomic_load(M + rb[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned pa = (ma >> 32) == (tag >> 32) ? (unsigned)ma : 0xFFFFFFFFu;
-                const unsigned pb = (mb >> 32) == (tag >> 32) ? (unsigned)mb : 0xFFFFFFFFu;
+                const unsigned pa = hold_a[u], pb = hold_b[u];                   // read in the last (unchanged) propagation step
                 if (pa < pos || pb < pos) { ++left; continue; }                  // waits for an earlier edge
                 if (want[u]) {
                     const int lo_r = min(ra[u], rb[u]), hi_r = max(ra[u], rb[u]);
