@@ -122,10 +122,13 @@ LIMITERS = {
     'k_conv3x3_f32<0, 256, 1, 256>': 'float32 MFMA pipe.  K = Cin is 8-16 K steps per 256 x 256 tile against 144 in the 3x3 form, so the '
                                              'tile prologue and the store of the output tile weigh more (0.83 against 0.88 of the peak) although the '
                                              'workgroups are persistent and stage the next tile before their epilogue',
-    'k_wino4_fused': 'both at once, by design: the layer is cut into work items (input-transform slices, 256 x 256 GEMM tiles, output-transform '
-                     'slices) popped from per-XCD lists, so the transforms\' HBM streaming (X -> V = 2.25 X, M = 2.25 Y -> Y) runs on a few '
-                     'compute units while the others are inside GEMM tiles; the launch is bound by the 16-bit matrix pipe + its feed for the '
-                     'tiles (the loop of k_gemm_f16x3) and by HBM for the bytes (see achieved_hbm_GBs), whichever is longer for the layer',
+    'k_wino4_fused': 'HBM by the roofline model (the bytes a Winograd layer moves by construction need 2.9 ms at 8 TB/s, its executed '
+                     'half-precision FLOPs 1.4 ms at 2.5 PFLOP/s); in practice CU time: the layer is cut into work items (input-transform '
+                     'slices, 256 x 256 GEMM tiles, output-transform slices) popped from per-XCD lists; in-kernel clocks: GEMM tiles '
+                     '921 CU-ms per layer at the standalone kernel\'s rate (0.96 PFLOP/s executed, 1.2 is what this part sustains), '
+                     'transform slices 540 CU-ms at 22-26 GB/s per compute unit (a CU streams ~10 B/cycle from HBM whatever it keeps in '
+                     'flight, so HBM\'s rate needs every CU streaming) = 5.7 ms + 0.35 ms ramp and tail; GEMM tiles and transform waves do '
+                     'not fit one CU together (256 registers x 8 waves, 128 KB LDS): tools/coresidency_probe.py, DESIGN.md section 5',
     'k_wino_in': 'HBM: reads X, writes V = 2.25x X (position-major, dense rows); 5.3 TB/s on the 512-channel layers',
     'k_wino_out': 'HBM: reads M = 2.25x Y (+ the residual), writes Y; 4.9 TB/s on the 512-channel layers',
     'k_conv3x3_f32<taps 9>(all)': 'float32 MFMA pipe: 0.88-0.89 of the 157.3 TFLOP/s peak on the 256/512-channel layers (MIOpen\'s hand-written '
@@ -521,13 +524,20 @@ def main():
             fl, nl, by = E['winof_flops'], max(1, E['winof_launches']), E['winof_bytes']
             tf = fl / a.steps / (ms / a.steps * 1e-3) / 1e12
             gbs = by / a.steps / (ms / a.steps * 1e-3) / 1e9
-            # (the launch also streams the layer's transforms: hbm_frac is that side; the matrix side is the roofline entry, as for
-            # every other convolution of the DRN — SURVEY.md 8d)
-            ent.update(bound='mfma', achieved=round(3 * tf, 1), peak=BF16_MATRIX_PEAK_TF, unit='TFLOP/s',
-                       frac=round(3 * tf / BF16_MATRIX_PEAK_TF, 4), float32_equivalent_tflops=round(tf, 1),
-                       flops_per_step=3 * fl / a.steps, flops_per_launch=3 * fl / nl,
-                       hbm_bytes_per_launch_by_construction=int(by / nl), achieved_hbm_GBs=round(gbs, 1),
-                       hbm_frac=round(gbs / HBM_PEAK_GBS, 4), traffic=pmc_traffic(name, B, H, W, by / nl))
+            # Roofline of a launch that does both: time >= max(bytes / HBM peak, FLOPs / matrix peak).  With the bytes a Winograd layer
+            # moves by construction (X + 2 V + 2 M + Y, V = 2.25 X, M = 2.25 Y) the arithmetic intensity of the launch is ~150
+            # executed half-precision FLOP per byte, below the part's balance of 312 (2.5 PFLOP/s / 8 TB/s): the binding roof is
+            # HBM, and that is the entry's `bound` / `frac`; the matrix side stays beside it (mfma_achieved_TFLOPs, mfma_frac).
+            hbm_side, mfma_side = gbs / HBM_PEAK_GBS, 3 * tf / BF16_MATRIX_PEAK_TF
+            common = dict(float32_equivalent_tflops=round(tf, 1), flops_per_step=3 * fl / a.steps, flops_per_launch=3 * fl / nl,
+                          hbm_bytes_per_launch_by_construction=int(by / nl), achieved_hbm_GBs=round(gbs, 1), hbm_frac=round(hbm_side, 4),
+                          mfma_achieved_TFLOPs=round(3 * tf, 1), mfma_frac=round(mfma_side, 4),
+                          arithmetic_intensity_flop_per_byte=round(3 * fl / max(1, by), 1), traffic=pmc_traffic(name, B, H, W, by / nl))
+            if hbm_side >= mfma_side:
+                ent.update(bound='hbm', achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(hbm_side, 4),
+                           algorithmic_bytes_per_launch=int(by / nl), **common)
+            else:
+                ent.update(bound='mfma', achieved=round(3 * tf, 1), peak=BF16_MATRIX_PEAK_TF, unit='TFLOP/s', frac=round(mfma_side, 4), **common)
         elif name in ('k_wino_in', 'k_wino_out'):
             ab = (E['wino_in_bytes'] if name == 'k_wino_in' else E['wino_out_bytes']) / max(1, E['wino_launches'])
             gbs = ab / (avg * 1e-3) / 1e9
@@ -564,6 +574,7 @@ def main():
                 'ms_per_step': e['ms_per_step'],
                 'algorithmic_bytes_per_launch': e.get('algorithmic_bytes_per_launch'),
                 'flops_per_launch': e.get('flops_per_launch'),
+                'hbm_frac': e.get('hbm_frac'), 'mfma_frac': e.get('mfma_frac'),
                 'traffic_source': 'profiles/pmc_traffic.json: HBM bytes per launch from separate rocprofv3 --pmc '
                                   'FETCH_SIZE / WRITE_SIZE passes (gfx950 corrections applied), scaled to this batch',
                 'limiter': e.get('limiter'),
