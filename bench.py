@@ -18,11 +18,12 @@ Prints ONE JSON line on rank 0 (see README/DESIGN for the fields).  `value` / `m
 batches of decoded 8-bit images in pinned host memory -> cluster + road masks in pinned host memory
 through pipeline.HostStream (uploads and downloads double buffered on copy streams under the kernels).
 `device_resident_value` / `device_resident_ms_per_step` time the same K steps with the batches already in
-HBM (a loop of its own, run first).  `kernels` holds one roofline-shaped entry per hand-written kernel
+HBM (a loop of its own, run first).  Both loops run the pipeline as the drivers do (LabelPipeline's default): the superpixel
+branch on a second stream beside the front of the DRN forward; `--one_stream` puts every kernel on its own.  `kernels` holds one roofline-shaped entry per hand-written kernel
 family of libspalign (HIP events on the launch stream, recorded during the headline loop): HBM-bound ones against 8 TB/s
 with their algorithmic bytes, the float32-MFMA stem against the fp32 matrix peak; `roofline` is the
-family with the most time per step, whichever it is.  `drn` reports the MFMA side of the step (the
-big convolutions are PyTorch-ROCm / MIOpen).  `cpu_baseline` times, on the host cores, the C
+family with the most time per step, whichever it is.  `drn` reports the matrix side of the step (libspalign's own
+convolutions; none is MIOpen's in the float32 forward).  `cpu_baseline` times, on the host cores, the C
 restatement (oracle, single thread and all cores with images sharded over threads), the same DRN
 through PyTorch-CPU and BASELINE.json's named comparator (NumPy pooling + scipy.cluster.vq.kmeans2)
 on a bounded sample, rank 0 at N = 1 only.
@@ -87,11 +88,13 @@ def parse():
     p.add_argument('--fp32_mfma_gemm', action='store_true', help='float32: the Winograd GEMMs on the float32 matrix instructions '
                    '(v_mfma_f32_16x16x4_f32) instead of two half-precision planes per operand on the 16-bit ones (same accuracy, 2.7x the matrix time)')
     p.add_argument('--no_winograd', action='store_true', help='float32: direct convolution (spa_conv3x3_f32) on the 256/512-channel layers too')
-    p.add_argument('--overlap', action='store_true',
-                   help='run the superpixel branch on a second stream under the DRN forward (+5%% '
-                        'images/s; per-kernel durations then include contention, so the roofline '
-                        'of the default run is measured without it). Anchor mode always overlaps: '
-                        'it hides the host-side random draws.')
+    p.add_argument('--one_stream', action='store_true',
+                   help='run the superpixel branch on the main stream instead of a second one beside the front of the DRN forward '
+                        '(the pipeline\'s and the drivers\' default, LabelPipeline(overlap=True): +3.5-4 %% images/s in same-box A/B runs). '
+                        'On one stream every label kernel\'s duration is its own; on two, the SLIC / connectivity kernels and the '
+                        'stem / narrow layers they run beside stretch each other (the Winograd launches, the headline roofline entry, '
+                        'are not touched: 6.08 vs 6.12 ms).')
+    p.add_argument('--overlap', action='store_true', help='(the default since round 4; kept for old command lines)')
     return p.parse_args()
 
 
@@ -324,7 +327,7 @@ def main():
     if a.fp32_mfma_gemm:
         drn._EPILOGUE['split_gemm'] = False
     model = drn.create_drn(a.arch, device='cuda:%d' % local, dtype=dtype)
-    overlap = a.overlap or a.pool_mode == 'anchor'
+    overlap = (not a.one_stream) or a.pool_mode == 'anchor'
     pipe = pipeline.LabelPipeline(args, model, overlap=overlap)
     eng = pipe.eng
 
@@ -633,8 +636,8 @@ def main():
                          'the big convolutions are PyTorch-ROCm (MIOpen); libspalign adds the fused float32-MFMA stem '
                          'of DRN-D (normalise + layer0 + layer1, k_drn_stem_d) and the bias/residual/ReLU epilogues')},
         'stage_ms_per_step': dict({k: round(v / a.steps, 3) for k, v in stage.items()},
-                                  streams='two: superpixel branch overlaps the DRN forward' if overlap
-                                  else 'one'),
+                                  streams='two: the superpixel branch runs beside the front of the DRN forward (stage times overlap; --one_stream for '
+                                          'every kernel on its own)' if overlap else 'one'),
         'kernels': kernels,
         'quality': {'superpixels_per_image': round(n_seg, 1), 'kmeans_iterations': int(info[0]),
                     'synthetic_road_iou': round(float(tp) / max(1.0, float(tp + fp + fn)), 4),

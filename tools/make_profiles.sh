@@ -19,8 +19,8 @@ rm -rf gpurun_out/final_pmc_FETCH_SIZE gpurun_out/final_pmc_WRITE_SIZE          
 v() { name=$1; shift; python3 bench.py --no_cpu_baseline --steps 20 --warmup 5 "$@" 2> gpurun_out/final_variant_$name.err | tail -1 > gpurun_out/final_variant_$name.json; }
 v bf16 --dtype bf16
 v cfg5 --dtype bf16 --n_slic_segments 400
-v cfg5_overlap --dtype bf16 --n_slic_segments 400 --overlap
-v overlap --overlap
+v cfg5_one_stream --dtype bf16 --n_slic_segments 400 --one_stream
+v one_stream --one_stream
 v anchor --pool_mode anchor
 v anchor_bf16 --pool_mode anchor --dtype bf16
 v anchor_bf16_device_rng --pool_mode anchor --dtype bf16 --device_rng
