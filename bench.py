@@ -356,8 +356,11 @@ def main():
 
     def step(s):
         cur[0] = s
-        res = pipe.run(dev[s % NB], check_status=False)
-        score(res)
+        # join=False: the calling stream is not made to wait for the batch's tail (pooling, k-means, paint run on the pipeline's
+        # second stream), so the next step's DRN forward starts under it — the drivers' loops do the same
+        res = pipe.run(dev[s % NB], check_status=False, join=False)
+        with torch.cuda.stream(res.stream):
+            score(res)
         return res
 
     for s in range(a.warmup):
@@ -371,6 +374,7 @@ def main():
 
     def gather(res):
         """the result.json reduction: one all_gather of per-image records (inside the timed region)"""
+        res.stream.synchronize()                   # the scores were accumulated on the stream the results live on
         info = res.info.cpu().numpy()
         conf = conf_total.cpu().numpy()
         n_sp = res.n_labels.cpu().numpy()

@@ -750,16 +750,20 @@ def main_labelled(argv=None, get=None, make_pipe=None, originals=False, make_mod
                     for t in (imgs, gt_dev):
                         if isinstance(t, torch.Tensor):
                             t.record_stream(main)
-                res = pipe.run(imgs, check_status=False)
+                # join=False: the batch's tail (pooling, k-means, paint) runs on the pipeline's second stream and this stream goes
+                # straight on to the next batch's DRN forward; everything below is enqueued where the result lives (res.stream)
+                res = pipe.run(imgs, check_status=False, join=False)
                 events = dict(pipe._ev)
-                road_d, cl_d, conf_d = res.road, res.cluster, None
-                if gt_dev is not None:
-                    road_d, cl_d = to_gt_size(res.road, gt_dev.shape[1:]), to_gt_size(res.cluster, gt_dev.shape[1:])
-                    gtm = torch.where(gt_dev <= 6, -1, torch.where(gt_dev == 7, 1, 0)).to(torch.int32)   # :279-296
-                    conf_d = eng.confusion(road_d.contiguous(), gtm)
-                status_h = eng.status_take_async()          # this batch's bits (copy, then clear, in stream order)
-                computed = torch.cuda.Event(enable_timing=True)
-                computed.record(main)
+                with torch.cuda.stream(res.stream):
+                    road_d, cl_d, conf_d = res.road, res.cluster, None
+                    if gt_dev is not None:
+                        gt_dev.record_stream(res.stream)
+                        road_d, cl_d = to_gt_size(res.road, gt_dev.shape[1:]), to_gt_size(res.cluster, gt_dev.shape[1:])
+                        gtm = torch.where(gt_dev <= 6, -1, torch.where(gt_dev == 7, 1, 0)).to(torch.int32)   # :279-296
+                        conf_d = eng.confusion(road_d.contiguous(), gtm)
+                    status_h = eng.status_take_async()          # the bits raised so far (one atomic exchange, in stream order)
+                    computed = torch.cuda.Event(enable_timing=True)
+                    computed.record(res.stream)
                 # the downloads are enqueued by finalize(), once the batch HAS been computed (the host waits, the copy stream does
                 # not): a copy queue whose head is a barrier waiting a batch's time for the compute stream slows every dispatch of
                 # that batch (measured: 82 -> 77.6 ms per batch of 30 in pipeline.HostStream, tools/h2h_probe2.py)

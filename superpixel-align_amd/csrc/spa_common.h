@@ -98,7 +98,8 @@ enum {
 struct spa_ctx {
     int device;
     int n_cu;
-    uint32_t *d_status;      // latched status bits
+    uint32_t *d_status;      // latched status bits (word 0; words 16-31: spa_status_take_async's ring)
+    unsigned status_takes;
     void *ws[WS_COUNT];
     size_t ws_bytes[WS_COUNT];
     int prof_on;

@@ -40,8 +40,8 @@ extern "C" int spa_ctx_create(int device, spa_ctx **out)
     ctx->device = device;
     ctx->n_cu = prop.multiProcessorCount;
     if (const char *e = getenv("SPA_SLIC_GENERAL")) ctx->slic_force_general = atoi(e) != 0;
-    SPA_HIP(hipMalloc((void **)&ctx->d_status, sizeof(uint32_t)));
-    SPA_HIP(hipMemset(ctx->d_status, 0, sizeof(uint32_t)));
+    SPA_HIP(hipMalloc((void **)&ctx->d_status, 32 * sizeof(uint32_t)));        // [0] the bits, [16..31] ring of taken words
+    SPA_HIP(hipMemset(ctx->d_status, 0, 32 * sizeof(uint32_t)));
     *out = ctx;
     return SPA_OK;
 }
@@ -101,11 +101,16 @@ extern "C" int spa_status_peek_async(spa_ctx *ctx, uint32_t *status_pinned, void
 
 // the same copy followed, in stream order, by the clear: every batch of an asynchronous loop reads ITS bits (an error
 // once, by the batch that raised it; informational bits do not stick to later batches)
+// (round 4: the batch loops run the next batch's DRN forward on another stream while this batch's tail finishes, so the read
+// and the clear are ONE atomic exchange — a bit raised by the other stream between a copy and a clear would be lost)
+__global__ void k_status_take(uint32_t *status, uint32_t *taken) { *taken = atomicExch(status, 0u); }
+
 extern "C" int spa_status_take_async(spa_ctx *ctx, uint32_t *status_pinned, void *stream)
 {
     SPA_ARG(ctx && status_pinned);
-    SPA_HIP(hipMemcpyAsync(status_pinned, ctx->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, spa_stream(stream)));
-    SPA_HIP(hipMemsetAsync(ctx->d_status, 0, sizeof(uint32_t), spa_stream(stream)));
+    uint32_t *slot = ctx->d_status + 16 + (ctx->status_takes++ & 15);           // 16 takes may be in flight
+    hipLaunchKernelGGL(k_status_take, dim3(1), dim3(1), 0, spa_stream(stream), ctx->d_status, slot);
+    SPA_HIP(hipMemcpyAsync(status_pinned, slot, sizeof(uint32_t), hipMemcpyDeviceToHost, spa_stream(stream)));
     return SPA_OK;
 }
 

@@ -17,6 +17,7 @@
 //    the five running sums (y, x, L, a, b) through the ring.  The chains of different segments
 //    are independent, so the GPU runs thousands of them concurrently (B * n_centroids waves).
 #include "spa_common.h"
+#include <stdlib.h>
 #include "spa_glibcf.h"
 
 int spa_slic_core_general_f32(spa_ctx *ctx, const float *lab, int32_t B, int32_t H, int32_t W, int32_t n_segments,
@@ -228,7 +229,6 @@ __global__ __launch_bounds__(256) void k_slic_assign(const float *__restrict__ l
                                                      uint32_t *__restrict__ status)
 {
     __shared__ uint4 cand[256 * 3];
-    __shared__ __attribute__((aligned(16))) float cdx[32 * TILE];
     __shared__ int wave_cnt[4];
     const int b = blockIdx.z;
     const int ty0 = blockIdx.y * TILE, tx0 = blockIdx.x * TILE;
@@ -265,6 +265,7 @@ __global__ __launch_bounds__(256) void k_slic_assign(const float *__restrict__ l
     const float fy = (float)y;
     const f32x2 pL2[2] = {{pL[0], pL[1]}, {pL[2], pL[3]}}, pA2[2] = {{pA[0], pA[1]}, {pA[2], pA[3]}},
                 pB2[2] = {{pB[0], pB[1]}, {pB[2], pB[3]}};
+    const f32x2 fx2[2] = {{(float)xb, (float)(xb + 1)}, {(float)(xb + 2), (float)(xb + 3)}};
 
     for (int kb = 0; kb < nC; kb += 256) {
         const int k = kb + tid;
@@ -294,62 +295,46 @@ __global__ __launch_bounds__(256) void k_slic_assign(const float *__restrict__ l
             cand[pos * 3 + 2] = make_uint4(w2.x, w2.y, 0u, 0u);
         }
         __syncthreads();
-        // The x part of the spatial term, (cx - x)^2, depends on (candidate, column) only: all 32 rows of the tile share
-        // it.  It is computed once per tile into LDS (round 4: 4 packed operations of ~23 per candidate and pixel pair less)
-        // with the window test folded in — +inf outside the candidate's columns or the image: the distance is then +inf and
-        // the strict comparison below never takes it, exactly what the window test did.  The same for the rows: dy = +inf.
-        // Sub-chunks of 32 candidates (a tile sees ~20).
-        for (int j0 = 0; j0 < total; j0 += 32) {
-            const int jn = min(32, total - j0);
-            for (int e = tid; e < jn * TILE; e += 256) {
-                const int j = j0 + (e >> 5), xi = e & 31;
-                const uint4 e0 = cand[j * 3 + 0], e2 = cand[j * 3 + 2];
-                const int xx = tx0 + xi;
-                const float t = __uint_as_float(e0.y) - (float)xx;
-                const bool in = ((unsigned)(xx - (int)e2.x) < (unsigned)((int)e2.y - (int)e2.x)) && xx < W;
-                cdx[(e >> 5) * TILE + xi] = in ? t * t : INFINITY;
-            }
-            __syncthreads();
-            if (row_ok) {
-                // straight-line body: the LDS reads of an entry are issued together (no divergent branches), so the compiler
-                // can overlap the next entry's reads with this entry's arithmetic.  The float arithmetic runs on pixel pairs
-                // (v_pk_add_f32 / v_pk_mul_f32: two IEEE float32 operations per instruction, each rounded exactly like the
-                // scalar one — no FMA).
+        if (row_ok) {
+            // straight-line body: the three 16-byte LDS reads of an entry are issued together and
+            // the window test is folded into the final comparison (no divergent branches), so the
+            // compiler can overlap the next entry's reads with this entry's arithmetic.  The
+            // float arithmetic runs on pixel pairs (v_pk_add_f32 / v_pk_mul_f32: two IEEE float32
+            // operations per instruction, each rounded exactly like the scalar one — no FMA).
 #pragma unroll 1
-                for (int jj = 0; jj < jn; ++jj) {
-                    const int j = j0 + jj;
-                    const uint4 e0 = cand[j * 3 + 0], e1 = cand[j * 3 + 1];
-                    const float4 dx4 = *(const float4 *)(cdx + jj * TILE + (tid & 7) * 4);
-                    const int y0 = (int)e1.z, y1 = (int)e1.w;
-                    const float cy = __uint_as_float(e0.x);
-                    const float cl = __uint_as_float(e0.z), ca = __uint_as_float(e0.w);
-                    const float cbb = __uint_as_float(e1.x);
-                    const int kk = (int)e1.y;
-                    const bool rowin = (y >= y0) && (y < y1);
-                    const float ty = cy - fy;
-                    const float dy = rowin ? ty * ty : INFINITY;
-                    const f32x2 dxp[2] = {{dx4.x, dx4.y}, {dx4.z, dx4.w}};
+            for (int j = 0; j < total; ++j) {
+                const uint4 e0 = cand[j * 3 + 0], e1 = cand[j * 3 + 1], e2 = cand[j * 3 + 2];
+                const int y0 = (int)e1.z, y1 = (int)e1.w, x0 = (int)e2.x, x1 = (int)e2.y;
+                const float cy = __uint_as_float(e0.x), cx = __uint_as_float(e0.y);
+                const float cl = __uint_as_float(e0.z), ca = __uint_as_float(e0.w);
+                const float cbb = __uint_as_float(e1.x);
+                const int kk = (int)e1.y;
+                const bool rowin = (y >= y0) && (y < y1);
+                const float ty = cy - fy;
+                const float dy = ty * ty;
+                const unsigned xw = (unsigned)(x1 - x0);
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        f32x2 dc = (f32x2{dy, dy} + dxp[h]) * f32x2{sw, sw};
-                        const f32x2 t0 = pL2[h] - f32x2{cl, cl}, t1 = pA2[h] - f32x2{ca, ca}, t2 = pB2[h] - f32x2{cbb, cbb};
-                        f32x2 col = t0 * t0;
-                        col = col + t1 * t1;
-                        col = col + t2 * t2;
-                        dc = dc + col;
+                for (int h = 0; h < 2; ++h) {
+                    const f32x2 tx = f32x2{cx, cx} - fx2[h];
+                    const f32x2 dx = tx * tx;
+                    f32x2 dc = (f32x2{dy, dy} + dx) * f32x2{sw, sw};
+                    const f32x2 t0 = pL2[h] - f32x2{cl, cl}, t1 = pA2[h] - f32x2{ca, ca}, t2 = pB2[h] - f32x2{cbb, cbb};
+                    f32x2 col = t0 * t0;
+                    col = col + t1 * t1;
+                    col = col + t2 * t2;
+                    dc = dc + col;
 #pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            const int i = 2 * h + q;
-                            const float d = q ? dc.y : dc.x;
-                            const bool take = best[i] > d;
-                            best[i] = take ? d : best[i];
-                            bl[i] = take ? kk : bl[i];
-                        }
+                    for (int q = 0; q < 2; ++q) {
+                        const int i = 2 * h + q;
+                        const float d = q ? dc.y : dc.x;
+                        const bool take = rowin && ok[i] && ((unsigned)(xb + i - x0) < xw) && (best[i] > d);
+                        best[i] = take ? d : best[i];
+                        bl[i] = take ? kk : bl[i];
                     }
                 }
             }
-            __syncthreads();
         }
+        __syncthreads();
     }
     bool uncovered = false;
 #pragma unroll
@@ -996,7 +981,12 @@ extern "C" int spa_slic_core(spa_ctx *ctx, const float *lab, int32_t B, int32_t 
     // cdef floating spatial_weight = 1.0 / (step * step)
     const float sw = (float)(1.0 / (double)(pl.step * pl.step));
     dim3 ga((W + TILE - 1) / TILE, (H + TILE - 1) / TILE, B);
+    // development aid (tools/race_probe7.py): SPA_SLIC_STOP = n stops after the n-th launch of the sweep loop (assign, update, ...)
+    const int stop_after = getenv("SPA_SLIC_STOP") ? atoi(getenv("SPA_SLIC_STOP")) : 1 << 30;
+    int launched = 0;
     for (int it = 0; it < max_iter; ++it) {
+        if (launched >= stop_after) break;
+        ++launched;
         { SpaProfScope prof_(ctx, PROF_SLIC_ASSIGN, s);
         // (the masks of the last sweep would never be read)
         const bool upd = it + 1 < max_iter || centres;
@@ -1005,7 +995,9 @@ extern "C" int spa_slic_core(spa_ctx *ctx, const float *lab, int32_t B, int32_t 
                            ctx->d_status); }
         SPA_LAUNCH_CHECK();
         // the centroids computed after the last sweep never influence the labels
+        if (launched >= stop_after) break;
         if (it + 1 < max_iter || centres) {
+            ++launched;
             SpaProfScope prof_(ctx, PROF_SLIC_UPDATE, s);
             hipLaunchKernelGGL(k_slic_order, dim3(8), dim3(1024), 0, s, cen, upd_total, upd_per_xcd, mean_px,
                                upd_order, upd_qhead);

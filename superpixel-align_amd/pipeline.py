@@ -79,6 +79,12 @@ class LabelPipeline(object):
         if os.environ.get('SPA_PIPE_OVERLAP') in ('0', '1'):
             overlap = os.environ['SPA_PIPE_OVERLAP'] == '1'
         self.aux = torch.cuda.Stream(device=self.eng.device) if overlap else None
+        # SPA_PIPE_TAIL_AUX=1 (mean pooling on two streams): everything but the DRN forward — superpixels, segment statistics
+        # AND the batch's tail (pooling, k-means, paint) — runs on the auxiliary stream, so the next batch's forward starts on the
+        # main stream while this batch's tail finishes (run(join=False)).  Built, bit-identical, and measured in same-box A/B runs
+        # at 400 against 403 images/s with the tail on the main stream: the tail's latency-bound kernels and the forward's front
+        # stretch each other by what the overlap gains, so the default keeps the tail on the main stream.
+        self.tail_on_aux = self.aux is not None and os.environ.get('SPA_PIPE_TAIL_AUX', '0') == '1'
         self._ev = {}
         # anchor mode, device_rng: the CPython `random` stream lives on the device (seeded like the reference's
         # module scope), its outputs produced a batch ahead on a side stream, and no superpixel size visits the
@@ -244,8 +250,12 @@ class LabelPipeline(object):
         ev.record()
         self._ev[name] = ev
 
-    def run(self, imgs, check_status=True):
-        """imgs: (B,3,H,W) float32 RGB 0..255, numpy (pinned or not) or CUDA tensor."""
+    def run(self, imgs, check_status=True, join=True):
+        """imgs: (B,3,H,W) float32 RGB 0..255, numpy (pinned or not) or CUDA tensor.
+        join=False (batch loops): the result is complete on `res.stream` (the auxiliary stream in the two-stream mean-pooling
+        flow, else the current one) at the event `res.ready`; whoever consumes it enqueues there or waits for the event, and the
+        calling stream is NOT made to wait — the next batch's DRN forward runs under this batch's pooling / k-means / paint.
+        join=True (default): the calling stream waits for the result, as a plain call must."""
         main = torch.cuda.current_stream()
         imgs_dev = torch.as_tensor(imgs)
         if not imgs_dev.is_cuda:
@@ -275,6 +285,49 @@ class LabelPipeline(object):
             main.wait_stream(self.aux)
             for t in [v for v in seg.values() if isinstance(v, torch.Tensor)]:
                 t.record_stream(main)
+        elif self.aux is not None and self.tail_on_aux and self.pool_mode == 'mean':
+            # main stream: the DRN forward only.  Auxiliary stream: superpixels, statistics, then — once the forward's maps
+            # exist — pooling, k-means, paint.  Every kernel that touches the context's shared workspaces is on the auxiliary
+            # stream, in order, batch after batch; the two streams meet at two events per batch.
+            aux = self.aux
+            given = torch.cuda.Event()
+            given.record(main)                       # the batch is complete on the calling stream
+            aux.wait_event(given)
+            imgs_dev.record_stream(aux)
+            with torch.cuda.stream(aux):
+                self._tick('sp_start')
+                labels, n_labels = self.superpixels(imgs_dev)
+                self._tick('superpixel')
+            fmap = self.features(imgs_dev)
+            self._tick('features')
+            feat = torch.cuda.Event()
+            feat.record(main)
+            fmap.record_stream(aux)
+            with torch.cuda.stream(aux):
+                seg = self.segments(imgs_dev.shape, labels, n_labels)
+                self._tick('segments')
+                aux.wait_event(feat)
+                self._tick('joined')
+                X = self.pool(imgs_dev.shape, labels, seg, fmap)
+                self._tick('describe')
+                assign, info, cluster, road, fail = self.cluster(labels, seg['off'], X, seg['prior'])
+                self._tick('kmeans')
+                done = torch.cuda.Event(enable_timing=True)
+                done.record(aux)
+            res = BatchResult(labels=labels, n_labels=n_labels, offsets=seg['off'], count=seg['count'],
+                              X=X, prior=seg['prior'], assign=assign, info=info, cluster=cluster,
+                              road=road, fmap=fmap, retry_fail=fail,
+                              strict_retry=bool(getattr(self.args, 'strict_retry', False)), stream=aux, ready=done)
+            if join:
+                main.wait_event(done)
+                for t in res.__dict__.values():
+                    if isinstance(t, torch.Tensor) and t.is_cuda:
+                        t.record_stream(main)
+                res.stream = main
+            if check_status:
+                self.eng.raise_on_status()
+                res.check_retry()
+            return res
         elif self.aux is not None:
             # superpixel branch on the auxiliary stream; it also waits for the previous batch's
             # consumers of the shared workspaces, which ran on the main stream
@@ -306,10 +359,12 @@ class LabelPipeline(object):
         self._tick('describe')
         assign, info, cluster, road, fail = self.cluster(labels, seg['off'], X, seg['prior'])
         self._tick('kmeans')
+        done = torch.cuda.Event(enable_timing=True)
+        done.record(main)
         res = BatchResult(labels=labels, n_labels=n_labels, offsets=seg['off'], count=seg['count'],
                           X=X, prior=seg['prior'], assign=assign, info=info, cluster=cluster,
                           road=road, fmap=fmap, retry_fail=fail,
-                          strict_retry=bool(getattr(self.args, 'strict_retry', False)))
+                          strict_retry=bool(getattr(self.args, 'strict_retry', False)), stream=main, ready=done)
         if check_status:
             self.eng.raise_on_status()
             res.check_retry()
@@ -433,16 +488,17 @@ class HostStream(object):
             if self.u8_hwc:
                 src = self.pipe.eng.resize_u8(src, (src.shape[1], src.shape[2]))       # same size: (B,3,H,W) float32 planar
                 self.in_free[slot].record(main)        # the 8-bit buffer is free as soon as it has been widened
-            res = self.pipe.run(src, check_status=False)
-            if self.after is not None:
-                self.after(res, s)
-            if not self.u8_hwc:
-                self.in_free[slot].record(main)
+            res = self.pipe.run(src, check_status=False, join=False)
+            with torch.cuda.stream(res.stream):      # the stream the result lives on (the pipeline's auxiliary one, or main)
+                if self.after is not None:
+                    self.after(res, s)
+                done = torch.cuda.Event()
+                done.record(res.stream)              # the forward (main) has finished before the tail (res.stream) could start
+                if not self.u8_hwc:
+                    self.in_free[slot].record(res.stream)
             if nxt is not None:
                 # under this batch's kernels (optionally behind one of its stage events, see _upload)
                 nb = self._upload(slot ^ 1, nxt, after=self.pipe._ev.get(self.upload_after) if self.upload_after else None)
-            done = torch.cuda.Event()
-            done.record(main)
             if not self.late_download:
                 self._download(slot, res, cur_n, done)
             if prev is not None:

@@ -427,6 +427,38 @@ def test_host_stream_matches_device_resident_path(mods, synth):
     pipe.eng.raise_on_status()
 
 
+def test_stream_layouts_return_the_same_bits(mods, synth, monkeypatch):
+    """The pipeline on one stream, on two (superpixel branch beside the DRN forward: the default) and with the batch's tail on
+    the second stream as well (SPA_PIPE_TAIL_AUX=1, run(join=False)) returns the same labels, descriptors, clusters and
+    masks, bit for bit, batch after batch and run after run — at the size where kernels of the two streams really share
+    compute units (12 x 1024 x 2048, batches enqueued back to back without a host synchronisation).  Round 4 found a variant
+    of k_slic_assign that was bit exact alone and changed ~100 labels per batch beside the stem kernel: this is the test
+    that sees such a thing (tools/determinism_check.py is the same loop at 30 images)."""
+    import hashlib
+    args = _args(pool_mode='mean', n_slic_segments=200)
+    B, H, W = 12, 1024, 2048
+    model = mods.drn.create_drn('drn_d_22', device='cuda')
+    batches = [torch.from_numpy(synth.synth_batch([500 + 40 * k + i for i in range(B)], H, W)).cuda() for k in range(2)]
+
+    def digest(t):
+        return hashlib.sha1(t.detach().cpu().contiguous().numpy().tobytes()).hexdigest()
+
+    seen = {}
+    for name, overlap, tail in (('one stream', False, '0'), ('two streams', True, '0'), ('two streams, tail on the second', True, '1')):
+        monkeypatch.setenv('SPA_PIPE_TAIL_AUX', tail)
+        pipe = mods.pipeline.LabelPipeline(args, model, mods.ops.engine(), overlap=overlap)
+        assert pipe.tail_on_aux == (tail == '1')
+        for rep in range(3):
+            rs = [pipe.run(batches[k % 2], check_status=False, join=False) for k in range(4)]
+            torch.cuda.synchronize()
+            for k, r in enumerate(rs):
+                n = int(r.offsets[-1])
+                d = (digest(r.labels), digest(r.X[:n]), digest(r.assign[:n]), digest(r.cluster), digest(r.road))
+                seen.setdefault(k % 2, set()).add(d)
+        pipe.eng.raise_on_status()
+    assert all(len(v) == 1 for v in seen.values()), {k: len(v) for k, v in seen.items()}
+
+
 @pytest.mark.parametrize('split', [False, True])
 @pytest.mark.parametrize('shape', [(2, 64, 96), (1, 100, 75), (3, 33, 130)])
 def test_fused_drn_d_stem_matches_convolution_path(mods, shape, split):
