@@ -70,9 +70,11 @@ int spa_status(spa_ctx *ctx, uint32_t *status_host, void *stream);
    the caller reads the word once an event recorded behind the call has completed.  (The reference has no
    counterpart: its per-image exceptions surface synchronously, batch_spalign_kmeans.py:538-548.) */
 int spa_status_peek_async(spa_ctx *ctx, uint32_t *status_pinned, void *stream);
-/* the same copy followed, in stream order, by the clear of the latch: the word then holds the bits raised since the previous
-   take — what a batch loop wants (an error is reported once, by the batch that raised it; informational bits of one batch
-   do not stick to the next). */
+/* read AND clear as one atomic exchange on the device, in stream order, then the copy of the taken word to *status_pinned: the
+   word holds the bits raised since the previous take — what a batch loop wants (an error is reported once, by the batch
+   that raised it; informational bits of one batch do not stick to the next).  One exchange rather than copy + clear: the
+   loops run the next batch's forward on another stream meanwhile, and a bit raised between a copy and a clear would be
+   lost.  Up to 16 takes may be in flight. */
 int spa_status_take_async(spa_ctx *ctx, uint32_t *status_pinned, void *stream);
 
 /* Per-kernel timing for the roofline report (bench.py): when enabled, HIP events are recorded on
