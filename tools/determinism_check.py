@@ -4,19 +4,22 @@ import argparse, hashlib, importlib, os, sys, types
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 ap = argparse.ArgumentParser(); ap.add_argument('--reps', type=int, default=6); ap.add_argument('--batch', type=int, default=30)
+ap.add_argument('--arch', default='drn_d_22'); ap.add_argument('--dtype', default='fp32'); ap.add_argument('--n', type=int, default=200)
 a = ap.parse_args()
 spa = importlib.import_module('superpixel-align_amd')
 pipeline = importlib.import_module('superpixel-align_amd.pipeline')
 drn = importlib.import_module('superpixel-align_amd.drn')
 bench = importlib.import_module('bench')
-args = types.SimpleNamespace(superpixel_method='slic', n_slic_segments=200, n_anchors=10, n_neighbors=4, without_pos=False,
+args = types.SimpleNamespace(superpixel_method='slic', n_slic_segments=a.n, n_anchors=10, n_neighbors=4, without_pos=False,
                              y_rel_pos=0.75, x_rel_pos=0.5, y_rel_sigma=0.1, x_rel_sigma=0.1, gpu=0, n_clusters=2,
                              use_feature_maps=[7], pool_mode='mean', mean_sampling='nearest')
 torch.manual_seed(0)
-model = drn.create_drn('drn_d_22', None, device='cuda', dtype=torch.float32)
+model = drn.create_drn(a.arch, None, device='cuda', dtype=torch.float32 if a.dtype == 'fp32' else torch.bfloat16)
 batches = [torch.from_numpy(bench.make_batch(spa.synth, a.batch, 1024, 2048, seed0=7 * k, integer=True)[0]).cuda() for k in range(2)]
 def digest(t):
-    return hashlib.sha1(t.detach().cpu().contiguous().numpy().tobytes()).hexdigest()[:10]
+    t = t.detach().contiguous()
+    if t.dtype == torch.bfloat16: t = t.view(torch.int16)
+    return hashlib.sha1(t.cpu().numpy().tobytes()).hexdigest()[:10]
 for name, env in (('one stream', dict(overlap=False)), ('two streams, tail on main', dict(overlap=True, tail='0')), ('two streams, tail on aux', dict(overlap=True, tail='1'))):
     os.environ['SPA_PIPE_TAIL_AUX'] = env.get('tail', '1')
     pipe = pipeline.LabelPipeline(args, model, overlap=env['overlap'])
@@ -30,4 +33,4 @@ for name, env in (('one stream', dict(overlap=False)), ('two streams, tail on ma
             key = (k % 2,)
             d = (digest(res.fmap), digest(res.labels), digest(res.X), digest(res.assign), digest(res.road), int(res.info[0]))
             seen.setdefault(key, set()).add(d)
-    print(name, {k: len(v) for k, v in seen.items()}, [sorted(v)[:3] for v in seen.values()][0][:2])
+    print(a.arch, a.dtype, a.n, name, {k: len(v) for k, v in seen.items()}, [sorted(v)[:3] for v in seen.values()][0][:2])
