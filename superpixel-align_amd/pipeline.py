@@ -78,7 +78,9 @@ class LabelPipeline(object):
         self.nprandom = NpRandom(getattr(args, 'seed', 1111))
         if os.environ.get('SPA_PIPE_OVERLAP') in ('0', '1'):
             overlap = os.environ['SPA_PIPE_OVERLAP'] == '1'
-        self.aux = torch.cuda.Stream(device=self.eng.device) if overlap else None
+        # (the second stream's queue priority, SPA_AUX_PRIORITY: see DESIGN.md section 5 for the A/B)
+        prio = int(os.environ.get('SPA_AUX_PRIORITY', '0'))
+        self.aux = torch.cuda.Stream(device=self.eng.device, priority=prio) if overlap else None
         # SPA_PIPE_TAIL_AUX=1 (mean pooling on two streams): everything but the DRN forward — superpixels, segment statistics
         # AND the batch's tail (pooling, k-means, paint) — runs on the auxiliary stream, so the next batch's forward starts on the
         # main stream while this batch's tail finishes (run(join=False)).  Built, bit-identical, and measured in same-box A/B runs
