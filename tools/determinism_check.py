@@ -4,18 +4,19 @@ import argparse, hashlib, importlib, os, sys, types
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 ap = argparse.ArgumentParser(); ap.add_argument('--reps', type=int, default=6); ap.add_argument('--batch', type=int, default=30)
+ap.add_argument('--method', default='slic'); ap.add_argument('--size', type=int, nargs=2, default=[1024, 2048]); ap.add_argument('--k', type=int, default=2)
 ap.add_argument('--arch', default='drn_d_22'); ap.add_argument('--dtype', default='fp32'); ap.add_argument('--n', type=int, default=200)
 a = ap.parse_args()
 spa = importlib.import_module('superpixel-align_amd')
 pipeline = importlib.import_module('superpixel-align_amd.pipeline')
 drn = importlib.import_module('superpixel-align_amd.drn')
 bench = importlib.import_module('bench')
-args = types.SimpleNamespace(superpixel_method='slic', n_slic_segments=a.n, n_anchors=10, n_neighbors=4, without_pos=False,
-                             y_rel_pos=0.75, x_rel_pos=0.5, y_rel_sigma=0.1, x_rel_sigma=0.1, gpu=0, n_clusters=2,
+args = types.SimpleNamespace(superpixel_method=a.method, n_slic_segments=a.n, felzenszwalb_scale=300.0, felzenszwalb_sigma=0.8, felzenszwalb_min_size=20, n_anchors=10, n_neighbors=4, without_pos=False,
+                             y_rel_pos=0.75, x_rel_pos=0.5, y_rel_sigma=0.1, x_rel_sigma=0.1, gpu=0, n_clusters=a.k,
                              use_feature_maps=[7], pool_mode='mean', mean_sampling='nearest')
 torch.manual_seed(0)
 model = drn.create_drn(a.arch, None, device='cuda', dtype=torch.float32 if a.dtype == 'fp32' else torch.bfloat16)
-batches = [torch.from_numpy(bench.make_batch(spa.synth, a.batch, 1024, 2048, seed0=7 * k, integer=True)[0]).cuda() for k in range(2)]
+batches = [torch.from_numpy(bench.make_batch(spa.synth, a.batch, a.size[0], a.size[1], seed0=7 * k, integer=True, scene=(a.method == 'felzenszwalb'))[0]).cuda() for k in range(2)]
 def digest(t):
     t = t.detach().contiguous()
     if t.dtype == torch.bfloat16: t = t.view(torch.int16)
