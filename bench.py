@@ -370,7 +370,7 @@ def main():
     COUNTERS = ('bytes', 'launches', 'conv_flops', 'conv16_flops', 'conv16_launches', 'conv16_bytes', 'gemm16_flops', 'gemm16_launches',
                 'gemm16_bytes', 'gemm16n_flops', 'gemm16n_launches', 'gemm16n_bytes', 'gemm_flops', 'gemm_launches', 'gemm_bytes',
                 'gemmn_flops', 'gemmn_launches', 'gemmn_bytes', 'wino_direct_flops', 'wino_saved_flops', 'wino_in_bytes',
-                'wino_out_bytes', 'wino_launches', 'winof_launches', 'winof_flops', 'winof_bytes')
+                'wino_out_bytes', 'wino_launches', 'winof_launches', 'winof_flops', 'winof_bytes', 'winof_layer_bytes')
 
     def gather(res):
         """the result.json reduction: one all_gather of per-image records (inside the timed region)"""
@@ -539,7 +539,11 @@ def main():
             common = dict(float32_equivalent_tflops=round(tf, 1), flops_per_step=3 * fl / a.steps, flops_per_launch=3 * fl / nl,
                           hbm_bytes_per_launch_by_construction=int(by / nl), achieved_hbm_GBs=round(gbs, 1), hbm_frac=round(hbm_side, 4),
                           mfma_achieved_TFLOPs=round(3 * tf, 1), mfma_frac=round(mfma_side, 4),
-                          arithmetic_intensity_flop_per_byte=round(3 * fl / max(1, by), 1), traffic=pmc_traffic(name, B, H, W, by / nl))
+                          arithmetic_intensity_flop_per_byte=round(3 * fl / max(1, by), 1), traffic=pmc_traffic(name, B, H, W, by / nl),
+                          # the layer's own bytes (X, Y, R and the weight planes once): what a convolution that kept V and M on chip
+                          # would move — the Winograd form moves `bytes_by_construction_over_layer_bytes` times that, by construction
+                          layer_bytes_per_launch=int(E['winof_layer_bytes'] / nl),
+                          bytes_by_construction_over_layer_bytes=round(by / max(1.0, E['winof_layer_bytes']), 2))
             if hbm_side >= mfma_side:
                 ent.update(bound='hbm', achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(hbm_side, 4),
                            algorithmic_bytes_per_launch=int(by / nl), **common)
@@ -582,6 +586,8 @@ def main():
                 'algorithmic_bytes_per_launch': e.get('algorithmic_bytes_per_launch'),
                 'flops_per_launch': e.get('flops_per_launch'),
                 'hbm_frac': e.get('hbm_frac'), 'mfma_frac': e.get('mfma_frac'),
+                'layer_bytes_per_launch': e.get('layer_bytes_per_launch'),
+                'bytes_by_construction_over_layer_bytes': e.get('bytes_by_construction_over_layer_bytes'),
                 'traffic_source': 'profiles/pmc_traffic.json: HBM bytes per launch from separate rocprofv3 --pmc '
                                   'FETCH_SIZE / WRITE_SIZE passes (gfx950 corrections applied), scaled to this batch',
                 'limiter': e.get('limiter'),

@@ -71,7 +71,7 @@ _EPILOGUE = {'engine': None, 'bytes': 0, 'launches': 0, 'own_conv': True, 'own_c
              # a Winograd layer as ONE persistent launch (transforms streamed under the GEMM tiles, csrc/spa_winof.hip);
              # SPA_WINO_FUSED=0 keeps the three launches
              'wino_fused': os.environ.get('SPA_WINO_FUSED', '1') != '0',
-             'winof_flops': 0.0, 'winof_launches': 0, 'winof_bytes': 0.0}
+             'winof_flops': 0.0, 'winof_launches': 0, 'winof_bytes': 0.0, 'winof_layer_bytes': 0.0}
 
 
 def conv_bias_act(conv, bn, x, residual=None, relu=True):
@@ -124,6 +124,9 @@ def conv_bias_act(conv, bn, x, residual=None, relu=True):
                 _EPILOGUE['winof_flops'] += direct * frac
                 _EPILOGUE['winof_launches'] += 1
                 _EPILOGUE['winof_bytes'] += in_bytes + mm_bytes + out_bytes
+                # what the LAYER needs whatever the algorithm: X and Y once (+ R), the 36 weight planes once
+                _EPILOGUE['winof_layer_bytes'] += 4.0 * px * (conv.in_channels + (2 if residual is not None else 1) * conv.out_channels) \
+                    + 4.0 * 36 * conv.in_channels * conv.out_channels
                 y, am = eng.conv3x3_wino_f16s(x, split[0], split[1], split[2], residual, relu, conv.dilation[0],
                                               amax_in=getattr(x, '_spa_amax', None), fused=True)
                 y._spa_amax = am
