@@ -86,6 +86,9 @@ const char *spa_prof_name(int slot);
 int spa_prof_read(spa_ctx *ctx, int slot, double *total_ms_host, int *launches_host);
 /* Diagnostics only: copy `bytes` of internal workspace `which` (byte offset) to the host. */
 int spa_debug_peek(spa_ctx *ctx, int which, size_t offset, size_t bytes, void *host);
+/* diagnostics (tools/lds_probe.py): an LDS table filled and read back per lane, n_wg workgroups of 256 threads, out[n_wg][256][4];
+   mode 0: 16-byte reads, 1: 4-byte reads, 2: broadcast reads.  No counterpart in the reference. */
+int spa_debug_lds_probe(spa_ctx *ctx, float *out, int32_t n_wg, int32_t steps, int32_t mode, void *stream);
 
 /* ---- DRN forward glue (the convolutions themselves stay in PyTorch-ROCm / MIOpen) -----------
  * spa_drn_normalise: DRN.batch_predict input arithmetic (models/drn.py:319-321): x/255 in float32,

@@ -272,6 +272,63 @@ int spa_aux_streams(spa_ctx *ctx)
     return SPA_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// diagnostics (tools/lds_probe.py): a kernel shaped like the k_slic_assign variant of DESIGN.md section 5 — every workgroup
+// fills an LDS table with values computed by its threads, then every thread reads four consecutive floats of a row per loop
+// step (address in a vector register advanced by a vector add) and folds them with packed adds — whose result is a pure
+// function of (workgroup, thread).  Run beside another kernel on a second stream and compared with a run alone.
+// mode 0: 16-byte reads; 1: four 4-byte reads; 2: the same address for every lane of a row group (broadcast)
+// ---------------------------------------------------------------------------------------
+typedef float dbg_f32x2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void k_debug_lds_probe(float *__restrict__ out, int steps, int mode, float seed)
+{
+    __shared__ __attribute__((aligned(16))) float tab[32 * 32];
+    __shared__ uint4 other[256 * 3];
+    const int tid = threadIdx.x;
+    other[tid * 3] = make_uint4(tid, blockIdx.x, 0u, 0u);
+    for (int e = tid; e < steps * 32; e += 256) {
+        const float t = seed * (float)(blockIdx.x % 977) - (float)(e & 31) * 1.25f - (float)(e >> 5);
+        tab[e] = ((e * 7 + (int)blockIdx.x) % 11 == 0) ? INFINITY : t * t;
+    }
+    __syncthreads();
+    dbg_f32x2 acc0 = {0.0f, 0.0f}, acc1 = {0.0f, 0.0f};
+    float best[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+    int bl[4] = {-1, -1, -1, -1};
+    const float fy = (float)(tid >> 3);
+#pragma unroll 1
+    for (int jj = 0; jj < steps; ++jj) {
+        const uint4 e0 = other[(jj * 3) % 768];
+        const float *q = tab + jj * 32 + (mode == 2 ? 0 : (tid & 7) * 4);
+        float4 d;
+        if (mode == 1) { d.x = ((const volatile float *)q)[0]; d.y = ((const volatile float *)q)[1]; d.z = ((const volatile float *)q)[2]; d.w = ((const volatile float *)q)[3]; }
+        else d = *(const float4 *)q;
+        const float ty = (float)(e0.x & 31u) - fy;
+        const float dy = (jj & 3) == 3 ? INFINITY : ty * ty;
+        const dbg_f32x2 p0 = (dbg_f32x2{dy, dy} + dbg_f32x2{d.x, d.y}) * dbg_f32x2{0.37f, 0.37f} + acc0 * dbg_f32x2{0.001f, 0.001f};
+        const dbg_f32x2 p1 = (dbg_f32x2{dy, dy} + dbg_f32x2{d.z, d.w}) * dbg_f32x2{0.37f, 0.37f} + acc1 * dbg_f32x2{0.001f, 0.001f};
+        const float dd[4] = {p0.x, p0.y, p1.x, p1.y};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool take = best[i] > dd[i];
+            best[i] = take ? dd[i] : best[i];
+            bl[i] = take ? jj : bl[i];
+        }
+        if (p0.x < 1e30f) acc0 = p0;
+        if (p1.x < 1e30f) acc1 = p1;
+    }
+    float4 r = make_float4(best[0] + (float)bl[0], best[1] + (float)bl[1], best[2] + (float)bl[2], best[3] + (float)bl[3]);
+    *(float4 *)(out + ((long long)blockIdx.x * 256 + tid) * 4) = r;
+}
+
+extern "C" int spa_debug_lds_probe(spa_ctx *ctx, float *out, int32_t n_wg, int32_t steps, int32_t mode, void *stream)
+{
+    SPA_ARG(ctx && out && n_wg > 0 && steps > 0 && steps <= 32 && mode >= 0 && mode <= 2);
+    hipLaunchKernelGGL(k_debug_lds_probe, dim3((unsigned)n_wg), dim3(256), 0, spa_stream(stream), out, steps, mode, 0.731f);
+    SPA_LAUNCH_CHECK();
+    return SPA_OK;
+}
+
 // diagnostics: copy `bytes` of workspace `which` (offset in bytes) to the host; synchronises
 extern "C" int spa_debug_peek(spa_ctx *ctx, int which, size_t offset, size_t bytes, void *host)
 {
