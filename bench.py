@@ -125,8 +125,8 @@ LIMITERS = {
     'k_conv3x3_f32<0, 256, 1, 256>': 'float32 MFMA pipe.  K = Cin is 8-16 K steps per 256 x 256 tile against 144 in the 3x3 form, so the '
                                              'tile prologue and the store of the output tile weigh more (0.83 against 0.88 of the peak) although the '
                                              'workgroups are persistent and stage the next tile before their epilogue',
-    'k_wino4_fused': 'HBM by the roofline model (the bytes a Winograd layer moves by construction need 2.9 ms at 8 TB/s, its executed '
-                     'half-precision FLOPs 1.4 ms at 2.5 PFLOP/s); in practice CU time: the layer is cut into work items (input-transform '
+    'k_wino4_fused': 'priced by SURVEY 8(d): executed half-precision FLOPs against the dense 16-bit MFMA peak (the V / M scratch the Winograd '
+                     'form streams through HBM is implementation traffic, ~4.7x the layer\'s own bytes, not achieved roofline); in practice CU time: the layer is cut into work items (input-transform '
                      'slices, 256 x 256 GEMM tiles, output-transform slices) popped from per-XCD lists; in-kernel clocks: GEMM tiles '
                      '921 CU-ms per layer at the standalone kernel\'s rate (0.96 PFLOP/s executed, 1.2 is what this part sustains), '
                      'transform slices 540 CU-ms at 22-26 GB/s per compute unit (a CU streams ~10 B/cycle from HBM whatever it keeps in '
@@ -531,24 +531,24 @@ def main():
             fl, nl, by = E['winof_flops'], max(1, E['winof_launches']), E['winof_bytes']
             tf = fl / a.steps / (ms / a.steps * 1e-3) / 1e12
             gbs = by / a.steps / (ms / a.steps * 1e-3) / 1e9
-            # Roofline of a launch that does both: time >= max(bytes / HBM peak, FLOPs / matrix peak).  With the bytes a Winograd layer
-            # moves by construction (X + 2 V + 2 M + Y, V = 2.25 X, M = 2.25 Y) the arithmetic intensity of the launch is ~150
-            # executed half-precision FLOP per byte, below the part's balance of 312 (2.5 PFLOP/s / 8 TB/s): the binding roof is
-            # HBM, and that is the entry's `bound` / `frac`; the matrix side stays beside it (mfma_achieved_TFLOPs, mfma_frac).
+            # SURVEY.md 8(d) prices the DRN by its FLOPs against the MFMA peak: `bound` / `achieved` / `frac` are the executed
+            # half-precision FLOPs of the launch against the dense 16-bit peak (0.22, not the 0.46 that divided the
+            # implementation's own V / M scratch traffic by the HBM peak).  `algorithmic_bytes_per_launch` = the LAYER's bytes (X, Y,
+            # the residual, the weight planes once: what a convolution that kept V and M on chip would move); the bytes the
+            # Winograd form moves through HBM by construction (X + 2 V + 2 M + Y, V = 2.25 X, M = 2.25 Y) are a side field, and
+            # `traffic` (PMC) against the layer's bytes is the waste: ~4.7x.
             hbm_side, mfma_side = gbs / HBM_PEAK_GBS, 3 * tf / BF16_MATRIX_PEAK_TF
-            common = dict(float32_equivalent_tflops=round(tf, 1), flops_per_step=3 * fl / a.steps, flops_per_launch=3 * fl / nl,
-                          hbm_bytes_per_launch_by_construction=int(by / nl), achieved_hbm_GBs=round(gbs, 1), hbm_frac=round(hbm_side, 4),
-                          mfma_achieved_TFLOPs=round(3 * tf, 1), mfma_frac=round(mfma_side, 4),
-                          arithmetic_intensity_flop_per_byte=round(3 * fl / max(1, by), 1), traffic=pmc_traffic(name, B, H, W, by / nl),
-                          # the layer's own bytes (X, Y, R and the weight planes once): what a convolution that kept V and M on chip
-                          # would move — the Winograd form moves `bytes_by_construction_over_layer_bytes` times that, by construction
-                          layer_bytes_per_launch=int(E['winof_layer_bytes'] / nl),
-                          bytes_by_construction_over_layer_bytes=round(by / max(1.0, E['winof_layer_bytes']), 2))
-            if hbm_side >= mfma_side:
-                ent.update(bound='hbm', achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(hbm_side, 4),
-                           algorithmic_bytes_per_launch=int(by / nl), **common)
-            else:
-                ent.update(bound='mfma', achieved=round(3 * tf, 1), peak=BF16_MATRIX_PEAK_TF, unit='TFLOP/s', frac=round(mfma_side, 4), **common)
+            layer_by = E['winof_layer_bytes'] / nl
+            ent.update(bound='mfma', achieved=round(3 * tf, 1), peak=BF16_MATRIX_PEAK_TF, unit='TFLOP/s', frac=round(mfma_side, 4),
+                       algorithmic_bytes_per_launch=int(layer_by),
+                       float32_equivalent_tflops=round(tf, 1), flops_per_step=3 * fl / a.steps, flops_per_launch=3 * fl / nl,
+                       mfma_achieved_TFLOPs=round(3 * tf, 1), mfma_frac=round(mfma_side, 4),
+                       layer_bytes_per_launch=int(layer_by),
+                       layer_bytes_GBs=round(layer_by / (avg * 1e-3) / 1e9, 1), layer_bytes_hbm_frac=round(layer_by / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                       hbm_bytes_per_launch_by_construction=int(by / nl), by_construction_GBs=round(gbs, 1),
+                       by_construction_hbm_frac=round(hbm_side, 4), hbm_frac=round(layer_by / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                       bytes_by_construction_over_layer_bytes=round(by / max(1.0, E['winof_layer_bytes']), 2),
+                       arithmetic_intensity_flop_per_byte=round(3 * fl / max(1, by), 1), traffic=pmc_traffic(name, B, H, W, by / nl))
         elif name in ('k_wino_in', 'k_wino_out'):
             ab = (E['wino_in_bytes'] if name == 'k_wino_in' else E['wino_out_bytes']) / max(1, E['wino_launches'])
             gbs = ab / (avg * 1e-3) / 1e9

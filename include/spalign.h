@@ -84,7 +84,7 @@ int spa_prof_enable(spa_ctx *ctx, int on);
 int spa_prof_slots(void);
 const char *spa_prof_name(int slot);
 int spa_prof_read(spa_ctx *ctx, int slot, double *total_ms_host, int *launches_host);
-/* Diagnostics only: copy `bytes` of internal workspace `which` (byte offset) to the host. */
+/* Diagnostics only: copy `bytes` of internal workspace `which` (byte offset; -1 = the stamp buffer of diagnostic kernel builds) to the host. */
 int spa_debug_peek(spa_ctx *ctx, int which, size_t offset, size_t bytes, void *host);
 /* diagnostics (tools/lds_probe.py): an LDS table filled and read back per lane, n_wg workgroups of 256 threads, out[n_wg][256][4];
    mode 0: 16-byte reads, 1: 4-byte reads, 2: broadcast reads.  No counterpart in the reference. */

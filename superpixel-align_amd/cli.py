@@ -115,7 +115,9 @@ def get_args_labelfree(argv=None):
     """utils/apply_spalign_kmeans.py:75-122"""
     extra = [('--img_list_fn', dict(type=str, default='data/demoVideo_fns.txt')),
              ('--label_shape', dict(type=int, nargs=2, default=[1024, 2048])),
-             ('--gpu', dict(type=int, default=-1)),
+             # (the reference's default here is -1 = its NumPy path, utils/apply_spalign_kmeans.py:84; this build has no CPU path —
+             # ops.create_model refuses a negative id — so the script run without --gpu takes device 0 instead of aborting)
+             ('--gpu', dict(type=int, default=0)),
              ('--out_dir', dict(type=str))]
     return _parser(extra).parse_args(argv)
 

@@ -84,6 +84,7 @@ enum {
     WS_RNG_JBUF,     // accepted swap partners of every shuffle (one int per pixel)
     WS_RNG_JOFF,     // offsets of the superpixels' swap lists
     WS_RUNS,         // connectivity: per-row lists of run starts (B,H,W) i32, used from the front of each row
+    WS_DEBUG,        // diagnostic builds: in-kernel stamps (tools read it with spa_debug_peek)
     WS_COUNT
 };
 
@@ -116,7 +117,7 @@ struct spa_ctx {
     size_t conn_claim_bytes;
     int upd_wg_per_cu, upd_wg_per_cu8;
     int slic_force_general;      // SPA_SLIC_GENERAL=1 at context creation: spa_slic_core takes the general kernels
-    int zero_line_ready, conv_attr_done, conv32_attr_done, fz_attr_done, gemm16_attr_done, winof_attr_done;
+    int zero_line_ready, conv_attr_done, conv32_attr_done, fz_attr_done, gemm16_attr_done, gemm16s_attr_done, winof_attr_done;
     // item lists of the fused Winograd layer kernel, one per (row blocks, channel blocks, slice counts) met (spa_winof.hip)
 #define SPA_WF_LISTS 8
     struct { int key[4]; unsigned *d; } wf_lists[SPA_WF_LISTS];

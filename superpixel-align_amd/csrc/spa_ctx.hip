@@ -332,6 +332,7 @@ extern "C" int spa_debug_lds_probe(spa_ctx *ctx, float *out, int32_t n_wg, int32
 // diagnostics: copy `bytes` of workspace `which` (offset in bytes) to the host; synchronises
 extern "C" int spa_debug_peek(spa_ctx *ctx, int which, size_t offset, size_t bytes, void *host)
 {
+    if (which == -1) which = WS_DEBUG;           // the stamp buffer of diagnostic kernel builds
     SPA_ARG(ctx && host && which >= 0 && which < WS_COUNT && offset + bytes <= ctx->ws_bytes[which]);
     SPA_HIP(hipDeviceSynchronize());
     SPA_HIP(hipMemcpy(host, (const char *)ctx->ws[which] + offset, bytes, hipMemcpyDeviceToHost));

@@ -42,6 +42,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 
 #define G16_THREADS 512
+// workgroup barrier that orders LDS only: __syncthreads() also waits for every outstanding global load and store
+__device__ __forceinline__ void g16_lds_barrier()
+{
+    __builtin_amdgcn_sched_barrier(0);          // nothing (the split's vector work included) moves across
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
 
 template <int BM, int BN>
 __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3(const char *__restrict__ X, const char *__restrict__ Wt,
@@ -206,6 +213,251 @@ __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3(const char *__restri
     }
 }
 
+// Round 5: the STAGGERED form.  In k_gemm_f16x3 every wave runs  [LDS reads + split] -> [MI * NJ * 3 matrix instructions] ->
+// wait -> workgroup barrier  per K step, so the two waves of a SIMD reach their matrix work together and their LDS reads
+// together: the matrix pipe idles while both read and split (45.7 % busy, profiles/r3_sq_counters_drn_split.txt).
+// Here a K step is two half periods  R = [LDS reads + split]  |  M = [matrix instructions (+ a tile's stores)]  with a
+// barrier after each, the K steps of ALL the tiles of a workgroup form one sequence q = 0, 1, ..., and waves 4-7 run the
+// same program HALF A PERIOD LATE (one extra barrier at their start): the second wave of every SIMD (a workgroup's waves go
+// to the SIMDs in cyclic order, so SIMD s holds waves s' and s' + 4: MI355X_MICROARCH.md, two waves per SIMD, item 9)
+// multiplies while its partner reads and splits, and the other way round — between two barriers every SIMD has one wave
+// in R and one in M.  Staging: the bytes of step q + 1 go to buffer (q + 1) & 1, whose last readers are the R(q - 1) of
+// both halves — the late half's ends at the barrier that ends the early half's period q - 1; the early waves therefore
+// stage their share at the top of their period q, the late waves theirs at the same moment (behind the barrier in the
+// middle of their period q - 1); both wait for them (counted, so that a tile's stores issued behind them stay in flight)
+// before the barrier that precedes the early half's R(q + 1): a full period in flight.  Every accumulator receives the
+// same matrix instructions in the same order as in k_gemm_f16x3 (K steps ascending; l.h, h.l, h.h inside a step): the
+// outputs are bit-identical.
+// XP (experiments, timing only — wrong numbers): 2 = no in-register split (the row tile read as if it held planes), 4 = no global loads
+template <int BM, int BN, int XP = 0>
+__global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3_stag(const char *__restrict__ X, const char *__restrict__ Wt,
+                                                                 float *__restrict__ Y, int rows_per_z, int Cin, int Cout,
+                                                                 int ntiles, int total_tiles, int zcount, long long xz,
+                                                                 long long wz, long long yz, const unsigned *__restrict__ amax,
+                                                                 unsigned *__restrict__ dbg = nullptr)
+{
+    extern __shared__ __attribute__((aligned(1024))) char lds16[];   // [2] weight tiles | [2] row tiles, 128 bytes per row
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool late = wave >= 4;
+    // XP & 16: in-kernel stamps (s_memtime, low word) of waves 0 and 4 of workgroup G16_STAMP_WG over periods [Q0, Q0 + NQ), kept
+    // in LDS behind the tiles (no global store inside the loop: the counted vmcnt waits stay what they are), copied out at the end
+    constexpr int G16_Q0 = 24, G16_NQ = 40;
+    unsigned *stamps = (unsigned *)(lds16 + 2 * (BM + BN) * 128) + (wave >> 2) * (G16_NQ * 8);
+    const bool stamp_wave = (XP & 16) && blockIdx.x == 77 && (wave & 3) == 0;
+    int stamp_q = -1;
+    auto STAMP = [&](int k) {
+        if ((XP & 16) && stamp_wave && stamp_q >= 0) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (lane == 0) stamps[stamp_q * 8 + k] = (unsigned)t;
+        }
+    };
+    const int all_i = zcount * total_tiles, gstep = (int)gridDim.x;
+    const int nwg = total_tiles;
+    float sb;
+    {
+        const unsigned bits = *amax;
+        int e = (int)(bits >> 23) - 127;
+        e = e < -100 ? -100 : (e > 100 ? 100 : e);
+        sb = __uint_as_float((unsigned)(127 + 14 - (bits == 0u ? 0 : e)) << 23);
+    }
+    // a tile's position is wave-uniform: scalar registers
+    int r0 = 0, n0 = 0, zz = 0;            // of the tile being staged
+    float zscale_s = 0.f;
+    auto locate = [&](int vid) {
+        const int z = vid / total_tiles;
+        const int zi = z / 6, zj = z - zi * 6;
+        const int psum = ((0x433444 >> (4 * zi)) & 15) + ((0x433444 >> (4 * zj)) & 15);
+        int id = vid - z * total_tiles;
+        {
+            const int q = nwg / 8, rem = nwg % 8, xcd = id % 8, idx = id / 8;
+            id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+        }
+        const int nt = id % ntiles, pt = id / ntiles;
+        zz = __builtin_amdgcn_readfirstlane(z);
+        r0 = __builtin_amdgcn_readfirstlane(pt * BN);
+        n0 = __builtin_amdgcn_readfirstlane(nt * BM);
+        zscale_s = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(sb * __uint_as_float((unsigned)(127 - psum) << 23))));
+    };
+    constexpr int WN = 4;
+    constexpr int MI = BM == 256 ? 8 : 4;
+    constexpr int NJ = BN / WN / 16;
+    constexpr int WROWS = MI * 16;
+    static_assert(BM / WROWS * WN == 8, "8 waves");
+    static_assert(MI * NJ <= 63, "vmcnt range");
+
+    char *wbuf = lds16, *xbuf = lds16 + 2 * (BM * 128);
+    const int sub = lane >> 3, cs = lane & 7;
+    const int chunk_byte = (cs ^ sub) << 4;
+    const int nk = Cin / 32;
+    // staging addresses = a scalar base (tile, K step, 64-row block) + ONE 32-bit lane offset shared by every load of the
+    // kernel (both operands have rows of Cin * 4 bytes): the late half stages between R and M with all fragments live
+    const char *s_w = nullptr, *s_x = nullptr;          // staged tile's operand bases (uniform)
+    const unsigned lane_off = (unsigned)((wave * 8 + sub) * Cin * 4 + chunk_byte);
+    auto stage_bases = [&]() {
+        s_w = Wt + ((long long)zz * wz + (long long)n0 * Cin) * 4;
+        s_x = X + ((long long)zz * xz + (long long)r0 * Cin) * 4;
+    };
+    auto stage = [&](int t, int buf) {
+        if (XP & 4) return;
+        const char *wk = s_w + (long long)t * 128;
+        char *dw = wbuf + buf * (BM * 128) + wave * 1024;
+#pragma unroll
+        for (int r = 0; r < BM / 64; ++r)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wk + (long long)r * 64 * Cin * 4 + lane_off),
+                                             (__attribute__((address_space(3))) void *)(dw + r * 8192), 16, 0, 0);
+        const char *xk = s_x + (long long)t * 128;
+        char *dx = xbuf + buf * (BN * 128) + wave * 1024;
+#pragma unroll
+        for (int r = 0; r < BN / 64; ++r)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xk + (long long)r * 64 * Cin * 4 + lane_off),
+                                             (__attribute__((address_space(3))) void *)(dx + r * 8192), 16, 0, 0);
+    };
+    const int wm = wave / WN, wn = wave % WN;
+    const int frow = lane & 15, fk = lane >> 4;
+    if ((int)blockIdx.x >= all_i) return;
+    const int my_tiles = (all_i - (int)blockIdx.x + gstep - 1) / gstep;
+    const int S = my_tiles * nk;                                    // K steps of this workgroup
+
+    // stage cursor (tile s_vid, step s_t, sequence number s_q); compute cursor (tile c_vid, step c_t)
+    int s_vid = (int)blockIdx.x, s_t = 0, s_q = 0;
+    locate(s_vid);
+    stage_bases();
+    int c_r0 = r0, c_n0 = n0, c_z = zz, c_t = 0, c_vid = s_vid;
+    float c_zscale = zscale_s;
+    auto stage_next = [&]() {                      // stage step s_q (if any) and move the cursor on
+        if (s_q < S) {
+            stage(s_t, s_q & 1);
+            ++s_q;
+            if (++s_t == nk) { s_t = 0; s_vid += gstep; if (s_vid < all_i) { locate(s_vid); stage_bases(); } }
+        }
+    };
+    stage_next();                                  // step 0
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    g16_lds_barrier();
+    if (late) { stage_next(); g16_lds_barrier(); }   // step 1; the extra barrier = half a period of delay
+    bool stored = false;
+
+    f32x4 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < S; ++q) {
+        const int buf = q & 1;
+        if (XP & 16) stamp_q = (q >= G16_Q0 && q < G16_Q0 + G16_NQ) ? q - G16_Q0 : -1;
+        STAMP(0);
+        if (!late) stage_next();                   // step q + 1
+        STAMP(1);
+        // ---- R
+        const char *lw = wbuf + buf * (BM * 128), *lx = xbuf + buf * (BN * 128);
+        f16x8 wh[MI], wl[MI], ph[NJ], pl[NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int row = wm * WROWS + i * 16 + frow;
+            wh[i] = *(const f16x8 *)(lw + row * 128 + ((fk ^ (row & 7)) << 4));
+            wl[i] = *(const f16x8 *)(lw + row * 128 + (((4 + fk) ^ (row & 7)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int row = wn * (NJ * 16) + j * 16 + frow;
+            if (XP & 2) {
+                ph[j] = *(const f16x8 *)(lx + row * 128 + (((2 * fk) ^ (row & 7)) << 4));
+                pl[j] = *(const f16x8 *)(lx + row * 128 + (((2 * fk + 1) ^ (row & 7)) << 4));
+                continue;
+            }
+            const f32x4 a = *(const f32x4 *)(lx + row * 128 + (((2 * fk) ^ (row & 7)) << 4));
+            const f32x4 b = *(const f32x4 *)(lx + row * 128 + (((2 * fk + 1) ^ (row & 7)) << 4));
+            const f32x8 v = (f32x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]} * c_zscale;
+            ph[j] = __builtin_convertvector(v, f16x8);
+            if (XP & 64) {
+                // l = rn16(v - h) as ONE mixed-precision fma per element (v * 1.0 - h, float32 inside, rounded once to half
+                // precision) instead of convert back + subtract + convert: 16 instead of 24 vector instructions per fragment
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 hu = __builtin_bit_cast(u32x4, ph[j]);
+                u32x4 lu;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    unsigned d;
+                    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel_hi:[0,0,1]\n\t"
+                        "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                        : "=&v"(d) : "v"(v[2 * e]), "v"(v[2 * e + 1]), "v"(hu[e]));
+                    lu[e] = d;
+                }
+                pl[j] = __builtin_bit_cast(f16x8, lu);
+            } else
+            pl[j] = __builtin_convertvector(v - __builtin_convertvector(ph[j], f32x8), f16x8);
+            asm volatile("" : "+v"(ph[j]), "+v"(pl[j]));        // the split belongs to R: not sunk behind the barrier to its uses
+        }
+        STAMP(2);
+        if (late) {
+            // the late half's share of step q + 1 (staged in the middle of its period q - 1) must have landed before the
+            // early half reads it behind this barrier; a tile's stores issued after it may stay in flight
+            if (stored) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MI * NJ) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        STAMP(3);
+        g16_lds_barrier();
+        STAMP(4);
+        stored = false;
+        if (late) stage_next();                    // step q + 2
+        // ---- M: small terms first: they meet the accumulator while it is small
+        if (XP & 8) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], ph[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], pl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], ph[j], acc[i][j], 0, 0, 0);
+        if (XP & 8) __builtin_amdgcn_s_setprio(0);
+        STAMP(5);
+        if (++c_t == nk) {
+            // ---- a tile is complete: lane holds channels c..c+3 (c = tile channel base + (lane>>4)*4) of row (lane & 15)
+            float *e_y = Y + (long long)c_z * yz;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const long long row = (long long)c_r0 + wn * (NJ * 16) + j * 16 + (lane & 15);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int c = c_n0 + wm * WROWS + i * 16 + (lane >> 4) * 4;
+                    *(float4 *)(e_y + row * Cout + c) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                    acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            stored = true;
+            c_t = 0; c_vid += gstep;
+            if (c_vid < all_i) {
+                // (the stage cursor is at most two steps ahead: its tile is this one's successor or the one after)
+                const int sr0 = r0, sn0 = n0, sz = zz; const float szs = zscale_s;
+                locate(c_vid);
+                c_r0 = r0; c_n0 = n0; c_z = zz; c_zscale = zscale_s;
+                r0 = sr0; n0 = sn0; zz = sz; zscale_s = szs;
+            }
+        }
+        if (!late) {
+            if (stored) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MI * NJ) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            STAMP(6);
+            g16_lds_barrier();
+            stored = false;
+        } else if (q + 1 < S) {
+            STAMP(6);
+            g16_lds_barrier();
+        }
+        STAMP(7);
+    }
+    if ((XP & 16) && stamp_wave && dbg) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int i = lane; i < G16_NQ * 8; i += 64) dbg[(wave >> 2) * (G16_NQ * 8) + i] = stamps[i];
+    }
+}
+
 // zcount = 36 problems  y[z] (rows, Cout) float32 = (scale_z x[z]) (rows, Cin) . wt[z]^T, wt[z] (Cout, Cin): x float32, wt in
 // the two-plane layout of the header (4 bytes per element); rows a multiple of 256, Cin a multiple of 32, Cout of 128;
 // amax: device word, bit pattern of a bound on the largest magnitude of the layer input (the scale's exponent)
@@ -233,6 +485,49 @@ int gemm_f16x3_raw(spa_ctx *ctx, const float *x, long long rows, int32_t Cin, co
     const int per_cu = force_per_cu > 0 ? force_per_cu : (lds > 80 * 1024 ? 1 : 2);
     long long grid = (long long)ctx->n_cu * per_cu;
     if (grid > total * zcount) grid = total * zcount;
+    static const int stagger = getenv("SPA_GEMM16_STAGGER") ? atoi(getenv("SPA_GEMM16_STAGGER")) : 0;
+    if (stagger) {
+        if (!ctx->gemm16s_attr_done) {
+            SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
+            SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
+            SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
+            SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
+            SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
+            SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
+            SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
+            SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128 + 4096));
+            SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 18>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128 + 4096));
+            SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 20>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128 + 4096));
+            SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 22>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128 + 4096));
+            SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 128));
+            ctx->gemm16s_attr_done = 1;
+        }
+        unsigned *dbg = nullptr;
+        if (stagger & 32) {
+            int rc = spa_ws_reserve(ctx, WS_DEBUG, 4096, (void **)&dbg);
+            if (rc != SPA_OK) return rc;
+        }
+#define G16S_LAUNCH(M, N, XP) hipLaunchKernelGGL((k_gemm_f16x3_stag<M, N, XP>), dim3((unsigned)grid), dim3(G16_THREADS), lds + ((XP) & 16 ? 4096 : 0), s, (const char *)x, (const char *)wt, y, \
+                               (int)rows, Cin, Cout, ntiles, (int)total, zcount, rows * Cin, (long long)Cout * Cin, rows * Cout, (const unsigned *)amax, dbg)
+        if (bm == 256) {
+            switch (stagger >> 1) {
+            case 1: G16S_LAUNCH(256, 256, 2); break;
+            case 2: G16S_LAUNCH(256, 256, 4); break;
+            case 3: G16S_LAUNCH(256, 256, 6); break;
+            case 4: G16S_LAUNCH(256, 256, 8); break;
+            case 5: G16S_LAUNCH(256, 256, 10); break;
+            case 32: G16S_LAUNCH(256, 256, 64); break;
+            case 16: G16S_LAUNCH(256, 256, 16); break;
+            case 17: G16S_LAUNCH(256, 256, 18); break;
+            case 18: G16S_LAUNCH(256, 256, 20); break;
+            case 19: G16S_LAUNCH(256, 256, 22); break;
+            default: G16S_LAUNCH(256, 256, 0);
+            }
+        } else G16S_LAUNCH(128, 128, 0);
+#undef G16S_LAUNCH
+        SPA_LAUNCH_CHECK();
+        return SPA_OK;
+    }
     if (bm == 256)
         hipLaunchKernelGGL((k_gemm_f16x3<256, 256>), dim3((unsigned)grid), dim3(G16_THREADS), lds, s, (const char *)x, (const char *)wt, y,
                            (int)rows, Cin, Cout, ntiles, (int)total, zcount, rows * Cin, (long long)Cout * Cin, rows * Cout, (const unsigned *)amax);

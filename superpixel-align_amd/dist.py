@@ -21,7 +21,7 @@ import torch.distributed as dist
 # writes for images of other ranks have the same schema as its own
 RECORD_FIELDS = ('index', 'TN', 'FP', 'FN', 'TP', 'n_superpixels', 'kmeans_iters', 'kmeans_status')
 TIMER_FIELDS = ('time_superpixel', 'time_roialign', 'time_prior', 'time_kmeans', 'time_feature_maps',
-                'elapsed_time', 'gpu')
+                'elapsed_time', 'gpu', 'time_device')      # time_device: the batch's own device time (cli.py), every rank's lines carry it
 RECORD_WIDTH = len(RECORD_FIELDS) + len(TIMER_FIELDS)
 
 

@@ -236,7 +236,10 @@ def test_cli_flags_match_reference_defaults():
     assert (a.y_rel_pos, a.x_rel_pos, a.y_rel_sigma, a.x_rel_sigma) == (0.75, 0.5, 0.1, 0.1)
     assert a.camera_param_dir == 'data/camera' and a.horizontal_line_filtering is False
     b = cli.get_args_labelfree([])
-    assert (b.gpu, b.label_shape, b.img_list_fn) == (-1, [1024, 2048], 'data/demoVideo_fns.txt')
+    # --gpu: the reference's default is -1 (its NumPy path, utils/apply_spalign_kmeans.py:84); this build has no CPU path, so
+    # the script run with default arguments takes device 0 — create_model still refuses an explicit negative id
+    assert (b.gpu, b.label_shape, b.img_list_fn) == (0, [1024, 2048], 'data/demoVideo_fns.txt')
+    assert cli.get_args_labelfree(['--gpu', '-1']).gpu == -1
 
 
 def test_label_archive_matches_find_zip_pipeline(tmp_path):
