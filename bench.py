@@ -125,13 +125,6 @@ LIMITERS = {
     'k_conv3x3_f32<0, 256, 1, 256>': 'float32 MFMA pipe.  K = Cin is 8-16 K steps per 256 x 256 tile against 144 in the 3x3 form, so the '
                                              'tile prologue and the store of the output tile weigh more (0.83 against 0.88 of the peak) although the '
                                              'workgroups are persistent and stage the next tile before their epilogue',
-    'k_wino4_fused': 'priced by SURVEY 8(d): executed half-precision FLOPs against the dense 16-bit MFMA peak (the V / M scratch the Winograd '
-                     'form streams through HBM is implementation traffic, ~4.7x the layer\'s own bytes, not achieved roofline); in practice CU time: the layer is cut into work items (input-transform '
-                     'slices, 256 x 256 GEMM tiles, output-transform slices) popped from per-XCD lists; in-kernel clocks: GEMM tiles '
-                     '921 CU-ms per layer at the standalone kernel\'s rate (0.96 PFLOP/s executed, 1.2 is what this part sustains), '
-                     'transform slices 540 CU-ms at 22-26 GB/s per compute unit (a CU streams ~10 B/cycle from HBM whatever it keeps in '
-                     'flight, so HBM\'s rate needs every CU streaming) = 5.7 ms + 0.35 ms ramp and tail; GEMM tiles and transform waves do '
-                     'not fit one CU together (256 registers x 8 waves, 128 KB LDS): tools/coresidency_probe.py, DESIGN.md section 5',
     'k_wino_in': 'HBM: reads X, writes V = 2.25x X (position-major, dense rows); 5.3 TB/s on the 512-channel layers',
     'k_wino_out': 'HBM: reads M = 2.25x Y (+ the residual), writes Y; 4.9 TB/s on the 512-channel layers',
     'k_conv3x3_f32<taps 9>(all)': 'float32 MFMA pipe: 0.88-0.89 of the 157.3 TFLOP/s peak on the 256/512-channel layers (MIOpen\'s hand-written '
@@ -370,7 +363,9 @@ def main():
     COUNTERS = ('bytes', 'launches', 'conv_flops', 'conv16_flops', 'conv16_launches', 'conv16_bytes', 'gemm16_flops', 'gemm16_launches',
                 'gemm16_bytes', 'gemm16n_flops', 'gemm16n_launches', 'gemm16n_bytes', 'gemm_flops', 'gemm_launches', 'gemm_bytes',
                 'gemmn_flops', 'gemmn_launches', 'gemmn_bytes', 'wino_direct_flops', 'wino_saved_flops', 'wino_in_bytes',
-                'wino_out_bytes', 'wino_launches', 'winof_launches', 'winof_flops', 'winof_bytes', 'winof_layer_bytes')
+                'wino_out_bytes', 'wino_launches', 'gemm16_layer_bytes')
+
+    gather_s, local_s = [0.0], [0.0]
 
     def gather(res):
         """the result.json reduction: one all_gather of per-image records (inside the timed region)"""
@@ -383,7 +378,10 @@ def main():
         rec[:, 1:5] = conf
         rec[:, 5] = n_sp
         rec[:, 6], rec[:, 7] = info[0], info[1]
-        return dist.gather_records(rec), info, n_sp
+        tg = time.perf_counter()
+        allrec = dist.gather_records(rec)          # nccl = RCCL over xGMI when N > 1
+        gather_s[0] = time.perf_counter() - tg
+        return allrec, info, n_sp
 
     def loop_device(headline):
         """K steps on batches already resident in HBM"""
@@ -395,6 +393,8 @@ def main():
             res = step(a.warmup + s)
             evs.append(dict(pipe._ev))             # device events, read after the timed region
         g = gather(res) if headline else None
+        torch.cuda.synchronize()
+        local_s[0] = time.perf_counter() - t0      # this rank's own time, before it waits for the others
         dist.barrier()
         torch.cuda.synchronize()
         dt = dist.max_over_ranks(time.perf_counter() - t0)
@@ -429,6 +429,8 @@ def main():
         for cluster_h, road_h, res in hs.process(iter(order[1:])):
             n_out += int(road_h.shape[0])
         g = gather(res) if headline else None
+        torch.cuda.synchronize()
+        local_s[0] = time.perf_counter() - t1      # this rank's own time, before it waits for the others
         dist.barrier()
         torch.cuda.synchronize()
         dt = dist.max_over_ranks(time.perf_counter() - t1)
@@ -449,6 +451,22 @@ def main():
         dt_h, res, evs, g = loop_host(headline=True)
     allrec, info, n_sp = g
     dt = dt_h if host_headline else dt_dev
+    # multi-GPU bookkeeping (every rank takes part in the collectives; rank 0 reports): each rank's own rate, the time of the one
+    # data-path collective, and where each rank's spa_ctx lives — ranks must sit on distinct devices
+    rank_rates = [round(B * a.steps / max(v, 1e-9), 3) for v in dist.all_values(local_s[0])]
+    rank_gather_ms = [round(v * 1e3, 3) for v in dist.all_values(gather_s[0])]
+    same_dev = os.environ.get('SPA_BENCH_SAME_DEVICE') == '1'
+    dev_index = eng.device.index if eng.device.index is not None else torch.cuda.current_device()
+    rank_devices = [int(v) for v in dist.all_values(dev_index)]
+    uuid = getattr(torch.cuda.get_device_properties(dev_index), 'uuid', None)
+    uuid_hash = float(int.from_bytes(__import__('hashlib').sha1(str(uuid).encode()).digest()[:6], 'big')) if uuid is not None else float(dev_index)
+    rank_uuid = dist.all_values(uuid_hash)
+    assert dev_index == (0 if same_dev else local), 'rank %d: spa_ctx on device %d, LOCAL_RANK %d' % (rank, dev_index, local)
+    if ws > 1 and not same_dev:
+        assert len(set(rank_devices)) == ws and len(set(rank_uuid)) == ws, 'two ranks share a device: %r' % (rank_devices,)
+    assert allrec.shape[0] == ws * B, 'gathered %d records, expected N x B = %d' % (allrec.shape[0], ws * B)
+    assert sorted(allrec[:, 0].tolist()) == list(range(ws * B)), 'record indices are not 0 .. N x B - 1'
+    backend = (torch.distributed.get_backend() if ws > 1 else None)
     stage = {'time_feature_maps': 0.0, 'time_superpixel': 0.0, 'time_roialign': 0.0, 'time_kmeans': 0.0}
     bias_bytes, bias_launches = drn._EPILOGUE['bytes'], drn._EPILOGUE['launches']
     conv_flops = drn._EPILOGUE['conv_flops']
@@ -525,30 +543,16 @@ def main():
                        flops_per_step=3 * fl / a.steps, flops_per_launch=3 * fl / nl,
                        hbm_bytes_per_launch_by_construction=int(by / nl),
                        traffic=pmc_traffic(name, B, H, W, by / nl))
-        elif name == 'k_wino4_fused':
-            # a whole Winograd layer per launch (csrc/spa_winof.hip): executed half-precision FLOPs of its 36 GEMMs against the dense
-            # 16-bit peak, and the HBM bytes its transforms + GEMM operands move by construction against the HBM peak
-            fl, nl, by = E['winof_flops'], max(1, E['winof_launches']), E['winof_bytes']
-            tf = fl / a.steps / (ms / a.steps * 1e-3) / 1e12
-            gbs = by / a.steps / (ms / a.steps * 1e-3) / 1e9
-            # SURVEY.md 8(d) prices the DRN by its FLOPs against the MFMA peak: `bound` / `achieved` / `frac` are the executed
-            # half-precision FLOPs of the launch against the dense 16-bit peak (0.22, not the 0.46 that divided the
-            # implementation's own V / M scratch traffic by the HBM peak).  `algorithmic_bytes_per_launch` = the LAYER's bytes (X, Y,
-            # the residual, the weight planes once: what a convolution that kept V and M on chip would move); the bytes the
-            # Winograd form moves through HBM by construction (X + 2 V + 2 M + Y, V = 2.25 X, M = 2.25 Y) are a side field, and
-            # `traffic` (PMC) against the layer's bytes is the waste: ~4.7x.
-            hbm_side, mfma_side = gbs / HBM_PEAK_GBS, 3 * tf / BF16_MATRIX_PEAK_TF
-            layer_by = E['winof_layer_bytes'] / nl
-            ent.update(bound='mfma', achieved=round(3 * tf, 1), peak=BF16_MATRIX_PEAK_TF, unit='TFLOP/s', frac=round(mfma_side, 4),
-                       algorithmic_bytes_per_launch=int(layer_by),
-                       float32_equivalent_tflops=round(tf, 1), flops_per_step=3 * fl / a.steps, flops_per_launch=3 * fl / nl,
-                       mfma_achieved_TFLOPs=round(3 * tf, 1), mfma_frac=round(mfma_side, 4),
-                       layer_bytes_per_launch=int(layer_by),
-                       layer_bytes_GBs=round(layer_by / (avg * 1e-3) / 1e9, 1), layer_bytes_hbm_frac=round(layer_by / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                       hbm_bytes_per_launch_by_construction=int(by / nl), by_construction_GBs=round(gbs, 1),
-                       by_construction_hbm_frac=round(hbm_side, 4), hbm_frac=round(layer_by / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                       bytes_by_construction_over_layer_bytes=round(by / max(1.0, E['winof_layer_bytes']), 2),
-                       arithmetic_intensity_flop_per_byte=round(3 * fl / max(1, by), 1), traffic=pmc_traffic(name, B, H, W, by / nl))
+            if pre == 'gemm16' and E['gemm16_layer_bytes'] > 0:
+                # SURVEY.md 8(d) prices the DRN by FLOPs against the MFMA peak (`frac` above, this launch alone).  The LAYER view
+                # beside it: the layer's own bytes — X, Y, the residual, the weight planes once — are the algorithmic
+                # bytes; V and M (2.25x the activations, written and read back by the three launches of the Winograd form) are the
+                # implementation's traffic, and the layer's executed FLOPs over the time of its three launches is what the matrix
+                # cores deliver per layer
+                layer_by = E['gemm16_layer_bytes'] / nl
+                ent['algorithmic_bytes_per_launch'] = int(layer_by)
+                ent['layer_bytes_per_launch'] = int(layer_by)
+                ent['v_m_scratch_over_layer_bytes'] = round((by / nl) / layer_by, 2)
         elif name in ('k_wino_in', 'k_wino_out'):
             ab = (E['wino_in_bytes'] if name == 'k_wino_in' else E['wino_out_bytes']) / max(1, E['wino_launches'])
             gbs = ab / (avg * 1e-3) / 1e9
@@ -652,6 +656,11 @@ def main():
         'quality': {'superpixels_per_image': round(n_seg, 1), 'kmeans_iterations': int(info[0]),
                     'synthetic_road_iou': round(float(tp) / max(1.0, float(tp + fp + fn)), 4),
                     'records_gathered': int(allrec.shape[0])},
+        'multi_gpu': {'ranks': ws, 'backend': backend, 'per_rank_images_per_sec': rank_rates,
+                      'gather_ms_per_rank': rank_gather_ms, 'records_gathered': int(allrec.shape[0]),
+                      'records_expected': ws * B, 'rank_devices': rank_devices,
+                      'note': 'one all_gather of %d-word records per image at the end of the timed region (the result.json reduction); '
+                              'no data-path collective; every rank\'s spa_ctx asserted on its own device' % dist.RECORD_WIDTH},
     }
     if ws == 1 and not a.no_cpu_baseline:
         try:

@@ -50,7 +50,6 @@ extern "C" {
 #define SPA_ST_KMEANS_BARRIER 0x10u      /* grid barrier timed out (should never happen)        */
 #define SPA_ST_LABEL_RANGE 0x20u         /* a label outside [0, S) was met                      */
 #define SPA_ST_RNG_UNDERRUN 0x40u        /* the device random stream ran dry (spa_pyrandom_dev_generate too small) */
-#define SPA_ST_WINO_SYNC 0x80u           /* fused Winograd layer: a dependency counter never arrived (should never happen) */
 
 #define SPA_CELL_SLOTS 16
 
@@ -180,24 +179,6 @@ int spa_conv3x3_wino4_f16s(spa_ctx *ctx, const float *x, int32_t B, int32_t H, i
                            const void *u2, const float *cs, int32_t Cout, const float *bias, const float *residual,
                            int32_t relu, int32_t dilation, const void *amax_in, void *amax_out, void *v_scratch,
                            float *m_scratch, float *y, void *stream);
-
-/* spa_conv3x3_wino4_f16s as ONE persistent launch (spa_winof.hip): the input transform, the 36 GEMMs and the output
- * transform of a layer are cut into work items that the workgroups pop from per-XCD lists, so the transforms' HBM streaming
- * runs under the matrix work of the other compute units instead of before and after it.  Same operands, same arithmetic,
- * same bytes in y and amax_out as spa_conv3x3_wino4_f16s.  Cout % 256 == 0.  sync_scratch:
- * spa_wino4_fused_scratch_words(spa_wino4_tiles(...), Cout) 32-bit words of device memory the caller owns for the duration
- * of the call (queue heads and dependency counters; never shared between streams). */
-int64_t spa_wino4_fused_scratch_words(int64_t tiles_padded, int32_t Cout);
-/* the work-item plan the kernel reads for a layer of n_row_blocks x 256 tiles and n_channel_blocks x 256 output channels (host
- * only, no GPU): 16 header words (offsets of the 8 per-XCD lists, [8] = total) + the lists; word = type (2 bits: 0 input-transform
- * slice, 1 GEMM tile, 2 output-transform slice) | channel block (2) | position z or slice (6) | row block (22).  Returns the
- * number of words written, SPA_ERR_CAPACITY when `capacity` words do not hold them. */
-int64_t spa_wino4_fused_plan(int32_t n_row_blocks, int32_t n_channel_blocks, int32_t in_slices, int32_t out_slices,
-                             uint32_t *out, int64_t capacity);
-int spa_conv3x3_wino4_fused(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W, int32_t Cin,
-                            const void *u2, const float *cs, int32_t Cout, const float *bias, const float *residual,
-                            int32_t relu, int32_t dilation, const void *amax_in, void *amax_out, void *v_scratch,
-                            float *m_scratch, void *sync_scratch, float *y, void *stream);
 
 /* spa_conv3x3_f32 / spa_conv1x1_f32 on the 16-bit matrix cores at float32 accuracy (the direct form of the scheme above,
  * for the 64-channel layers and the 1x1 projections): wt2 (Cout, taps, Cin/32, 2, 32) half precision = the planes of t * wt,

@@ -20,7 +20,6 @@ STATUS_BITS = {
     0x10: 'k-means: grid barrier timed out',
     0x20: 'a superpixel label outside [0, n_labels) was met',
     0x40: 'anchor selection: the device random stream ran dry',
-    0x80: 'fused Winograd layer: a dependency counter never arrived',
 }
 
 # informational bits: the condition is handled exactly like the reference handles it; never an error
@@ -80,9 +79,6 @@ PROTOTYPES = {
     'spa_drn_layer2_f16s': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_p, c_f32, c_p, c_p, c_p, c_p, c_p]),
     'spa_amax_f32': (ctypes.c_int, [c_p, c_p, c_i64, c_p, c_p]),
     'spa_conv3x3_wino4_f16s': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_i32, c_p, c_p, c_i32, c_i32, c_p, c_p, c_p, c_p, c_p, c_p]),
-    'spa_wino4_fused_scratch_words': (ctypes.c_int64, [c_i64, c_i32]),
-    'spa_wino4_fused_plan': (ctypes.c_int64, [c_i32, c_i32, c_i32, c_i32, c_p, c_i64]),
-    'spa_conv3x3_wino4_fused': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_i32, c_p, c_p, c_i32, c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     'spa_resize_bicubic_u8': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p]),
     'spa_resize_cvcubic_u8': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p]),
     'spa_debug_peek': (ctypes.c_int, [c_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, c_p]),

@@ -93,7 +93,7 @@ enum {
 enum {
     PROF_RGB2LAB = 0, PROF_SLIC_ASSIGN, PROF_SLIC_UPDATE, PROF_CONNECT, PROF_STATS,
     PROF_CELL_WEIGHTS, PROF_POOL_MEAN, PROF_POOL_ANCHOR, PROF_KMEANS, PROF_PAINT,
-    PROF_DRN_STEM, PROF_DRN_BIAS_ACT, PROF_DRN_CONV, PROF_DRN_CONV32, PROF_DRN_GEMM32, PROF_DRN_GEMM32_N, PROF_WINO_IN, PROF_WINO_OUT, PROF_DRN_GEMM16, PROF_DRN_GEMM16_N, PROF_DRN_CONV16, PROF_WINO_FUSED, PROF_SLOTS
+    PROF_DRN_STEM, PROF_DRN_BIAS_ACT, PROF_DRN_CONV, PROF_DRN_CONV32, PROF_DRN_GEMM32, PROF_DRN_GEMM32_N, PROF_WINO_IN, PROF_WINO_OUT, PROF_DRN_GEMM16, PROF_DRN_GEMM16_N, PROF_DRN_CONV16, PROF_SLOTS
 };
 
 struct spa_ctx {
@@ -117,12 +117,7 @@ struct spa_ctx {
     size_t conn_claim_bytes;
     int upd_wg_per_cu, upd_wg_per_cu8;
     int slic_force_general;      // SPA_SLIC_GENERAL=1 at context creation: spa_slic_core takes the general kernels
-    int zero_line_ready, conv_attr_done, conv32_attr_done, fz_attr_done, gemm16_attr_done, gemm16s_attr_done, winof_attr_done;
-    // item lists of the fused Winograd layer kernel, one per (row blocks, channel blocks, slice counts) met (spa_winof.hip)
-#define SPA_WF_LISTS 8
-    struct { int key[4]; unsigned *d; } wf_lists[SPA_WF_LISTS];
-    int wf_n;
-    unsigned long long *wf_dbg;
+    int zero_line_ready, conv_attr_done, conv32_attr_done, fz_attr_done, gemm16_attr_done, gemm16s_attr_done;
     int rng_seeded;
     int rs_key[4], rs_ks[2];       // bicubic tables held in WS_RESIZE_TAB: (H, W, h, w) and tap counts
 };

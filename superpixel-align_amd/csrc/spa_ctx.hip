@@ -56,8 +56,6 @@ extern "C" void spa_ctx_destroy(spa_ctx *ctx)
     for (int i = 0; i < WS_COUNT; ++i)
         if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
-    for (int i = 0; i < SPA_WF_LISTS; ++i)
-        if (ctx->wf_lists[i].d) (void)hipFree(ctx->wf_lists[i].d);
     if (ctx->aux_ready) {
         for (int i = 0; i < 2; ++i) { (void)hipStreamDestroy(ctx->aux[i]); (void)hipEventDestroy(ctx->ev_join[i]); }
         (void)hipEventDestroy(ctx->ev_fork);
@@ -235,7 +233,7 @@ extern "C" const char *spa_prof_name(int slot)
 {
     static const char *names[PROF_SLOTS] = {"k_rgb2lab", "k_slic_assign", "k_slic_update",
         "connectivity(all)", "segment_stats(all)", "k_cell_weights", "k_pool_mean", "k_pool_anchor",
-        "k_kmeans", "k_paint", "k_drn_stem_d(+normalise)", "k_bias_act(all)", "k_conv3x3_bf16(all)", "k_conv3x3_f32<taps 9>(all)", "k_conv3x3_f32<0, 256, 1, 256>", "k_conv3x3_f32<taps 1, narrow tiles>(all)", "k_wino_in", "k_wino_out", "k_gemm_f16x3<256, 256>", "k_gemm_f16x3<128, 128>", "k_conv3x3_f32<split>(all)", "k_wino4_fused"};
+        "k_kmeans", "k_paint", "k_drn_stem_d(+normalise)", "k_bias_act(all)", "k_conv3x3_bf16(all)", "k_conv3x3_f32<taps 9>(all)", "k_conv3x3_f32<0, 256, 1, 256>", "k_conv3x3_f32<taps 1, narrow tiles>(all)", "k_wino_in", "k_wino_out", "k_gemm_f16x3<256, 256>", "k_gemm_f16x3<128, 128>", "k_conv3x3_f32<split>(all)"};
     return (slot >= 0 && slot < PROF_SLOTS) ? names[slot] : "";
 }
 

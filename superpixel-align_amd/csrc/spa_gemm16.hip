@@ -239,7 +239,7 @@ __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3_stag(const char *__r
     extern __shared__ __attribute__((aligned(1024))) char lds16[];   // [2] weight tiles | [2] row tiles, 128 bytes per row
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool late = wave >= 4;
+    const bool late = (XP & 256) ? false : wave >= 4;        // XP & 256: every wave early (the two-barrier loop without the lag)
     // XP & 16: in-kernel stamps (s_memtime, low word) of waves 0 and 4 of workgroup G16_STAMP_WG over periods [Q0, Q0 + NQ), kept
     // in LDS behind the tiles (no global store inside the loop: the counted vmcnt waits stay what they are), copied out at the end
     constexpr int G16_Q0 = 24, G16_NQ = 40;
@@ -335,7 +335,9 @@ __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3_stag(const char *__r
     stage_next();                                  // step 0
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     g16_lds_barrier();
-    if (late) { stage_next(); g16_lds_barrier(); }   // step 1; the extra barrier = half a period of delay
+    // XP & 512: the late half stages ITS share of step q + 1 at the top of its period q as well (half a period in flight instead of a
+    // whole one, but issued while the partner wave multiplies instead of in front of its own matrix work)
+    if (late) { if (!(XP & 512)) stage_next(); g16_lds_barrier(); }   // step 1; the extra barrier = half a period of delay
     bool stored = false;
 
     f32x4 acc[MI][NJ];
@@ -347,11 +349,79 @@ __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3_stag(const char *__r
         const int buf = q & 1;
         if (XP & 16) stamp_q = (q >= G16_Q0 && q < G16_Q0 + G16_NQ) ? q - G16_Q0 : -1;
         STAMP(0);
-        if (!late) stage_next();                   // step q + 1
+        if (!late || (XP & 512)) stage_next();     // step q + 1
         STAMP(1);
         // ---- R
         const char *lw = wbuf + buf * (BM * 128), *lx = xbuf + buf * (BN * 128);
         f16x8 wh[MI], wl[MI], ph[NJ], pl[NJ];
+        if constexpr ((XP & 128) != 0) {
+            // XP & 128: the split INSIDE the matrix work.  R only issues the LDS reads (weight fragments, raw float32 rows) and
+            // splits row fragment 0; M walks the row fragments j = 0 .. NJ - 1 (per accumulator still l.h, h.l, h.h) and splits
+            // fragment j + 1 between the matrix instructions of fragment j: 16 single-issue vector instructions per
+            // fragment — h = rn16(x * scale) and l = rn16(x * scale - h) are ONE mixed-precision fma each (v_fma_mixlo/hi_f16:
+            // the product by a power of two and the difference are exact in float32, so the one rounding is the conversion) —
+            // no packed float32 operation (an anti-lever beside MFMAs, MI355X_MICROARCH.md), in the issue slots a
+            // v_mfma_f32_16x16x32_f16 leaves free (8 of its 16 cycles)
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            f32x4 ra[NJ], rb[NJ];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int row = wm * WROWS + i * 16 + frow;
+                wh[i] = *(const f16x8 *)(lw + row * 128 + ((fk ^ (row & 7)) << 4));
+                wl[i] = *(const f16x8 *)(lw + row * 128 + (((4 + fk) ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int row = wn * (NJ * 16) + j * 16 + frow;
+                ra[j] = *(const f32x4 *)(lx + row * 128 + (((2 * fk) ^ (row & 7)) << 4));
+                rb[j] = *(const f32x4 *)(lx + row * 128 + (((2 * fk + 1) ^ (row & 7)) << 4));
+            }
+            const float sc = c_zscale;
+            u32x4 hu[NJ], lu[NJ];
+            // elements 2e, 2e + 1 of row fragment j: the two high halves, then (a dependent pair, issued a group of matrix
+            // instructions later) the two low halves
+            auto split_h = [&](int j, int e) {
+                const float x0 = e < 2 ? ra[j][2 * e] : rb[j][2 * e - 4], x1 = e < 2 ? ra[j][2 * e + 1] : rb[j][2 * e - 3];
+                unsigned h;
+                asm volatile("v_fma_mixlo_f16 %0, %1, %3, 0 op_sel_hi:[0,0,0]\n\t"
+                             "v_fma_mixhi_f16 %0, %2, %3, 0 op_sel_hi:[0,0,0]"
+                             : "=&v"(h) : "v"(x0), "v"(x1), "s"(sc));
+                hu[j][e] = h;
+            };
+            auto split_l = [&](int j, int e) {
+                const float x0 = e < 2 ? ra[j][2 * e] : rb[j][2 * e - 4], x1 = e < 2 ? ra[j][2 * e + 1] : rb[j][2 * e - 3];
+                unsigned l;
+                asm volatile("v_fma_mixlo_f16 %0, %1, %3, -%4 op_sel_hi:[0,0,1]\n\t"
+                             "v_fma_mixhi_f16 %0, %2, %3, -%4 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                             : "=&v"(l) : "v"(x0), "v"(x1), "s"(sc), "v"(hu[j][e]));
+                lu[j][e] = l;
+            };
+            auto split_pair = [&](int j, int e) { split_h(j, e); split_l(j, e); };
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split_pair(0, e);
+            STAMP(2);
+            if (late) {
+                if (stored && !(XP & 512)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MI * NJ) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            STAMP(3);
+            g16_lds_barrier();
+            STAMP(4);
+            stored = false;
+            if (late && !(XP & 512)) stage_next();     // step q + 2
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const f16x8 phj = __builtin_bit_cast(f16x8, hu[j]), plj = __builtin_bit_cast(f16x8, lu[j]);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], phj, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], plj, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], phj, acc[i][j], 0, 0, 0);
+                    if (j + 1 < NJ) { if ((i & 1) == 0) split_h(j + 1, i >> 1); else split_l(j + 1, i >> 1); }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int row = wm * WROWS + i * 16 + frow;
@@ -400,7 +470,7 @@ __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3_stag(const char *__r
         g16_lds_barrier();
         STAMP(4);
         stored = false;
-        if (late) stage_next();                    // step q + 2
+        if (late && !(XP & 512)) stage_next();     // step q + 2
         // ---- M: small terms first: they meet the accumulator while it is small
         if (XP & 8) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -415,6 +485,7 @@ __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3_stag(const char *__r
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], ph[j], acc[i][j], 0, 0, 0);
+        }
         if (XP & 8) __builtin_amdgcn_s_setprio(0);
         STAMP(5);
         if (++c_t == nk) {
@@ -495,6 +566,12 @@ int gemm_f16x3_raw(spa_ctx *ctx, const float *x, long long rows, int32_t Cin, co
             SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
             SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
             SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
+            SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
+            SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 640>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
+            SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 656>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128 + 4096));
+            SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 384>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
+            SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
+            SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 144>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128 + 4096));
             SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128 + 4096));
             SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 18>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128 + 4096));
             SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 20>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128 + 4096));
@@ -517,6 +594,12 @@ int gemm_f16x3_raw(spa_ctx *ctx, const float *x, long long rows, int32_t Cin, co
             case 4: G16S_LAUNCH(256, 256, 8); break;
             case 5: G16S_LAUNCH(256, 256, 10); break;
             case 32: G16S_LAUNCH(256, 256, 64); break;
+            case 64: G16S_LAUNCH(256, 256, 128); break;
+            case 320: G16S_LAUNCH(256, 256, 640); break;
+            case 336: G16S_LAUNCH(256, 256, 656); break;
+            case 192: G16S_LAUNCH(256, 256, 384); break;
+            case 80: G16S_LAUNCH(256, 256, 144); break;
+            case 128: G16S_LAUNCH(256, 256, 256); break;
             case 16: G16S_LAUNCH(256, 256, 16); break;
             case 17: G16S_LAUNCH(256, 256, 18); break;
             case 18: G16S_LAUNCH(256, 256, 20); break;

@@ -77,6 +77,15 @@ static int km_build_tree(KmTree &t, int start, int n)
     return a;
 }
 
+// Grid-wide barrier of the persistent k-means launch.  Residency: the launch is a plain one — ROCm's
+// cooperative launch checks the grid against the occupancy of an EMPTY device and serialises behind its own queue; it does not
+// gang-schedule against kernels of other streams or processes either — so the host caps the grid at what the occupancy query
+// says fits the device at once (spa_kmeans_weighted) and a workgroup that arrives early simply waits for the others to be
+// placed: beside the DRN's persistent kernels of the next batch (run(join = False)) that is until one of them retires a
+// workgroup, i.e. at most one such kernel's duration (<= 7 ms); none of those kernels waits for this one, so the wait ends.
+// Two spin-barrier launches of DIFFERENT processes on one device could each hold compute units the other needs: the wait is
+// bounded in WALL-CLOCK time (s_memrealtime, 100 MHz: 20 s without the counter reaching its target), after which the launch
+// gives up, latches SPA_ST_KMEANS_BARRIER — every caller checks the status word — and runs to its end without hanging the device.
 __device__ __forceinline__ void grid_sync(unsigned *ctr, unsigned G, unsigned &epoch,
                                           uint32_t *status)
 {
@@ -88,10 +97,14 @@ __device__ __forceinline__ void grid_sync(unsigned *ctr, unsigned G, unsigned &e
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned target = epoch * G;
-        long long spins = 0;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        int spins = 0;
         while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1ll << 26)) { atomicOr(status, SPA_ST_KMEANS_BARRIER); break; }
+            if ((++spins & 1023) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > 2000000000ull) {      // 20 s at 100 MHz
+                atomicOr(status, SPA_ST_KMEANS_BARRIER);
+                break;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -718,6 +731,8 @@ extern "C" int spa_kmeans_weighted(spa_ctx *ctx, const void *X, int32_t x_dtype,
     if (G < n_task) G = n_task;
     if (G > ctx->n_cu) G = ctx->n_cu;
     if (G < 1) G = 1;
+    // (G <= one workgroup per compute unit: resident at once on an otherwise idle device whenever the occupancy query below
+    // answers >= 1 — grid_sync's comment has the rest)
     // member lists: one region per workgroup that runs update tasks
     const int regions = G < n_task ? G : n_task;
     char *lists;
@@ -742,6 +757,9 @@ extern "C" int spa_kmeans_weighted(spa_ctx *ctx, const void *X, int32_t x_dtype,
         if (!(ctx->km_attr_done[SLOT / 3] & (1 << (SLOT % 3)))) {                                                \
             SPA_HIP(hipFuncSetAttribute((const void *)k_kmeans<TT, KK>,                                          \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));                \
+            int per_cu = 0;                                                                                      \
+            SPA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_kmeans<TT, KK>, KM_THREADS, 150 * 1024)); \
+            if (per_cu < 1) { spa_set_error("k_kmeans: no workgroup fits a compute unit"); return SPA_ERR_ARG; } \
             ctx->km_attr_done[SLOT / 3] |= (1 << (SLOT % 3));                                                    \
         }                                                                                                        \
         hipLaunchKernelGGL((k_kmeans<TT, KK>), dim3(G), dim3(KM_THREADS), lds, s, (const TT *)X, (long long)ld, \

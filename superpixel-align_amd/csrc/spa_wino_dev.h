@@ -1,4 +1,4 @@
-// Device helpers shared by the Winograd kernels (spa_wino.hip: separate transforms; spa_winof.hip: the fused layer kernel).
+// Device helpers of the Winograd kernels (spa_wino.hip).
 #pragma once
 #include "spa_common.h"
 

@@ -117,6 +117,19 @@ def barrier():
         dist.barrier()
 
 
+def all_values(value, device=None):
+    """One float per rank -> the list over ranks, on every rank (bench.py: per-rank rates and gather times)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [float(value)]
+    if device is None:
+        device = torch.device('cuda', torch.cuda.current_device()) \
+            if dist.get_backend() == 'nccl' else torch.device('cpu')
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    parts = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    return [float(p.item()) for p in parts]
+
+
 def max_over_ranks(value, device=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(value)

@@ -68,10 +68,9 @@ _EPILOGUE = {'engine': None, 'bytes': 0, 'launches': 0, 'own_conv': True, 'own_c
              'split_gemm': os.environ.get('SPA_SPLIT_GEMM', '1') != '0',
              'gemm16_flops': 0.0, 'gemm16_launches': 0, 'gemm16_bytes': 0.0,
              'gemm16n_flops': 0.0, 'gemm16n_launches': 0, 'gemm16n_bytes': 0.0, 'conv16_flops': 0.0, 'conv16_launches': 0, 'conv16_bytes': 0.0,
-             # a Winograd layer as ONE persistent launch (transforms streamed under the GEMM tiles, csrc/spa_winof.hip);
-             # SPA_WINO_FUSED=0 keeps the three launches
-             'wino_fused': os.environ.get('SPA_WINO_FUSED', '1') != '0',
-             'winof_flops': 0.0, 'winof_launches': 0, 'winof_bytes': 0.0, 'winof_layer_bytes': 0.0}
+             # the layer's OWN bytes of the 256 x 256-tile Winograd layers (X, Y, the residual, the weight planes once): what a
+             # convolution that kept V and M on chip would move — bench.py's `algorithmic_bytes` of the GEMM entry
+             'gemm16_layer_bytes': 0.0}
 
 
 def conv_bias_act(conv, bn, x, residual=None, relu=True):
@@ -110,30 +109,15 @@ def conv_bias_act(conv, bn, x, residual=None, relu=True):
             _EPILOGUE['wino_saved_flops'] += direct * (1.0 - frac)
             px = x.shape[0] * x.shape[2] * x.shape[3]
             split = wino[0].shape[0] == 36 and _EPILOGUE['split_gemm'] and conv._spa_wino.get('4s')
-            # the one-launch form wins where a GEMM tile is long (K = 512: 6.37-6.44 against 6.54-6.72 ms per 30 images; at
-            # K = 256 its transform slices weigh more: 2.80-2.88 against 2.60-2.66, tools/winof_bench.py), SPA_WINO_FUSED_MIN_CIN
-            fused = (bool(split) and _EPILOGUE['wino_fused'] and conv.out_channels % 256 == 0
-                     and conv.in_channels >= int(os.environ.get('SPA_WINO_FUSED_MIN_CIN', '512'))
-                     # ... and where the launch has work to spread: from 64 row blocks of 256 tiles up (30 images of 224 x 224: six
-                     # row blocks, the lists' prologue and epilogue dominate — 6.6 against 5.7 ms for that forward)
-                     and px >= int(os.environ.get('SPA_WINO_FUSED_MIN_PX', '262144')))
             in_bytes = 4.0 * px * (1 + expand) * conv.in_channels            # k_wino_in reads X and writes V
             mm_bytes = 4.0 * px * expand * (conv.in_channels + conv.out_channels)     # V read, M written
             out_bytes = 4.0 * px * ((2 if residual is not None else 1) + expand) * conv.out_channels   # M [+ R] read, Y written
-            if fused:
-                _EPILOGUE['winof_flops'] += direct * frac
-                _EPILOGUE['winof_launches'] += 1
-                _EPILOGUE['winof_bytes'] += in_bytes + mm_bytes + out_bytes
-                # what the LAYER needs whatever the algorithm: X and Y once (+ R), the 36 weight planes once
-                _EPILOGUE['winof_layer_bytes'] += 4.0 * px * (conv.in_channels + (2 if residual is not None else 1) * conv.out_channels) \
-                    + 4.0 * 36 * conv.in_channels * conv.out_channels
-                y, am = eng.conv3x3_wino_f16s(x, split[0], split[1], split[2], residual, relu, conv.dilation[0],
-                                              amax_in=getattr(x, '_spa_amax', None), fused=True)
-                y._spa_amax = am
-                return y
             key = 'gemm' if conv.out_channels % 256 == 0 else 'gemmn'       # the 256 x 256 instance / the narrow tiles
             if split:
                 key = key.replace('gemm', 'gemm16')
+                if key == 'gemm16':
+                    _EPILOGUE['gemm16_layer_bytes'] += 4.0 * px * (conv.in_channels + (2 if residual is not None else 1) * conv.out_channels) \
+                        + 4.0 * 36 * conv.in_channels * conv.out_channels
             _EPILOGUE[key + '_flops'] += direct * frac
             _EPILOGUE[key + '_launches'] += 1
             _EPILOGUE[key + '_bytes'] += mm_bytes

@@ -410,7 +410,7 @@ class Engine(object):
         check(self._lib.spa_amax_f32(self._ctx, _ptr(x), x.numel(), _ptr(a), self._s()))
         return a
 
-    def conv3x3_wino_f16s(self, x, u2, cs, bias, residual=None, relu=True, dilation=1, amax_in=None, track_amax=True, fused=False, _keep=None):
+    def conv3x3_wino_f16s(self, x, u2, cs, bias, residual=None, relu=True, dilation=1, amax_in=None, track_amax=True, _keep=None):
         """conv3x3_wino_f32's F(4x4,3x3) with the GEMMs on the 16-bit matrix cores at float32 accuracy (two half-precision
         planes per operand, three products).  (u2, cs) = winograd_weights_split(weight).  Returns (y, amax of y or None);
         amax_in: the amax the producing call returned for x (computed here when None)."""
@@ -431,13 +431,6 @@ class Engine(object):
         m = torch.empty((36, T, Cout), dtype=torch.float32, device=x.device)
         if _keep is not None:                    # tools / tests: look at the transformed operands
             _keep['v'], _keep['m'] = v, m
-        if fused and Cout % 256 == 0 and Cin >= 160:
-            # the layer as ONE persistent launch: transforms streamed under the GEMM tiles (csrc/spa_winof.hip)
-            sync = torch.empty((int(self._lib.spa_wino4_fused_scratch_words(T, Cout)),), dtype=torch.int32, device=x.device)
-            check(self._lib.spa_conv3x3_wino4_fused(self._ctx, _ptr(x), B, H, W, Cin, _ptr(u2), cs.ctypes.data, Cout, _ptr(bias),
-                                                    _ptr(residual), 1 if relu else 0, int(dilation), _ptr(amax_in), _ptr(amax_out),
-                                                    _ptr(v), _ptr(m), _ptr(sync), _ptr(y), self._s()))
-            return y, amax_out
         check(self._lib.spa_conv3x3_wino4_f16s(self._ctx, _ptr(x), B, H, W, Cin, _ptr(u2), cs.ctypes.data, Cout, _ptr(bias),
                                                _ptr(residual), 1 if relu else 0, int(dilation), _ptr(amax_in), _ptr(amax_out),
                                                _ptr(v), _ptr(m), _ptr(y), self._s()))

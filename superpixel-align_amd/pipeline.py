@@ -98,6 +98,15 @@ class LabelPipeline(object):
         self._gen_stream = None
         self._gen_done = None
 
+    def reseed(self, seed=None):
+        """Both host generators back to their state at process start (batch_spalign_kmeans.py:33-34): a run that follows is
+        comparable bit for bit with any other run from the same state (anchor draws, the k > 2 initial assignment)."""
+        if self.device_rng and self._rng_ready:
+            raise ValueError('reseed: the generator state lives on the device (device_rng)')
+        seed = getattr(self.args, 'seed', 1111) if seed is None else seed
+        self.pyrandom = PyRandom(seed)
+        self.nprandom = NpRandom(seed)
+
     # ---------------------------------------------------------------- stages
     def features(self, imgs_dev):
         """model.batch_predict + F.concat(use_maps) (:431-435) -> (B, C, fh, fw), channels-last."""

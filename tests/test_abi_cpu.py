@@ -86,43 +86,6 @@ def test_host_rng_streams(spa, orc):
         off += S
 
 
-def test_fused_winograd_plan_orders_producers_before_consumers():
-    """spa_wino4_fused_plan (host only): the per-XCD work-item lists the fused Winograd layer kernel pops
-    (csrc/spa_winof.hip).  Every input-transform slice, GEMM tile and output-transform slice of the layer appears
-    exactly once, a row block lives in ONE list, and inside a list every slice of a row block's input transform
-    precedes its first GEMM tile and all 36 tiles of a (row block, channel block) precede its output slices — the
-    order that makes the in-kernel waits deadlock free whatever the residency of the workgroups."""
-    import ctypes
-    import importlib
-    import numpy as np
-    spa = importlib.import_module('superpixel-align_amd')
-    L = spa._lib.lib()
-    for NRB, NCB, PI, PO in [(0, 1, 8, 4), (1, 1, 8, 4), (2, 2, 8, 4), (9, 1, 4, 2), (40, 2, 8, 4), (240, 2, 8, 4), (241, 1, 8, 8), (533, 3, 2, 1)]:
-        n_items = NRB * (PI + 36 * NCB + PO * NCB)
-        out = np.zeros(16 + n_items + 4, np.uint32)
-        n = L.spa_wino4_fused_plan(NRB, NCB, PI, PO, out.ctypes.data_as(ctypes.c_void_p), out.size)
-        assert n == 16 + n_items
-        assert L.spa_wino4_fused_plan(NRB, NCB, PI, PO, out.ctypes.data_as(ctypes.c_void_p), max(0, n - 1)) == -5      # SPA_ERR_CAPACITY
-        off, items = out[:9], out[16:n]
-        assert off[0] == 0 and off[8] == n_items and np.all(np.diff(off.astype(np.int64)) >= 0)
-        seen, owner = set(), {}
-        for x in range(8):
-            ins, mms = {}, {}
-            for it in items[off[x]:off[x + 1]].tolist():
-                t, cb, zp, rb = it & 3, (it >> 2) & 3, (it >> 4) & 63, it >> 10
-                assert it not in seen and rb < NRB and cb < NCB and owner.setdefault(rb, x) == x
-                seen.add(it)
-                if t == 0:
-                    assert zp < PI
-                    ins[rb] = ins.get(rb, 0) + 1
-                elif t == 1:
-                    assert zp < 36 and ins.get(rb, 0) == PI
-                    mms[rb, cb] = mms.get((rb, cb), 0) + 1
-                else:
-                    assert t == 2 and zp < PO and mms.get((rb, cb), 0) == 36
-        assert len(seen) == n_items
-
-
 def test_host_rng_vector_and_scalar_forms_agree():
     """spa_pyrandom_shuffle_select_host has an AVX-512 form (16 generator outputs per step of the rejection sampling; the
     anchors' places traced backwards through the swaps with vector compares) chosen at run time and a scalar form

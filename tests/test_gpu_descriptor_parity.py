@@ -81,13 +81,13 @@ def _run(mods, arch, weights, imgs, split):
     saved = E['split_gemm']
     try:
         E['split_gemm'] = split
-        for k in ('gemm16_launches', 'gemm16n_launches', 'winof_launches', 'conv16_launches'):
+        for k in ('gemm16_launches', 'gemm16n_launches', 'conv16_launches'):
             E[k] = 0
         model = mods.drn.create_drn(arch, weights=weights, device='cuda', dtype=torch.float32)
         pipe = mods.pipeline.LabelPipeline(_args(arch=arch), model, mods.ops.engine())
         res = pipe.run(imgs)
         torch.cuda.synchronize()
-        ran16 = E['gemm16_launches'] + E['gemm16n_launches'] + E['winof_launches'] + E['conv16_launches']
+        ran16 = E['gemm16_launches'] + E['gemm16n_launches'] + E['conv16_launches']
         assert (ran16 > 0) == split, 'the arithmetic asked for is not the one that ran'
         N = int(res.info.cpu()[2])
         out = types.SimpleNamespace(X=res.X[:N].cpu().numpy().copy(), labels=res.labels.cpu().numpy().copy(),

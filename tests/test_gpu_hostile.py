@@ -92,9 +92,9 @@ def test_hostile_channel_scales_through_the_whole_network_and_a_reference_pth(en
         E['winograd'], E['own_conv32'] = 4, True
         E['split_gemm'] = True
         model = drn.create_drn('drn_d_22', weights=path, device='cuda', dtype=torch.float32)
-        E['gemm16_launches'] = E['winof_launches'] = E['conv16_launches'] = 0
+        E['gemm16_launches'] = E['conv16_launches'] = 0
         _, split = model.batch_predict(x, need=[2, 4, 7])
-        assert E['gemm16_launches'] + E['winof_launches'] > 0 and E['conv16_launches'] > 0       # the planes really ran
+        assert E['gemm16_launches'] > 0 and E['conv16_launches'] > 0       # the planes really ran
         E['split_gemm'] = False
         model32 = drn.create_drn('drn_d_22', weights=path, device='cuda', dtype=torch.float32)
         _, f32 = model32.batch_predict(x, need=[2, 4, 7])
@@ -160,9 +160,6 @@ def test_heavy_tailed_activations_single_layers(eng, Cin, Cout, dil, form):
         u2, cs = eng.winograd_weights_split(w)
         y, _ = eng.conv3x3_wino_f16s(x, u2, cs, bias, None, False, dil)
         y32 = eng.conv3x3_wino_f32(x, eng.winograd_weights(w, 4), bias, None, False, dil)
-        if Cin >= 160:
-            yf, _ = eng.conv3x3_wino_f16s(x, u2, cs, bias, None, False, dil, fused=True)
-            assert torch.equal(yf, y)
     else:
         taps = k * k
         wt = w.permute(0, 2, 3, 1).reshape(Cout, taps, Cin).contiguous()

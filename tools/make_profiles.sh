@@ -29,8 +29,6 @@ v fp32_mfma_gemm --fp32_mfma_gemm
 v drn_c_26 --arch drn_c_26
 v drn_c_26_bf16 --arch drn_c_26 --dtype bf16
 v reference_operating_point --superpixel_method felzenszwalb --height 224 --width 224 --arch drn_c_26 --pool_mode anchor --n_clusters 4
-SPA_WINO_FUSED=0 python3 bench.py --no_cpu_baseline --steps 20 --warmup 5 2> gpurun_out/final_variant_three_launch_winograd.err | tail -1 > gpurun_out/final_variant_three_launch_winograd.json
-python3 tools/winof_bench.py --reps 5 > gpurun_out/final_winof_bench.txt 2>&1
 python3 tools/h2h_probe2.py --steps 10 2>&1 | grep -E "device resident|host loop" > gpurun_out/final_h2h_probe.txt
 SPA_LATE_DOWNLOAD=0 python3 tools/h2h_probe2.py --steps 10 2>&1 | grep -E "device resident|host loop" | sed "s/^/[downloads enqueued at once, behind an event] /" >> gpurun_out/final_h2h_probe.txt
 python3 -m pytest tests/test_gpu_hostile.py -q -s 2>&1 | grep -E "hostile|per-channel|bulk error|passed|failed" > gpurun_out/final_hostile.txt

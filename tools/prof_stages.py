@@ -76,8 +76,6 @@ if a.wino:
     am = eng.amax(x)
     for _ in range(a.reps):
         eng.conv3x3_wino_f16s(x, u2, cs, b, None, True, 2, amax_in=am)
-    for _ in range(a.reps):                          # the same layer as ONE launch (csrc/spa_winof.hip)
-        eng.conv3x3_wino_f16s(x, u2, cs, b, None, True, 2, amax_in=am, fused=True)
     x2 = torch.relu(torch.randn((a.batch, 128, h, w), device='cuda')).contiguous(memory_format=torch.channels_last)
     w2 = (torch.randn((128, 128, 3, 3), device='cuda') * (2.0 / (9 * 128)) ** 0.5).permute(0, 2, 3, 1).reshape(128, 9, 128).contiguous()
     b2 = torch.randn((128,), device='cuda')

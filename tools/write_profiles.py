@@ -118,9 +118,7 @@ if bkey:
 # transform, each against the bytes it moves by construction (bench.py scales these ratios to its launches' mix)
 def hbm_of(kname):
     key = [k for k in fe if k.replace('void ', '').startswith(kname)]           # (pmc_summary truncates long template names)
-    # the fused layer kernel mixes 8-byte loads (output transform), 16-byte loads and LDS-DMA: FETCH_SIZE is uncalibrated for
-    # that mix (MI355X_MICROARCH.md) and is taken as it stands — it then equals the bytes read by construction to 1 %
-    fx = 1 if kname.startswith('k_wino4_fused') else 2
+    fx = 2
     return (fe[key[0]][1] * 1024 * fx + wr.get(key[0], (0, 0.0))[1] * 1024) if key else None
 if any(k.replace('void ', '').startswith('k_wino4_in') for k in fe):
     act = 4.0 * B * (1024 // 8) * (2048 // 8) * 512           # one 512-channel activation at 1/8 resolution
@@ -129,8 +127,7 @@ if any(k.replace('void ', '').startswith('k_wino4_in') for k in fe):
             ('k_conv3x3_f32<0, 256, 1, 256>', 'k_conv3x3_f32<taps 1>(GEMM form, all)', 4.5 * act, 'V = 2.25 X read + M = 2.25 Y written'),
             ('k_gemm_f16x3<256, 256', 'k_gemm_f16x3<256, 256>', 4.5 * act, 'V = 2.25 X read + M = 2.25 Y written'),
             ('k_wino4_out_s<0', 'k_wino_out', 3.25 * act, 'M = 2.25 Y read + Y written'),
-            ('k_wino4_out<0', 'k_wino_out', 3.25 * act, 'M = 2.25 Y read + Y written'),
-            ('k_wino4_fused', 'k_wino4_fused', 11.0 * act, 'the three kernels above in one launch: X read, V written and read, M written and read, Y written')):
+            ('k_wino4_out<0', 'k_wino_out', 3.25 * act, 'M = 2.25 Y read + Y written')):
         h = hbm_of(kname)
         if h:
             ratio[bench_name] = h / built
