@@ -50,6 +50,7 @@ extern "C" {
 #define SPA_ST_KMEANS_BARRIER 0x10u      /* grid barrier timed out (should never happen)        */
 #define SPA_ST_LABEL_RANGE 0x20u         /* a label outside [0, S) was met                      */
 #define SPA_ST_RNG_UNDERRUN 0x40u        /* the device random stream ran dry (spa_pyrandom_dev_generate too small) */
+#define SPA_ST_NP_SHUFFLE 0x80u          /* spa_np_kmeans_init_dev: more points at or below the median weight than its LDS vector holds */
 
 #define SPA_CELL_SLOTS 16
 
@@ -348,6 +349,21 @@ typedef struct spa_nprandom spa_nprandom;
 int spa_nprandom_create(uint32_t seed, spa_nprandom **out);
 void spa_nprandom_destroy(spa_nprandom *rng);
 int spa_nprandom_shuffle_host(spa_nprandom *rng, int64_t *a_host, int64_t n);
+/* numpy's rk_state of the generator as it stands: 624 state words + the position inside the current block (628 words written,
+   the last three zero) — what spa_np_kmeans_init_dev keeps in device memory. */
+int spa_nprandom_state(spa_nprandom *rng, uint32_t *state628_host);
+/* The k > 2 initial assignment (:141-149) drawn ON THE DEVICE from numpy's stream (csrc/spa_nprng.hip): thr = sort(w)[N // 2],
+   m = #(w <= thr), idx = arange(m) % (k - 1) + 1, np.random.shuffle(idx) -> init_other[0 .. m) for spa_kmeans_weighted.
+   state_dev: 628 words of device memory holding the generator (advanced by the call); n_ptr: device word N; gate: device word
+   or NULL — with a gate the launch runs, and consumes outputs, only if *gate > 0 (speculatively enqueued retry runs,
+   batch_spalign_kmeans.py:201-205); m_out: device word or NULL.  Ncap <= 65536, 2 < k <= 8. */
+int spa_np_kmeans_init_dev(spa_ctx *ctx, void *state_dev, const double *w, const int32_t *n_ptr, int32_t Ncap,
+                           int32_t k, const int32_t *gate, int64_t *init_other, int32_t *m_out, void *stream);
+/* the retry bookkeeping of one k-means run (:201-205) on the device: n_fail = images whose superpixels assign[offsets[b] ..
+   offsets[b+1]) hold no 0.  gate == NULL (the batch's first run): *pending = n_fail, *made = 0; a gated retry run: nothing
+   unless *gate > 0, then *pending += n_fail - 1, *made += 1.  fail_out: B bytes (1 = image without cluster 0) or NULL. */
+int spa_kmeans_retry_update(spa_ctx *ctx, const int32_t *assign, const int32_t *offsets, int32_t B, const int32_t *gate,
+                            int32_t *pending, int32_t *made, uint8_t *fail_out, void *stream);
 
 /* The same selection entirely on the device (no superpixel size ever visits the host): a device-resident
    CPython generator (seeded like random.seed()), its outputs produced ahead of use into a ring
@@ -409,6 +425,12 @@ int spa_kmeans_weighted(spa_ctx *ctx, const void *X, int32_t x_dtype, int64_t ld
                         const double *w, const int32_t *n_ptr, int32_t Ncap, int32_t k,
                         int32_t max_iter, const int64_t *init_other, int32_t *assign,
                         int32_t *info, void *stream);
+/* the same launch behind a device-side gate: nothing runs (assign / info untouched) unless *gate > 0 — the retry runs of
+   weighted_kmeans (:201-205), enqueued speculatively by the pipeline and decided on the device.  gate == NULL: always runs. */
+int spa_kmeans_weighted_gated(spa_ctx *ctx, const void *X, int32_t x_dtype, int64_t ld, int32_t D,
+                              const double *w, const int32_t *n_ptr, int32_t Ncap, int32_t k,
+                              int32_t max_iter, const int64_t *init_other, const int32_t *gate, int32_t *assign,
+                              int32_t *info, void *stream);
 
 /* weighted_kmeans() paint loop (:193-199) and `clustering_result == 0` (:207):
    cluster[p] = assign[offsets[b] + labels[p]], road[p] = cluster[p] == 0; (B,H,W) uint8.  */

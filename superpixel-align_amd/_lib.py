@@ -20,6 +20,7 @@ STATUS_BITS = {
     0x10: 'k-means: grid barrier timed out',
     0x20: 'a superpixel label outside [0, n_labels) was met',
     0x40: 'anchor selection: the device random stream ran dry',
+    0x80: 'k-means initial assignment on the device: more than 65 536 points at or below the median weight',
 }
 
 # informational bits: the condition is handled exactly like the reference handles it; never an error
@@ -104,6 +105,9 @@ PROTOTYPES = {
     'spa_nprandom_create': (ctypes.c_int, [ctypes.c_uint32, ctypes.POINTER(c_p)]),
     'spa_nprandom_destroy': (None, [c_p]),
     'spa_nprandom_shuffle_host': (ctypes.c_int, [c_p, c_p, c_i64]),
+    'spa_nprandom_state': (ctypes.c_int, [c_p, c_p]),
+    'spa_np_kmeans_init_dev': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_i32, c_i32, c_p, c_p, c_p, c_p]),
+    'spa_kmeans_retry_update': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_p, c_p, c_p, c_p, c_p]),
     'spa_pyrandom_dev_seed': (ctypes.c_int, [c_p, ctypes.c_uint64, c_p]),
     'spa_pyrandom_dev_generate': (ctypes.c_int, [c_p, c_i64, c_p]),
     'spa_anchor_ranks_dev': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_i64, c_p, c_p, c_p]),
@@ -115,6 +119,8 @@ PROTOTYPES = {
                                      c_p, c_i32, c_p, c_i32, c_p, c_i32, c_p, c_i32, c_i64, c_p]),
     'spa_kmeans_weighted': (ctypes.c_int, [c_p, c_p, c_i32, c_i64, c_i32, c_p, c_p, c_i32, c_i32,
                                            c_i32, c_p, c_p, c_p, c_p]),
+    'spa_kmeans_weighted_gated': (ctypes.c_int, [c_p, c_p, c_i32, c_i64, c_i32, c_p, c_p, c_i32, c_i32,
+                                                 c_i32, c_p, c_p, c_p, c_p, c_p]),
     'spa_paint': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p]),
     'spa_confusion': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i64, c_p, c_p]),
 }

@@ -59,6 +59,8 @@ _COMMON_FLAGS = [
     ('--io_threads', dict(type=int, default=8)),
     ('--decode_procs', dict(type=int, default=0)),       # > 0: decode PNGs in this many worker processes (shared-memory slabs)
     ('--strict_retry', dict(action='store_true', default=False)),     # k = 2: die with RecursionError where the reference does
+    # k > 2: draw the initial assignment (np.random.shuffle) on the host, synchronously, as round 4 did (default: on the device)
+    ('--host_kmeans_init', dict(action='store_true', default=False)),
     ('--host_resize', dict(action='store_true', default=False)),      # resize with Pillow on the host threads instead
     ('--resize_backend', dict(type=str, default='pil', choices=['pil', 'cv2'])),   # cv2: OpenCV's INTER_CUBIC algorithm (not pinned)
 ]
@@ -722,6 +724,8 @@ def main_labelled(argv=None, get=None, make_pipe=None, originals=False, make_mod
                 eng.raise_on_word(st['status_h'])
                 if st['fail_h'] is not None:
                     st['res'].check_retry(st['fail_h'])
+                elif getattr(st['res'], 'retry_info', None) is not None:
+                    st['res'].check_retry()                 # k > 2 on the device: retry runs made / still pending
                 times = pipe.elapsed_times(st['events'])
                 # `elapsed_time` stays what the reference reports (:420: wall clock since the batch was started, which in this
                 # loop includes the batches in flight ahead of it); the batch's own device time goes under its own key

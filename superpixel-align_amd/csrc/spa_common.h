@@ -93,7 +93,7 @@ enum {
 enum {
     PROF_RGB2LAB = 0, PROF_SLIC_ASSIGN, PROF_SLIC_UPDATE, PROF_CONNECT, PROF_STATS,
     PROF_CELL_WEIGHTS, PROF_POOL_MEAN, PROF_POOL_ANCHOR, PROF_KMEANS, PROF_PAINT,
-    PROF_DRN_STEM, PROF_DRN_BIAS_ACT, PROF_DRN_CONV, PROF_DRN_CONV32, PROF_DRN_GEMM32, PROF_DRN_GEMM32_N, PROF_WINO_IN, PROF_WINO_OUT, PROF_DRN_GEMM16, PROF_DRN_GEMM16_N, PROF_DRN_CONV16, PROF_SLOTS
+    PROF_DRN_STEM, PROF_DRN_BIAS_ACT, PROF_DRN_CONV, PROF_DRN_CONV32, PROF_DRN_GEMM32, PROF_DRN_GEMM32_N, PROF_WINO_IN, PROF_WINO_OUT, PROF_DRN_GEMM16, PROF_DRN_GEMM16_N, PROF_DRN_CONV16, PROF_DRN_CONV16_128, PROF_DRN_CONV16_256, PROF_DRN_CONV16_1X1, PROF_DRN_CONV16_FRONT, PROF_SLOTS
 };
 
 struct spa_ctx {
@@ -117,10 +117,29 @@ struct spa_ctx {
     size_t conn_claim_bytes;
     int upd_wg_per_cu, upd_wg_per_cu8;
     int slic_force_general;      // SPA_SLIC_GENERAL=1 at context creation: spa_slic_core takes the general kernels
-    int zero_line_ready, conv_attr_done, conv32_attr_done, fz_attr_done, gemm16_attr_done, gemm16s_attr_done;
+    int zero_line_ready, conv_attr_done, conv32_attr_done, fz_attr_done, gemm16_attr_done, gemm16s_attr_done, nprng_attr_done, conv_stag_attr_done;
     int rng_seeded;
     int rs_key[4], rs_ks[2];       // bicubic tables held in WS_RESIZE_TAB: (H, W, h, w) and tap counts
 };
+
+#ifdef __HIPCC__
+// Two float32 values scaled by a power of two and split into half-precision planes: h = rn16(x * sc), l = rn16(x * sc - h), each
+// ONE mixed-precision fma (v_fma_mixlo/hi_f16: the product by a power of two and the difference are exact in float32, so the
+// only rounding is the conversion — the same bits as multiply, convert, convert back, subtract, convert).  Returns h as the
+// packed pair (x0 low half, x1 high half), l likewise through `l`.  Single-issue vector instructions: no packed float32
+// operation (slow beside matrix instructions, MI355X_MICROARCH.md).
+__device__ __forceinline__ unsigned spa_split16_pair(float x0, float x1, float sc, unsigned &l)
+{
+    unsigned h, lo;
+    asm("v_fma_mixlo_f16 %0, %2, %4, 0 op_sel_hi:[0,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %3, %4, 0 op_sel_hi:[0,0,0]\n\t"
+        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(h), "=&v"(lo) : "v"(x0), "v"(x1), "v"(sc));
+    l = lo;
+    return h;
+}
+#endif
 
 int spa_aux_streams(spa_ctx *ctx);
 

@@ -35,6 +35,7 @@
 //     peak (the chip lowers its clock under dense bf16 MFMA on random data: MI355X_MICROARCH.md, DVFS give-back),
 //     so the kernel is at ~0.9 of what its loop can deliver.
 #include "spa_common.h"
+#include <stdlib.h>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -199,6 +200,169 @@ __global__ __launch_bounds__(CV_THREADS) void k_conv3x3_bf16(const __bf16 *__res
     }
 }
 
+// workgroup barrier that orders LDS only: __syncthreads() also waits for every outstanding global load and store
+__device__ __forceinline__ void cv_lds_barrier()
+{
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// Round 5: the same convolution with the two waves of every SIMD in OPPOSITE phases (the half-period lag of
+// k_gemm_f16x3_stag, spa_gemm16.hip, where the in-kernel stamps and the argument are).  A K step is two half periods
+// R = [stage step t + 1, read the step's 24 fragments from LDS]  |  M = [its 64 matrix instructions]  with an LDS-only barrier after
+// each; waves 4-7 run the same program half a period late (one extra barrier at their start), so every SIMD has one wave
+// staging / reading and one multiplying instead of both doing the same thing.  Buffers as before (two weight tiles, two pixel
+// segments staged in thirds): a buffer's last readers are the R of both halves one step (one group) earlier, the late half's
+// ends at the barrier that ends the early half's period; both halves stage at the top of their period and wait for their own
+// loads before the barrier that precedes the early half's next R.  Every accumulator receives the same matrix instructions in the
+// same order: bit-identical outputs (tests/test_gpu_pipeline.py, tools/conv_bench.py).
+template <int HAS_RES, int BM>
+__global__ __launch_bounds__(CV_THREADS) void k_conv3x3_bf16_stag(const __bf16 *__restrict__ X, const __bf16 *__restrict__ Wt,
+                                                                  const float *__restrict__ bias,
+                                                                  const __bf16 *__restrict__ R, __bf16 *__restrict__ Y,
+                                                                  const char *__restrict__ zero_line, int B, int H, int W,
+                                                                  int Cin, int Cout, int dil, int relu, int xtiles,
+                                                                  int ntiles, int total_tiles)
+{
+    extern __shared__ __attribute__((aligned(1024))) char lds[];     // [2] weight tiles 32 KB | [2] pixel segments 33 KB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool late = wave >= 4;
+    const int nwg = total_tiles;
+    int id = blockIdx.x;
+    {
+        const int q = nwg / 8, rem = nwg % 8, xcd = id % 8, idx = id / 8;
+        id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+    }
+    const int nt = id % ntiles, pt = id / ntiles;
+    const int xt = pt % xtiles, row_id = pt / xtiles;               // row_id = b * H + y
+    const int y = row_id % H;
+    const int x0 = xt * CV_BN, n0 = nt * BM;
+    constexpr int WN = BM == 64 ? 8 : 4;
+    constexpr int MI = BM == 256 ? 8 : 4;
+    constexpr int NJ = 256 / WN / 16;
+    constexpr int WROWS = MI * 16;
+
+    char *wbuf = lds, *xbuf = lds + 2 * CV_TILE_BYTES;
+    const int sub = lane >> 3, cs = lane & 7;
+    const int chunk_byte = (cs ^ sub) << 4;
+    const char *wbase = (const char *)(Wt + (long long)n0 * 9 * Cin);
+    const char *xbase = (const char *)(X + (long long)row_id * W * Cin);
+    const int ks = Cin / CV_BK;
+    const int nk = 9 * ks, ngroups = 3 * ks;
+
+    auto stage_w = [&](int t, int buf) {
+        const int g = t / 3, dxi = t - g * 3;
+        const int dyi = g / ks, kc = g - dyi * ks;
+        const char *wk = wbase + ((long long)(dyi * 3 + dxi) * Cin + (long long)kc * CV_BK) * 2 + chunk_byte;
+        char *dst = wbuf + buf * CV_TILE_BYTES;
+#pragma unroll
+        for (int r = 0; r < BM / 64; ++r) {
+            const int blk = r * 8 + wave;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wk + (long long)(blk * 8 + sub) * 9 * Cin * 2),
+                                             (__attribute__((address_space(3))) void *)(dst + blk * 1024), 16, 0, 0);
+        }
+    };
+    auto stage_x = [&](int g, int third) {
+        const int dyi = g / ks, kc = g - dyi * ks;
+        const int yy = y + (dyi - 1) * dil;
+        const bool yok = yy >= 0 && yy < H;
+        const char *xk = xbase + ((long long)(dyi - 1) * dil * W) * Cin * 2 + (long long)kc * CV_BK * 2 + chunk_byte;
+        char *dst = xbuf + (g & 1) * CV_XSEG_BYTES;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int i = r * 8 + wave;
+            if (i >= 11) break;
+            const int blk = third * 11 + i;
+            const int px = x0 - CV_HALO + blk * 8 + sub;
+            const bool ok = yok && px >= 0 && px < W;
+            const char *src = ok ? xk + (long long)px * Cin * 2 : zero_line + chunk_byte;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(dst + blk * 1024), 16, 0, 0);
+        }
+    };
+
+    const int wm = wave / WN, wn = wave % WN;
+    f32x4 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fk = lane >> 4;
+
+    stage_w(0, 0);
+    stage_x(0, 0); stage_x(0, 1); stage_x(0, 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    cv_lds_barrier();
+    if (late) cv_lds_barrier();                    // the extra barrier = half a period of delay
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        const int g = t / 3, dxi = t - g * 3;
+        // ---- R: stage step t + 1 (while the partner wave multiplies), read this step's fragments
+        if (t + 1 < nk) stage_w(t + 1, cur ^ 1);
+        if (g + 1 < ngroups) stage_x(g + 1, dxi);
+        const char *lw = wbuf + cur * CV_TILE_BYTES, *lx = xbuf + (g & 1) * CV_XSEG_BYTES;
+        const int xshift = CV_HALO + (dxi - 1) * dil + wn * (NJ * 16) + frow;
+        bf16x8 wf[2][MI], pf[2][NJ];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int chunk = kk * 4 + fk;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int row = wm * WROWS + i * 16 + frow;
+                wf[kk][i] = *(const bf16x8 *)(lw + row * 128 + ((chunk ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int row = xshift + j * 16;
+                pf[kk][j] = *(const bf16x8 *)(lx + row * 128 + ((chunk ^ (row & 7)) << 4));
+            }
+        }
+        // the late half's loads (staged at the top of this period) must have landed before the early half reads them behind this barrier
+        if (late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        cv_lds_barrier();
+        // ---- M
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][i], pf[kk][j], acc[i][j], 0, 0, 0);
+        if (!late) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            cv_lds_barrier();
+        } else if (t + 1 < nk) {
+            cv_lds_barrier();
+        }
+    }
+
+    // ---- epilogue: lane holds channels c..c+3 (c = tile channel base + (lane>>4)*4) of pixel (lane & 15)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int xx = x0 + wn * (NJ * 16) + j * 16 + (lane & 15);
+        if (xx >= W) continue;
+        const long long pix = (long long)row_id * W + xx;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int c = n0 + wm * WROWS + i * 16 + (lane >> 4) * 4;
+            const float4 bv = *(const float4 *)(bias + c);
+            float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y, v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
+            if (HAS_RES) {
+                const uint2 rr = *(const uint2 *)(R + pix * Cout + c);
+                v0 += __uint_as_float(rr.x << 16); v1 += __uint_as_float(rr.x & 0xffff0000u);
+                v2 += __uint_as_float(rr.y << 16); v3 += __uint_as_float(rr.y & 0xffff0000u);
+            }
+            if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+            uint2 o;
+            o.x = (unsigned)f32_to_bf16_bits(v0) | ((unsigned)f32_to_bf16_bits(v1) << 16);
+            o.y = (unsigned)f32_to_bf16_bits(v2) | ((unsigned)f32_to_bf16_bits(v3) << 16);
+            *(uint2 *)(Y + pix * Cout + c) = o;
+        }
+    }
+}
+
 // x (B,H,W,Cin) bf16 channels-last, wt (Cout,9,Cin) bf16 (tap = ky*3 + kx), bias (Cout) float32,
 // residual (B,H,W,Cout) bf16 or NULL, y (B,H,W,Cout) bf16.  stride 1, padding = dilation.
 extern "C" int spa_conv3x3_bf16(spa_ctx *ctx, const void *x, int32_t B, int32_t H, int32_t W, int32_t Cin,
@@ -229,6 +393,25 @@ extern "C" int spa_conv3x3_bf16(spa_ctx *ctx, const void *x, int32_t B, int32_t 
         ctx->conv_attr_done = 1;
     }
     SpaProfScope prof_(ctx, PROF_DRN_CONV, s);
+    // SPA_CONV16_STAGGER (read once): unset / 1 = the half-period-lag kernel for the 256-channel tile (512 -> 512, 30 images: 4.14
+    // against 4.48 ms with the residual, 3.99 against 4.39 without; 256 -> 512 2.24 against 2.45; 256 -> 256 1.31 against 1.39:
+    // tools/conv16_ab.py, digests equal), 0 = round 1's kernel (also the narrow tiles')
+    static const int stag = getenv("SPA_CONV16_STAGGER") ? atoi(getenv("SPA_CONV16_STAGGER")) : 1;
+    if (stag && bm == 256) {
+        if (!ctx->conv_stag_attr_done) {
+            SPA_HIP(hipFuncSetAttribute((const void *)k_conv3x3_bf16_stag<0, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            SPA_HIP(hipFuncSetAttribute((const void *)k_conv3x3_bf16_stag<1, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            ctx->conv_stag_attr_done = 1;
+        }
+#define CV_LAUNCH_S(R)                                                                                                   \
+    hipLaunchKernelGGL((k_conv3x3_bf16_stag<R, 256>), dim3((unsigned)total), dim3(CV_THREADS), lds, s, (const __bf16 *)x, \
+                       (const __bf16 *)wt, bias, (const __bf16 *)residual, (__bf16 *)y, (const char *)zero, B, H, W,    \
+                       Cin, Cout, dilation, relu, xtiles, ntiles, (int)total)
+        if (residual) CV_LAUNCH_S(1); else CV_LAUNCH_S(0);
+#undef CV_LAUNCH_S
+        SPA_LAUNCH_CHECK();
+        return SPA_OK;
+    }
 #define CV_LAUNCH(R, M)                                                                                                  \
     hipLaunchKernelGGL((k_conv3x3_bf16<R, M>), dim3((unsigned)total), dim3(CV_THREADS), lds, s, (const __bf16 *)x,       \
                        (const __bf16 *)wt, bias, (const __bf16 *)residual, (__bf16 *)y, (const char *)zero, B, H, W,    \

@@ -282,9 +282,16 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
                 const int pos = (2 * fk) ^ xg(lrow);
                 const f32x4 a = *(const f32x4 *)(pr + (pos << 4));                 // chunk 2 fk
                 const f32x4 b = *(const f32x4 *)(pr + ((pos ^ 1) << 4));           // chunk 2 fk + 1
-                const f32x8 v = (f32x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]} * sc16;
-                ph[j] = __builtin_convertvector(v, f16x8);
-                pl[j] = __builtin_convertvector(v - __builtin_convertvector(ph[j], f32x8), f16x8);
+                // (round 5: the split as four mixed-precision fmas per element pair, spa_split16_pair — 16 single-issue vector
+                // instructions per fragment instead of 24 with packed float32 ones; the same bits)
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                u32x4 hu, lu;
+                { unsigned l; hu[0] = spa_split16_pair(a[0], a[1], sc16, l); lu[0] = l; }
+                { unsigned l; hu[1] = spa_split16_pair(a[2], a[3], sc16, l); lu[1] = l; }
+                { unsigned l; hu[2] = spa_split16_pair(b[0], b[1], sc16, l); lu[2] = l; }
+                { unsigned l; hu[3] = spa_split16_pair(b[2], b[3], sc16, l); lu[3] = l; }
+                ph[j] = __builtin_bit_cast(f16x8, hu);
+                pl[j] = __builtin_bit_cast(f16x8, lu);
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
@@ -438,7 +445,7 @@ static int conv_f32_launch(spa_ctx *ctx, const float *x, int32_t B, int32_t H, i
     // one slot per kernel form: the 3x3 convolutions, and the GEMM form (1x1 projections and the Winograd GEMM batches)
     // (the GEMM form's 256 x 256 instance has its own slot: it is the kernel with the most time per step, and its
     // average must be comparable with the rocprofv3 row of exactly that instance)
-    SpaProfScope prof_(ctx, prof ? (split ? PROF_DRN_CONV16 : (TAPS == 9 ? PROF_DRN_CONV32 : (bm == 256 && !residual ? PROF_DRN_GEMM32 : PROF_DRN_GEMM32_N))) : -1, s);
+    SpaProfScope prof_(ctx, prof ? (split ? (TAPS == 1 ? PROF_DRN_CONV16_1X1 : (bm == 256 ? PROF_DRN_CONV16_256 : (bm == 128 ? PROF_DRN_CONV16_128 : PROF_DRN_CONV16))) : (TAPS == 9 ? PROF_DRN_CONV32 : (bm == 256 && !residual ? PROF_DRN_GEMM32 : PROF_DRN_GEMM32_N))) : -1, s);
     // persistent workgroups: as many as are resident at once (LDS: one per CU for the wide tiles, two or three for the
     // 128-pixel ones), each looping over its share of the tiles
     // (the split-plane form of the 64-channel tile is bound by its LDS reads — all eight waves read the same weight tile —
@@ -555,7 +562,7 @@ extern "C" int spa_conv3x3_s2_f16s(spa_ctx *ctx, const float *x, int32_t B, int3
         SPA_HIP(hipFuncSetAttribute((const void *)k_conv3x3_f32<0, 128, 9, 128, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * 128 + 2 * (256 + 2 * C32_HALO + 8) * 128));
         ctx->conv32_attr_done |= 4;
     }
-    SpaProfScope prof_(ctx, PROF_DRN_CONV16, s);
+    SpaProfScope prof_(ctx, PROF_DRN_CONV16_FRONT, s);
     const int per_cu = lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3);
     long long grid = (long long)ctx->n_cu * per_cu;
     if (grid > total) grid = total;

@@ -205,7 +205,7 @@ extern "C" int spa_conv_small_f16s(spa_ctx *ctx, const float *x, int32_t B, int3
     const int TH = stride == 2 ? 4 : 8;
     const long long n_tiles = (long long)((Wo + 31) / 32) * ((Ho + TH - 1) / TH) * B;
     SPA_ARG(n_tiles < (1ll << 31) && (long long)B * H * W * Cin < (1ll << 40));
-    SpaProfScope prof_(ctx, PROF_DRN_CONV16, s);
+    SpaProfScope prof_(ctx, PROF_DRN_CONV16_FRONT, s);
     long long grid = 2ll * ctx->n_cu;
     if (grid > n_tiles) grid = n_tiles;
 #define CS_LAUNCH(CI, NC, ST, NP)                                                                                              \

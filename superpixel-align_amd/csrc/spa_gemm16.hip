@@ -213,23 +213,39 @@ __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3(const char *__restri
     }
 }
 
-// Round 5: the STAGGERED form.  In k_gemm_f16x3 every wave runs  [LDS reads + split] -> [MI * NJ * 3 matrix instructions] ->
-// wait -> workgroup barrier  per K step, so the two waves of a SIMD reach their matrix work together and their LDS reads
-// together: the matrix pipe idles while both read and split (45.7 % busy, profiles/r3_sq_counters_drn_split.txt).
-// Here a K step is two half periods  R = [LDS reads + split]  |  M = [matrix instructions (+ a tile's stores)]  with a
-// barrier after each, the K steps of ALL the tiles of a workgroup form one sequence q = 0, 1, ..., and waves 4-7 run the
-// same program HALF A PERIOD LATE (one extra barrier at their start): the second wave of every SIMD (a workgroup's waves go
-// to the SIMDs in cyclic order, so SIMD s holds waves s' and s' + 4: MI355X_MICROARCH.md, two waves per SIMD, item 9)
-// multiplies while its partner reads and splits, and the other way round — between two barriers every SIMD has one wave
-// in R and one in M.  Staging: the bytes of step q + 1 go to buffer (q + 1) & 1, whose last readers are the R(q - 1) of
-// both halves — the late half's ends at the barrier that ends the early half's period q - 1; the early waves therefore
-// stage their share at the top of their period q, the late waves theirs at the same moment (behind the barrier in the
-// middle of their period q - 1); both wait for them (counted, so that a tile's stores issued behind them stay in flight)
-// before the barrier that precedes the early half's R(q + 1): a full period in flight.  Every accumulator receives the
-// same matrix instructions in the same order as in k_gemm_f16x3 (K steps ascending; l.h, h.l, h.h inside a step): the
-// outputs are bit-identical.
-// XP (experiments, timing only — wrong numbers): 2 = no in-register split (the row tile read as if it held planes), 4 = no global loads
-template <int BM, int BN, int XP = 0>
+// Round 5: the STAGGERED form (the default for the 256 x 256 tile).  In k_gemm_f16x3 every wave runs  [stage] -> [LDS reads +
+// split] -> [MI * NJ * 3 matrix instructions] -> wait -> workgroup barrier  per K step, so the two waves of a SIMD reach their
+// matrix work together and their reads together: the matrix pipe idles while both stage, read and split (45.7 % busy,
+// profiles/r3_sq_counters_drn_split.txt).  In-kernel stamps (profiles/r5_gemm16_stagger_stamps.txt) put numbers on a wave's
+// K step: issuing its 8 LDS-DMA pieces 430-690 cycles, reads + split 1 000-2 400 (2 400 beside a partner that multiplies:
+// a matrix instruction holds the SIMD's vector issue for half its cycles and packed float32 operations are slow there), the 96
+// matrix instructions 1 650, waits and barriers ~400 — one wave's chain is longer than the 3 072 matrix cycles of the SIMD's
+// two waves, so nothing short of overlapping the two waves' phases helps.  Three changes, each measured:
+//   1. HALF-PERIOD LAG.  A K step is two half periods  R = [stage, LDS reads, split of the first row fragment]  |  M = [matrix
+//      instructions with the other fragments' splits between them (+ a tile's stores)]  with a barrier after each; the K steps
+//      of ALL the tiles of a workgroup form one sequence q = 0, 1, ...; waves 4-7 run the same program HALF A PERIOD LATE (one
+//      extra barrier at their start).  The second wave of every SIMD (a workgroup's waves go to the SIMDs in cyclic order, so
+//      SIMD s holds waves s' and s' + 4: MI355X_MICROARCH.md, two waves per SIMD, item 9) multiplies while its partner stages,
+//      reads and splits, and the other way round.  Alone (the split still in R) this was SLOWER, 3.97 against 3.70 ms on the
+//      512 -> 512 layer: R beside a multiplying partner takes 2 000-2 400 cycles.
+//   2. THE SPLIT INSIDE THE MATRIX WORK, as single-issue instructions: h = rn16(x * scale) and l = rn16(x * scale - h) are ONE
+//      mixed-precision fma each (v_fma_mixlo/hi_f16: the product by a power of two and the difference are exact in float32, so
+//      the only rounding is the conversion — the same bits as multiply, convert, convert back, subtract, convert), 16 vector
+//      instructions per fragment instead of 24, none of them a packed float32 operation; M walks the row fragments j (per
+//      accumulator still l.h, h.l, h.h) and splits fragment j + 1 between the matrix instructions of fragment j.  R shrinks to
+//      ~750 cycles.  With 1.: 3.65 ms.
+//   3. BOTH HALVES STAGE AT THE TOP OF THEIR PERIOD, i.e. while the partner multiplies, not in front of their own matrix work
+//      (the late half's share of step q + 1 then has half a period to land instead of a whole one: enough).  With 1. and 2.:
+//      3.42 ms = 1.02 PFLOP/s executed (0.41 of the dense 16-bit peak), 256 -> 256 1.13 against 1.22, 256 -> 512 2.09 against 2.26.
+// Buffer safety: step q + 1 goes to buffer (q + 1) & 1, whose last readers are the R(q - 1) of both halves — the late half's
+// ends at the barrier that ends the early half's period q - 1; the early waves stage at the top of their period q, the late
+// waves at the top of theirs (half a period later); each waits for its own loads (the early half counted, so that a tile's
+// stores issued behind them stay in flight) before the barrier that precedes the early half's R(q + 1).  Every accumulator
+// receives the same matrix instructions in the same order as in k_gemm_f16x3 (K steps ascending; l.h, h.l, h.h inside a
+// step): the outputs are bit-identical (tools/gemm16_ab.py compares digests across processes; tests/test_gpu_conv.py).
+// RS: row fragments split in R (1-4, the others in M; 512 -> 512 layer: 3.48 / 3.41 / 3.35 / 3.37 ms for RS = 1 / 2 / 3 / 4: default 3).  XP (diagnostic builds, tools/gemm16_stamps.py): 2 = no split (timing
+// only: the row tile read as if it held planes), 4 = no global loads (timing only), 16 = in-kernel stamps.
+template <int BM, int BN, int RS = 1, int XP = 0>
 __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3_stag(const char *__restrict__ X, const char *__restrict__ Wt,
                                                                  float *__restrict__ Y, int rows_per_z, int Cin, int Cout,
                                                                  int ntiles, int total_tiles, int zcount, long long xz,
@@ -239,9 +255,9 @@ __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3_stag(const char *__r
     extern __shared__ __attribute__((aligned(1024))) char lds16[];   // [2] weight tiles | [2] row tiles, 128 bytes per row
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool late = (XP & 256) ? false : wave >= 4;        // XP & 256: every wave early (the two-barrier loop without the lag)
-    // XP & 16: in-kernel stamps (s_memtime, low word) of waves 0 and 4 of workgroup G16_STAMP_WG over periods [Q0, Q0 + NQ), kept
-    // in LDS behind the tiles (no global store inside the loop: the counted vmcnt waits stay what they are), copied out at the end
+    const bool late = wave >= 4;
+    // XP & 16: stamps (s_memtime, low word) of waves 0 and 4 of one workgroup over periods [Q0, Q0 + NQ), kept in LDS behind the
+    // tiles (no global store inside the loop: the counted vmcnt waits stay what they are), copied out at the end
     constexpr int G16_Q0 = 24, G16_NQ = 40;
     unsigned *stamps = (unsigned *)(lds16 + 2 * (BM + BN) * 128) + (wave >> 2) * (G16_NQ * 8);
     const bool stamp_wave = (XP & 16) && blockIdx.x == 77 && (wave & 3) == 0;
@@ -285,13 +301,14 @@ __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3_stag(const char *__r
     constexpr int WROWS = MI * 16;
     static_assert(BM / WROWS * WN == 8, "8 waves");
     static_assert(MI * NJ <= 63, "vmcnt range");
+    static_assert(RS >= 1 && RS <= NJ && MI == 8, "split schedule: 4 element pairs over 8 groups of matrix instructions");
 
     char *wbuf = lds16, *xbuf = lds16 + 2 * (BM * 128);
     const int sub = lane >> 3, cs = lane & 7;
     const int chunk_byte = (cs ^ sub) << 4;
     const int nk = Cin / 32;
     // staging addresses = a scalar base (tile, K step, 64-row block) + ONE 32-bit lane offset shared by every load of the
-    // kernel (both operands have rows of Cin * 4 bytes): the late half stages between R and M with all fragments live
+    // kernel (both operands have rows of Cin * 4 bytes)
     const char *s_w = nullptr, *s_x = nullptr;          // staged tile's operand bases (uniform)
     const unsigned lane_off = (unsigned)((wave * 8 + sub) * Cin * 4 + chunk_byte);
     auto stage_bases = [&]() {
@@ -335,11 +352,10 @@ __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3_stag(const char *__r
     stage_next();                                  // step 0
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     g16_lds_barrier();
-    // XP & 512: the late half stages ITS share of step q + 1 at the top of its period q as well (half a period in flight instead of a
-    // whole one, but issued while the partner wave multiplies instead of in front of its own matrix work)
-    if (late) { if (!(XP & 512)) stage_next(); g16_lds_barrier(); }   // step 1; the extra barrier = half a period of delay
+    if (late) g16_lds_barrier();                   // the extra barrier = half a period of delay
     bool stored = false;
 
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     f32x4 acc[MI][NJ];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -349,79 +365,12 @@ __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3_stag(const char *__r
         const int buf = q & 1;
         if (XP & 16) stamp_q = (q >= G16_Q0 && q < G16_Q0 + G16_NQ) ? q - G16_Q0 : -1;
         STAMP(0);
-        if (!late || (XP & 512)) stage_next();     // step q + 1
+        stage_next();                              // step q + 1
         STAMP(1);
-        // ---- R
+        // ---- R: the LDS reads (weight fragments, raw float32 rows) and the split of the first RS row fragments
         const char *lw = wbuf + buf * (BM * 128), *lx = xbuf + buf * (BN * 128);
-        f16x8 wh[MI], wl[MI], ph[NJ], pl[NJ];
-        if constexpr ((XP & 128) != 0) {
-            // XP & 128: the split INSIDE the matrix work.  R only issues the LDS reads (weight fragments, raw float32 rows) and
-            // splits row fragment 0; M walks the row fragments j = 0 .. NJ - 1 (per accumulator still l.h, h.l, h.h) and splits
-            // fragment j + 1 between the matrix instructions of fragment j: 16 single-issue vector instructions per
-            // fragment — h = rn16(x * scale) and l = rn16(x * scale - h) are ONE mixed-precision fma each (v_fma_mixlo/hi_f16:
-            // the product by a power of two and the difference are exact in float32, so the one rounding is the conversion) —
-            // no packed float32 operation (an anti-lever beside MFMAs, MI355X_MICROARCH.md), in the issue slots a
-            // v_mfma_f32_16x16x32_f16 leaves free (8 of its 16 cycles)
-            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            f32x4 ra[NJ], rb[NJ];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int row = wm * WROWS + i * 16 + frow;
-                wh[i] = *(const f16x8 *)(lw + row * 128 + ((fk ^ (row & 7)) << 4));
-                wl[i] = *(const f16x8 *)(lw + row * 128 + (((4 + fk) ^ (row & 7)) << 4));
-            }
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int row = wn * (NJ * 16) + j * 16 + frow;
-                ra[j] = *(const f32x4 *)(lx + row * 128 + (((2 * fk) ^ (row & 7)) << 4));
-                rb[j] = *(const f32x4 *)(lx + row * 128 + (((2 * fk + 1) ^ (row & 7)) << 4));
-            }
-            const float sc = c_zscale;
-            u32x4 hu[NJ], lu[NJ];
-            // elements 2e, 2e + 1 of row fragment j: the two high halves, then (a dependent pair, issued a group of matrix
-            // instructions later) the two low halves
-            auto split_h = [&](int j, int e) {
-                const float x0 = e < 2 ? ra[j][2 * e] : rb[j][2 * e - 4], x1 = e < 2 ? ra[j][2 * e + 1] : rb[j][2 * e - 3];
-                unsigned h;
-                asm volatile("v_fma_mixlo_f16 %0, %1, %3, 0 op_sel_hi:[0,0,0]\n\t"
-                             "v_fma_mixhi_f16 %0, %2, %3, 0 op_sel_hi:[0,0,0]"
-                             : "=&v"(h) : "v"(x0), "v"(x1), "s"(sc));
-                hu[j][e] = h;
-            };
-            auto split_l = [&](int j, int e) {
-                const float x0 = e < 2 ? ra[j][2 * e] : rb[j][2 * e - 4], x1 = e < 2 ? ra[j][2 * e + 1] : rb[j][2 * e - 3];
-                unsigned l;
-                asm volatile("v_fma_mixlo_f16 %0, %1, %3, -%4 op_sel_hi:[0,0,1]\n\t"
-                             "v_fma_mixhi_f16 %0, %2, %3, -%4 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-                             : "=&v"(l) : "v"(x0), "v"(x1), "s"(sc), "v"(hu[j][e]));
-                lu[j][e] = l;
-            };
-            auto split_pair = [&](int j, int e) { split_h(j, e); split_l(j, e); };
-#pragma unroll
-            for (int e = 0; e < 4; ++e) split_pair(0, e);
-            STAMP(2);
-            if (late) {
-                if (stored && !(XP & 512)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MI * NJ) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            STAMP(3);
-            g16_lds_barrier();
-            STAMP(4);
-            stored = false;
-            if (late && !(XP & 512)) stage_next();     // step q + 2
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const f16x8 phj = __builtin_bit_cast(f16x8, hu[j]), plj = __builtin_bit_cast(f16x8, lu[j]);
-#pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], phj, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], plj, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], phj, acc[i][j], 0, 0, 0);
-                    if (j + 1 < NJ) { if ((i & 1) == 0) split_h(j + 1, i >> 1); else split_l(j + 1, i >> 1); }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        } else {
+        f16x8 wh[MI], wl[MI];
+        f32x4 ra[NJ], rb[NJ];
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int row = wm * WROWS + i * 16 + frow;
@@ -431,62 +380,56 @@ __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3_stag(const char *__r
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int row = wn * (NJ * 16) + j * 16 + frow;
-            if (XP & 2) {
-                ph[j] = *(const f16x8 *)(lx + row * 128 + (((2 * fk) ^ (row & 7)) << 4));
-                pl[j] = *(const f16x8 *)(lx + row * 128 + (((2 * fk + 1) ^ (row & 7)) << 4));
-                continue;
-            }
-            const f32x4 a = *(const f32x4 *)(lx + row * 128 + (((2 * fk) ^ (row & 7)) << 4));
-            const f32x4 b = *(const f32x4 *)(lx + row * 128 + (((2 * fk + 1) ^ (row & 7)) << 4));
-            const f32x8 v = (f32x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]} * c_zscale;
-            ph[j] = __builtin_convertvector(v, f16x8);
-            if (XP & 64) {
-                // l = rn16(v - h) as ONE mixed-precision fma per element (v * 1.0 - h, float32 inside, rounded once to half
-                // precision) instead of convert back + subtract + convert: 16 instead of 24 vector instructions per fragment
-                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                const u32x4 hu = __builtin_bit_cast(u32x4, ph[j]);
-                u32x4 lu;
+            ra[j] = *(const f32x4 *)(lx + row * 128 + (((2 * fk) ^ (row & 7)) << 4));
+            rb[j] = *(const f32x4 *)(lx + row * 128 + (((2 * fk + 1) ^ (row & 7)) << 4));
+        }
+        const float sc = c_zscale;
+        u32x4 hu[NJ], lu[NJ];
+        // elements 2e, 2e + 1 of row fragment j: the two high halves, then (a dependent pair, issued a group of matrix
+        // instructions later) the two low halves
+        auto split_h = [&](int j, int e) {
+            if (XP & 2) { hu[j][e] = __float_as_uint(e < 2 ? ra[j][2 * e] : rb[j][2 * e - 4]); return; }
+            const float x0 = e < 2 ? ra[j][2 * e] : rb[j][2 * e - 4], x1 = e < 2 ? ra[j][2 * e + 1] : rb[j][2 * e - 3];
+            unsigned h;
+            asm volatile("v_fma_mixlo_f16 %0, %1, %3, 0 op_sel_hi:[0,0,0]\n\t"
+                         "v_fma_mixhi_f16 %0, %2, %3, 0 op_sel_hi:[0,0,0]"
+                         : "=&v"(h) : "v"(x0), "v"(x1), "s"(sc));
+            hu[j][e] = h;
+        };
+        auto split_l = [&](int j, int e) {
+            if (XP & 2) { lu[j][e] = __float_as_uint(e < 2 ? ra[j][2 * e + 1] : rb[j][2 * e - 3]); return; }
+            const float x0 = e < 2 ? ra[j][2 * e] : rb[j][2 * e - 4], x1 = e < 2 ? ra[j][2 * e + 1] : rb[j][2 * e - 3];
+            unsigned l;
+            asm volatile("v_fma_mixlo_f16 %0, %1, %3, -%4 op_sel_hi:[0,0,1]\n\t"
+                         "v_fma_mixhi_f16 %0, %2, %3, -%4 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                         : "=&v"(l) : "v"(x0), "v"(x1), "s"(sc), "v"(hu[j][e]));
+            lu[j][e] = l;
+        };
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    unsigned d;
-                    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel_hi:[0,0,1]\n\t"
-                        "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-                        : "=&v"(d) : "v"(v[2 * e]), "v"(v[2 * e + 1]), "v"(hu[e]));
-                    lu[e] = d;
-                }
-                pl[j] = __builtin_bit_cast(f16x8, lu);
-            } else
-            pl[j] = __builtin_convertvector(v - __builtin_convertvector(ph[j], f32x8), f16x8);
-            asm volatile("" : "+v"(ph[j]), "+v"(pl[j]));        // the split belongs to R: not sunk behind the barrier to its uses
-        }
+        for (int j = 0; j < RS; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { split_h(j, e); split_l(j, e); }
         STAMP(2);
-        if (late) {
-            // the late half's share of step q + 1 (staged in the middle of its period q - 1) must have landed before the
-            // early half reads it behind this barrier; a tile's stores issued after it may stay in flight
-            if (stored) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MI * NJ) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        // the late half's share of step q + 1 (staged at the top of this period) must have landed before the early half reads it
+        // behind this barrier (its own stores of the period before are older and have long drained)
+        if (late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         STAMP(3);
         g16_lds_barrier();
         STAMP(4);
-        stored = false;
-        if (late && !(XP & 512)) stage_next();     // step q + 2
-        // ---- M: small terms first: they meet the accumulator while it is small
-        if (XP & 8) __builtin_amdgcn_s_setprio(1);
+        // ---- M: row fragment by row fragment, small terms first (they meet the accumulator while it is small); the split of
+        // fragment j + RS rides between the matrix instructions of fragment j
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+        for (int j = 0; j < NJ; ++j) {
+            const f16x8 phj = __builtin_bit_cast(f16x8, hu[j]), plj = __builtin_bit_cast(f16x8, lu[j]);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], ph[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], pl[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], ph[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < MI; ++i) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], phj, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], plj, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], phj, acc[i][j], 0, 0, 0);
+                if (j + RS < NJ) { if ((i & 1) == 0) split_h(j + RS, i >> 1); else split_l(j + RS, i >> 1); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        if (XP & 8) __builtin_amdgcn_s_setprio(0);
         STAMP(5);
         if (++c_t == nk) {
             // ---- a tile is complete: lane holds channels c..c+3 (c = tile channel base + (lane>>4)*4) of row (lane & 15)
@@ -504,7 +447,7 @@ __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3_stag(const char *__r
             stored = true;
             c_t = 0; c_vid += gstep;
             if (c_vid < all_i) {
-                // (the stage cursor is at most two steps ahead: its tile is this one's successor or the one after)
+                // (the stage cursor is at most one step ahead: its tile is this one's successor or this one)
                 const int sr0 = r0, sn0 = n0, sz = zz; const float szs = zscale_s;
                 locate(c_vid);
                 c_r0 = r0; c_n0 = n0; c_z = zz; c_zscale = zscale_s;
@@ -512,15 +455,16 @@ __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3_stag(const char *__r
             }
         }
         if (!late) {
+            // the early half's share of step q + 1 (staged at the top of this period): a tile's stores issued after it may stay in flight
             if (stored) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MI * NJ) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             STAMP(6);
             g16_lds_barrier();
-            stored = false;
         } else if (q + 1 < S) {
             STAMP(6);
             g16_lds_barrier();
         }
+        stored = false;
         STAMP(7);
     }
     if ((XP & 16) && stamp_wave && dbg) {
@@ -556,27 +500,17 @@ int gemm_f16x3_raw(spa_ctx *ctx, const float *x, long long rows, int32_t Cin, co
     const int per_cu = force_per_cu > 0 ? force_per_cu : (lds > 80 * 1024 ? 1 : 2);
     long long grid = (long long)ctx->n_cu * per_cu;
     if (grid > total * zcount) grid = total * zcount;
-    static const int stagger = getenv("SPA_GEMM16_STAGGER") ? atoi(getenv("SPA_GEMM16_STAGGER")) : 0;
-    if (stagger) {
+    // SPA_GEMM16_STAGGER (read once): unset = the staggered kernel with three of the four row fragments split in R (the default for the 256 x 256
+    // tile); 0 = k_gemm_f16x3 (round 3's kernel: kept for A/B runs and for the 128 x 128 tile); 1-4 = row fragments split in R;
+    // diagnostic builds of the RS = 1 form (timing only unless stamps alone): + 8 no split, + 16 no global loads, + 32 in-kernel
+    // stamps (tools/gemm16_stamps.py; RS = 1 or 2)
+    static const int stagger = getenv("SPA_GEMM16_STAGGER") ? atoi(getenv("SPA_GEMM16_STAGGER")) : 3;
+    if (stagger && bm == 256) {
         if (!ctx->gemm16s_attr_done) {
-            SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
-            SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
-            SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
-            SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
-            SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
-            SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
-            SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
-            SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
-            SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 640>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
-            SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 656>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128 + 4096));
-            SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 384>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
-            SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
-            SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 144>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128 + 4096));
-            SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128 + 4096));
-            SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 18>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128 + 4096));
-            SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 20>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128 + 4096));
-            SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, 22>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128 + 4096));
-            SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 128));
+#define G16S_ATTR(RS, XP) SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, RS, XP>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128 + ((XP) & 16 ? 4096 : 0)))
+            G16S_ATTR(1, 0); G16S_ATTR(2, 0); G16S_ATTR(3, 0); G16S_ATTR(4, 0); G16S_ATTR(1, 2); G16S_ATTR(1, 4); G16S_ATTR(1, 6); G16S_ATTR(1, 16); G16S_ATTR(2, 16);
+            G16S_ATTR(1, 18); G16S_ATTR(1, 20);
+#undef G16S_ATTR
             ctx->gemm16s_attr_done = 1;
         }
         unsigned *dbg = nullptr;
@@ -584,29 +518,16 @@ int gemm_f16x3_raw(spa_ctx *ctx, const float *x, long long rows, int32_t Cin, co
             int rc = spa_ws_reserve(ctx, WS_DEBUG, 4096, (void **)&dbg);
             if (rc != SPA_OK) return rc;
         }
-#define G16S_LAUNCH(M, N, XP) hipLaunchKernelGGL((k_gemm_f16x3_stag<M, N, XP>), dim3((unsigned)grid), dim3(G16_THREADS), lds + ((XP) & 16 ? 4096 : 0), s, (const char *)x, (const char *)wt, y, \
+#define G16S_LAUNCH(RS, XP) hipLaunchKernelGGL((k_gemm_f16x3_stag<256, 256, RS, XP>), dim3((unsigned)grid), dim3(G16_THREADS), lds + ((XP) & 16 ? 4096 : 0), s, (const char *)x, (const char *)wt, y, \
                                (int)rows, Cin, Cout, ntiles, (int)total, zcount, rows * Cin, (long long)Cout * Cin, rows * Cout, (const unsigned *)amax, dbg)
-        if (bm == 256) {
-            switch (stagger >> 1) {
-            case 1: G16S_LAUNCH(256, 256, 2); break;
-            case 2: G16S_LAUNCH(256, 256, 4); break;
-            case 3: G16S_LAUNCH(256, 256, 6); break;
-            case 4: G16S_LAUNCH(256, 256, 8); break;
-            case 5: G16S_LAUNCH(256, 256, 10); break;
-            case 32: G16S_LAUNCH(256, 256, 64); break;
-            case 64: G16S_LAUNCH(256, 256, 128); break;
-            case 320: G16S_LAUNCH(256, 256, 640); break;
-            case 336: G16S_LAUNCH(256, 256, 656); break;
-            case 192: G16S_LAUNCH(256, 256, 384); break;
-            case 80: G16S_LAUNCH(256, 256, 144); break;
-            case 128: G16S_LAUNCH(256, 256, 256); break;
-            case 16: G16S_LAUNCH(256, 256, 16); break;
-            case 17: G16S_LAUNCH(256, 256, 18); break;
-            case 18: G16S_LAUNCH(256, 256, 20); break;
-            case 19: G16S_LAUNCH(256, 256, 22); break;
-            default: G16S_LAUNCH(256, 256, 0);
-            }
-        } else G16S_LAUNCH(128, 128, 0);
+        const int rs = stagger & 7, diag = stagger >> 3;          // diag: 1 no split, 2 no loads, 4 stamps
+        if (diag == 0) { if (rs == 1) G16S_LAUNCH(1, 0); else if (rs == 2) G16S_LAUNCH(2, 0); else if (rs == 4) G16S_LAUNCH(4, 0); else G16S_LAUNCH(3, 0); }
+        else if (diag == 1) G16S_LAUNCH(1, 2);
+        else if (diag == 2) G16S_LAUNCH(1, 4);
+        else if (diag == 3) G16S_LAUNCH(1, 6);
+        else if (diag == 4) { if (rs == 2) G16S_LAUNCH(2, 16); else G16S_LAUNCH(1, 16); }
+        else if (diag == 5) G16S_LAUNCH(1, 18);
+        else G16S_LAUNCH(1, 20);
 #undef G16S_LAUNCH
         SPA_LAUNCH_CHECK();
         return SPA_OK;

@@ -329,7 +329,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_kmeans(const T *__restrict__ X, 
                                                        const double *__restrict__ w,
                                                        const int32_t *__restrict__ n_ptr, int Ncap,
                                                        int k, int max_iter,
-                                                       const long long *__restrict__ init_other,
+                                                       const long long *__restrict__ init_other, const int32_t *__restrict__ gate,
                                                        int32_t *__restrict__ assign,
                                                        int32_t *__restrict__ new_assign,
                                                        double *__restrict__ sums,      // [k][D]
@@ -345,6 +345,9 @@ __global__ __launch_bounds__(KM_THREADS) void k_kmeans(const T *__restrict__ X, 
                                                        const KmTree tree)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    // a gated launch (a speculative retry run, spa_kmeans_weighted_gated) that is not wanted: every workgroup leaves before the
+    // first grid barrier, outputs untouched
+    if (gate && *gate <= 0) return;
     // [0, k*D*8): centres (T) | then KM_CHUNK_BYTES shared by the chain buffer and the sweep scratch
     T *lds_c = (T *)lds_raw;
     unsigned char *scratch = lds_raw + (((size_t)k * D * sizeof(double) + 15) & ~(size_t)15);
@@ -707,10 +710,23 @@ __global__ __launch_bounds__(KM_THREADS) void k_kmeans(const T *__restrict__ X, 
     if (g == 0 && tid == 0) { info[0] = it; info[1] = st; info[2] = N; info[3] = 0; }
 }
 
+extern "C" int spa_kmeans_weighted_gated(spa_ctx *ctx, const void *X, int32_t x_dtype, int64_t ld,
+                                         int32_t D, const double *w, const int32_t *n_ptr, int32_t Ncap,
+                                         int32_t k, int32_t max_iter, const int64_t *init_other, const int32_t *gate,
+                                         int32_t *assign, int32_t *info, void *stream);
+
 extern "C" int spa_kmeans_weighted(spa_ctx *ctx, const void *X, int32_t x_dtype, int64_t ld,
                                    int32_t D, const double *w, const int32_t *n_ptr, int32_t Ncap,
                                    int32_t k, int32_t max_iter, const int64_t *init_other,
                                    int32_t *assign, int32_t *info, void *stream)
+{
+    return spa_kmeans_weighted_gated(ctx, X, x_dtype, ld, D, w, n_ptr, Ncap, k, max_iter, init_other, nullptr, assign, info, stream);
+}
+
+extern "C" int spa_kmeans_weighted_gated(spa_ctx *ctx, const void *X, int32_t x_dtype, int64_t ld,
+                                         int32_t D, const double *w, const int32_t *n_ptr, int32_t Ncap,
+                                         int32_t k, int32_t max_iter, const int64_t *init_other, const int32_t *gate,
+                                         int32_t *assign, int32_t *info, void *stream)
 {
     SPA_ARG(ctx && X && w && n_ptr && assign && info);
     SPA_ARG(k >= 2 && k <= KM_MAXK && D > 0 && Ncap > 0 && max_iter >= 0 && ld >= D);
@@ -763,7 +779,7 @@ extern "C" int spa_kmeans_weighted(spa_ctx *ctx, const void *X, int32_t x_dtype,
             ctx->km_attr_done[SLOT / 3] |= (1 << (SLOT % 3));                                                    \
         }                                                                                                        \
         hipLaunchKernelGGL((k_kmeans<TT, KK>), dim3(G), dim3(KM_THREADS), lds, s, (const TT *)X, (long long)ld, \
-                           D, w, n_ptr, Ncap, k, max_iter, (const long long *)init_other, assign,               \
+                           D, w, n_ptr, Ncap, k, max_iter, (const long long *)init_other, gate, assign,         \
                            (int32_t *)(misc + o_na), (double *)(misc + o_sum), (double *)(misc + o_ws),          \
                            (int *)(misc + o_cn), (int *)(misc + o_pn), mlist, wlist, (int *)(misc + o_ch),       \
                            (KmShared *)(misc + o_sh), info, ctx->d_status, tree);                                \

@@ -47,6 +47,7 @@ struct MT {
         idx = 624;
     }
     uint32_t out[624];
+    void export_state(uint32_t *state, int *pos) const { for (int i = 0; i < 624; ++i) state[i] = mt[i]; *pos = idx; }
     void refill() { refill_to(out); idx = 0; }
     void refill_to(uint32_t *dst)
     {
@@ -428,6 +429,14 @@ extern "C" int spa_nprandom_create(uint32_t seed, spa_nprandom **out)
     return SPA_OK;
 }
 extern "C" void spa_nprandom_destroy(spa_nprandom *r) { delete r; }
+
+extern "C" int spa_nprandom_state(spa_nprandom *r, uint32_t *state628)
+{
+    if (!r || !state628) return SPA_ERR_ARG;
+    r->g.export_state(state628, (int *)&state628[624]);
+    state628[625] = state628[626] = state628[627] = 0u;
+    return SPA_OK;
+}
 
 extern "C" int spa_nprandom_shuffle_host(spa_nprandom *r, int64_t *a, int64_t n)
 {

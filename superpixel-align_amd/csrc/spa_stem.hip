@@ -746,7 +746,7 @@ extern "C" int spa_drn_layer2_f16s(spa_ctx *ctx, const float *x, int32_t B, int3
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
     const long long n_tiles = (long long)((Wo + L2_TW - 1) / L2_TW) * ((Ho + L2_TH - 1) / L2_TH) * B;
     SPA_ARG(n_tiles < (1ll << 31));
-    SpaProfScope prof_(ctx, PROF_DRN_CONV16, s);
+    SpaProfScope prof_(ctx, PROF_DRN_CONV16_FRONT, s);
     long long grid = 3ll * ctx->n_cu;
     if (grid > n_tiles) grid = n_tiles;
     hipLaunchKernelGGL(k_drn_layer2_f16x3, dim3((unsigned)grid), dim3(256), 0, s, x, B, H, W, Ho, Wo, (const unsigned short *)wp, bias,

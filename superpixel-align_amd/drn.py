@@ -68,9 +68,19 @@ _EPILOGUE = {'engine': None, 'bytes': 0, 'launches': 0, 'own_conv': True, 'own_c
              'split_gemm': os.environ.get('SPA_SPLIT_GEMM', '1') != '0',
              'gemm16_flops': 0.0, 'gemm16_launches': 0, 'gemm16_bytes': 0.0,
              'gemm16n_flops': 0.0, 'gemm16n_launches': 0, 'gemm16n_bytes': 0.0, 'conv16_flops': 0.0, 'conv16_launches': 0, 'conv16_bytes': 0.0,
+             # ... and per kernel instantiation (one `kernels` entry = one rocprofv3 row): c16[kind] = [flops, bytes, launches]
+             'c16': {},
              # the layer's OWN bytes of the 256 x 256-tile Winograd layers (X, Y, the residual, the weight planes once): what a
              # convolution that kept V and M on chip would move — bench.py's `algorithmic_bytes` of the GEMM entry
              'gemm16_layer_bytes': 0.0}
+
+
+def _c16(kind, flops, nbytes, launches=1):
+    """per-instantiation counters of the split-plane direct kernels (bench.py prices each against its own rocprofv3 row)"""
+    c = _EPILOGUE['c16'].setdefault(kind, [0.0, 0.0, 0])
+    c[0] += flops
+    c[1] += nbytes
+    c[2] += launches
 
 
 def conv_bias_act(conv, bn, x, residual=None, relu=True):
@@ -147,9 +157,11 @@ def conv_bias_act(conv, bn, x, residual=None, relu=True):
             p16 = getattr(conv, '_spa_packed16', None)
             if p16 is not None and _EPILOGUE['split_gemm']:
                 # ... on the 16-bit matrix cores at float32 accuracy (two half-precision planes per operand)
+                by = 4.0 * x.shape[0] * x.shape[2] * x.shape[3] * (conv.in_channels + conv.out_channels * (2 if residual is not None else 1))
                 _EPILOGUE['conv16_flops'] += fl
-                _EPILOGUE['conv16_bytes'] += 4.0 * x.shape[0] * x.shape[2] * x.shape[3] * (conv.in_channels + conv.out_channels * (2 if residual is not None else 1))
+                _EPILOGUE['conv16_bytes'] += by
                 _EPILOGUE['conv16_launches'] += 1
+                _c16('1x1' if packed32[0].shape[1] == 1 else ('256' if conv.out_channels % 256 == 0 else ('128' if conv.out_channels % 128 == 0 else '64')), fl, by)
                 y, am = eng.conv3x3_f16s(x, p16[0], p16[1], packed32[1], residual, relu, conv.dilation[0],
                                          amax_in=getattr(x, '_spa_amax', None))
                 y._spa_amax = am
@@ -166,9 +178,12 @@ def conv_bias_act(conv, bn, x, residual=None, relu=True):
         if (l2 is not None and _EPILOGUE['split_gemm'] and _EPILOGUE['own_conv32'] and x.dtype == torch.float32 and relu
                 and residual is None and x.is_contiguous(memory_format=torch.channels_last)):
             # layer 2 of arch D (16 -> 32 channels, stride 2): its own kernel on the 16-bit matrix cores
-            _EPILOGUE['conv16_flops'] += 2.0 * x.shape[0] * ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2) * 32 * 9 * 16
-            _EPILOGUE['conv16_bytes'] += 4.0 * x.shape[0] * (x.shape[2] * x.shape[3] * 16 + ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2) * 32)
+            fl2 = 2.0 * x.shape[0] * ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2) * 32 * 9 * 16
+            by2 = 4.0 * x.shape[0] * (x.shape[2] * x.shape[3] * 16 + ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2) * 32)
+            _EPILOGUE['conv16_flops'] += fl2
+            _EPILOGUE['conv16_bytes'] += by2
             _EPILOGUE['conv16_launches'] += 1
+            _c16('front', fl2, by2)
             return eng.drn_layer2_f16s(x, l2[0], l2[1], l2[2], amax_in=getattr(x, '_spa_amax', None))
         y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation)
         vec = 4 if y.dtype == torch.float32 else 8
@@ -207,9 +222,12 @@ class BasicBlock(nn.Module):
                 and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
                 and 128 * -(-((x.shape[3] + 1) // 2) // 128) <= 1.25 * ((x.shape[3] + 1) // 2)):
             # the stride-2 opening convolution and the 1x1 stride-2 projection in ONE pass over x (csrc/spa_conv32.hip)
-            _EPILOGUE['conv16_flops'] += 2.0 * x.shape[0] * ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2) * s2[3] * 10 * x.shape[1]
-            _EPILOGUE['conv16_bytes'] += 4.0 * x.shape[0] * (x.shape[2] * x.shape[3] * x.shape[1] + ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2) * 2 * s2[3])
+            fl2 = 2.0 * x.shape[0] * ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2) * s2[3] * 10 * x.shape[1]
+            by2 = 4.0 * x.shape[0] * (x.shape[2] * x.shape[3] * x.shape[1] + ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2) * 2 * s2[3])
+            _EPILOGUE['conv16_flops'] += fl2
+            _EPILOGUE['conv16_bytes'] += by2
             _EPILOGUE['conv16_launches'] += 1
+            _c16('front', fl2, by2)
             y, res, am = eng.conv3x3_s2_f16s(x, s2[0], s2[1], s2[2], s2[3], True, amax_in=getattr(x, '_spa_amax', None))
             y._spa_amax = am
             return conv_bias_act(self.conv2, self.bn2, y, res, True)
@@ -466,9 +484,12 @@ class DRN(nn.Module):
             a2, proj = eng.conv_small_f16s(l1, fc['l2c1'][0], fc['l2c1'][1], fc['l2c1'][2], 32, 2, 32, None, True, amax_in=l1._spa_amax)
             l2, _ = eng.conv_small_f16s(a2, fc['l2c2'][0], fc['l2c2'][1], fc['l2c2'][2], 32, 1, 0, proj, True, amax_in=a2._spa_amax)
             Ho, Wo = a2.shape[2], a2.shape[3]
-            E['conv16_flops'] += 2.0 * B * (H * W * 16 * 9 * 16 + Ho * Wo * (32 * 9 * 16 + 32 * 16 + 32 * 9 * 32))
-            E['conv16_bytes'] += 4.0 * B * (H * W * (16 + 16 + 16) + H * W * 16 + Ho * Wo * (32 + 32) + Ho * Wo * (32 + 32 + 32))
+            fl2 = 2.0 * B * (H * W * 16 * 9 * 16 + Ho * Wo * (32 * 9 * 16 + 32 * 16 + 32 * 9 * 32))
+            by2 = 4.0 * B * (H * W * (16 + 16 + 16) + H * W * 16 + Ho * Wo * (32 + 32) + Ho * Wo * (32 + 32 + 32))
+            E['conv16_flops'] += fl2
+            E['conv16_bytes'] += by2
             E['conv16_launches'] += 3
+            _c16('front', fl2, by2, 3)
             return self.forward_maps(None, front_maps=[l1, l2])
         if eng is not None and xc.is_cuda and getattr(self, '_stem', None) is not None and self.use_fused_stem:
             l1 = eng.drn_stem_d(xc.float().contiguous(), *self._stem, dtype=self.compute_dtype,

@@ -677,18 +677,38 @@ class Engine(object):
         return X
 
     # ------------------------------------------------------------------ k-means + paint
-    def kmeans(self, X, w, n_ptr, k, max_iter=1000, init_other=None):
-        """-> assign (ncap) i32, info (4) i32 {iterations, status, N, -} (both on the device)."""
+    def kmeans(self, X, w, n_ptr, k, max_iter=1000, init_other=None, gate=None):
+        """-> assign (ncap) i32, info (4) i32 {iterations, status, N, -} (both on the device).
+        gate: device int32 word — the launch runs only if it holds a positive number (outputs stay zero otherwise)."""
         if X.dtype not in (torch.float32, torch.float64) or not X.is_contiguous():
             raise SpalignError('X must be contiguous float32/float64')
         w = _req(w, torch.float64, 'weights')
         ncap, D = X.shape
         assign = torch.zeros((ncap,), dtype=torch.int32, device=X.device)
         info = torch.zeros((4,), dtype=torch.int32, device=X.device)
-        check(self._lib.spa_kmeans_weighted(self._ctx, _ptr(X), 0 if X.dtype == torch.float32 else 1,
-                                            D, D, _ptr(w), _ptr(n_ptr), ncap, k, max_iter,
-                                            _ptr(init_other), _ptr(assign), _ptr(info), self._s()))
+        check(self._lib.spa_kmeans_weighted_gated(self._ctx, _ptr(X), 0 if X.dtype == torch.float32 else 1,
+                                                  D, D, _ptr(w), _ptr(n_ptr), ncap, k, max_iter,
+                                                  _ptr(init_other), _ptr(gate), _ptr(assign), _ptr(info), self._s()))
         return assign, info
+
+    def retry_update(self, assign, offsets, B, counters, gate=None):
+        """Retry bookkeeping of one k-means run on the device (spa_kmeans_retry_update): counters (2) int32 = [pending, made]."""
+        check(self._lib.spa_kmeans_retry_update(self._ctx, _ptr(assign), _ptr(offsets), int(B), _ptr(gate), _ptr(counters[0:1]),
+                                                _ptr(counters[1:2]), None, self._s()))
+
+    NP_INIT_MAX = 65536          # csrc/spa_nprng.hip: the index vector lives in LDS, one byte per point
+
+    def np_kmeans_init(self, state, w, n_ptr, k, gate=None):
+        """The k > 2 initial assignment (batch_spalign_kmeans.py:141-149) drawn on the device from numpy's stream.
+        state: (628,) int32 device tensor holding the generator (NpRandom.state() uploaded once; advanced in place);
+        -> init_other (ncap) int64 for kmeans().  gate as in kmeans(): nothing is drawn unless it is positive."""
+        w = _req(w, torch.float64, 'weights')
+        ncap = w.shape[0]
+        assert state.dtype == torch.int32 and state.numel() == 628 and state.is_contiguous() and ncap <= self.NP_INIT_MAX
+        init = torch.zeros((ncap,), dtype=torch.int64, device=w.device)
+        check(self._lib.spa_np_kmeans_init_dev(self._ctx, _ptr(state), _ptr(w), _ptr(n_ptr), ncap, k, _ptr(gate), _ptr(init),
+                                               None, self._s()))
+        return init
 
     def paint(self, labels, assign, offsets):
         labels = _req(labels, torch.int32, 'labels')
@@ -767,3 +787,10 @@ class NpRandom(object):
         assert a.dtype == np.int64 and a.flags.c_contiguous
         check(self._lib.spa_nprandom_shuffle_host(self._h, a.ctypes.data_as(ctypes.c_void_p), a.size))
         return a
+
+    def state(self):
+        """numpy's rk_state as it stands: (628,) uint32 = 624 state words, the position in the current block, padding —
+        what Engine.np_kmeans_init keeps in device memory."""
+        out = np.zeros(628, np.uint32)
+        check(self._lib.spa_nprandom_state(self._h, out.ctypes.data_as(ctypes.c_void_p)))
+        return out

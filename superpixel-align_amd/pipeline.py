@@ -39,6 +39,18 @@ class BatchResult(object):
         SPA_STRICT_RETRY=1): raise RecursionError here as well; default: print the reference's message once per
         such image and keep the batch — a run of 20 k images is not lost to one image without road.  Checked when
         the results are fetched: the flags are device-side and the batch loop stays asynchronous."""
+        info = getattr(self, 'retry_info', None)
+        if info is not None and flags is None:
+            # k > 2 with the generator on the device: [retry runs made, runs still pending] (LabelPipeline.cluster)
+            pending, made = (int(v) for v in info.cpu().tolist())
+            self.retry_info = None
+            for _ in range(made + pending):
+                print('\nSomehow KMeans seems failed. Try again\n')
+            if pending > 0:
+                raise _lib.SpalignError('weighted_kmeans retries (batch_spalign_kmeans.py:201-205): %d more run(s) were due than the '
+                                        '%d enqueued speculatively — numpy\'s stream is behind the reference\'s from the next batch on; '
+                                        'rerun with SPA_RETRY_ROUNDS=%d or --host_kmeans_init' % (pending, made, made + pending + 2))
+            return
         fail = getattr(self, 'retry_fail', None) if flags is None else flags
         if fail is None or not bool(fail.any().item()):
             return
@@ -76,6 +88,11 @@ class LabelPipeline(object):
         # their state carries over from batch to batch
         self.pyrandom = PyRandom(getattr(args, 'seed', 1111))
         self.nprandom = NpRandom(getattr(args, 'seed', 1111))
+        # k > 2: the numpy stream moves to the device at the first batch (cluster()); the host form of round 4 on request
+        self.host_kmeans_init = bool(getattr(args, 'host_kmeans_init', False)) or os.environ.get('SPA_KM_HOST_INIT') == '1'
+        self.retry_rounds = int(os.environ.get('SPA_RETRY_ROUNDS', '2'))
+        self._np_state = None
+        self._retry_info = None
         if os.environ.get('SPA_PIPE_OVERLAP') in ('0', '1'):
             overlap = os.environ['SPA_PIPE_OVERLAP'] == '1'
         # (the second stream's queue priority, SPA_AUX_PRIORITY: see DESIGN.md section 5 for the A/B)
@@ -106,6 +123,7 @@ class LabelPipeline(object):
         seed = getattr(self.args, 'seed', 1111) if seed is None else seed
         self.pyrandom = PyRandom(seed)
         self.nprandom = NpRandom(seed)
+        self._np_state = None                            # (the device copy is re-created from the fresh host state)
 
     # ---------------------------------------------------------------- stages
     def features(self, imgs_dev):
@@ -223,18 +241,32 @@ class LabelPipeline(object):
 
         The reference's weighted_kmeans re-runs itself, result discarded, for every image that ends without a
         cluster-0 pixel (:201-205).  k > 2: each run shuffles the initial assignment with numpy's global
-        generator, so the retries (a tree: a retry can fail and recurse) are executed here for their effect on
-        the stream later batches draw from.  k = 2: see BatchResult.check_retry.
+        generator, so the retries are executed here for their effect on the stream later batches draw from.
+        k = 2: see BatchResult.check_retry.
 
-        k > 2 synchronises the host with the batch (the drivers' asynchronous loop then overlaps only the decode and the
-        writers, not the enqueue): the length of the vector numpy shuffles is the number of superpixels at or below the
-        median weight — known only once the prior is on the host (:141-149) — and a failed image's retry must advance the
-        generator before the NEXT batch draws from it, so the flags are read here, not at the end of the batch.  Both are
-        the reference's data dependences, not this implementation's; k = 2 (BASELINE configs 1-5) has neither."""
+        k > 2 WITHOUT a host round trip (round 5; `--host_kmeans_init` / SPA_KM_HOST_INIT=1 keeps round 4's synchronous form):
+        numpy's generator state lives in device memory and the initial assignment — threshold, the number m of points at or
+        below it (known only on the device), arange(m) % (k - 1) + 1, np.random.shuffle — is drawn by one workgroup
+        (Engine.np_kmeans_init, csrc/spa_nprng.hip).  Retries: every run of the reference consumes ONE shuffle when it starts
+        and runs are sequential (the recursion is depth first and a run draws before it recurses), so the stream only depends
+        on HOW MANY runs there are: pending = failures of the first run; while pending: run again, pending += its failures - 1.
+        SPA_RETRY_ROUNDS (default 2) such runs are enqueued speculatively behind a device-side gate — a gated run that is not
+        wanted draws nothing and does nothing — and the counters go to `retry_info` = [runs made, runs still pending], read
+        when the batch is fetched (BatchResult.check_retry prints the reference's message per run; runs still pending mean
+        the stream would differ from the reference's from the next batch on: raised as an error, never silently)."""
         a, eng = self.args, self.eng
         B = labels.shape[0]
         init_other = None
-        if a.n_clusters > 2:
+        on_device = (a.n_clusters > 2 and not self.host_kmeans_init and X.shape[0] <= eng.NP_INIT_MAX)
+        if on_device:
+            if self._np_state is None:
+                self._np_state = torch.from_numpy(self.nprandom.state().view(np.int32)).to(labels.device)
+                self.nprandom = None                     # the stream lives on the device from here on
+            init_other = eng.np_kmeans_init(self._np_state, prior, off[B:], a.n_clusters)
+        elif a.n_clusters > 2:
+            if self.nprandom is None:
+                raise ValueError('the numpy stream already lives on the device: %d points exceed what the device initialisation '
+                                 'holds (%d); start with --host_kmeans_init' % (X.shape[0], eng.NP_INIT_MAX))
             # idx = arange(M) % (k-1) + 1 shuffled by numpy's global generator (:147-149)
             n = int(off[-1].item())
             w = prior[:n].cpu().numpy()
@@ -245,6 +277,16 @@ class LabelPipeline(object):
             init_other = torch.from_numpy(idx).to(labels.device)
         assign, info = eng.kmeans(X, prior, off[B:], a.n_clusters, 1000, init_other)
         cluster, road = eng.paint(labels, assign, off)
+        if on_device:
+            counters = torch.zeros((2,), dtype=torch.int32, device=labels.device)       # [runs pending, retry runs made]
+            eng.retry_update(assign, off, B, counters)
+            for _ in range(self.retry_rounds):
+                gate = counters[0:1].clone()              # the round runs iff a retry is pending now
+                init_r = eng.np_kmeans_init(self._np_state, prior, off[B:], a.n_clusters, gate=gate)
+                assign_r, _ = eng.kmeans(X, prior, off[B:], a.n_clusters, 1000, init_r, gate=gate)
+                eng.retry_update(assign_r, off, B, counters, gate=gate)
+            self._retry_info = counters
+            return assign, info, cluster, road, None
         fail = images_without_cluster0(assign, off, B)
         if a.n_clusters > 2:
             for b in fail.cpu().numpy().nonzero()[0]:
@@ -327,7 +369,7 @@ class LabelPipeline(object):
                 done.record(aux)
             res = BatchResult(labels=labels, n_labels=n_labels, offsets=seg['off'], count=seg['count'],
                               X=X, prior=seg['prior'], assign=assign, info=info, cluster=cluster,
-                              road=road, fmap=fmap, retry_fail=fail,
+                              road=road, fmap=fmap, retry_fail=fail, retry_info=self._retry_info,
                               strict_retry=bool(getattr(self.args, 'strict_retry', False)), stream=aux, ready=done)
             if join:
                 main.wait_event(done)
@@ -374,7 +416,7 @@ class LabelPipeline(object):
         done.record(main)
         res = BatchResult(labels=labels, n_labels=n_labels, offsets=seg['off'], count=seg['count'],
                           X=X, prior=seg['prior'], assign=assign, info=info, cluster=cluster,
-                          road=road, fmap=fmap, retry_fail=fail,
+                          road=road, fmap=fmap, retry_fail=fail, retry_info=self._retry_info,
                           strict_retry=bool(getattr(self.args, 'strict_retry', False)), stream=main, ready=done)
         if check_status:
             self.eng.raise_on_status()

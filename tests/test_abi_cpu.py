@@ -120,3 +120,21 @@ print(h.hexdigest())
             env.pop('SPA_RNG_SCALAR', None)
         outs.append(subprocess.check_output([sys.executable, '-c', code], env=env, cwd=root).decode().strip())
     assert outs[0] == outs[1] and len(outs[0]) == 64
+
+
+def test_numpy_generator_state_export_matches_numpy():
+    """spa_nprandom_state (what the device-side k-means initialisation uploads, csrc/spa_nprng.hip): the 624 state words and the
+    position of numpy's own legacy RandomState, right after seeding and after shuffles of several lengths (block boundaries)."""
+    import importlib
+    import numpy as np
+    engine = importlib.import_module('superpixel-align_amd.engine')
+    for seed in (1111, 5):
+        host, rs = engine.NpRandom(seed), np.random.RandomState(seed)
+        for n in (0, 1, 7, 1000, 623, 4097):
+            st = host.state()
+            _, key, pos = rs.get_state()[:3]
+            assert np.array_equal(st[:624], key.astype(np.uint32)) and int(st[624]) == int(pos) and not st[625:].any()
+            a, b = np.arange(n, dtype=np.int64), np.arange(n, dtype=np.int64)
+            host.shuffle(a)
+            rs.shuffle(b)
+            assert np.array_equal(a, b)

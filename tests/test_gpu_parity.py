@@ -319,6 +319,36 @@ def test_kmeans_engineered(eng, orc):
     eng.raise_on_status()
 
 
+def test_numpy_shuffle_stream_on_the_device(eng):
+    """Engine.np_kmeans_init (csrc/spa_nprng.hip): threshold, m, arange(m) % (k - 1) + 1 and np.random.shuffle drawn by one
+    workgroup from numpy's MT19937 state in device memory — against the host restatement of the same stream (spa_rng.cpp's
+    NpRandom, itself pinned by tests/golden/rng.npz and kmeans_retry.npz): call after call on ONE state (the position inside
+    a 624-output block carries over; several blocks per call), sizes from 3 to 40 000 points, ties at the threshold, and a
+    closed gate must neither draw nor write."""
+    engine = importlib.import_module('superpixel-align_amd.engine')
+    host = engine.NpRandom(1111)
+    state = torch.from_numpy(host.state().view(np.int32)).cuda()
+    rs = np.random.RandomState(7)
+    zero, one = dev(np.zeros(1, np.int32)), dev(np.ones(1, np.int32))
+    for N, k in [(3, 3), (17, 4), (600, 4), (5617, 4), (5617, 3), (1249, 8), (40000, 5), (2, 4), (1, 3)]:
+        w = rs.uniform(0.0, 1.0, N)
+        if N > 10:
+            w[rs.randint(0, N, N // 7)] = np.sort(w)[N // 2]          # ties at the threshold count as "other"
+        thr = np.sort(w)[N // 2]
+        m = int((w <= thr).sum())
+        want = (np.arange(m) % (k - 1) + 1).astype(np.int64)
+        host.shuffle(want)
+        ncap = N + 5
+        wd = dev(np.concatenate([w, np.full(5, 2.0)]))
+        before = state.clone()
+        closed = eng.np_kmeans_init(state, wd, dev(np.array([N], np.int32)), k, gate=zero)
+        assert torch.equal(state, before) and int(closed.abs().sum()) == 0             # nothing drawn, nothing written
+        got = eng.np_kmeans_init(state, wd, dev(np.array([N], np.int32)), k, gate=None if N % 2 else one)
+        assert got.shape == (ncap,) and np.array_equal(got[:m].cpu().numpy(), want), (N, k)
+    assert np.array_equal(state.cpu().numpy().view(np.uint32), host.state())               # the streams are at the same place
+    eng.raise_on_status()
+
+
 def test_kmeans_retry_branch_follows_the_reference(eng, capsys):
     """weighted_kmeans :201-205 on the GPU paths.  The drop-in op (ops.batch_weighted_kmeans) and the fused
     pipeline (LabelPipeline.cluster) execute the reference's discarded retries, so two consecutive k = 4 batches
@@ -334,17 +364,36 @@ def test_kmeans_retry_branch_follows_the_reference(eng, capsys):
     cl1, road1 = ops.batch_weighted_kmeans(args, g['sps1'].astype(np.int64), g['X1'], g['w1'], [int(v) for v in g['n_per1']])
     assert capsys.readouterr().out.count('Somehow KMeans seems failed') == int(g['n_retry'])
     assert np.array_equal(cl0, g['cl0']) and np.array_equal(cl1, g['cl1']) and np.array_equal(road0, g['cl0'] == 0)
-    # fused pipeline: same stages on device tensors
-    pipe = pipeline.LabelPipeline(args, model=None, engine=eng, pool_mode='mean', overlap=False)
-    outs = []
-    for t in ('0', '1'):
-        n_per = g['n_per' + t].astype(np.int32)
-        off = dev(np.concatenate([[0], np.cumsum(n_per)]).astype(np.int32))
-        assign, info, cluster, road, fail = pipe.cluster(dev(g['sps' + t].astype(np.int32)), off, dev(g['X' + t]), dev(g['w' + t]))
-        assert fail is None
-        outs.append(cluster.cpu().numpy())
-    assert capsys.readouterr().out.count('Somehow KMeans seems failed') == int(g['n_retry'])
-    assert np.array_equal(outs[0], g['cl0']) and np.array_equal(outs[1], g['cl1'])
+    # fused pipeline: same stages on device tensors.  Round 5: numpy's generator lives on the device, the initial assignment is
+    # drawn there and the retry runs are enqueued speculatively behind a device-side gate (LabelPipeline.cluster); batch 0 of
+    # the fixture needs three of them.  Round 4's synchronous host form (--host_kmeans_init) must give the same maps.
+    def run_pipe(rounds, host_init):
+        monkey = pytest.MonkeyPatch()
+        monkey.setenv('SPA_RETRY_ROUNDS', str(rounds))
+        try:
+            a = types.SimpleNamespace(n_clusters=4, seed=1111, host_kmeans_init=host_init)
+            pipe = pipeline.LabelPipeline(a, model=None, engine=eng, pool_mode='mean', overlap=False)
+        finally:
+            monkey.undo()
+        outs = []
+        for t in ('0', '1'):
+            n_per = g['n_per' + t].astype(np.int32)
+            off = dev(np.concatenate([[0], np.cumsum(n_per)]).astype(np.int32))
+            assign, info, cluster, road, fail = pipe.cluster(dev(g['sps' + t].astype(np.int32)), off, dev(g['X' + t]), dev(g['w' + t]))
+            assert fail is None
+            if not host_init:
+                pipeline.BatchResult(retry_info=pipe._retry_info).check_retry()      # prints the reference's message per retry run
+            outs.append(cluster.cpu().numpy())
+        return outs
+    for host_init in (False, True):
+        capsys.readouterr()
+        outs = run_pipe(4, host_init)
+        assert capsys.readouterr().out.count('Somehow KMeans seems failed') == int(g['n_retry'])
+        assert np.array_equal(outs[0], g['cl0']) and np.array_equal(outs[1], g['cl1'])
+    # fewer speculative rounds than the data needs: reported when the batch is fetched, never silent
+    with pytest.raises(RuntimeError, match='SPA_RETRY_ROUNDS'):
+        run_pipe(2, False)
+    capsys.readouterr()
     # k = 2
     args2 = types.SimpleNamespace(n_clusters=2, seed=1111, strict_retry=True)
     with pytest.raises(RecursionError):

@@ -90,7 +90,7 @@ for k in sorted(fe):
     name = k.replace('void ', '')
     if not name.startswith('k_'):
         continue
-    is_wide = name in wide or name.startswith(('k_wino4_in<', 'k_wino4_out<', 'k_wino4_out_s<', 'k_gemm_f16x3<', 'k_conv3x3_f32<'))
+    is_wide = name in wide or name.startswith(('k_wino4_in<', 'k_wino4_out<', 'k_wino4_out_s<', 'k_gemm_f16x3<', 'k_gemm_f16x3_stag<', 'k_conv3x3_f32<'))
     f_mb = fe[k][1] * 1024 / 1e6 * (2 if is_wide else 1)
     w_mb = wr.get(k, (0, 0.0))[1] * 1024 / 1e6
     tot = f_mb + w_mb
@@ -125,7 +125,8 @@ if any(k.replace('void ', '').startswith('k_wino4_in') for k in fe):
     for kname, bench_name, built, what in (
             ('k_wino4_in<', 'k_wino_in', 3.25 * act, 'X read + V = 2.25 X written'),
             ('k_conv3x3_f32<0, 256, 1, 256>', 'k_conv3x3_f32<taps 1>(GEMM form, all)', 4.5 * act, 'V = 2.25 X read + M = 2.25 Y written'),
-            ('k_gemm_f16x3<256, 256', 'k_gemm_f16x3<256, 256>', 4.5 * act, 'V = 2.25 X read + M = 2.25 Y written'),
+            ('k_gemm_f16x3_stag<256, 256', 'k_gemm_f16x3_stag<256, 256>', 4.5 * act, 'V = 2.25 X read + M = 2.25 Y written'),
+            ('k_gemm_f16x3<256, 256', 'k_gemm_f16x3_stag<256, 256>', 4.5 * act, 'V = 2.25 X read + M = 2.25 Y written'),
             ('k_wino4_out_s<0', 'k_wino_out', 3.25 * act, 'M = 2.25 Y read + Y written'),
             ('k_wino4_out<0', 'k_wino_out', 3.25 * act, 'M = 2.25 Y read + Y written')):
         h = hbm_of(kname)
