@@ -28,7 +28,12 @@ for name, env in (('one stream', dict(overlap=False)), ('two streams, tail on ma
     for r in range(a.reps):
         outs = []
         # back to back without a host sync in between, alternating two batches: the loop shape of the drivers
-        rs = [pipe.run(batches[k % 2], check_status=False, join=False) for k in range(4)]
+        # (both generators back to their start before EVERY run: anchor draws and the k > 2 initial assignment are then the
+        # same function of the batch, so that runs are comparable — VERDICT r4, weak #7)
+        rs = []
+        for k in range(4):
+            pipe.reseed()
+            rs.append(pipe.run(batches[k % 2], check_status=False, join=False))
         torch.cuda.synchronize()
         for k, res in enumerate(rs):
             key = (k % 2,)
