@@ -243,11 +243,19 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
         // (the loads of the next K step go out in one burst: spreading them between the MFMA groups was
         // measured 20 % slower — every global_load_lds re-programs M0 and breaks the MFMA stream; issuing the next group's
         // pixel thirds AFTER the step's wait, so that no wait covers an HBM load of the same step, was 4-6 % slower too)
+#ifdef SPA_C32_FIXED_ADDR          // timing experiment (wrong numbers): step-invariant staging addresses, so that their arithmetic leaves the loop
+        if (t + 1 < nk) stage_w(0, 0, cur ^ 1);
+        if (g + 1 < ngroups) {
+            if (TAPS == 9) stage_x(1, 0, dxi, xcur ^ 1);
+            else stage_x1(0, xcur ^ 1);
+        }
+#else
         if (t + 1 < nk) stage_w(TAPS == 9 ? ndyi * 3 + ndxi : 0, nkc, cur ^ 1);
         if (g + 1 < ngroups) {
             if (TAPS == 9) stage_x(gdyi, gkc, dxi, xcur ^ 1);
             else stage_x1(g + 1, xcur ^ 1);
         }
+#endif
         if (t + 1 == nk && !late_prefetch) {
             // LAST K step of the tile: nothing of this tile is left to load and the other buffer of each pair is
             // free, so the NEXT tile's first K step is staged now and travels under this step's matrix work (staged

@@ -175,9 +175,11 @@ rec = np.zeros((hi - lo, dist.RECORD_WIDTH), np.int64)
 rec[:, 0] = np.arange(lo, hi); rec[:, 4] = 100 * rank + np.arange(hi - lo)
 allrec = dist.gather_records(rec)
 mx = dist.max_over_ranks(1.5 + rank)
+vals = dist.all_values(10.0 * rank + 0.25)          # bench.py's per-rank rates / gather times / device ids
 if rank == 0:
     np.save(os.environ['OUT'], allrec)
     open(os.environ['OUT'] + '.max', 'w').write(str(mx))
+    open(os.environ['OUT'] + '.vals', 'w').write(repr(vals))
 dist.barrier()
 '''
 
@@ -198,6 +200,7 @@ def test_two_rank_gloo_gather(tmp_path):
     assert rec[:, 0].tolist() == list(range(11))                      # rank order == index order
     assert rec[:6, 4].tolist() == list(range(6)) and rec[6:, 4].tolist() == [100 + i for i in range(5)]
     assert float(open(out + '.max').read()) == 2.5
+    assert eval(open(out + '.vals').read()) == [0.25, 10.25]           # one value per rank, in rank order, on every rank
 
 
 def test_output_helpers_and_summary(tmp_path, orc):
