@@ -538,6 +538,15 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
     unsigned *lres = lkey + cells;                         // reservation: (tag << 10) | position in the window
     unsigned *lsz = lres + cells;                          // !LPAR only
     unsigned *wbuf = LPAR ? lsz : lsz + cells;             // the window: sorted positions of its live edges
+    // !LPAR (round 5): the forest of the window's OWN merges over the table's cells — lcp[c] = the cell c's component was merged
+    // into (itself: still a root).  The rounds of a window then find their roots through LDS alone; the global parent array is
+    // still written at every merge (the next window's set-up walks it) but never read inside a window's rounds
+    unsigned short *lcp = (unsigned short *)(wbuf + FZ_THREADS);
+    auto cfind = [&](int c) -> int {
+        int p;
+        while ((p = (int)__hip_atomic_load(lcp + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != c) c = p;
+        return c;
+    };
     __shared__ int wave_cnt[2 * FZ_CK * (FZ_THREADS / 64)];
     __shared__ unsigned cut_s[2];
     __shared__ int tail_ea[64], tail_eb[64];
@@ -669,7 +678,7 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
         FZ_T(1)
         if (nlive == 0) break;
         // ---- the window
-        for (int i = tid; i < cells; i += FZ_THREADS) { lkey[i] = FZL_EMPTY; lres[i] = 0xFFFFFFFFu; }
+        for (int i = tid; i < cells; i += FZ_THREADS) { lkey[i] = FZL_EMPTY; lres[i] = 0xFFFFFFFFu; if (!LPAR) lcp[i] = (unsigned short)i; }
         bool pend = tid < nlive;
         int ea = 0, eb = 0;
         double cost = 0.0;
@@ -697,11 +706,17 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
             if (pend) {
                 if (round) {
                     // from the roots of the last round (one LDS read each while they still are roots)
-                    const int na = find(ra), nb = find(rb);
-                    if (na == nb) pend = false;
-                    else {
-                        if (na != ra) { ra = na; ca = lookup(ra); }
-                        if (nb != rb) { rb = nb; cb = lookup(rb); }
+                    if (LPAR) {
+                        const int na = find(ra), nb = find(rb);
+                        if (na == nb) pend = false;
+                        else {
+                            if (na != ra) { ra = na; ca = lookup(ra); }
+                            if (nb != rb) { rb = nb; cb = lookup(rb); }
+                        }
+                    } else {
+                        ca = cfind(ca); cb = cfind(cb);
+                        if (ca == cb) pend = false;
+                        else { ra = (int)lkey[ca]; rb = (int)lkey[cb]; }
                     }
                 }
                 if (pend) {
@@ -749,7 +764,8 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
                         const int lo_r = a_lo ? ra : rb, hi_r = a_lo ? rb : ra, c_lo = a_lo ? ca : cb;
                         const unsigned ns = csize(ca) + csize(cb);
                         setp(hi_r, lo_r);
-                        if (LPAR) lkey[c_lo] = ((unsigned)lo_r << 16) | ns; else lsz[c_lo] = ns;
+                        if (LPAR) lkey[c_lo] = ((unsigned)lo_r << 16) | ns;
+                        else { lsz[c_lo] = ns; lcp[a_lo ? cb : ca] = (unsigned short)c_lo; }
                         if (mode == 0) lci[c_lo] = cost;
                     }
                     pend = false;
@@ -777,6 +793,7 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
                 if (wv == 0) {
                     bool tp = lane < nleft;
                     int tra = tp ? tail_ea[lane] : 0, trb = tp ? tail_eb[lane] : 0, tca = -1, tcb = -1;
+                    if (!LPAR && tp) { tca = lookup(tra); tcb = lookup(trb); }       // (the roots handed over are table roots)
                     const double tcost = tp ? tail_cost[lane] : 0.0;
                     for (unsigned tr = round + 1; __ballot(tp); ++tr) {
                         ++trounds;
@@ -784,11 +801,17 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
                         const unsigned mykey = (tag << 10) | (unsigned)lane;
                         bool want = false, resv = false;
                         if (tp) {
-                            const int na = find(tra), nb = find(trb);
-                            if (na == nb) tp = false;
-                            else {
-                                if (na != tra || tca < 0) { tra = na; tca = lookup(tra); }
-                                if (nb != trb || tcb < 0) { trb = nb; tcb = lookup(trb); }
+                            if (LPAR) {
+                                const int na = find(tra), nb = find(trb);
+                                if (na == nb) tp = false;
+                                else {
+                                    if (na != tra || tca < 0) { tra = na; tca = lookup(tra); }
+                                    if (nb != trb || tcb < 0) { trb = nb; tcb = lookup(trb); }
+                                }
+                            } else {
+                                tca = cfind(tca); tcb = cfind(tcb);
+                                if (tca == tcb) tp = false;
+                                else { tra = (int)lkey[tca]; trb = (int)lkey[tcb]; }
                             }
                         }
                         if (tp) {
@@ -831,7 +854,8 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
                                     const int lo_r = a_lo ? tra : trb, hi_r = a_lo ? trb : tra, c_lo = a_lo ? tca : tcb;
                                     const unsigned ns = csize(tca) + csize(tcb);
                                     setp(hi_r, lo_r);
-                                    if (LPAR) lkey[c_lo] = ((unsigned)lo_r << 16) | ns; else lsz[c_lo] = ns;
+                                    if (LPAR) lkey[c_lo] = ((unsigned)lo_r << 16) | ns;
+                                    else { lsz[c_lo] = ns; lcp[a_lo ? tcb : tca] = (unsigned short)c_lo; }
                                     if (mode == 0) lci[c_lo] = tcost;
                                 }
                                 tp = false;
@@ -1089,7 +1113,7 @@ static int fz_run(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t 
     // k_fz_pass — their passes are chains of hundreds of dependent rounds per window, and a round of the table kernel
     // still chases the parent array through L2; SPA_FZ_TAB_LARGE=1 selects it for experiments)
     const bool tab = G == 1 && !getenv("SPA_FZ_NO_LDS_STATE") && (lpar || getenv("SPA_FZ_TAB_LARGE"));
-    const size_t tab_lds = lpar ? par_bytes + (size_t)cells * 16 + FZ_THREADS * 4 : (size_t)cells * 20 + FZ_THREADS * 4;
+    const size_t tab_lds = lpar ? par_bytes + (size_t)cells * 16 + FZ_THREADS * 4 : (size_t)cells * 22 + FZ_THREADS * 4;
     if (tab && !(ctx->fz_attr_done & 2)) {
         SPA_HIP(hipFuncSetAttribute((const void *)k_fz_pass_tab<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
         SPA_HIP(hipFuncSetAttribute((const void *)k_fz_pass_tab<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
