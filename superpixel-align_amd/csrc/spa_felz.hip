@@ -29,7 +29,9 @@
 
 #include "spa_common.h"
 
+#ifndef FZ_THREADS
 #define FZ_THREADS 1024
+#endif
 #define FZ_EPT 1                 // edges per thread per window (1: a window of 1 024 sorted edges; larger windows only add serial work per round — measured 11.6 / 14.1 / 19.0 / 41 ms per 30 images of 224x224 for 1 / 2 / 4 / 8)
 
 #define FZ_MAXB 256               // images per launch (one resident workgroup each)
@@ -507,7 +509,9 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass(const unsigned long long
 // Decisions are those of k_fz_pass: same tests on the same values in the same order.
 // ---------------------------------------------------------------------------------------
 #define FZL_EMPTY 0xFFFFFFFFu
+#ifndef FZ_CK
 #define FZ_CK 2
+#endif
 // one wave's LDS and global accesses have completed and are visible to its own lanes
 __device__ __forceinline__ void fz_wave_sync()
 {
@@ -1109,10 +1113,12 @@ static int fz_run(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t 
     const bool lpar = G == 1 && npix <= 65535 && par_bytes + 2560 * 16 + FZ_THREADS * 4 <= lds_limit;
     long long cells = lpar ? (long long)((lds_limit - par_bytes - FZ_THREADS * 4) / 16) : 4096;
     if (cells > 4096) cells = 4096;
-    // (larger images: the table kernel with the parent array in L2 measured 0.90 s per full-size image against 0.60 s of
-    // k_fz_pass — their passes are chains of hundreds of dependent rounds per window, and a round of the table kernel
-    // still chases the parent array through L2; SPA_FZ_TAB_LARGE=1 selects it for experiments)
-    const bool tab = G == 1 && !getenv("SPA_FZ_NO_LDS_STATE") && (lpar || getenv("SPA_FZ_TAB_LARGE"));
+    // (larger images.  Round 3: the table kernel with the parent array in L2 measured 0.90 s per full-size image against 0.60 s of
+    // k_fz_pass — a round of it still chased the parent array through L2.  Round 5: the window's own merges form a forest over
+    // the table's CELLS (lcp), so a round finds its roots through LDS alone: 0.40 s against 0.52 s alone, 17.3 against 22.4 ms per
+    // image at batch 30, the same labels — the table kernel serves every image size; SPA_FZ_TAB_LARGE=0 keeps k_fz_pass)
+    const char *tab_large = getenv("SPA_FZ_TAB_LARGE");
+    const bool tab = G == 1 && !getenv("SPA_FZ_NO_LDS_STATE") && (lpar || !tab_large || atoi(tab_large) != 0);
     const size_t tab_lds = lpar ? par_bytes + (size_t)cells * 16 + FZ_THREADS * 4 : (size_t)cells * 22 + FZ_THREADS * 4;
     if (tab && !(ctx->fz_attr_done & 2)) {
         SPA_HIP(hipFuncSetAttribute((const void *)k_fz_pass_tab<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));

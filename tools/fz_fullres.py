@@ -23,6 +23,15 @@ if len(sys.argv) > 1:
     torch.cuda.synchronize()
     print('B=%d G=%s: %.1f ms per batch, %.1f ms per image, segments %d' % (
         B, os.environ.get('SPA_FZ_GROUP', '1'), (time.time() - t0) / 2 * 1e3, (time.time() - t0) / 2 / B * 1e3, int(n[0])))
+    # pass diagnostics of the last call (k_fz_pass_tab): windows, chunks, rounds summed over images and both passes
+    import ctypes, re
+    lib_mod = importlib.import_module('superpixel-align_amd._lib')
+    src = open(os.path.join(os.path.dirname(lib_mod.__file__), 'csrc', 'spa_common.h')).read()
+    names = re.findall(r'^\s*(WS_[A-Z_0-9]+)\s*(?:=\s*0)?,', src, re.M)
+    host = (ctypes.c_int32 * 9)()
+    lib_mod.check(lib_mod.lib().spa_debug_peek(eng._ctx, names.index('WS_CONNMISC'), 256 * 32 + 256 * 4, 36, host))
+    print('   per image and both passes: %.0f windows, %.0f chunks of 1024 sorted edges, %.0f full rounds, %.0f tail rounds' % tuple(v / float(B) for v in host[:4]))
+    print('   kilo-cycles per image: flatten %.0f | collect %.0f | window set-up + write-back %.0f | full rounds %.0f | tail %.0f' % tuple(v / float(B) for v in host[4:9]))
 else:
     for B in (1, 8, 30):
         for G in (1, 2, 4, 8):
