@@ -381,6 +381,13 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert d['roofline']['ms_per_step'] == max(k['ms_per_step'] for k in d['kernels'].values())
     h = d['host_to_host']                                    # SURVEY 8d's region, second timed loop
     assert h['value'] > 0 and h['images_downloaded'] == 2 * 2 * 2
+    # round 5: multi-GPU bookkeeping of the line (per-rank rates, the gather's time on each rank, where the ranks sit) and the
+    # same region on float32 matrix instructions
+    m = d['multi_gpu']
+    assert m['ranks'] == 2 and m['backend'] == 'gloo' and m['records_gathered'] == m['records_expected'] == 4
+    assert len(m['per_rank_images_per_sec']) == 2 and all(v > 0 for v in m['per_rank_images_per_sec'])
+    assert len(m['gather_ms_per_rank']) == 2 and m['rank_devices'] == [0, 0]          # SPA_BENCH_SAME_DEVICE: both on cuda:0
+    assert d['exact_fp32_value'] > 0 and d['dtype'].startswith('f32 as 2 x f16')
 
 
 def test_bench_launches_its_own_ranks(tmp_path):
