@@ -525,7 +525,7 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
                                                             int *__restrict__ parent, int *__restrict__ size,
                                                             double *__restrict__ cint, double scale, int min_size,
                                                             int mode, const int *__restrict__ zcount,
-                                                            int flatten_every, int cells, int *__restrict__ diag)
+                                                            int flatten_every, int cells, int *__restrict__ diag, int hub_on = 0)
 {
     const int b = blockIdx.x;
     const int npix = g.H * g.W;
@@ -546,6 +546,18 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
     // into (itself: still a root).  The rounds of a window then find their roots through LDS alone; the global parent array is
     // still written at every merge (the next window's set-up walks it) but never read inside a window's rounds
     unsigned short *lcp = (unsigned short *)(wbuf + FZ_THREADS);
+    // !LPAR, hub chains (round 5, below): pending edges per cell, hub slot per cell, the edges' cells / costs / decided flags,
+    // per-hub bitmaps of the window positions that touch the hub
+    constexpr int NHUB = 16, HUB_TH = 4;
+    unsigned short *lcnt = lcp + cells;
+    unsigned short *e_ca = lcnt + cells, *e_cb = e_ca + FZ_THREADS;
+    unsigned char *lslot = (unsigned char *)(e_cb + FZ_THREADS);
+    unsigned char *e_done = lslot + cells;
+    double *e_cost = (double *)(((uintptr_t)(e_done + FZ_THREADS) + 7) & ~(uintptr_t)7);
+    unsigned *hbits = (unsigned *)(e_cost + FZ_THREADS);
+    int *hcell = (int *)(hbits + NHUB * (FZ_THREADS / 32));
+    int *nhub = hcell + NHUB;
+    float *e_thr = (float *)(nhub + 4);                    // merge threshold of an edge's non-hub side (computed by its own thread)
     auto cfind = [&](int c) -> int {
         int p;
         while ((p = (int)__hip_atomic_load(lcp + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != c) c = p;
@@ -642,16 +654,55 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
             unsigned long long m[FZ_CK];
             int *wc = wave_cnt + (step_par ? FZ_CK * (FZ_THREADS / 64) : 0);
             unsigned *cut = cut_s + step_par;
+            if (LPAR) {
 #pragma unroll
-            for (int k = 0; k < FZ_CK; ++k) {
-                const long long e = cursor + (long long)k * FZ_THREADS + tid;
-                live[k] = false;
-                if (e < g.nE) {
-                    int a, c;
-                    fz_endpoints(g, (long long)vcur[k], a, c);
-                    const int ra_ = find(a), rb_ = find(c);
-                    live[k] = ra_ != rb_;
-                    if (live[k] && mode == 1) live[k] = S[ra_] < min_size || S[rb_] < min_size;
+                for (int k = 0; k < FZ_CK; ++k) {
+                    const long long e = cursor + (long long)k * FZ_THREADS + tid;
+                    live[k] = false;
+                    if (e < g.nE) {
+                        int a, c;
+                        fz_endpoints(g, (long long)vcur[k], a, c);
+                        const int ra_ = find(a), rb_ = find(c);
+                        live[k] = ra_ != rb_;
+                        if (live[k] && mode == 1) live[k] = S[ra_] < min_size || S[rb_] < min_size;
+                    }
+                }
+            } else {
+                // parent array in global memory (round 5): the 2 FZ_CK walks of a thread advance LEVEL BY LEVEL — every level is one
+                // batch of independent loads instead of 2 FZ_CK dependent chains one after the other — and an edge whose endpoints
+                // point at the same parent is dead without looking further (most sorted positions of a late pass are: after a
+                // flattening sweep both pixels point straight at their root)
+                int ea_[FZ_CK], eb_[FZ_CK];
+                bool act[FZ_CK];
+#pragma unroll
+                for (int k = 0; k < FZ_CK; ++k) {
+                    const long long e = cursor + (long long)k * FZ_THREADS + tid;
+                    act[k] = e < g.nE;
+                    live[k] = false;
+                    ea_[k] = eb_[k] = 0;
+                    if (act[k]) fz_endpoints(g, (long long)vcur[k], ea_[k], eb_[k]);
+                }
+                for (;;) {
+                    int pa_[FZ_CK], pb_[FZ_CK];
+                    bool any = false;
+#pragma unroll
+                    for (int k = 0; k < FZ_CK; ++k) { pa_[k] = act[k] ? P[ea_[k]] : -1; pb_[k] = act[k] ? P[eb_[k]] : -1; }
+#pragma unroll
+                    for (int k = 0; k < FZ_CK; ++k) {
+                        if (!act[k]) continue;
+                        if (pa_[k] >= 0 && pa_[k] == pb_[k]) { act[k] = false; continue; }        // same parent: one component
+                        if (pa_[k] >= 0) ea_[k] = pa_[k];
+                        if (pb_[k] >= 0) eb_[k] = pb_[k];
+                        if (pa_[k] < 0 && pb_[k] < 0) { act[k] = false; live[k] = ea_[k] != eb_[k]; }   // both are roots
+                        else if (ea_[k] == eb_[k]) act[k] = false;                                  // met on the way up
+                        else any = true;
+                    }
+                    if (!any) break;
+                }
+                if (mode == 1) {
+#pragma unroll
+                    for (int k = 0; k < FZ_CK; ++k)
+                        if (live[k]) live[k] = S[ea_[k]] < min_size || S[eb_[k]] < min_size;
                 }
             }
 #pragma unroll
@@ -698,6 +749,7 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
             if (ra == rb) pend = false;                     // same component for ever
             else { ca = enter(ra); cb = enter(rb); }
         }
+        if (!LPAR && hub_on) e_cost[tid] = cost;
         __syncthreads();
         FZ_T(2)
         for (unsigned round = 0;; ++round) {
@@ -753,6 +805,90 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
                     }
                 }
                 if (__syncthreads_or(changed) == 0) break;
+            }
+            // ---- hub chains (!LPAR, round 5).  On a smooth full-size image nearly every live edge of a late window joins a
+            // small component to ONE giant one; the protocol above decides the earliest of them per round (the others wait for
+            // its reservation), 50 rounds per window.  Their decisions are a recurrence over the hub's state alone — internal
+            // cost = the last merged edge's, size = the running sum — whenever the other side of each edge is touched by NO other
+            // pending edge of the window (then nothing but the hub's own chain can change what the edge sees, and merging it pulls
+            // no further edge into the chain).  So: count the pending edges per cell; the earliest reserver of a cell with >=
+            // HUB_TH of them opens a hub slot; every pending edge sets its bit in the bitmaps of its cells' slots; one thread per
+            // hub walks the bitmap in window order — exactly the sequential pass over those edges — and stops at the first edge whose
+            // other side has company.  Walked edges are decided (merged with the state written as phase 2 writes it, or dropped);
+            // the rest of the round proceeds as before.
+            if (!LPAR && hub_on && round >= 1) {
+                for (int i = tid; i < cells; i += FZ_THREADS) { lcnt[i] = 0; lslot[i] = 0; }
+                if (tid < NHUB * (FZ_THREADS / 32)) hbits[tid] = 0u;
+                if (tid == 0) *nhub = 0;
+                e_done[tid] = 0;
+                __syncthreads();
+                if (pend) {
+                    atomicAdd((unsigned *)(lcnt + (ca & ~1)), (ca & 1) ? 0x10000u : 1u);       // 16-bit counters, two per word (no carry: <= 2 048 per cell)
+                    atomicAdd((unsigned *)(lcnt + (cb & ~1)), (cb & 1) ? 0x10000u : 1u);
+                    e_ca[tid] = (unsigned short)ca; e_cb[tid] = (unsigned short)cb;
+                }
+                __syncthreads();
+                if (pend) {
+                    const unsigned ma = lres[ca], mb = lres[cb];
+                    if (ma == mykey && lcnt[ca] >= HUB_TH) { const int sl = atomicAdd(nhub, 1); if (sl < NHUB) { hcell[sl] = ca; lslot[ca] = (unsigned char)(sl + 1); } }
+                    if (mb == mykey && lcnt[cb] >= HUB_TH) { const int sl = atomicAdd(nhub, 1); if (sl < NHUB) { hcell[sl] = cb; lslot[cb] = (unsigned char)(sl + 1); } }
+                }
+                __syncthreads();
+                if (pend) {
+                    const int sa = lslot[ca], sb = lslot[cb];
+                    if (sa) atomicOr(hbits + (sa - 1) * (FZ_THREADS / 32) + (tid >> 5), 1u << (tid & 31));
+                    if (sb) atomicOr(hbits + (sb - 1) * (FZ_THREADS / 32) + (tid >> 5), 1u << (tid & 31));
+                    if (mode == 0 && (sa != 0) != (sb != 0)) {        // the leaf side's threshold, off the walking thread's chain
+                        const int c = sa ? cb : ca;
+                        e_thr[tid] = (float)(lci[c] + scale / (double)(int)lsz[c]);
+                    }
+                }
+                __syncthreads();
+                const int nh = min(*nhub, NHUB);
+                if (tid < nh) {
+                    const int h0 = hcell[tid];
+                    int hcur = h0, hroot = (int)lkey[h0];
+                    unsigned hsz = lsz[h0];
+                    double hci = mode == 0 ? lci[h0] : 0.0;
+                    bool stop = false, t0_stale = true;
+                    float t0 = 0.f;
+                    for (int w = 0; w < FZ_THREADS / 32 && !stop; ++w) {
+                        unsigned bits = hbits[tid * (FZ_THREADS / 32) + w];
+                        while (bits) {
+                            const int pp = w * 32 + __ffs((int)bits) - 1;
+                            bits &= bits - 1;
+                            const int xa = e_ca[pp], xb = e_cb[pp];
+                            const int c = xa == h0 ? xb : xa;
+                            if (lcnt[c] != 1) { stop = true; break; }
+                            const unsigned csz = lsz[c];
+                            const double ecost = e_cost[pp];
+                            bool w_;
+                            if (mode == 0) {
+                                if (t0_stale) { t0 = (float)(hci + scale / (double)(int)hsz); t0_stale = false; }
+                                const float t1 = e_thr[pp];            // (c is no hub: lcnt[c] == 1 < HUB_TH)
+                                w_ = ecost < (double)(t0 < t1 ? t0 : t1);
+                            } else {
+                                w_ = (int)hsz < min_size || (int)csz < min_size;
+                            }
+                            if (w_) {
+                                const int croot = (int)lkey[c];
+                                const bool h_lo = hroot < croot;
+                                const int lo_r = h_lo ? hroot : croot, hi_r = h_lo ? croot : hroot;
+                                const int surv = h_lo ? hcur : c, dead = h_lo ? c : hcur;
+                                const unsigned ns = hsz + csz;
+                                setp(hi_r, lo_r);
+                                lsz[surv] = ns;
+                                lcp[dead] = (unsigned short)surv;
+                                if (mode == 0) { lci[surv] = ecost; hci = ecost; }
+                                hcur = surv; hroot = lo_r; hsz = ns;
+                                t0_stale = true;
+                            }
+                            e_done[pp] = 1;
+                        }
+                    }
+                }
+                __syncthreads();
+                if (pend && e_done[tid]) pend = false;
             }
             // ---- phase 2: decide every edge no earlier reservation can influence
             int left = 0;
@@ -1119,7 +1255,13 @@ static int fz_run(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t 
     // image at batch 30, the same labels — the table kernel serves every image size; SPA_FZ_TAB_LARGE=0 keeps k_fz_pass)
     const char *tab_large = getenv("SPA_FZ_TAB_LARGE");
     const bool tab = G == 1 && !getenv("SPA_FZ_NO_LDS_STATE") && (lpar || !tab_large || atoi(tab_large) != 0);
-    const size_t tab_lds = lpar ? par_bytes + (size_t)cells * 16 + FZ_THREADS * 4 : (size_t)cells * 22 + FZ_THREADS * 4;
+    // (!lpar: + the hub-chain state: cells * 3 + per-edge cells / flags / costs + 16 bitmaps)
+    const size_t tab_lds = lpar ? par_bytes + (size_t)cells * 16 + FZ_THREADS * 4
+                                : (size_t)cells * 22 + FZ_THREADS * 4 + (size_t)cells * 3 + FZ_THREADS * 13 + 16 + 16 * (FZ_THREADS / 32) * 4 + 16 * 4 + 16 + FZ_THREADS * 4;
+    // hub chains (k_fz_pass_tab, !LPAR): on by default — one 1024 x 2048 image alone 0.40 -> 0.25 s (109 000 -> 8 000 full rounds),
+    // 16.9 -> 11.3 ms per image at batch 30, the same labels; SPA_FZ_HUB=0 switches them off
+    const char *hub_env = getenv("SPA_FZ_HUB");
+    const int hub_on = hub_env ? atoi(hub_env) : 1;
     if (tab && !(ctx->fz_attr_done & 2)) {
         SPA_HIP(hipFuncSetAttribute((const void *)k_fz_pass_tab<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
         SPA_HIP(hipFuncSetAttribute((const void *)k_fz_pass_tab<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
@@ -1135,7 +1277,7 @@ static int fz_run(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t 
         else if (tab)
             hipLaunchKernelGGL(k_fz_pass_tab<false>, dim3(B), dim3(FZ_THREADS), tab_lds, s,
                                (const unsigned long long *)keys1, (const unsigned *)vals1, g, parent, size, cint, k,
-                               min_size, mode, (const int *)zcount, flatten_every, (int)cells, diag);
+                               min_size, mode, (const int *)zcount, flatten_every, (int)cells, diag, hub_on);
         else if (ldsp)
             hipLaunchKernelGGL(k_fz_pass<true>, dim3(G, B), dim3(FZ_THREADS), lds_par, s, (const unsigned long long *)keys1,
                                (const unsigned *)vals1, g, parent, size, cint, mark, st, k, min_size, mode, r0,

@@ -80,3 +80,14 @@ def test_felzenszwalb_full_size(eng, orc, synth):
     eng.raise_on_status()
     ref = orc.felzenszwalb(img, 300.0, 0.8, 20)
     assert np.array_equal(labels[0].cpu().numpy().astype(np.int64), ref)
+
+
+def test_felzenszwalb_full_size_smooth_image(eng, orc, synth):
+    """The bench generator's smooth 1024x2048 image: it ends in ~15 segments, i.e. nearly every live edge of a late window joins a
+    small component to one giant one — the case the hub chains of k_fz_pass_tab walk (round 5); labels against the oracle."""
+    img = synth.synth_image(3, 1024, 2048)
+    labels, n_labels = eng.felzenszwalb(torch.from_numpy(img[None]).cuda(), 300.0, 0.8, 20)
+    eng.raise_on_status()
+    ref = orc.felzenszwalb(img, 300.0, 0.8, 20)
+    assert int(n_labels[0]) == ref.max() + 1 and int(n_labels[0]) < 100
+    assert np.array_equal(labels[0].cpu().numpy().astype(np.int64), ref)
