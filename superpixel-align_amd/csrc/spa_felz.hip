@@ -745,7 +745,18 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
         __syncthreads();
         int ra = 0, rb = 0, ca = 0, cb = 0;
         if (pend) {
-            ra = find(ea); rb = find(eb);
+            if (LPAR) { ra = find(ea); rb = find(eb); }
+            else {
+                // (both walks level by level: two independent loads per level instead of two chains one after the other)
+                int xa = ea, xb = eb;
+                bool fa = false, fb = false;
+                while (!(fa && fb)) {
+                    const int pa = fa ? -1 : P[xa], pb = fb ? -1 : P[xb];
+                    if (pa < 0) fa = true; else xa = pa;
+                    if (pb < 0) fb = true; else xb = pb;
+                }
+                ra = xa; rb = xb;
+            }
             if (ra == rb) pend = false;                     // same component for ever
             else { ca = enter(ra); cb = enter(rb); }
         }
@@ -845,45 +856,66 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
                 }
                 __syncthreads();
                 const int nh = min(*nhub, NHUB);
-                if (tid < nh) {
-                    const int h0 = hcell[tid];
+                if (wv < nh) {
+                    // one WAVE per hub: lane i of block q stands for window position 64 q + i and fetches that edge's record (its
+                    // leaf cell, whether the leaf is private, the leaf's size / root / threshold, the cost) with its own loads;
+                    // the walk itself runs over the set lanes in order on wave-uniform values (v_readlane), so an edge costs a
+                    // handful of register reads instead of three dependent LDS round trips; lane 0 writes what a merge changes
+                    const int h0 = hcell[wv];
                     int hcur = h0, hroot = (int)lkey[h0];
                     unsigned hsz = lsz[h0];
                     double hci = mode == 0 ? lci[h0] : 0.0;
                     bool stop = false, t0_stale = true;
                     float t0 = 0.f;
-                    for (int w = 0; w < FZ_THREADS / 32 && !stop; ++w) {
-                        unsigned bits = hbits[tid * (FZ_THREADS / 32) + w];
-                        while (bits) {
-                            const int pp = w * 32 + __ffs((int)bits) - 1;
-                            bits &= bits - 1;
+                    for (int q = 0; q < FZ_THREADS / 64 && !stop; ++q) {
+                        const int pp = q * 64 + lane;
+                        const bool bit = (hbits[wv * (FZ_THREADS / 32) + (pp >> 5)] >> (pp & 31)) & 1u;
+                        int c = 0, okc = 0, croot = 0;
+                        unsigned csz = 0;
+                        float thr = 0.f;
+                        double ecost = 0.0;
+                        if (bit) {
                             const int xa = e_ca[pp], xb = e_cb[pp];
-                            const int c = xa == h0 ? xb : xa;
-                            if (lcnt[c] != 1) { stop = true; break; }
-                            const unsigned csz = lsz[c];
-                            const double ecost = e_cost[pp];
+                            c = xa == h0 ? xb : xa;
+                            okc = lcnt[c] == 1;
+                            csz = lsz[c];
+                            croot = (int)lkey[c];
+                            thr = e_thr[pp];
+                            ecost = e_cost[pp];
+                        }
+                        unsigned long long mask = __ballot(bit);
+                        while (mask) {
+                            const int j = __builtin_amdgcn_readfirstlane(__ffsll((long long)mask) - 1);
+                            mask &= mask - 1;
+                            if (!__builtin_amdgcn_readlane(okc, j)) { stop = true; break; }
+                            const int c_j = __builtin_amdgcn_readlane(c, j), croot_j = __builtin_amdgcn_readlane(croot, j);
+                            const unsigned csz_j = (unsigned)__builtin_amdgcn_readlane((int)csz, j);
+                            const double cost_j = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ecost), j),
+                                                                   __builtin_amdgcn_readlane(__double2loint(ecost), j));
                             bool w_;
                             if (mode == 0) {
                                 if (t0_stale) { t0 = (float)(hci + scale / (double)(int)hsz); t0_stale = false; }
-                                const float t1 = e_thr[pp];            // (c is no hub: lcnt[c] == 1 < HUB_TH)
-                                w_ = ecost < (double)(t0 < t1 ? t0 : t1);
+                                const float t1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(thr), j));
+                                w_ = cost_j < (double)(t0 < t1 ? t0 : t1);
                             } else {
-                                w_ = (int)hsz < min_size || (int)csz < min_size;
+                                w_ = (int)hsz < min_size || (int)csz_j < min_size;
                             }
                             if (w_) {
-                                const int croot = (int)lkey[c];
-                                const bool h_lo = hroot < croot;
-                                const int lo_r = h_lo ? hroot : croot, hi_r = h_lo ? croot : hroot;
-                                const int surv = h_lo ? hcur : c, dead = h_lo ? c : hcur;
-                                const unsigned ns = hsz + csz;
-                                setp(hi_r, lo_r);
-                                lsz[surv] = ns;
-                                lcp[dead] = (unsigned short)surv;
-                                if (mode == 0) { lci[surv] = ecost; hci = ecost; }
+                                const bool h_lo = hroot < croot_j;
+                                const int lo_r = h_lo ? hroot : croot_j, hi_r = h_lo ? croot_j : hroot;
+                                const int surv = h_lo ? hcur : c_j, dead = h_lo ? c_j : hcur;
+                                const unsigned ns = hsz + csz_j;
+                                if (lane == 0) {
+                                    setp(hi_r, lo_r);
+                                    lsz[surv] = ns;
+                                    lcp[dead] = (unsigned short)surv;
+                                    if (mode == 0) lci[surv] = cost_j;
+                                }
+                                if (mode == 0) hci = cost_j;
                                 hcur = surv; hroot = lo_r; hsz = ns;
                                 t0_stale = true;
                             }
-                            e_done[pp] = 1;
+                            if (lane == 0) e_done[q * 64 + j] = 1;
                         }
                     }
                 }
@@ -1258,8 +1290,8 @@ static int fz_run(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t 
     // (!lpar: + the hub-chain state: cells * 3 + per-edge cells / flags / costs + 16 bitmaps)
     const size_t tab_lds = lpar ? par_bytes + (size_t)cells * 16 + FZ_THREADS * 4
                                 : (size_t)cells * 22 + FZ_THREADS * 4 + (size_t)cells * 3 + FZ_THREADS * 13 + 16 + 16 * (FZ_THREADS / 32) * 4 + 16 * 4 + 16 + FZ_THREADS * 4;
-    // hub chains (k_fz_pass_tab, !LPAR): on by default — one 1024 x 2048 image alone 0.40 -> 0.25 s (109 000 -> 8 000 full rounds),
-    // 16.9 -> 11.3 ms per image at batch 30, the same labels; SPA_FZ_HUB=0 switches them off
+    // hub chains (k_fz_pass_tab, !LPAR): on by default — one 1024 x 2048 image alone 0.40 -> 0.22 s (109 000 -> 8 000 full rounds),
+    // 16.9 -> 10.2 ms per image at batch 30, the same labels; SPA_FZ_HUB=0 switches them off
     const char *hub_env = getenv("SPA_FZ_HUB");
     const int hub_on = hub_env ? atoi(hub_env) : 1;
     if (tab && !(ctx->fz_attr_done & 2)) {
