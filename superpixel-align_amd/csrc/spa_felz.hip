@@ -525,12 +525,16 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
                                                             int *__restrict__ parent, int *__restrict__ size,
                                                             double *__restrict__ cint, double scale, int min_size,
                                                             int mode, const int *__restrict__ zcount,
-                                                            int flatten_every, int cells, int *__restrict__ diag, int hub_on = 0)
+                                                            int flatten_every, int cells, int *__restrict__ diag, int hub_on = 0,
+                                                            const int *__restrict__ n_edges = nullptr)
 {
     const int b = blockIdx.x;
     const int npix = g.H * g.W;
     const unsigned long long *K = keys + (long long)b * g.nE;
     const unsigned *V = vals + (long long)b * g.nE;
+    // n_edges (the clean-up pass of a large image, round 5): keys / vals hold only the n_edges[b] sorted edges that can still merge
+    // something (the prefilter kernels in front of fz_run), from position 0
+    const long long nEb = n_edges ? (long long)n_edges[b] : g.nE;
     int *P = parent + (long long)b * npix;
     int *S = size + (long long)b * npix;
     double *CI = cint + (long long)b * npix;
@@ -609,17 +613,17 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
     }
     __syncthreads();
 
-    int win = 0, chunks = 0, rounds = 0, trounds = 0;
+    int win = n_edges ? 1 : 0, chunks = 0, rounds = 0, trounds = 0;      // (n_edges: the forest was flattened by the prefilter)
     long long tc[5] = {0, 0, 0, 0, 0};        // diagnostics: cycles of flatten | collect | window set-up | full rounds | tail
     long long t_ = (long long)__builtin_readcyclecounter();
 #define FZ_T(i) { const long long n_ = (long long)__builtin_readcyclecounter(); tc[i] += n_ - t_; t_ = n_; }
-    long long cursor = zcount[b];                           // zero-cost edges: done up front
+    long long cursor = n_edges ? 0 : zcount[b];             // zero-cost edges: done up front
     unsigned vpre[FZ_CK];
     long long vpre_at = -1;
     int step_par = 0;
     if (tid == 0) { cut_s[0] = 0xFFFFFFFFu; cut_s[1] = 0xFFFFFFFFu; }
     __syncthreads();
-    while (cursor < g.nE) {
+    while (cursor < nEb) {
         if ((win++ % flatten_every) == 0) {
             for (int p = tid; p < npix; p += FZ_THREADS) {
                 const int q = getp(p);
@@ -630,7 +634,7 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
         FZ_T(0)
         // ---- collect the next (up to) 1 024 live edges, in sorted order
         int nlive = 0;
-        while (nlive < FZ_THREADS && cursor < g.nE) {
+        while (nlive < FZ_THREADS && cursor < nEb) {
             // FZ_CK chunks of 1 024 sorted positions per step; the edge indices of the next step are already on
             // their way (vpre, loaded for `vpre_at`), the step's counters alternate between two LDS sets so that
             // a step needs two barriers
@@ -639,14 +643,14 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
 #pragma unroll
             for (int k = 0; k < FZ_CK; ++k) {
                 const long long e = cursor + (long long)k * FZ_THREADS + tid;
-                vcur[k] = vpre_at == cursor ? vpre[k] : (e < g.nE ? V[e] : 0u);
+                vcur[k] = vpre_at == cursor ? vpre[k] : (e < nEb ? V[e] : 0u);
             }
             {
                 const long long nx = cursor + (long long)FZ_CK * FZ_THREADS;
 #pragma unroll
                 for (int k = 0; k < FZ_CK; ++k) {
                     const long long e = nx + (long long)k * FZ_THREADS + tid;
-                    vpre[k] = e < g.nE ? V[e] : 0u;
+                    vpre[k] = e < nEb ? V[e] : 0u;
                 }
                 vpre_at = nx;
             }
@@ -659,7 +663,7 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
                 for (int k = 0; k < FZ_CK; ++k) {
                     const long long e = cursor + (long long)k * FZ_THREADS + tid;
                     live[k] = false;
-                    if (e < g.nE) {
+                    if (e < nEb) {
                         int a, c;
                         fz_endpoints(g, (long long)vcur[k], a, c);
                         const int ra_ = find(a), rb_ = find(c);
@@ -677,7 +681,7 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
 #pragma unroll
                 for (int k = 0; k < FZ_CK; ++k) {
                     const long long e = cursor + (long long)k * FZ_THREADS + tid;
-                    act[k] = e < g.nE;
+                    act[k] = e < nEb;
                     live[k] = false;
                     ea_[k] = eb_[k] = 0;
                     if (act[k]) fz_endpoints(g, (long long)vcur[k], ea_[k], eb_[k]);
@@ -1156,6 +1160,104 @@ extern "C" int spa_felzenszwalb_u8(spa_ctx *ctx, const float *rgb, int32_t B, in
     return fz_run(ctx, rgb, B, H, W, scale, sigma, min_size, labels, n_labels, stream, true);
 }
 
+// ---- between the passes of a large image (round 5): the clean-up pass (mode 1) can only ever merge across an edge whose
+// endpoints lie in different components one of which is below min_size NOW — components only grow —, a vanishing share of the
+// sorted list, yet the pass's single workgroup walked all of it again (half of its collect phase).  Every compute unit does that
+// test once: the forest is flattened, the survivors are counted per block of 1 024 sorted positions, scanned, and copied in order.
+__global__ __launch_bounds__(256) void k_fz_flatten_all(int *__restrict__ parent, int npix)
+{
+    int *P = parent + (long long)blockIdx.y * npix;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < npix; p += gridDim.x * 256) {
+        const int q = P[p];
+        if (q < 0) continue;
+        int r = q, n;
+        while ((n = P[r]) >= 0) r = n;
+        if (r != q) P[p] = r;
+    }
+}
+__device__ __forceinline__ bool fz_live1(const FzGeom &g, const unsigned *V, const int *P, const int *S, long long e, int min_size)
+{
+    int a, c;
+    fz_endpoints(g, (long long)V[e], a, c);
+    const int pa = P[a], pc = P[c];
+    int ra = pa < 0 ? a : pa, rc = pc < 0 ? c : pc;
+    int n;
+    while ((n = P[ra]) >= 0) ra = n;             // (flattened: the root already)
+    while ((n = P[rc]) >= 0) rc = n;
+    return ra != rc && (S[ra] < min_size || S[rc] < min_size);
+}
+__global__ __launch_bounds__(256) void k_fz_live_count(const unsigned *__restrict__ vals, FzGeom g, const int *__restrict__ parent,
+                                                       const int *__restrict__ size, const int *__restrict__ zcount, int min_size,
+                                                       int npix, int *__restrict__ blkcnt, int nblk)
+{
+    const int b = blockIdx.y;
+    const unsigned *V = vals + (long long)b * g.nE;
+    const int *P = parent + (long long)b * npix, *S = size + (long long)b * npix;
+    __shared__ int wc[4];
+    for (int kb = blockIdx.x; kb < nblk; kb += gridDim.x) {
+        int cnt = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long e = (long long)kb * 1024 + u * 256 + threadIdx.x;
+            const bool live = e >= zcount[b] && e < g.nE && fz_live1(g, V, P, S, e, min_size);
+            cnt += __popcll(__ballot(live));
+        }
+        if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = cnt;
+        __syncthreads();
+        if (threadIdx.x == 0) blkcnt[(long long)b * nblk + kb] = wc[0] + wc[1] + wc[2] + wc[3];
+        __syncthreads();
+    }
+}
+// exclusive scan of an image's block counts (in place), total -> n_edges[b]
+__global__ __launch_bounds__(1024) void k_fz_live_scan(int *__restrict__ blkcnt, int nblk, int *__restrict__ n_edges)
+{
+    int *c = blkcnt + (long long)blockIdx.x * nblk;
+    __shared__ int part[1024];
+    const int per = (nblk + 1023) / 1024, lo = min(nblk, (int)threadIdx.x * per), hi = min(nblk, lo + per);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += c[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int i = 0; i < 1024; ++i) { const int v = part[i]; part[i] = run; run += v; }
+        n_edges[blockIdx.x] = run;
+    }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (int i = lo; i < hi; ++i) { const int v = c[i]; c[i] = run; run += v; }
+}
+__global__ __launch_bounds__(256) void k_fz_live_copy(const unsigned long long *__restrict__ keys, const unsigned *__restrict__ vals,
+                                                      FzGeom g, const int *__restrict__ parent, const int *__restrict__ size,
+                                                      const int *__restrict__ zcount, int min_size, int npix,
+                                                      const int *__restrict__ blkoff, int nblk,
+                                                      unsigned long long *__restrict__ keys_out, unsigned *__restrict__ vals_out)
+{
+    const int b = blockIdx.y;
+    const unsigned long long *K = keys + (long long)b * g.nE;
+    const unsigned *V = vals + (long long)b * g.nE;
+    unsigned long long *KO = keys_out + (long long)b * g.nE;
+    unsigned *VO = vals_out + (long long)b * g.nE;
+    const int *P = parent + (long long)b * npix, *S = size + (long long)b * npix;
+    __shared__ int wc[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int kb = blockIdx.x; kb < nblk; kb += gridDim.x) {
+        int base = blkoff[(long long)b * nblk + kb];
+        for (int u = 0; u < 4; ++u) {
+            const long long e = (long long)kb * 1024 + u * 256 + threadIdx.x;
+            const bool live = e >= zcount[b] && e < g.nE && fz_live1(g, V, P, S, e, min_size);
+            const unsigned long long m = __ballot(live);
+            if (lane == 0) wc[wv] = __popcll(m);
+            __syncthreads();
+            int off = base;
+            for (int i = 0; i < wv; ++i) off += wc[i];
+            if (live) { const int pos = off + (int)spa_rank_in_mask(m); KO[pos] = K[e]; VO[pos] = V[e]; }
+            base += wc[0] + wc[1] + wc[2] + wc[3];
+            __syncthreads();
+        }
+    }
+}
+
 static int fz_run(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t W, double scale,
                   double sigma, int32_t min_size, int32_t *labels, int32_t *n_labels, void *stream,
                   bool wide)
@@ -1300,8 +1402,36 @@ static int fz_run(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t 
         ctx->fz_attr_done |= 2;
     }
     int *diag = zcount + FZ_MAXB;              // windows, chunks, rounds of the batch (diagnostics, spa_debug_peek)
+    // large images: the clean-up pass walks only the edges that can still merge something (the prefilter kernels above);
+    // SPA_FZ_PREFILTER=0 lets it walk the whole sorted list again
+    const char *pf_env = getenv("SPA_FZ_PREFILTER");
+    const int nblk_e = (int)((g.nE + 1023) / 1024);
+    // (block counts in the radix sort's scratch — the sorts are done —, the survivors in the sort's INPUT buffers)
+    const bool prefilter = tab && !lpar && (!pf_env || atoi(pf_env) != 0) &&
+                           (size_t)B * nblk_e * 4 + (size_t)B * 4 <= tmp_bytes * (par_sort ? 3 : 1);
+    int *blkcnt = nullptr, *n_edges = nullptr;
+    if (prefilter) {
+        blkcnt = (int *)tmp;
+        n_edges = blkcnt + (size_t)B * nblk_e;
+    }
     for (int mode = 0; mode < 2; ++mode) {
         const unsigned r0 = mode ? 0x40000000u : 0u;
+        if (mode == 1 && prefilter) {
+            int gp = (int)((npix + 255) / 256);
+            if (gp > 1024) gp = 1024;
+            int gb = nblk_e < 2048 ? nblk_e : 2048;
+            hipLaunchKernelGGL(k_fz_flatten_all, dim3(gp, B), dim3(256), 0, s, parent, (int)npix);
+            hipLaunchKernelGGL(k_fz_live_count, dim3(gb, B), dim3(256), 0, s, (const unsigned *)vals1, g, (const int *)parent,
+                               (const int *)size, (const int *)zcount, min_size, (int)npix, blkcnt, nblk_e);
+            hipLaunchKernelGGL(k_fz_live_scan, dim3(B), dim3(1024), 0, s, blkcnt, nblk_e, n_edges);
+            hipLaunchKernelGGL(k_fz_live_copy, dim3(gb, B), dim3(256), 0, s, (const unsigned long long *)keys1, (const unsigned *)vals1,
+                               g, (const int *)parent, (const int *)size, (const int *)zcount, min_size, (int)npix,
+                               (const int *)blkcnt, nblk_e, keys0, vals0);
+            hipLaunchKernelGGL(k_fz_pass_tab<false>, dim3(B), dim3(FZ_THREADS), tab_lds, s,
+                               (const unsigned long long *)keys0, (const unsigned *)vals0, g, parent, size, cint, k,
+                               min_size, mode, (const int *)zcount, flatten_every, (int)cells, diag, hub_on, (const int *)n_edges);
+            continue;
+        }
         if (tab && lpar)
             hipLaunchKernelGGL(k_fz_pass_tab<true>, dim3(B), dim3(FZ_THREADS), tab_lds, s,
                                (const unsigned long long *)keys1, (const unsigned *)vals1, g, parent, size, cint, k,
