@@ -513,6 +513,31 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass(const unsigned long long
 #define FZ_CK 2
 #endif
 // one wave's LDS and global accesses have completed and are visible to its own lanes
+// inclusive scans over the 64 lanes of a wave (row-shift DPP inside the rows of 16, the three row totals by v_readlane)
+__device__ __forceinline__ int fz_scan_add(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);
+    const int r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31), r2 = __builtin_amdgcn_readlane(v, 47);
+    const int row = (int)(threadIdx.x & 63) >> 4;
+    return v + (row >= 1 ? r0 : 0) + (row >= 2 ? r1 : 0) + (row >= 3 ? r2 : 0);
+}
+__device__ __forceinline__ int fz_scan_min(int v)
+{
+    v = min(v, __builtin_amdgcn_update_dpp(0x7FFFFFFF, v, 0x111, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0x7FFFFFFF, v, 0x112, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0x7FFFFFFF, v, 0x114, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0x7FFFFFFF, v, 0x118, 0xF, 0xF, false));
+    const int r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31), r2 = __builtin_amdgcn_readlane(v, 47);
+    const int row = (int)(threadIdx.x & 63) >> 4;
+    int m = v;
+    if (row >= 1) m = min(m, r0);
+    if (row >= 2) m = min(m, r1);
+    if (row >= 3) m = min(m, r2);
+    return m;
+}
 __device__ __forceinline__ void fz_wave_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -526,15 +551,23 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
                                                             double *__restrict__ cint, double scale, int min_size,
                                                             int mode, const int *__restrict__ zcount,
                                                             int flatten_every, int cells, int *__restrict__ diag, int hub_on = 0,
-                                                            const int *__restrict__ n_edges = nullptr)
+                                                            const unsigned *__restrict__ idx = nullptr, int *__restrict__ seg = nullptr,
+                                                            int seg_div = 1, int skip_first_flatten = 0)
 {
     const int b = blockIdx.x;
     const int npix = g.H * g.W;
     const unsigned long long *K = keys + (long long)b * g.nE;
     const unsigned *V = vals + (long long)b * g.nE;
-    // n_edges (the clean-up pass of a large image, round 5): keys / vals hold only the n_edges[b] sorted edges that can still merge
-    // something (the prefilter kernels in front of fz_run), from position 0
-    const long long nEb = n_edges ? (long long)n_edges[b] : g.nE;
+    // large images (round 5): the pass walks a LIST of sorted positions — idx[b * nE + e] (idx == NULL: e itself) for e in
+    // [seg[2b], seg[2b + 1]) — and of that only the first 1 / seg_div: the prefilter kernels in front of fz_run cut pass 0 into
+    // segments and drop, between two segments and before the clean-up pass, every edge that can no longer merge anything
+    const unsigned *IX = idx ? idx + (long long)b * g.nE : nullptr;
+    long long nEb = g.nE, seg_start = -1;
+    if (seg) {
+        const long long st0 = seg[2 * b], n0 = seg[2 * b + 1];
+        seg_start = st0;
+        nEb = st0 + (n0 - st0 + seg_div - 1) / seg_div;
+    }
     int *P = parent + (long long)b * npix;
     int *S = size + (long long)b * npix;
     double *CI = cint + (long long)b * npix;
@@ -613,11 +646,11 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
     }
     __syncthreads();
 
-    int win = n_edges ? 1 : 0, chunks = 0, rounds = 0, trounds = 0;      // (n_edges: the forest was flattened by the prefilter)
+    int win = skip_first_flatten ? 1 : 0, chunks = 0, rounds = 0, trounds = 0;      // (the prefilter has just flattened the forest)
     long long tc[5] = {0, 0, 0, 0, 0};        // diagnostics: cycles of flatten | collect | window set-up | full rounds | tail
     long long t_ = (long long)__builtin_readcyclecounter();
 #define FZ_T(i) { const long long n_ = (long long)__builtin_readcyclecounter(); tc[i] += n_ - t_; t_ = n_; }
-    long long cursor = n_edges ? 0 : zcount[b];             // zero-cost edges: done up front
+    long long cursor = seg ? seg_start : zcount[b];         // zero-cost edges: done up front
     unsigned vpre[FZ_CK];
     long long vpre_at = -1;
     int step_par = 0;
@@ -643,14 +676,14 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
 #pragma unroll
             for (int k = 0; k < FZ_CK; ++k) {
                 const long long e = cursor + (long long)k * FZ_THREADS + tid;
-                vcur[k] = vpre_at == cursor ? vpre[k] : (e < nEb ? V[e] : 0u);
+                vcur[k] = vpre_at == cursor ? vpre[k] : (e < nEb ? V[IX ? IX[e] : e] : 0u);
             }
             {
                 const long long nx = cursor + (long long)FZ_CK * FZ_THREADS;
 #pragma unroll
                 for (int k = 0; k < FZ_CK; ++k) {
                     const long long e = nx + (long long)k * FZ_THREADS + tid;
-                    vpre[k] = e < nEb ? V[e] : 0u;
+                    vpre[k] = e < nEb ? V[IX ? IX[e] : e] : 0u;
                 }
                 vpre_at = nx;
             }
@@ -742,7 +775,8 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
         int ea = 0, eb = 0;
         double cost = 0.0;
         if (pend) {
-            const unsigned e = wbuf[tid];
+            const unsigned el = wbuf[tid];
+            const unsigned e = IX ? IX[el] : el;
             fz_endpoints(g, (long long)V[e], ea, eb);
             cost = __longlong_as_double((long long)K[e]);
         }
@@ -888,6 +922,66 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
                             ecost = e_cost[pp];
                         }
                         unsigned long long mask = __ballot(bit);
+                        // (round 5, later) the walk in RUNS.  Nearly every walked edge of a late window merges, so the lanes
+                        // decide all at once under the assumption that every earlier edge of the block merged — the hub's size
+                        // before lane i is then the hub's plus a prefix sum of leaf sizes, its root a prefix minimum of leaf
+                        // roots, its internal cost the previous edge's — and the assumption is TRUE for every lane up to the
+                        // first one that does not merge: those lanes write their merges in parallel (distinct parents, distinct
+                        // dying cells), the first failing lane is dropped (or ends the walk: company), and the rest decides
+                        // again from the new state.  Runs shorter than 4 hand the rest of the block to the edge-by-edge loop
+                        // below, whose decisions these are by construction (same expressions on the same values).
+                        while (mask) {
+                            const bool act = (mask >> lane) & 1ull;
+                            const int s_in = fz_scan_add(act ? (int)csz : 0);
+                            const int m_in = fz_scan_min(act ? croot : 0x7FFFFFFF);
+                            const int s_ex = s_in - (act ? (int)csz : 0);
+                            int m_ex = __builtin_amdgcn_update_dpp(0x7FFFFFFF, m_in, 0x138, 0xF, 0xF, false);      // wave_shr:1
+                            const unsigned long long below = mask & ((1ull << lane) - 1ull);
+                            const int prev = below ? 63 - __clzll((long long)below) : -1;
+                            const double pcost = __shfl(ecost, prev < 0 ? 0 : prev);
+                            const double hci_b = prev < 0 ? hci : pcost;
+                            const unsigned hsz_b = hsz + (unsigned)s_ex;
+                            const int hroot_b = min(hroot, m_ex);
+                            bool w_;
+                            if (mode == 0) {
+                                const float t0b = (float)(hci_b + scale / (double)(int)hsz_b);
+                                w_ = ecost < (double)(t0b < thr ? t0b : thr);
+                            } else {
+                                w_ = (int)hsz_b < min_size || (int)csz < min_size;
+                            }
+                            const unsigned long long fail = __ballot(act && (!okc || !w_));
+                            const int f = fail ? __ffsll((long long)fail) - 1 : 64;
+                            const unsigned long long run = f == 64 ? mask : mask & ((1ull << f) - 1ull);
+                            // the hub's cell before lane i: the leaf cell of the latest earlier lane that lowered the root
+                            const unsigned long long rec = __ballot(act && croot < hroot_b) & run;
+                            const unsigned long long rbelow = rec & ((1ull << lane) - 1ull);
+                            const int rprev = rbelow ? 63 - __clzll((long long)rbelow) : -1;
+                            const int rcell = __shfl(c, rprev < 0 ? 0 : rprev);
+                            const int hcur_b = rprev < 0 ? hcur : rcell;
+                            if (act && lane < f) {
+                                const bool h_lo = hroot_b < croot;
+                                const int lo_r = h_lo ? hroot_b : croot, hi_r = h_lo ? croot : hroot_b;
+                                const int surv = h_lo ? hcur_b : c, dead = h_lo ? c : hcur_b;
+                                setp(hi_r, lo_r);
+                                lcp[dead] = (unsigned short)surv;
+                                e_done[pp] = 1;
+                            }
+                            if (run) {
+                                const int L = 63 - __clzll((long long)run);
+                                hsz += (unsigned)__builtin_amdgcn_readlane(s_in, L);
+                                hroot = min(hroot, __builtin_amdgcn_readlane(m_in, L));
+                                if (rec) hcur = __builtin_amdgcn_readlane(c, 63 - __clzll((long long)rec));
+                                if (mode == 0) hci = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ecost), L),
+                                                                      __builtin_amdgcn_readlane(__double2loint(ecost), L));
+                                if (lane == 0) { lsz[hcur] = hsz; if (mode == 0) lci[hcur] = hci; }
+                                t0_stale = true;
+                            }
+                            if (f == 64) { mask = 0; break; }
+                            if (!__builtin_amdgcn_readlane(okc, f)) { stop = true; mask = 0; break; }
+                            if (lane == 0) e_done[q * 64 + f] = 1;                  // dropped
+                            mask &= ~((2ull << f) - 1ull);
+                            if (__popcll(run) < 4) break;
+                        }
                         while (mask) {
                             const int j = __builtin_amdgcn_readfirstlane(__ffsll((long long)mask) - 1);
                             mask &= mask - 1;
@@ -1061,6 +1155,7 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
         __syncthreads();
         for (int p = tid; p < npix; p += FZ_THREADS) { const unsigned v = lpar[p]; P[p] = v == 0xFFFFu ? -1 : (int)v; }
     }
+    if (tid == 0 && seg) seg[2 * b] = (int)nEb;             // the next segment (or the filter in front of it) starts here
     if (tid == 0 && diag) {
         atomicAdd(diag + 0, win); atomicAdd(diag + 1, chunks); atomicAdd(diag + 2, rounds); atomicAdd(diag + 3, trounds);
         for (int i = 0; i < 5; ++i) atomicAdd(diag + 4 + i, (int)(tc[i] >> 10));
@@ -1160,10 +1255,12 @@ extern "C" int spa_felzenszwalb_u8(spa_ctx *ctx, const float *rgb, int32_t B, in
     return fz_run(ctx, rgb, B, H, W, scale, sigma, min_size, labels, n_labels, stream, true);
 }
 
-// ---- between the passes of a large image (round 5): the clean-up pass (mode 1) can only ever merge across an edge whose
-// endpoints lie in different components one of which is below min_size NOW — components only grow —, a vanishing share of the
-// sorted list, yet the pass's single workgroup walked all of it again (half of its collect phase).  Every compute unit does that
-// test once: the forest is flattened, the survivors are counted per block of 1 024 sorted positions, scanned, and copied in order.
+// ---- filters of a large image's passes (round 5).  The passes' single workgroup spent half its time testing sorted positions
+// whose endpoints already share a component (and, in the clean-up pass, all 8.4 M positions again for the handful of edges that
+// touch a component below min_size).  Dead edges stay dead — components only grow —, so every compute unit drops them ahead of
+// the pass: the forest is flattened, the survivors of the list's unprocessed part are counted per block of 1 024 list
+// positions, scanned, and their positions in the sorted list written out in order.  Pass 0 runs as SPA_FZ_SEGMENTS launches with
+// such a filter between two of them, the clean-up pass as one launch behind a filter over the whole sorted list.
 __global__ __launch_bounds__(256) void k_fz_flatten_all(int *__restrict__ parent, int npix)
 {
     int *P = parent + (long long)blockIdx.y * npix;
@@ -1175,32 +1272,43 @@ __global__ __launch_bounds__(256) void k_fz_flatten_all(int *__restrict__ parent
         if (r != q) P[p] = r;
     }
 }
-__device__ __forceinline__ bool fz_live1(const FzGeom &g, const unsigned *V, const int *P, const int *S, long long e, int min_size)
+__global__ void k_fz_seg_init(int *__restrict__ seg, const int *__restrict__ zcount, int nE, int B)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) { seg[2 * b] = zcount[b]; seg[2 * b + 1] = nE; }
+}
+// mode 0: the endpoints lie in different components; mode 1: ... one of which is below min_size
+__device__ __forceinline__ bool fz_live_edge(const FzGeom &g, const unsigned *V, const int *P, const int *S, unsigned oe, int mode, int min_size)
 {
     int a, c;
-    fz_endpoints(g, (long long)V[e], a, c);
+    fz_endpoints(g, (long long)V[oe], a, c);
     const int pa = P[a], pc = P[c];
     int ra = pa < 0 ? a : pa, rc = pc < 0 ? c : pc;
     int n;
     while ((n = P[ra]) >= 0) ra = n;             // (flattened: the root already)
     while ((n = P[rc]) >= 0) rc = n;
-    return ra != rc && (S[ra] < min_size || S[rc] < min_size);
+    return ra != rc && (mode == 0 || S[ra] < min_size || S[rc] < min_size);
 }
 __global__ __launch_bounds__(256) void k_fz_live_count(const unsigned *__restrict__ vals, FzGeom g, const int *__restrict__ parent,
-                                                       const int *__restrict__ size, const int *__restrict__ zcount, int min_size,
-                                                       int npix, int *__restrict__ blkcnt, int nblk)
+                                                       const int *__restrict__ size, const unsigned *__restrict__ idx,
+                                                       const int *__restrict__ seg, int mode, int min_size, int npix,
+                                                       int *__restrict__ blkcnt, int nblk)
 {
     const int b = blockIdx.y;
     const unsigned *V = vals + (long long)b * g.nE;
+    const unsigned *IX = idx ? idx + (long long)b * g.nE : nullptr;
     const int *P = parent + (long long)b * npix, *S = size + (long long)b * npix;
+    const long long lo = seg[2 * b], hi = seg[2 * b + 1];
     __shared__ int wc[4];
     for (int kb = blockIdx.x; kb < nblk; kb += gridDim.x) {
         int cnt = 0;
+        if ((long long)(kb + 1) * 1024 > lo && (long long)kb * 1024 < hi) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const long long e = (long long)kb * 1024 + u * 256 + threadIdx.x;
-            const bool live = e >= zcount[b] && e < g.nE && fz_live1(g, V, P, S, e, min_size);
-            cnt += __popcll(__ballot(live));
+            for (int u = 0; u < 4; ++u) {
+                const long long e = (long long)kb * 1024 + u * 256 + threadIdx.x;
+                const bool live = e >= lo && e < hi && fz_live_edge(g, V, P, S, IX ? IX[e] : (unsigned)e, mode, min_size);
+                cnt += __popcll(__ballot(live));
+            }
         }
         if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = cnt;
         __syncthreads();
@@ -1208,8 +1316,8 @@ __global__ __launch_bounds__(256) void k_fz_live_count(const unsigned *__restric
         __syncthreads();
     }
 }
-// exclusive scan of an image's block counts (in place), total -> n_edges[b]
-__global__ __launch_bounds__(1024) void k_fz_live_scan(int *__restrict__ blkcnt, int nblk, int *__restrict__ n_edges)
+// exclusive scan of an image's block counts (in place); the new list is [0, total): seg_out
+__global__ __launch_bounds__(1024) void k_fz_live_scan(int *__restrict__ blkcnt, int nblk, int *__restrict__ seg_out)
 {
     int *c = blkcnt + (long long)blockIdx.x * nblk;
     __shared__ int part[1024];
@@ -1221,37 +1329,39 @@ __global__ __launch_bounds__(1024) void k_fz_live_scan(int *__restrict__ blkcnt,
     if (threadIdx.x == 0) {
         int run = 0;
         for (int i = 0; i < 1024; ++i) { const int v = part[i]; part[i] = run; run += v; }
-        n_edges[blockIdx.x] = run;
+        seg_out[2 * blockIdx.x] = 0;
+        seg_out[2 * blockIdx.x + 1] = run;
     }
     __syncthreads();
     int run = part[threadIdx.x];
     for (int i = lo; i < hi; ++i) { const int v = c[i]; c[i] = run; run += v; }
 }
-__global__ __launch_bounds__(256) void k_fz_live_copy(const unsigned long long *__restrict__ keys, const unsigned *__restrict__ vals,
-                                                      FzGeom g, const int *__restrict__ parent, const int *__restrict__ size,
-                                                      const int *__restrict__ zcount, int min_size, int npix,
-                                                      const int *__restrict__ blkoff, int nblk,
-                                                      unsigned long long *__restrict__ keys_out, unsigned *__restrict__ vals_out)
+__global__ __launch_bounds__(256) void k_fz_live_copy(const unsigned *__restrict__ vals, FzGeom g, const int *__restrict__ parent,
+                                                      const int *__restrict__ size, const unsigned *__restrict__ idx,
+                                                      const int *__restrict__ seg, int mode, int min_size, int npix,
+                                                      const int *__restrict__ blkoff, int nblk, unsigned *__restrict__ idx_out)
 {
     const int b = blockIdx.y;
-    const unsigned long long *K = keys + (long long)b * g.nE;
     const unsigned *V = vals + (long long)b * g.nE;
-    unsigned long long *KO = keys_out + (long long)b * g.nE;
-    unsigned *VO = vals_out + (long long)b * g.nE;
+    const unsigned *IX = idx ? idx + (long long)b * g.nE : nullptr;
+    unsigned *OX = idx_out + (long long)b * g.nE;
     const int *P = parent + (long long)b * npix, *S = size + (long long)b * npix;
+    const long long lo = seg[2 * b], hi = seg[2 * b + 1];
     __shared__ int wc[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int kb = blockIdx.x; kb < nblk; kb += gridDim.x) {
+        if (!((long long)(kb + 1) * 1024 > lo && (long long)kb * 1024 < hi)) continue;
         int base = blkoff[(long long)b * nblk + kb];
         for (int u = 0; u < 4; ++u) {
             const long long e = (long long)kb * 1024 + u * 256 + threadIdx.x;
-            const bool live = e >= zcount[b] && e < g.nE && fz_live1(g, V, P, S, e, min_size);
+            const unsigned oe = (e >= lo && e < hi) ? (IX ? IX[e] : (unsigned)e) : 0u;
+            const bool live = e >= lo && e < hi && fz_live_edge(g, V, P, S, oe, mode, min_size);
             const unsigned long long m = __ballot(live);
             if (lane == 0) wc[wv] = __popcll(m);
             __syncthreads();
             int off = base;
             for (int i = 0; i < wv; ++i) off += wc[i];
-            if (live) { const int pos = off + (int)spa_rank_in_mask(m); KO[pos] = K[e]; VO[pos] = V[e]; }
+            if (live) OX[off + (int)spa_rank_in_mask(m)] = oe;
             base += wc[0] + wc[1] + wc[2] + wc[3];
             __syncthreads();
         }
@@ -1402,36 +1512,55 @@ static int fz_run(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t 
         ctx->fz_attr_done |= 2;
     }
     int *diag = zcount + FZ_MAXB;              // windows, chunks, rounds of the batch (diagnostics, spa_debug_peek)
-    // large images: the clean-up pass walks only the edges that can still merge something (the prefilter kernels above);
-    // SPA_FZ_PREFILTER=0 lets it walk the whole sorted list again
+    // large images: pass 0 in SPA_FZ_SEGMENTS launches (default 8) with a filter of the remaining sorted list between two of them, the
+    // clean-up pass behind a filter over the whole list (the filter kernels above); SPA_FZ_PREFILTER=0: one launch per pass over
+    // the sorted list itself, as round 4 ran them
     const char *pf_env = getenv("SPA_FZ_PREFILTER");
     const int nblk_e = (int)((g.nE + 1023) / 1024);
-    // (block counts in the radix sort's scratch — the sorts are done —, the survivors in the sort's INPUT buffers)
+    // (block counts and segment words in the radix sort's scratch — the sorts are done —, the lists in the sort's INPUT key buffer)
     const bool prefilter = tab && !lpar && (!pf_env || atoi(pf_env) != 0) &&
-                           (size_t)B * nblk_e * 4 + (size_t)B * 4 <= tmp_bytes * (par_sort ? 3 : 1);
-    int *blkcnt = nullptr, *n_edges = nullptr;
+                           (size_t)B * nblk_e * 4 + (size_t)B * 32 <= tmp_bytes * (par_sort ? 3 : 1);
+    int nseg = 8;
+    if (const char *e = getenv("SPA_FZ_SEGMENTS")) nseg = atoi(e) > 0 ? atoi(e) : 1;
     if (prefilter) {
-        blkcnt = (int *)tmp;
-        n_edges = blkcnt + (size_t)B * nblk_e;
-    }
-    for (int mode = 0; mode < 2; ++mode) {
-        const unsigned r0 = mode ? 0x40000000u : 0u;
-        if (mode == 1 && prefilter) {
-            int gp = (int)((npix + 255) / 256);
-            if (gp > 1024) gp = 1024;
-            int gb = nblk_e < 2048 ? nblk_e : 2048;
+        int *blkcnt = (int *)tmp;
+        int *segA = blkcnt + (size_t)B * nblk_e, *segB = segA + 2 * B, *segF = segB + 2 * B;
+        unsigned *idxA = (unsigned *)keys0, *idxB = idxA + (size_t)B * g.nE;
+        int gp = (int)((npix + 255) / 256);
+        if (gp > 1024) gp = 1024;
+        const int gb = nblk_e < 2048 ? nblk_e : 2048;
+        auto filter = [&](const unsigned *in_idx, const int *seg_in, int fmode, int *seg_out, unsigned *out_idx) {
             hipLaunchKernelGGL(k_fz_flatten_all, dim3(gp, B), dim3(256), 0, s, parent, (int)npix);
             hipLaunchKernelGGL(k_fz_live_count, dim3(gb, B), dim3(256), 0, s, (const unsigned *)vals1, g, (const int *)parent,
-                               (const int *)size, (const int *)zcount, min_size, (int)npix, blkcnt, nblk_e);
-            hipLaunchKernelGGL(k_fz_live_scan, dim3(B), dim3(1024), 0, s, blkcnt, nblk_e, n_edges);
-            hipLaunchKernelGGL(k_fz_live_copy, dim3(gb, B), dim3(256), 0, s, (const unsigned long long *)keys1, (const unsigned *)vals1,
-                               g, (const int *)parent, (const int *)size, (const int *)zcount, min_size, (int)npix,
-                               (const int *)blkcnt, nblk_e, keys0, vals0);
+                               (const int *)size, in_idx, seg_in, fmode, min_size, (int)npix, blkcnt, nblk_e);
+            hipLaunchKernelGGL(k_fz_live_scan, dim3(B), dim3(1024), 0, s, blkcnt, nblk_e, seg_out);
+            hipLaunchKernelGGL(k_fz_live_copy, dim3(gb, B), dim3(256), 0, s, (const unsigned *)vals1, g, (const int *)parent,
+                               (const int *)size, in_idx, seg_in, fmode, min_size, (int)npix, (const int *)blkcnt, nblk_e, out_idx);
+        };
+        auto pass = [&](int pmode, const unsigned *in_idx, int *seg_io, int div, int skip_flat) {
             hipLaunchKernelGGL(k_fz_pass_tab<false>, dim3(B), dim3(FZ_THREADS), tab_lds, s,
-                               (const unsigned long long *)keys0, (const unsigned *)vals0, g, parent, size, cint, k,
-                               min_size, mode, (const int *)zcount, flatten_every, (int)cells, diag, hub_on, (const int *)n_edges);
-            continue;
+                               (const unsigned long long *)keys1, (const unsigned *)vals1, g, parent, size, cint, k,
+                               min_size, pmode, (const int *)zcount, flatten_every, (int)cells, diag, hub_on, in_idx, seg_io, div, skip_flat);
+        };
+        hipLaunchKernelGGL(k_fz_seg_init, dim3((B + 63) / 64), dim3(64), 0, s, segA, (const int *)zcount, (int)g.nE, B);
+        hipLaunchKernelGGL(k_fz_seg_init, dim3((B + 63) / 64), dim3(64), 0, s, segF, (const int *)zcount, (int)g.nE, B);
+        const unsigned *cur = nullptr;
+        int *sc = segA, *sn = segB;
+        unsigned *other = idxA;
+        for (int i = 0; i < nseg; ++i) {
+            pass(0, cur, sc, nseg - i, i > 0);
+            if (i + 1 < nseg) {
+                filter(cur, sc, 0, sn, other);
+                cur = other;
+                other = other == idxA ? idxB : idxA;
+                int *t = sc; sc = sn; sn = t;
+            }
         }
+        filter(nullptr, segF, 1, sn, other);
+        pass(1, other, sn, 1, 1);
+    }
+    for (int mode = 0; mode < 2 && !prefilter; ++mode) {
+        const unsigned r0 = mode ? 0x40000000u : 0u;
         if (tab && lpar)
             hipLaunchKernelGGL(k_fz_pass_tab<true>, dim3(B), dim3(FZ_THREADS), tab_lds, s,
                                (const unsigned long long *)keys1, (const unsigned *)vals1, g, parent, size, cint, k,
