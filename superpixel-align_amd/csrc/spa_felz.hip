@@ -578,7 +578,7 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
     unsigned *lkey = (unsigned *)(lci + cells);            // LPAR: (root << 16) | size; else root, size in lsz
     unsigned *lres = lkey + cells;                         // reservation: (tag << 10) | position in the window
     unsigned *lsz = lres + cells;                          // !LPAR only
-    unsigned *wbuf = LPAR ? lsz : lsz + cells;             // the window: sorted positions of its live edges
+    unsigned *wbuf = LPAR ? lsz : lsz + cells;             // the window: positions of its live edges in the sorted arrays
     // !LPAR (round 5): the forest of the window's OWN merges over the table's cells — lcp[c] = the cell c's component was merged
     // into (itself: still a root).  The rounds of a window then find their roots through LDS alone; the global parent array is
     // still written at every merge (the next window's set-up walks it) but never read inside a window's rounds
@@ -595,6 +595,7 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
     int *hcell = (int *)(hbits + NHUB * (FZ_THREADS / 32));
     int *nhub = hcell + NHUB;
     float *e_thr = (float *)(nhub + 4);                    // merge threshold of an edge's non-hub side (computed by its own thread)
+    int *wra = (int *)(e_thr + FZ_THREADS), *wrb = wra + FZ_THREADS;      // !LPAR: the live edges' roots as the collect step found them
     auto cfind = [&](int c) -> int {
         int p;
         while ((p = (int)__hip_atomic_load(lcp + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != c) c = p;
@@ -640,6 +641,18 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
             h = h + 1 == cells ? 0 : h + 1;
         }
     };
+    auto claim = [&](int root, bool &own) -> int {         // !LPAR: enter() without the fetch of the root's state (own: the caller's to fill)
+        int h = hash(root);
+        for (;;) {
+            unsigned w = __hip_atomic_load(lkey + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (w == FZL_EMPTY) {
+                w = atomicCAS(lkey + h, FZL_EMPTY, (unsigned)root);
+                if (w == FZL_EMPTY) { own = true; return h; }
+            }
+            if (w == (unsigned)root) return h;
+            h = h + 1 == cells ? 0 : h + 1;
+        }
+    };
     auto csize = [&](int c) -> unsigned { return LPAR ? (lkey[c] & 0xFFFFu) : lsz[c]; };
     if (LPAR) {
         for (int p = tid; p < npix; p += FZ_THREADS) { const int q = P[p]; lpar[p] = q < 0 ? (unsigned short)0xFFFFu : (unsigned short)q; }
@@ -647,11 +660,12 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
     __syncthreads();
 
     int win = skip_first_flatten ? 1 : 0, chunks = 0, rounds = 0, trounds = 0;      // (the prefilter has just flattened the forest)
-    long long tc[5] = {0, 0, 0, 0, 0};        // diagnostics: cycles of flatten | collect | window set-up | full rounds | tail
+    long long tc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // diagnostics: cycles of flatten + write-back | collect | window set-up (table entry) | full rounds | tail | (of the rounds) propagation | hub chains | (set-up) table reset + cost loads
+    int props = 0;
     long long t_ = (long long)__builtin_readcyclecounter();
 #define FZ_T(i) { const long long n_ = (long long)__builtin_readcyclecounter(); tc[i] += n_ - t_; t_ = n_; }
     long long cursor = seg ? seg_start : zcount[b];         // zero-cost edges: done up front
-    unsigned vpre[FZ_CK];
+    unsigned vpre[FZ_CK], opre[FZ_CK];                      // edge indices and sorted-array positions of the next step
     long long vpre_at = -1;
     int step_par = 0;
     if (tid == 0) { cut_s[0] = 0xFFFFFFFFu; cut_s[1] = 0xFFFFFFFFu; }
@@ -672,18 +686,23 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
             // their way (vpre, loaded for `vpre_at`), the step's counters alternate between two LDS sets so that
             // a step needs two barriers
             chunks += FZ_CK;
-            unsigned vcur[FZ_CK];
+            unsigned vcur[FZ_CK], ocur[FZ_CK];
 #pragma unroll
             for (int k = 0; k < FZ_CK; ++k) {
                 const long long e = cursor + (long long)k * FZ_THREADS + tid;
-                vcur[k] = vpre_at == cursor ? vpre[k] : (e < nEb ? V[IX ? IX[e] : e] : 0u);
+                if (vpre_at == cursor) { vcur[k] = vpre[k]; ocur[k] = opre[k]; }
+                else {
+                    ocur[k] = e < nEb ? (IX ? IX[e] : (unsigned)e) : 0u;
+                    vcur[k] = e < nEb ? V[ocur[k]] : 0u;
+                }
             }
             {
                 const long long nx = cursor + (long long)FZ_CK * FZ_THREADS;
 #pragma unroll
                 for (int k = 0; k < FZ_CK; ++k) {
                     const long long e = nx + (long long)k * FZ_THREADS + tid;
-                    vpre[k] = e < nEb ? V[IX ? IX[e] : e] : 0u;
+                    opre[k] = e < nEb ? (IX ? IX[e] : (unsigned)e) : 0u;
+                    vpre[k] = e < nEb ? V[opre[k]] : 0u;
                 }
                 vpre_at = nx;
             }
@@ -691,6 +710,7 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
             unsigned long long m[FZ_CK];
             int *wc = wave_cnt + (step_par ? FZ_CK * (FZ_THREADS / 64) : 0);
             unsigned *cut = cut_s + step_par;
+            int ea_[FZ_CK], eb_[FZ_CK];
             if (LPAR) {
 #pragma unroll
                 for (int k = 0; k < FZ_CK; ++k) {
@@ -709,7 +729,6 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
                 // batch of independent loads instead of 2 FZ_CK dependent chains one after the other — and an edge whose endpoints
                 // point at the same parent is dead without looking further (most sorted positions of a late pass are: after a
                 // flattening sweep both pixels point straight at their root)
-                int ea_[FZ_CK], eb_[FZ_CK];
                 bool act[FZ_CK];
 #pragma unroll
                 for (int k = 0; k < FZ_CK; ++k) {
@@ -758,7 +777,10 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
                 if (live[k]) {
                     const long long e = cursor + (long long)k * FZ_THREADS + tid;
                     const int pos = off + (int)spa_rank_in_mask(m[k]);
-                    if (pos < FZ_THREADS) wbuf[pos] = (unsigned)e;
+                    if (pos < FZ_THREADS) {
+                        wbuf[pos] = ocur[k];
+                        if (!LPAR) { wra[pos] = ea_[k]; wrb[pos] = eb_[k]; }      // (both are roots, and stay roots until the window runs)
+                    }
                     else atomicMin(cut, (unsigned)e);       // the first live edge that does not fit starts the next window
                 }
             }
@@ -774,31 +796,35 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
         bool pend = tid < nlive;
         int ea = 0, eb = 0;
         double cost = 0.0;
+        int ra = 0, rb = 0, ca = 0, cb = 0;
         if (pend) {
-            const unsigned el = wbuf[tid];
-            const unsigned e = IX ? IX[el] : el;
-            fz_endpoints(g, (long long)V[e], ea, eb);
+            const unsigned e = wbuf[tid];
+            if (LPAR) fz_endpoints(g, (long long)V[e], ea, eb);
+            else { ra = wra[tid]; rb = wrb[tid]; }          // (no merge since the collect step walked up to them)
             cost = __longlong_as_double((long long)K[e]);
         }
         __syncthreads();
-        int ra = 0, rb = 0, ca = 0, cb = 0;
+        FZ_T(7)
         if (pend) {
             if (LPAR) { ra = find(ea); rb = find(eb); }
-            else {
-                // (both walks level by level: two independent loads per level instead of two chains one after the other)
-                int xa = ea, xb = eb;
-                bool fa = false, fb = false;
-                while (!(fa && fb)) {
-                    const int pa = fa ? -1 : P[xa], pb = fb ? -1 : P[xb];
-                    if (pa < 0) fa = true; else xa = pa;
-                    if (pb < 0) fb = true; else xb = pb;
-                }
-                ra = xa; rb = xb;
-            }
             if (ra == rb) pend = false;                     // same component for ever
+            else if (!LPAR && (hub_on & 2)) {
+                // both cells claimed first, then the (up to four) loads of the roots' state in one batch: one global round trip
+                // per window set-up instead of two (62 -> 31 M cycles of set-up per full-size image; SPA_FZ_HUB=1 keeps enter()).
+                // Measured and NOT kept: fetching the next step's first level of parents before the rounds (-15 M cycles of collect,
+                // +15 M here: the single compute unit's gather rate is the bound, not the latency of a level)
+                bool oa = false, ob = false;
+                ca = claim(ra, oa); cb = claim(rb, ob);
+                unsigned sa = 0, sb = 0;
+                double cia = 0.0, cib = 0.0;
+                if (oa) { sa = (unsigned)S[ra]; if (mode == 0) cia = CI[ra]; }
+                if (ob) { sb = (unsigned)S[rb]; if (mode == 0) cib = CI[rb]; }
+                if (oa) { lsz[ca] = sa; if (mode == 0) lci[ca] = cia; }
+                if (ob) { lsz[cb] = sb; if (mode == 0) lci[cb] = cib; }
+            }
             else { ca = enter(ra); cb = enter(rb); }
         }
-        if (!LPAR && hub_on) e_cost[tid] = cost;
+        if (!LPAR && (hub_on & 1)) e_cost[tid] = cost;
         __syncthreads();
         FZ_T(2)
         for (unsigned round = 0;; ++round) {
@@ -839,8 +865,10 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
             __syncthreads();
             // ---- propagation: an edge that does not want to merge NOW may want to once an earlier reserved edge
             // has changed one of its components, so while it waits it holds its components too
+            FZ_T(3)
             for (;;) {
                 int changed = 0;
+                ++props;
                 if (pend && !resv) {
                     const unsigned ma = __hip_atomic_load(lres + ca, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     const unsigned mb = __hip_atomic_load(lres + cb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -855,6 +883,7 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
                 }
                 if (__syncthreads_or(changed) == 0) break;
             }
+            FZ_T(5)
             // ---- hub chains (!LPAR, round 5).  On a smooth full-size image nearly every live edge of a late window joins a
             // small component to ONE giant one; the protocol above decides the earliest of them per round (the others wait for
             // its reservation), 50 rounds per window.  Their decisions are a recurrence over the hub's state alone — internal
@@ -865,7 +894,7 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
             // hub walks the bitmap in window order — exactly the sequential pass over those edges — and stops at the first edge whose
             // other side has company.  Walked edges are decided (merged with the state written as phase 2 writes it, or dropped);
             // the rest of the round proceeds as before.
-            if (!LPAR && hub_on && round >= 1) {
+            if (!LPAR && (hub_on & 1) && round >= 1) {
                 for (int i = tid; i < cells; i += FZ_THREADS) { lcnt[i] = 0; lslot[i] = 0; }
                 if (tid < NHUB * (FZ_THREADS / 32)) hbits[tid] = 0u;
                 if (tid == 0) *nhub = 0;
@@ -1019,6 +1048,7 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
                 }
                 __syncthreads();
                 if (pend && e_done[tid]) pend = false;
+                FZ_T(6)
             }
             // ---- phase 2: decide every edge no earlier reservation can influence
             int left = 0;
@@ -1158,7 +1188,8 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
     if (tid == 0 && seg) seg[2 * b] = (int)nEb;             // the next segment (or the filter in front of it) starts here
     if (tid == 0 && diag) {
         atomicAdd(diag + 0, win); atomicAdd(diag + 1, chunks); atomicAdd(diag + 2, rounds); atomicAdd(diag + 3, trounds);
-        for (int i = 0; i < 5; ++i) atomicAdd(diag + 4 + i, (int)(tc[i] >> 10));
+        for (int i = 0; i < 8; ++i) atomicAdd(diag + 4 + i, (int)(tc[i] >> 10));
+        atomicAdd(diag + 12, props);
     }
 }
 
@@ -1501,11 +1532,11 @@ static int fz_run(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t 
     const bool tab = G == 1 && !getenv("SPA_FZ_NO_LDS_STATE") && (lpar || !tab_large || atoi(tab_large) != 0);
     // (!lpar: + the hub-chain state: cells * 3 + per-edge cells / flags / costs + 16 bitmaps)
     const size_t tab_lds = lpar ? par_bytes + (size_t)cells * 16 + FZ_THREADS * 4
-                                : (size_t)cells * 22 + FZ_THREADS * 4 + (size_t)cells * 3 + FZ_THREADS * 13 + 16 + 16 * (FZ_THREADS / 32) * 4 + 16 * 4 + 16 + FZ_THREADS * 4;
+                                : (size_t)cells * 22 + FZ_THREADS * 4 + (size_t)cells * 3 + FZ_THREADS * 13 + 16 + 16 * (FZ_THREADS / 32) * 4 + 16 * 4 + 16 + FZ_THREADS * 4 + FZ_THREADS * 8;
     // hub chains (k_fz_pass_tab, !LPAR): on by default — one 1024 x 2048 image alone 0.40 -> 0.22 s (109 000 -> 8 000 full rounds),
     // 16.9 -> 10.2 ms per image at batch 30, the same labels; SPA_FZ_HUB=0 switches them off
     const char *hub_env = getenv("SPA_FZ_HUB");
-    const int hub_on = hub_env ? atoi(hub_env) : 1;
+    const int hub_on = hub_env ? atoi(hub_env) : 3;          // bit 0: hub chains, bit 1: batched table entry
     if (tab && !(ctx->fz_attr_done & 2)) {
         SPA_HIP(hipFuncSetAttribute((const void *)k_fz_pass_tab<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
         SPA_HIP(hipFuncSetAttribute((const void *)k_fz_pass_tab<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
@@ -1520,7 +1551,7 @@ static int fz_run(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t 
     // (block counts and segment words in the radix sort's scratch — the sorts are done —, the lists in the sort's INPUT key buffer)
     const bool prefilter = tab && !lpar && (!pf_env || atoi(pf_env) != 0) &&
                            (size_t)B * nblk_e * 4 + (size_t)B * 32 <= tmp_bytes * (par_sort ? 3 : 1);
-    int nseg = 8;
+    int nseg = B < 4 ? 16 : 8;             // (measured at B = 1 / 8 / 30: 116 / 158 / 255 ms with 16, 122 / 152 / 231 ms with 8)
     if (const char *e = getenv("SPA_FZ_SEGMENTS")) nseg = atoi(e) > 0 ? atoi(e) : 1;
     if (prefilter) {
         int *blkcnt = (int *)tmp;

@@ -28,10 +28,12 @@ if len(sys.argv) > 1:
     lib_mod = importlib.import_module('superpixel-align_amd._lib')
     src = open(os.path.join(os.path.dirname(lib_mod.__file__), 'csrc', 'spa_common.h')).read()
     names = re.findall(r'^\s*(WS_[A-Z_0-9]+)\s*(?:=\s*0)?,', src, re.M)
-    host = (ctypes.c_int32 * 9)()
-    lib_mod.check(lib_mod.lib().spa_debug_peek(eng._ctx, names.index('WS_CONNMISC'), 256 * 32 + 256 * 4, 36, host))
+    host = (ctypes.c_int32 * 13)()
+    lib_mod.check(lib_mod.lib().spa_debug_peek(eng._ctx, names.index('WS_CONNMISC'), 256 * 32 + 256 * 4, 52, host))
     print('   per image and both passes: %.0f windows, %.0f chunks of 1024 sorted edges, %.0f full rounds, %.0f tail rounds' % tuple(v / float(B) for v in host[:4]))
     print('   kilo-cycles per image: flatten %.0f | collect %.0f | window set-up + write-back %.0f | full rounds %.0f | tail %.0f' % tuple(v / float(B) for v in host[4:9]))
+    print('   of the rounds: propagation %.0f kilo-cycles in %.0f steps | hub chains %.0f kilo-cycles' % (host[9] / float(B), host[12] / float(B), host[10] / float(B)))
+    print('   of the set-up: table reset + cost loads %.0f kilo-cycles (the rest: table entry)' % (host[11] / float(B)))
 else:
     for B in (1, 8, 30):
         for G in (1, 2, 4, 8):
