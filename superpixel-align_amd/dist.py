@@ -57,7 +57,8 @@ def init(backend=None):
             # bind this process to its GPU and create its spa_ctx BEFORE the process group exists:
             # RCCL then initialises on the device the label kernels already use, and no rank ever
             # touches device 0 by accident (SPA_BENCH_SAME_DEVICE: several ranks share GPU 0 in tests)
-            dev = 0 if os.environ.get('SPA_BENCH_SAME_DEVICE') == '1' else local
+            # (ranks isolated by device visibility see one device each: ordinal 0)
+            dev = 0 if os.environ.get('SPA_BENCH_SAME_DEVICE') == '1' else local % max(torch.cuda.device_count(), 1)
             torch.cuda.set_device(dev)
             from .engine import default_engine
             default_engine()
