@@ -513,6 +513,17 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass(const unsigned long long
 #define FZ_CK 2
 #endif
 // one wave's LDS and global accesses have completed and are visible to its own lanes
+// Large images (round 5): a root's internal cost and size in ONE 16-byte record (the table pass fetches and writes back both per
+// root and window: one scattered access instead of two).  The records live where the internal costs and the legacy pass's
+// reservation words do (WS_FZ_STATE, 16 bytes per pixel: the table pass needs no reservation words in global memory).
+struct __attribute__((aligned(16))) FzRec { double ci; int size; int pad; };
+__global__ __launch_bounds__(256) void k_fz_records(FzRec *__restrict__ rec, const int *__restrict__ size, long long n)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        FzRec r; r.ci = 0.0; r.size = size[i]; r.pad = 0;       // (before pass 0 every internal cost is 0: only zero-cost edges are merged)
+        rec[i] = r;
+    }
+}
 // inclusive scans over the 64 lanes of a wave (row-shift DPP inside the rows of 16, the three row totals by v_readlane)
 __device__ __forceinline__ int fz_scan_add(int v)
 {
@@ -571,6 +582,8 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
     int *P = parent + (long long)b * npix;
     int *S = size + (long long)b * npix;
     double *CI = cint + (long long)b * npix;
+    FzRec *SC = (FzRec *)cint + (long long)b * npix;          // !LPAR with hub_on bit 2: records instead of S / CI
+    const bool recs = !LPAR && (hub_on & 4);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     extern __shared__ __attribute__((aligned(16))) unsigned char fzl[];
     unsigned short *lpar = (unsigned short *)fzl;
@@ -632,6 +645,7 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
                 if (w == FZL_EMPTY) {                       // this thread's cell: fetch the root's state
                     if (LPAR) __hip_atomic_store(lkey + h, ((unsigned)root << 16) | (unsigned)S[root], __ATOMIC_RELAXED,
                                                  __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else if (recs) { const FzRec q = SC[root]; lsz[h] = (unsigned)q.size; lci[h] = q.ci; return h; }
                     else lsz[h] = (unsigned)S[root];
                     if (mode == 0) lci[h] = CI[root];
                     return h;
@@ -758,7 +772,8 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
                 if (mode == 1) {
 #pragma unroll
                     for (int k = 0; k < FZ_CK; ++k)
-                        if (live[k]) live[k] = S[ea_[k]] < min_size || S[eb_[k]] < min_size;
+                        if (live[k]) live[k] = recs ? (SC[ea_[k]].size < min_size || SC[eb_[k]].size < min_size)
+                                                    : (S[ea_[k]] < min_size || S[eb_[k]] < min_size);
                 }
             }
 #pragma unroll
@@ -817,8 +832,16 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
                 ca = claim(ra, oa); cb = claim(rb, ob);
                 unsigned sa = 0, sb = 0;
                 double cia = 0.0, cib = 0.0;
-                if (oa) { sa = (unsigned)S[ra]; if (mode == 0) cia = CI[ra]; }
-                if (ob) { sb = (unsigned)S[rb]; if (mode == 0) cib = CI[rb]; }
+                if (recs) {
+                    FzRec qa, qb;
+                    qa.ci = qb.ci = 0.0; qa.size = qb.size = 0;
+                    if (oa) qa = SC[ra];
+                    if (ob) qb = SC[rb];
+                    sa = (unsigned)qa.size; cia = qa.ci; sb = (unsigned)qb.size; cib = qb.ci;
+                } else {
+                    if (oa) { sa = (unsigned)S[ra]; if (mode == 0) cia = CI[ra]; }
+                    if (ob) { sb = (unsigned)S[rb]; if (mode == 0) cib = CI[rb]; }
+                }
                 if (oa) { lsz[ca] = sa; if (mode == 0) lci[ca] = cia; }
                 if (ob) { lsz[cb] = sb; if (mode == 0) lci[cb] = cib; }
             }
@@ -1175,8 +1198,13 @@ __global__ __launch_bounds__(FZ_THREADS) void k_fz_pass_tab(const unsigned long 
         for (int i = tid; i < cells; i += FZ_THREADS) {
             const unsigned w = lkey[i];
             if (w != FZL_EMPTY) {
-                S[keyroot(w)] = (int)csize(i);
-                if (mode == 0) CI[keyroot(w)] = lci[i];
+                if (recs) {
+                    if (mode == 0) { FzRec r; r.ci = lci[i]; r.size = (int)csize(i); r.pad = 0; SC[keyroot(w)] = r; }
+                    else SC[keyroot(w)].size = (int)csize(i);
+                } else {
+                    S[keyroot(w)] = (int)csize(i);
+                    if (mode == 0) CI[keyroot(w)] = lci[i];
+                }
             }
         }
         __syncthreads();
@@ -1309,7 +1337,8 @@ __global__ void k_fz_seg_init(int *__restrict__ seg, const int *__restrict__ zco
     if (b < B) { seg[2 * b] = zcount[b]; seg[2 * b + 1] = nE; }
 }
 // mode 0: the endpoints lie in different components; mode 1: ... one of which is below min_size
-__device__ __forceinline__ bool fz_live_edge(const FzGeom &g, const unsigned *V, const int *P, const int *S, unsigned oe, int mode, int min_size)
+__device__ __forceinline__ bool fz_live_edge(const FzGeom &g, const unsigned *V, const int *P, const int *S, unsigned oe, int mode, int min_size,
+                                             const FzRec *SC)
 {
     int a, c;
     fz_endpoints(g, (long long)V[oe], a, c);
@@ -1318,13 +1347,16 @@ __device__ __forceinline__ bool fz_live_edge(const FzGeom &g, const unsigned *V,
     int n;
     while ((n = P[ra]) >= 0) ra = n;             // (flattened: the root already)
     while ((n = P[rc]) >= 0) rc = n;
-    return ra != rc && (mode == 0 || S[ra] < min_size || S[rc] < min_size);
+    if (ra == rc) return false;
+    if (mode == 0) return true;
+    return SC ? (SC[ra].size < min_size || SC[rc].size < min_size) : (S[ra] < min_size || S[rc] < min_size);
 }
 __global__ __launch_bounds__(256) void k_fz_live_count(const unsigned *__restrict__ vals, FzGeom g, const int *__restrict__ parent,
                                                        const int *__restrict__ size, const unsigned *__restrict__ idx,
                                                        const int *__restrict__ seg, int mode, int min_size, int npix,
-                                                       int *__restrict__ blkcnt, int nblk)
+                                                       int *__restrict__ blkcnt, int nblk, const FzRec *__restrict__ rec)
 {
+    const FzRec *SC = rec ? rec + (long long)blockIdx.y * npix : nullptr;
     const int b = blockIdx.y;
     const unsigned *V = vals + (long long)b * g.nE;
     const unsigned *IX = idx ? idx + (long long)b * g.nE : nullptr;
@@ -1337,7 +1369,7 @@ __global__ __launch_bounds__(256) void k_fz_live_count(const unsigned *__restric
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const long long e = (long long)kb * 1024 + u * 256 + threadIdx.x;
-                const bool live = e >= lo && e < hi && fz_live_edge(g, V, P, S, IX ? IX[e] : (unsigned)e, mode, min_size);
+                const bool live = e >= lo && e < hi && fz_live_edge(g, V, P, S, IX ? IX[e] : (unsigned)e, mode, min_size, SC);
                 cnt += __popcll(__ballot(live));
             }
         }
@@ -1370,8 +1402,10 @@ __global__ __launch_bounds__(1024) void k_fz_live_scan(int *__restrict__ blkcnt,
 __global__ __launch_bounds__(256) void k_fz_live_copy(const unsigned *__restrict__ vals, FzGeom g, const int *__restrict__ parent,
                                                       const int *__restrict__ size, const unsigned *__restrict__ idx,
                                                       const int *__restrict__ seg, int mode, int min_size, int npix,
-                                                      const int *__restrict__ blkoff, int nblk, unsigned *__restrict__ idx_out)
+                                                      const int *__restrict__ blkoff, int nblk, unsigned *__restrict__ idx_out,
+                                                      const FzRec *__restrict__ rec)
 {
+    const FzRec *SC = rec ? rec + (long long)blockIdx.y * npix : nullptr;
     const int b = blockIdx.y;
     const unsigned *V = vals + (long long)b * g.nE;
     const unsigned *IX = idx ? idx + (long long)b * g.nE : nullptr;
@@ -1386,7 +1420,7 @@ __global__ __launch_bounds__(256) void k_fz_live_copy(const unsigned *__restrict
         for (int u = 0; u < 4; ++u) {
             const long long e = (long long)kb * 1024 + u * 256 + threadIdx.x;
             const unsigned oe = (e >= lo && e < hi) ? (IX ? IX[e] : (unsigned)e) : 0u;
-            const bool live = e >= lo && e < hi && fz_live_edge(g, V, P, S, oe, mode, min_size);
+            const bool live = e >= lo && e < hi && fz_live_edge(g, V, P, S, oe, mode, min_size, SC);
             const unsigned long long m = __ballot(live);
             if (lane == 0) wc[wv] = __popcll(m);
             __syncthreads();
@@ -1536,7 +1570,7 @@ static int fz_run(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t 
     // hub chains (k_fz_pass_tab, !LPAR): on by default — one 1024 x 2048 image alone 0.40 -> 0.22 s (109 000 -> 8 000 full rounds),
     // 16.9 -> 10.2 ms per image at batch 30, the same labels; SPA_FZ_HUB=0 switches them off
     const char *hub_env = getenv("SPA_FZ_HUB");
-    const int hub_on = hub_env ? atoi(hub_env) : 3;          // bit 0: hub chains, bit 1: batched table entry
+    const int hub_on = hub_env ? atoi(hub_env) : 7;          // bit 0: hub chains, bit 1: batched table entry, bit 2: 16-byte root records (99 against 102 ms alone)
     if (tab && !(ctx->fz_attr_done & 2)) {
         SPA_HIP(hipFuncSetAttribute((const void *)k_fz_pass_tab<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
         SPA_HIP(hipFuncSetAttribute((const void *)k_fz_pass_tab<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
@@ -1560,13 +1594,16 @@ static int fz_run(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t 
         int gp = (int)((npix + 255) / 256);
         if (gp > 1024) gp = 1024;
         const int gb = nblk_e < 2048 ? nblk_e : 2048;
+        // (hub_on bit 2: size and internal cost of a root in one 16-byte record, the table pass's only view of them)
+        const FzRec *recp = (hub_on & 4) ? (const FzRec *)cint : nullptr;
+        if (recp) hipLaunchKernelGGL(k_fz_records, dim3(2048), dim3(256), 0, s, (FzRec *)cint, (const int *)size, (long long)B * npix);
         auto filter = [&](const unsigned *in_idx, const int *seg_in, int fmode, int *seg_out, unsigned *out_idx) {
             hipLaunchKernelGGL(k_fz_flatten_all, dim3(gp, B), dim3(256), 0, s, parent, (int)npix);
             hipLaunchKernelGGL(k_fz_live_count, dim3(gb, B), dim3(256), 0, s, (const unsigned *)vals1, g, (const int *)parent,
-                               (const int *)size, in_idx, seg_in, fmode, min_size, (int)npix, blkcnt, nblk_e);
+                               (const int *)size, in_idx, seg_in, fmode, min_size, (int)npix, blkcnt, nblk_e, recp);
             hipLaunchKernelGGL(k_fz_live_scan, dim3(B), dim3(1024), 0, s, blkcnt, nblk_e, seg_out);
             hipLaunchKernelGGL(k_fz_live_copy, dim3(gb, B), dim3(256), 0, s, (const unsigned *)vals1, g, (const int *)parent,
-                               (const int *)size, in_idx, seg_in, fmode, min_size, (int)npix, (const int *)blkcnt, nblk_e, out_idx);
+                               (const int *)size, in_idx, seg_in, fmode, min_size, (int)npix, (const int *)blkcnt, nblk_e, out_idx, recp);
         };
         auto pass = [&](int pmode, const unsigned *in_idx, int *seg_io, int div, int skip_flat) {
             hipLaunchKernelGGL(k_fz_pass_tab<false>, dim3(B), dim3(FZ_THREADS), tab_lds, s,
@@ -1599,7 +1636,7 @@ static int fz_run(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t 
         else if (tab)
             hipLaunchKernelGGL(k_fz_pass_tab<false>, dim3(B), dim3(FZ_THREADS), tab_lds, s,
                                (const unsigned long long *)keys1, (const unsigned *)vals1, g, parent, size, cint, k,
-                               min_size, mode, (const int *)zcount, flatten_every, (int)cells, diag, hub_on);
+                               min_size, mode, (const int *)zcount, flatten_every, (int)cells, diag, hub_on & 3);
         else if (ldsp)
             hipLaunchKernelGGL(k_fz_pass<true>, dim3(G, B), dim3(FZ_THREADS), lds_par, s, (const unsigned long long *)keys1,
                                (const unsigned *)vals1, g, parent, size, cint, mark, st, k, min_size, mode, r0,
