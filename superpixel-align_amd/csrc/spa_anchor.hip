@@ -117,7 +117,6 @@ __global__ __launch_bounds__(SCAN_T) void k_anchor_scan(RngDev *__restrict__ st,
                                                         long long jcap, int32_t *__restrict__ n_valid,
                                                         uint32_t *__restrict__ status)
 {
-    __shared__ int scr[16];
     __shared__ long long run_s;
     __shared__ int stop_s;
     const int tid = threadIdx.x;

@@ -652,7 +652,7 @@ __global__ __launch_bounds__(64) void k_conn_split(int *__restrict__ parent, int
                     if (cand[d]) atomicMin(CL + v[d], keyd[d]);
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 __builtin_amdgcn_s_waitcnt(0);
-                int mywins = 0, before = 0, tot = 0;
+                int before = 0, tot = 0;
                 bool win[4];
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
@@ -669,7 +669,7 @@ __global__ __launch_bounds__(64) void k_conn_split(int *__restrict__ parent, int
                     if (win[d]) {
                         if (pos < room) st_i32(Q + tail + pos, v[d]);
                         else __hip_atomic_store(CL + v[d], INF_KEY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ++pos; ++mywins;
+                        ++pos;
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
