@@ -151,6 +151,10 @@ struct SpaProfScope {
 };
 
 int spa_ws_reserve(spa_ctx *ctx, int which, size_t bytes, void **out);
+// one 32-bit word set to zero by a KERNEL on stream s (the tracked maxima of the DRN path).  Not hipMemsetAsync: as memset nodes
+// of a captured graph (drn.py replays small forwards as HIP graphs) these 4-byte fills were observed to run out of order with
+// the graph's kernels while a second stream was busy — a replay then scaled a layer by a maximum of 0 and returned zeros.
+void spa_zero_word(void *word, hipStream_t s);
 
 static inline hipStream_t spa_stream(void *s) { return (hipStream_t)s; }
 

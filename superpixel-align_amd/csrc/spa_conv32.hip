@@ -435,7 +435,7 @@ static int conv_f32_launch(spa_ctx *ctx, const float *x, int32_t B, int32_t H, i
     const size_t lds = 2 * (size_t)bm * 128 + 2 * (size_t)(bn + 2 * C32_HALO) * 128;
     if (split) {
         SPA_ARG(bias && zcount == 1 && inv_t > 0.f);
-        if (amax_out) SPA_HIP(hipMemsetAsync(amax_out, 0, 4, s));
+        if (amax_out) spa_zero_word(amax_out, s);
     }
     const int bit = TAPS == 9 ? 1 : 2;
     if (!(ctx->conv32_attr_done & bit)) {
@@ -555,7 +555,7 @@ extern "C" int spa_conv3x3_s2_f16s(spa_ctx *ctx, const float *x, int32_t B, int3
         SPA_HIP(hipMemsetAsync(zero, 0, 4096, s));
         ctx->zero_line_ready = 1;
     }
-    if (amax_out) SPA_HIP(hipMemsetAsync(amax_out, 0, 4, s));
+    if (amax_out) spa_zero_word(amax_out, s);
     const int H = (Hi + 1) / 2, W = (Wi + 1) / 2;
     // (64-pixel tiles, two workgroups per CU for the 128-row form, were measured: 2.06 vs 1.95 ms on the 32 -> 64+64 layer)
     const int bm = Cout % 256 == 0 ? 256 : 128, bn = 128;

@@ -200,7 +200,7 @@ extern "C" int spa_conv_small_f16s(spa_ctx *ctx, const float *x, int32_t B, int3
     SPA_ARG(n_proj == 0 || (n_proj == 32 && stride == 2 && Cin == 16 && Cout == 32 && y2 && !residual));
     SPA_ARG((((uintptr_t)x | (uintptr_t)wp | (uintptr_t)bias | (uintptr_t)y | (uintptr_t)y2 | (uintptr_t)residual) & 15) == 0);
     hipStream_t s = spa_stream(stream);
-    if (amax_out) SPA_HIP(hipMemsetAsync(amax_out, 0, 4, s));
+    if (amax_out) spa_zero_word(amax_out, s);
     const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
     const int TH = stride == 2 ? 4 : 8;
     const long long n_tiles = (long long)((Wo + 31) / 32) * ((Ho + TH - 1) / TH) * B;

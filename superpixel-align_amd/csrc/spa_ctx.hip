@@ -63,6 +63,9 @@ extern "C" void spa_ctx_destroy(spa_ctx *ctx)
     free(ctx);
 }
 
+__global__ void k_zero_word(unsigned *w) { *w = 0u; }
+void spa_zero_word(void *word, hipStream_t s) { hipLaunchKernelGGL(k_zero_word, dim3(1), dim3(1), 0, s, (unsigned *)word); }
+
 int spa_ws_reserve(spa_ctx *ctx, int which, size_t bytes, void **out)
 {
     if (bytes == 0) bytes = 16;

@@ -150,7 +150,7 @@ extern "C" int spa_bias_act_amax(spa_ctx *ctx, float *y, int64_t rows, int32_t C
                                  const float *residual, int32_t relu, void *amax, void *stream)
 {
     SPA_ARG(amax);
-    SPA_HIP(hipMemsetAsync(amax, 0, 4, spa_stream(stream)));
+    spa_zero_word(amax, spa_stream(stream));
     return bias_act_impl(ctx, y, 0, rows, C, bias, residual, relu, amax, stream);
 }
 

@@ -742,7 +742,7 @@ extern "C" int spa_drn_layer2_f16s(spa_ctx *ctx, const float *x, int32_t B, int3
     SPA_ARG(ctx && x && wp && bias && amax_in && y && B > 0 && H > 0 && W > 0 && inv_t > 0.f);
     SPA_ARG((((uintptr_t)x | (uintptr_t)wp | (uintptr_t)bias | (uintptr_t)y) & 15) == 0);
     hipStream_t s = spa_stream(stream);
-    if (amax_out) SPA_HIP(hipMemsetAsync(amax_out, 0, 4, s));
+    if (amax_out) spa_zero_word(amax_out, s);
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
     const long long n_tiles = (long long)((Wo + L2_TW - 1) / L2_TW) * ((Ho + L2_TH - 1) / L2_TH) * B;
     SPA_ARG(n_tiles < (1ll << 31));
@@ -894,7 +894,7 @@ static int stem_impl(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t
     rc = spa_drn_normalise(ctx, x, B, H, W, xn, 0, mean3_host, std3_host, stream);
     if (rc != SPA_OK) return rc;
     if (out_dtype == 2) {
-        if (amax_out) SPA_HIP(hipMemsetAsync(amax_out, 0, 4, spa_stream(stream)));
+        if (amax_out) spa_zero_word(amax_out, spa_stream(stream));
         unsigned short *wp;
         if ((rc = spa_ws_reserve(ctx, WS_STEM_WPACK, (size_t)22 * 64 * 8 * 2 + 16, (void **)&wp)) != SPA_OK) return rc;
         hipLaunchKernelGGL(k_stem_pack_f16, dim3(23), dim3(64), 0, spa_stream(stream), w0, b0, w1, wp);

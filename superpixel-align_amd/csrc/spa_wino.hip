@@ -449,7 +449,7 @@ extern "C" int spa_amax_f32(spa_ctx *ctx, const float *x, int64_t n, void *amax,
 {
     SPA_ARG(ctx && x && amax && n > 0 && n % 4 == 0 && ((uintptr_t)x % 16) == 0);
     hipStream_t s = spa_stream(stream);
-    SPA_HIP(hipMemsetAsync(amax, 0, 4, s));
+    spa_zero_word(amax, s);
     long long blocks = (n / 4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_amax, dim3((unsigned)blocks), dim3(256), 0, s, (const float4 *)x, (long long)(n / 4), (unsigned *)amax);
@@ -477,7 +477,7 @@ extern "C" int spa_conv3x3_wino4_f16s(spa_ctx *ctx, const float *x, int32_t B, i
     SPA_ARG(g.T * (Cin > Cout ? Cin : Cout) / 4 < (1ll << 31) * 256);
     WinoScale sc;
     for (int i = 0; i < 36; ++i) sc.c[i] = cs[i];
-    if (amax_out) SPA_HIP(hipMemsetAsync(amax_out, 0, 4, s));
+    if (amax_out) spa_zero_word(amax_out, s);
     {
         SpaProfScope prof_(ctx, PROF_WINO_IN, s);
         const long long n = g.T * (Cin / 4);

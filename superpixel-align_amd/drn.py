@@ -72,7 +72,9 @@ _EPILOGUE = {'engine': None, 'bytes': 0, 'launches': 0, 'own_conv': True, 'own_c
              'c16': {},
              # the layer's OWN bytes of the 256 x 256-tile Winograd layers (X, Y, the residual, the weight planes once): what a
              # convolution that kept V and M on chip would move — bench.py's `algorithmic_bytes` of the GEMM entry
-             'gemm16_layer_bytes': 0.0}
+             'gemm16_layer_bytes': 0.0,
+             # convolutions handed to MIOpen (F.conv2d) by conv_bias_act: a forward that has any is not captured into a graph
+             'library_convs': 0}
 
 
 def _c16(kind, flops, nbytes, launches=1):
@@ -81,6 +83,51 @@ def _c16(kind, flops, nbytes, launches=1):
     c[0] += flops
     c[1] += nbytes
     c[2] += launches
+
+
+def _epi_snapshot():
+    """The numeric counters of _EPILOGUE (bench.py's FLOP / byte accounting), for the graph replay below."""
+    snap = {k: v for k, v in _EPILOGUE.items() if isinstance(v, (int, float)) and not isinstance(v, bool)}
+    snap['c16'] = {k: list(v) for k, v in _EPILOGUE['c16'].items()}
+    return snap
+
+
+def _epi_restore(snap):
+    for k, v in snap.items():
+        if k != 'c16':
+            _EPILOGUE[k] = v
+    _EPILOGUE['c16'] = {k: list(v) for k, v in snap['c16'].items()}
+
+
+def _epi_delta(before):
+    d = {k: _EPILOGUE[k] - v for k, v in before.items() if k != 'c16'}
+    d['c16'] = {k: [a - b for a, b in zip(v, before['c16'].get(k, [0.0, 0.0, 0]))] for k, v in _EPILOGUE['c16'].items()}
+    return d
+
+
+def _epi_add(delta):
+    for k, v in delta.items():
+        if k != 'c16':
+            _EPILOGUE[k] += v
+    for k, v in delta['c16'].items():
+        c = _EPILOGUE['c16'].setdefault(k, [0.0, 0.0, 0])
+        for i in range(3):
+            c[i] += v[i]
+
+
+# The forward of a SMALL batch is bound by its ~100 launches, not by the GPU (30 images of 224 x 224, the reference's operating
+# point: 9.3 ms of wall clock for 6 ms of kernels; every layer is a few python calls and a ctypes call): such shapes are captured
+# once into a HIP graph (torch.cuda.CUDAGraph: the libspalign launches go to torch's current stream, which is the capturing one)
+# and replayed — the same kernels with the same arguments, hence the same bits.  SPA_DRN_GRAPH: 1 = every shape, 0 = never,
+# unset = batches of at most SPA_DRN_GRAPH_PIXELS pixels (default 4 Mi: full-size batches are GPU bound and keep their
+# per-kernel timers).
+def _graph_wanted(x):
+    mode = os.environ.get('SPA_DRN_GRAPH', '')
+    if mode == '0' or not x.is_cuda:
+        return False
+    if mode == '1':
+        return True
+    return x.shape[0] * x.shape[2] * x.shape[3] <= int(os.environ.get('SPA_DRN_GRAPH_PIXELS', str(4 << 20)))
 
 
 def conv_bias_act(conv, bn, x, residual=None, relu=True):
@@ -145,9 +192,13 @@ def conv_bias_act(conv, bn, x, residual=None, relu=True):
         # the direct kernel tiles an image ROW into 256 (128) pixels: on narrow maps most of a tile is padding
         # (28 pixels at the reference's 224 x 224 operating point: 403 images/s against 2 113 with MIOpen there), so
         # it is used where a row fills its tiles to 80 % (the Winograd path above flattens the tiles and does not care)
-        if packed32 is not None:
+        if packed32 is not None and not (packed32[0].shape[1] == 1 and getattr(conv, '_spa_packed16', None) is not None
+                                         and _EPILOGUE['split_gemm']):
+            # (the split-plane 1x1 form takes the image as one row: no such limit, engine.conv3x3_f16s)
+            # (... unless the layer is so small that a library convolution's launches cost more than the empty part of the tiles:
+            # the 64-channel layers of a 224 x 224 input; the forward then has no library call left and runs as a captured graph)
             bn = 256 if conv.out_channels % 256 == 0 else 128
-            if -(-x.shape[3] // bn) * bn > 1.25 * x.shape[3]:
+            if -(-x.shape[3] // bn) * bn > 1.25 * x.shape[3] and x.shape[0] * x.shape[2] * x.shape[3] > (1 << 20):
                 packed32 = None
         if (packed32 is not None and x.dtype == torch.float32 and _EPILOGUE['own_conv32']
                 and x.is_contiguous(memory_format=torch.channels_last)
@@ -185,6 +236,11 @@ def conv_bias_act(conv, bn, x, residual=None, relu=True):
             _EPILOGUE['conv16_launches'] += 1
             _c16('front', fl2, by2)
             return eng.drn_layer2_f16s(x, l2[0], l2[1], l2[2], amax_in=getattr(x, '_spa_amax', None))
+        _EPILOGUE['library_convs'] += 1               # (MIOpen picks its algorithm per call context: such a forward is not captured)
+        if os.environ.get('SPA_DRN_TRACE_LIBRARY'):
+            import sys
+            sys.stderr.write('[drn] library convolution: %d -> %d, kernel %s stride %s dilation %s on %s %s\n' % (
+                conv.in_channels, conv.out_channels, tuple(conv.kernel_size), tuple(conv.stride), tuple(conv.dilation), tuple(x.shape), x.dtype))
         y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation)
         vec = 4 if y.dtype == torch.float32 else 8
         if (y.is_contiguous(memory_format=torch.channels_last) and y.shape[1] % vec == 0
@@ -194,6 +250,7 @@ def conv_bias_act(conv, bn, x, residual=None, relu=True):
             return eng.bias_act_(y, conv.bias, residual, relu, track_amax=_EPILOGUE['split_gemm'])
         y = y + conv.bias.view(1, -1, 1, 1)
     else:
+        _EPILOGUE['library_convs'] += 1
         y = bn(conv(x))
     if residual is not None:
         y = y + residual
@@ -220,7 +277,11 @@ class BasicBlock(nn.Module):
         eng = _EPILOGUE['engine']
         if (s2 is not None and eng is not None and _EPILOGUE['split_gemm'] and _EPILOGUE['own_conv32'] and x.is_cuda
                 and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
-                and 128 * -(-((x.shape[3] + 1) // 2) // 128) <= 1.25 * ((x.shape[3] + 1) // 2)):
+                and (128 * -(-((x.shape[3] + 1) // 2) // 128) <= 1.25 * ((x.shape[3] + 1) // 2)
+                     # (narrow maps — 224 x 224 inputs, the reference's operating point — leave most of a 128-pixel tile empty; the
+                     # layer is then so small that this costs less than the launches of a library convolution and its epilogue
+                     # pass, and the forward stays on libspalign's kernels, which is what lets it run as a captured graph)
+                     or x.shape[0] * ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2) <= (1 << 20))):
             # the stride-2 opening convolution and the 1x1 stride-2 projection in ONE pass over x (csrc/spa_conv32.hip)
             fl2 = 2.0 * x.shape[0] * ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2) * s2[3] * 10 * x.shape[1]
             by2 = 4.0 * x.shape[0] * (x.shape[2] * x.shape[3] * x.shape[1] + ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2) * 2 * s2[3])
@@ -546,6 +607,8 @@ class DRN(nn.Module):
                 for m in parts[i]:
                     if m is not None:
                         m.record_stream(cur)
+        elif not sub_batch and _EPILOGUE['engine'] is not None and _graph_wanted(x) and not torch.is_grad_enabled():
+            parts.append(self._graph_forward(x, keep, pick))
         else:
             sub = B if not sub_batch else sub_batch
             for s in range(0, B, sub):
@@ -555,6 +618,67 @@ class DRN(nn.Module):
             col = [p[i] for p in parts]
             maps.append(None if col[0] is None else (col[0] if len(col) == 1 else torch.cat(col, 0)))
         return None, maps
+
+    def _graph_forward(self, x, keep, pick):
+        """batch_predict's single-chunk forward as a captured graph (see _graph_wanted).  Falls back to the eager forward for a
+        shape whose capture failed (and says so once)."""
+        E = _EPILOGUE
+        eng = E['engine']
+        key = (tuple(x.shape), x.dtype, tuple(x.stride()), self.compute_dtype, tuple(sorted(keep)), E['split_gemm'], E['own_conv'],
+               E['own_conv32'], E['winograd'], id(eng), self.use_fused_stem,
+               tuple(os.environ.get(k) for k in ('SPA_WINO_MIN_CIN', 'SPA_GEMM16_STAGGER', 'SPA_CONV16_STAGGER', 'SPA_C32_LATE_PREFETCH')))
+        cache = self.__dict__.setdefault('_graphs', {})
+        ent = cache.get(key)
+        if ent is None:
+            if len(cache) >= 8:                     # (a graph keeps its activations: bound what a stream of odd shapes can pin)
+                cache.pop(next(iter(cache)))
+            ent = cache[key] = self._graph_capture(x, pick)
+        if ent is False:
+            return pick(self._forward_chunk(x))
+        graph, g_in, g_out, delta = ent
+        g_in.copy_(x)
+        graph.replay()
+        _epi_add(delta)
+        # (the graph's outputs are overwritten by the next replay: the caller gets its own copy)
+        return [None if m is None else m.clone(memory_format=torch.preserve_format) for m in g_out]
+
+    def _graph_capture(self, x, pick):
+        eng = _EPILOGUE['engine']
+        dev = x.device
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(device=dev)
+        g_in = x.clone(memory_format=torch.preserve_format)
+        snap = _epi_snapshot()
+        prof_was = eng.prof_is_on()
+        try:
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                for _ in range(2):                  # workspaces, kernel attributes, MIOpen's find: nothing of that inside the capture
+                    self._forward_chunk(g_in)
+            cur.wait_stream(side)
+            torch.cuda.synchronize(dev)
+            _epi_restore(snap)
+            if prof_was:
+                eng.prof_enable(False)              # (event records of the per-kernel timers do not belong into a graph)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side, capture_error_mode='thread_local'):
+                g_out = pick(self._forward_chunk(g_in))
+            delta = _epi_delta(snap)
+            _epi_restore(snap)
+            if delta.get('library_convs', 0) > 0 and os.environ.get('SPA_DRN_GRAPH') != '1':
+                # MIOpen chooses its algorithm (and with it the summation order) differently inside a capture: the bits of an
+                # eager forward are the contract, so a forward with library convolutions in it stays eager
+                return False
+            return graph, g_in, g_out, delta
+        except Exception as e:                      # noqa: BLE001 - any capture failure means: run this shape eagerly
+            import warnings
+            warnings.warn('DRN forward of shape %s not captured into a graph (%s: %s); running it launch by launch'
+                          % (tuple(x.shape), type(e).__name__, e))
+            _epi_restore(snap)
+            return False
+        finally:
+            if prof_was:
+                eng.prof_enable(True)
 
     class _XP(object):
         """`model.xp` of the reference API (utils/apply_spalign_kmeans.py:30)."""

@@ -99,6 +99,10 @@ class Engine(object):
     # ------------------------------------------------------------------ per-kernel timing
     def prof_enable(self, on=True):
         check(self._lib.spa_prof_enable(self._ctx, 1 if on else 0))
+        self._prof_on = bool(on)
+
+    def prof_is_on(self):
+        return bool(getattr(self, '_prof_on', False))
 
     def prof_read(self):
         """{kernel name: (total ms, launches)} since prof_enable (synchronises)."""
@@ -321,6 +325,9 @@ class Engine(object):
             amax_in = self.amax(x)
         amax_out = torch.empty(1, dtype=torch.int32, device=x.device) if track_amax else None
         if taps == 1:
+            # (a 1x1 convolution does not see rows: the image goes in as ONE row of H * W pixels, so the kernel's 128- / 256-pixel
+            # tiles are full whatever the width — the same sums per pixel, hence the same bits)
+            H, W = 1, H * W
             check(self._lib.spa_conv1x1_f16s(self._ctx, _ptr(x), B, H, W, Cin, _ptr(wt2), ctypes.c_float(inv_t), Cout, _ptr(bias),
                                              _ptr(residual), 1 if relu else 0, _ptr(amax_in), _ptr(amax_out), _ptr(y), self._s()))
         else:

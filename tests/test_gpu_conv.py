@@ -150,7 +150,9 @@ def test_conv3x3_split_planes_direct_matches_float64(eng, B, Cin, Cout, H, W, di
     assert float(am.view(torch.float32)) == float(y.abs().max())
 
 
-@pytest.mark.parametrize('B,Cin,Cout,Hi,Wi', [(2, 32, 64, 37, 301), (1, 64, 128, 20, 270), (1, 64, 64, 9, 130), (2, 32, 128, 16, 256)])
+@pytest.mark.parametrize('B,Cin,Cout,Hi,Wi', [(2, 32, 64, 37, 301), (1, 64, 128, 20, 270), (1, 64, 64, 9, 130), (2, 32, 128, 16, 256),
+                                              # maps narrower than one pixel tile (224 x 224 inputs: 112 -> 56 -> 28)
+                                              (3, 32, 64, 112, 112), (3, 64, 128, 56, 56), (2, 64, 128, 29, 27)])
 def test_conv3x3_stride2_with_projection_matches_float64(eng, B, Cin, Cout, Hi, Wi):
     """the stride-2 opening convolution of layers 3/4 and the block's 1x1 stride-2 projection in one pass
     (spa_conv3x3_s2_f16s): both outputs against float64 convolutions, odd input sizes included"""

@@ -1,0 +1,101 @@
+"""The captured-graph forward of small batches (drn.py: _graph_wanted / _graph_forward) against the launch-by-launch forward:
+the same kernels with the same arguments, so every map must be bit-identical — for both architectures, both arithmetic types,
+across replays with different inputs, and through the whole label pipeline at the reference's operating point (224 x 224,
+utils/create_random300_labels.sh:4-34)."""
+import importlib
+import os
+import types
+import warnings
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+
+@pytest.fixture(scope='module')
+def mods():
+    names = ('ops', 'pipeline', 'drn', 'engine', 'synth')
+    return types.SimpleNamespace(**{n: importlib.import_module('superpixel-align_amd.' + n) for n in names})
+
+
+def _maps(model, x, mode):
+    """mode '0': launch by launch; 'auto': the default rule (small batches are captured when no library convolution is in them)"""
+    old = os.environ.pop('SPA_DRN_GRAPH', None)
+    if mode != 'auto':
+        os.environ['SPA_DRN_GRAPH'] = mode
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter('error')              # a capture that fell back must fail the test, not pass by the eager path
+            _, maps = model.batch_predict(x, need=[6, 7])
+        torch.cuda.synchronize()
+        return [None if m is None else m.clone() for m in maps]
+    finally:
+        os.environ.pop('SPA_DRN_GRAPH', None)
+        if old is not None:
+            os.environ['SPA_DRN_GRAPH'] = old
+
+
+@pytest.mark.parametrize('arch,dtype', [('drn_d_22', 'fp32'), ('drn_c_26', 'fp32'), ('drn_d_22', 'bf16'), ('drn_c_26', 'bf16')])
+def test_graph_forward_is_the_eager_forward_bit_for_bit(mods, arch, dtype):
+    mods.ops.engine()                                    # the forward's kernels need the engine registered
+    tdt = {'fp32': torch.float32, 'bf16': torch.bfloat16}[dtype]
+    model = mods.drn.create_drn(arch, device='cuda', dtype=tdt)
+    xs = [torch.from_numpy(mods.synth.synth_batch([s, s + 1, s + 2, s + 3], 224, 224)).cuda() for s in (3, 40)]
+    eager = [_maps(model, x, '0') for x in xs]
+    assert not getattr(model, '_graphs', None)
+    before = mods.drn._EPILOGUE['library_convs']
+    graph = [_maps(model, x, 'auto') for x in xs]        # first call captures, the second replays with another input
+    again = _maps(model, xs[0], 'auto')
+    ents = list(model._graphs.values())
+    assert len(ents) == 1
+    if dtype == 'fp32':
+        # the float32 forward is libspalign's kernels at every shape: captured, and no convolution went to the library
+        assert ents[0] is not False, 'the forward was not captured'
+        assert mods.drn._EPILOGUE['library_convs'] == before
+    else:
+        # bf16: the light layers are still MIOpen's, whose algorithm choice differs inside a capture: such a forward stays eager
+        assert ents[0] is False
+    for e, g in zip(eager + [eager[0]], graph + [again]):
+        for i in (6, 7):
+            assert g[i].dtype == e[i].dtype and g[i].shape == e[i].shape
+            if dtype == 'fp32':
+                assert torch.equal(g[i], e[i]), 'map %d differs between the graph and the eager forward' % i
+            else:
+                # (both are eager forwards here, and MIOpen's light layers are not bit-stable from call to call)
+                assert float((g[i].float() - e[i].float()).abs().max()) <= 0.05 * float(e[i].float().abs().max())
+        assert all(g[i] is None for i in range(6))
+    # a replay must not hand out the graph's own buffer
+    assert graph[0][7].data_ptr() != again[7].data_ptr()
+
+
+def test_pipeline_at_the_reference_operating_point_same_bits_with_and_without_graph(mods):
+    """224 x 224, DRN-C-26, felzenszwalb, anchors, k = 4 (create_random300_labels.sh): whole pipeline, two batches each way."""
+    def args():
+        return types.SimpleNamespace(superpixel_method='felzenszwalb', felzenszwalb_scale=300.0, felzenszwalb_sigma=0.8,
+                                     felzenszwalb_min_size=20, n_slic_segments=200, n_anchors=10, n_neighbors=4,
+                                     without_pos=False, y_rel_pos=0.75, x_rel_pos=0.5, y_rel_sigma=0.1, x_rel_sigma=0.1,
+                                     gpu=0, n_clusters=4, use_feature_maps=[7], pool_mode='anchor', mean_sampling='nearest',
+                                     arch='drn_c_26', dtype='fp32', drn_weights=None)
+    out = {}
+    for mode in ('0', '1'):
+        os.environ.pop('SPA_DRN_GRAPH', None)
+        if mode == '0':
+            os.environ['SPA_DRN_GRAPH'] = '0'
+        try:
+            model = mods.drn.create_drn('drn_c_26', device='cuda', dtype=torch.float32)
+            pipe = mods.pipeline.LabelPipeline(args(), model, mods.ops.engine())
+            res = []
+            for seeds in ([1, 2, 3, 4, 5, 6], [7, 8, 9, 10, 11, 12]):
+                r = pipe.run(mods.synth.synth_batch(seeds, 224, 224))
+                torch.cuda.synchronize()
+                res.append((r.cluster.cpu().numpy().copy(), r.road.cpu().numpy().copy(), r.labels.cpu().numpy().copy()))
+            out[mode] = res
+            if mode == '1':
+                assert any(e is not False for e in model._graphs.values()), 'not captured at the reference operating point'
+        finally:
+            os.environ.pop('SPA_DRN_GRAPH', None)
+    for a, b in zip(out['0'], out['1']):
+        for u, v in zip(a, b):
+            assert np.array_equal(u, v)
