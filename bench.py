@@ -681,6 +681,9 @@ def main():
                 'achieved': round(drn_tf, 2), 'peak': peak_tf if not split16 else None, 'unit': 'TFLOP/s',
                 'frac': round(drn_tf / peak_tf, 4) if not split16 else None, 'ms_per_step': round(drn_ms, 3),
                 'effective_TFLOPs_direct_equivalent': round(flops_direct / (drn_ms * 1e-3) / 1e12, 2),
+                # small batches: the forward is replayed as one captured HIP graph (drn.py); its kernels then carry no per-kernel timers
+                'captured_graph': any(e is not False for e in getattr(model, '_graphs', {}).values()),
+                'library_convolutions': int(E.get('library_convs', 0)),      # F.conv2d calls of the whole run (0: every convolution was libspalign's)
                 'note': ('%s' % (('float32 with the Winograd GEMMs on the 16-bit matrix cores: every float32 operand of a GEMM is two half-precision '
                                   'planes (22 significand bits after an exact power-of-two scaling) and every product three '
                                   'v_mfma_f32_16x16x32_f16 accumulated in float32 — the final map is as close to the float64 network as with '
