@@ -227,9 +227,9 @@ def test_winograd_layers_inside_the_network(eng):
         E['split_gemm'], E['gemm16_launches'], E['gemm16n_launches'], E['conv16_launches'] = True, 0, 0, 0
         _, a4s = m.batch_predict(x, need=[7])
         assert E['wino_launches'] == 13 and E['gemm16_launches'] + E['gemm16n_launches'] == 13 and E['conv16_launches'] >= 3
-        # run to run the same bits — checked where every convolution of the forward is libspalign's (at this 256 x 512 size the
-        # stride-2 openers of layers 3 / 4 are MIOpen's, whose results differ in the last bit from run to run, and so are the 1x1
-        # projections on maps narrower than 205 pixels): 64 x 2048 pixels fill every kernel's pixel tiles
+        # run to run the same bits (every convolution of the float32 forward is libspalign's at every shape since round 5; before,
+        # the stride-2 openers and the 1x1 projections of narrow maps were MIOpen's, whose results differ in the last bit from run
+        # to run): 64 x 2048 pixels fill every kernel's pixel tiles
         xw = synth.synth_batch([5, 6], 64, 2048)
         _, ws = m.batch_predict(xw, need=[7])
         _, ws2 = m.batch_predict(xw, need=[7])
