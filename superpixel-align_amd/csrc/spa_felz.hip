@@ -1555,7 +1555,9 @@ static int fz_run(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t 
     // the window's root table (+ the parent array of a small image) in LDS
     const size_t lds_limit = 156 * 1024;
     const size_t par_bytes = ((size_t)npix * 2 + 15) & ~(size_t)15;
-    const bool lpar = G == 1 && npix <= 65535 && par_bytes + 2560 * 16 + FZ_THREADS * 4 <= lds_limit;
+    // (SPA_FZ_LPAR=0: experiments — small images through the large images' kernel: parent array in global memory, hub chains)
+    const bool lpar = G == 1 && npix <= 65535 && par_bytes + 2560 * 16 + FZ_THREADS * 4 <= lds_limit &&
+                      !(getenv("SPA_FZ_LPAR") && atoi(getenv("SPA_FZ_LPAR")) == 0);
     long long cells = lpar ? (long long)((lds_limit - par_bytes - FZ_THREADS * 4) / 16) : 4096;
     if (cells > 4096) cells = 4096;
     // (larger images.  Round 3: the table kernel with the parent array in L2 measured 0.90 s per full-size image against 0.60 s of
@@ -1627,7 +1629,35 @@ static int fz_run(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t 
         filter(nullptr, segF, 1, sn, other);
         pass(1, other, sn, 1, 1);
     }
-    for (int mode = 0; mode < 2 && !prefilter; ++mode) {
+    // small images (parent array in LDS): pass 0 as one launch, then the same filter in front of the clean-up pass — the pass kernel
+    // wrote the parent array back, the other compute units flatten it and list the few edges that can still merge a component below
+    // min_size, and the clean-up launch walks that list instead of testing every sorted position again (SPA_FZ_PREFILTER=0: off)
+    const bool prefilter_small = tab && lpar && !prefilter && (!pf_env || atoi(pf_env) != 0) &&
+                                 (size_t)B * nblk_e * 4 + (size_t)B * 32 <= tmp_bytes * (par_sort ? 3 : 1);
+    if (prefilter_small) {
+        int *blkcnt = (int *)tmp;
+        int *segF = blkcnt + (size_t)B * nblk_e, *segL = segF + 2 * B;
+        unsigned *idxA = (unsigned *)keys0;
+        int gp = (int)((npix + 255) / 256);
+        if (gp > 1024) gp = 1024;
+        const int gb = nblk_e < 2048 ? nblk_e : 2048;
+        hipLaunchKernelGGL(k_fz_pass_tab<true>, dim3(B), dim3(FZ_THREADS), tab_lds, s,
+                           (const unsigned long long *)keys1, (const unsigned *)vals1, g, parent, size, cint, k,
+                           min_size, 0, (const int *)zcount, flatten_every, (int)cells, diag);
+        hipLaunchKernelGGL(k_fz_seg_init, dim3((B + 63) / 64), dim3(64), 0, s, segF, (const int *)zcount, (int)g.nE, B);
+        hipLaunchKernelGGL(k_fz_flatten_all, dim3(gp, B), dim3(256), 0, s, parent, (int)npix);
+        hipLaunchKernelGGL(k_fz_live_count, dim3(gb, B), dim3(256), 0, s, (const unsigned *)vals1, g, (const int *)parent,
+                           (const int *)size, (const unsigned *)nullptr, (const int *)segF, 1, min_size, (int)npix, blkcnt, nblk_e,
+                           (const FzRec *)nullptr);
+        hipLaunchKernelGGL(k_fz_live_scan, dim3(B), dim3(1024), 0, s, blkcnt, nblk_e, segL);
+        hipLaunchKernelGGL(k_fz_live_copy, dim3(gb, B), dim3(256), 0, s, (const unsigned *)vals1, g, (const int *)parent,
+                           (const int *)size, (const unsigned *)nullptr, (const int *)segF, 1, min_size, (int)npix, (const int *)blkcnt,
+                           nblk_e, idxA, (const FzRec *)nullptr);
+        hipLaunchKernelGGL(k_fz_pass_tab<true>, dim3(B), dim3(FZ_THREADS), tab_lds, s,
+                           (const unsigned long long *)keys1, (const unsigned *)vals1, g, parent, size, cint, k,
+                           min_size, 1, (const int *)zcount, flatten_every, (int)cells, diag, 0, (const unsigned *)idxA, segL, 1, 1);
+    }
+    for (int mode = 0; mode < 2 && !prefilter && !prefilter_small; ++mode) {
         const unsigned r0 = mode ? 0x40000000u : 0u;
         if (tab && lpar)
             hipLaunchKernelGGL(k_fz_pass_tab<true>, dim3(B), dim3(FZ_THREADS), tab_lds, s,
