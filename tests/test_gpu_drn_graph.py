@@ -99,3 +99,40 @@ def test_pipeline_at_the_reference_operating_point_same_bits_with_and_without_gr
     for a, b in zip(out['0'], out['1']):
         for u, v in zip(a, b):
             assert np.array_equal(u, v)
+
+
+def test_forty_batches_beside_the_superpixel_branch_graph_vs_eager(mods):
+    """The failure the 4-byte memset nodes produced needed a busy second stream and showed from the second
+    replay on: forty batches of 128 x 256 through the two-stream pipeline and through HostStream (uploads / downloads on copy
+    streams, the next forward under the previous tail), graph replays against the launch-by-launch forward, every batch's
+    feature map, descriptors and masks bit for bit."""
+    def args():
+        return types.SimpleNamespace(superpixel_method='slic', n_slic_segments=60, n_anchors=10, n_neighbors=4, without_pos=False,
+                                     y_rel_pos=0.75, x_rel_pos=0.5, y_rel_sigma=0.1, x_rel_sigma=0.1, gpu=0, n_clusters=2,
+                                     use_feature_maps=[7], pool_mode='mean', mean_sampling='nearest')
+    H, W, B, N = 128, 256, 4, 40
+    batches = [mods.synth.synth_batch([1000 + B * s + i for i in range(B)], H, W) for s in range(N)]
+    model = mods.drn.create_drn('drn_d_22', device='cuda')
+    got = {}
+    for mode in ('0', 'auto'):
+        os.environ.pop('SPA_DRN_GRAPH', None)
+        if mode == '0':
+            os.environ['SPA_DRN_GRAPH'] = '0'
+        try:
+            pipe = mods.pipeline.LabelPipeline(args(), model, mods.ops.engine(), overlap=True)
+            direct = []
+            for b in batches:
+                r = pipe.run(b)
+                direct.append((r.fmap.float().cpu().numpy().copy(), r.X.cpu().numpy().copy(), r.cluster.cpu().numpy().copy()))
+            hs = mods.pipeline.HostStream(pipe, B, H, W)
+            hosted = [(res.fmap.float().cpu().numpy().copy(), cl.copy()) for cl, road, res in hs.process(iter(batches))]
+            got[mode] = (direct, hosted)
+        finally:
+            os.environ.pop('SPA_DRN_GRAPH', None)
+    assert any(e is not False for e in model._graphs.values())
+    for s in range(N):
+        for u, v in zip(got['0'][0][s], got['auto'][0][s]):
+            assert np.array_equal(u, v), 'batch %d differs between graph replays and the eager forward' % s
+        assert np.array_equal(got['0'][1][s][0], got['auto'][1][s][0]) and np.array_equal(got['0'][1][s][1], got['auto'][1][s][1]), \
+            'HostStream batch %d differs' % s
+        assert np.array_equal(got['auto'][1][s][0], got['auto'][0][s][0])
