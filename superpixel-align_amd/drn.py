@@ -395,6 +395,7 @@ class DRN(nn.Module):
         self.compute_dtype = dtype
         self.to(device=device, dtype=dtype, memory_format=torch.channels_last)
         self.eval()
+        self.__dict__.pop('_graphs', None)              # captured forwards hold the OLD packed operands' addresses
         self._stem = None
         if torch.device(device).type == 'cuda':
             from .engine import default_engine, Engine        # fused glue kernels of libspalign
