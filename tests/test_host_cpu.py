@@ -449,3 +449,40 @@ def test_eight_ranks_label_the_full_training_split(tmp_path):
     keys = set(lines[0])
     assert all(set(l) == keys for l in lines)
     assert len(list(out.glob('*_leftImg8bit.npy'))) == n
+
+
+def test_graph_replay_bookkeeping_and_eligibility(monkeypatch):
+    """The host side of the captured-graph forward (drn.py): the FLOP / byte counters bench.py prices the DRN with advance by one
+    forward's worth per replay (snapshot / delta / add), and the eligibility rule reads SPA_DRN_GRAPH and the pixel bound."""
+    E = drn._EPILOGUE
+    saved = drn._epi_snapshot()
+    try:
+        before = drn._epi_snapshot()
+        E['gemm16_flops'] += 5.0
+        E['library_convs'] += 2
+        drn._c16('front', 7.0, 11.0, 3)
+        delta = drn._epi_delta(before)
+        assert delta['gemm16_flops'] == 5.0 and delta['library_convs'] == 2 and delta['c16']['front'] == [7.0, 11.0, 3]
+        assert isinstance(E['split_gemm'], bool) and 'split_gemm' not in delta and 'engine' not in delta      # settings are not counters
+        drn._epi_restore(before)
+        assert drn._epi_delta(before)['gemm16_flops'] == 0.0 and E['c16'].get('front', [0, 0, 0])[2] == before['c16'].get('front', [0, 0, 0])[2]
+        drn._epi_add(delta)
+        drn._epi_add(delta)
+        assert drn._epi_delta(before)['gemm16_flops'] == 10.0 and drn._epi_delta(before)['c16']['front'] == [14.0, 22.0, 6]
+    finally:
+        drn._epi_restore(saved)
+
+    class FakeX(object):
+        def __init__(self, shape, cuda):
+            self.shape, self.is_cuda = shape, cuda
+    small, big = FakeX((30, 3, 224, 224), True), FakeX((30, 3, 1024, 2048), True)
+    monkeypatch.delenv('SPA_DRN_GRAPH', raising=False)
+    monkeypatch.delenv('SPA_DRN_GRAPH_PIXELS', raising=False)
+    assert drn._graph_wanted(small) and not drn._graph_wanted(big) and not drn._graph_wanted(FakeX((1, 3, 8, 8), False))
+    monkeypatch.setenv('SPA_DRN_GRAPH', '0')
+    assert not drn._graph_wanted(small)
+    monkeypatch.setenv('SPA_DRN_GRAPH', '1')
+    assert drn._graph_wanted(big)
+    monkeypatch.delenv('SPA_DRN_GRAPH')
+    monkeypatch.setenv('SPA_DRN_GRAPH_PIXELS', '1000')
+    assert not drn._graph_wanted(small)
