@@ -427,7 +427,11 @@ static int conv_f32_launch(spa_ctx *ctx, const float *x, int32_t B, int32_t H, i
     // (split-plane form, 64 channels: every wave reads the whole weight tile from LDS, so 256 pixels per tile halve those reads
     // per matrix instruction: 1.53 vs 1.69 ms on the 64 -> 64 layer of 30 images — where a row fills 256-pixel tiles to 80 %)
     const bool wide64 = split && bm == 64 && (long long)((W + 255) / 256) * 256 * 4 <= 5ll * W;
-    const int bn = bm == 256 || wide64 || getenv("SPA_CONV32_BN256") ? 256 : 128;
+    // (round 5: 512 pixels per tile where a row fills them — every wave then owns 64 channels x 64 pixels, 16 LDS fragment reads per
+    // 48 matrix instructions instead of 12 per 24; one workgroup per CU, 150 KB of LDS.  SPA_CONV32_BN512=0: the 256-pixel tile)
+    static const int bn512_on = getenv("SPA_CONV32_BN512") ? atoi(getenv("SPA_CONV32_BN512")) : 1;
+    const bool wide512 = split && bm == 64 && TAPS == 9 && bn512_on && (long long)((W + 511) / 512) * 512 * 4 <= 5ll * W;
+    const int bn = wide512 ? 512 : (bm == 256 || wide64 || getenv("SPA_CONV32_BN256") ? 256 : 128);
     const int xtiles = (W + bn - 1) / bn, ntiles = Cout / bm;
     const long long total = (long long)B * H * xtiles * ntiles;
     SPA_ARG(total < (1ll << 31));
@@ -471,6 +475,24 @@ static int conv_f32_launch(spa_ctx *ctx, const float *x, int32_t B, int32_t H, i
                        (const unsigned *)amax_in, (unsigned *)amax_out, inv_t)
     if (split) {
         // (128 channels x 256 pixels, one workgroup per CU: 1.06 vs 1.04 ms — no gain, not kept)
+        if (TAPS == 9 && bm == 64 && bn == 512) {
+            static bool attr512 = false;
+            if (!attr512) {
+                SPA_HIP(hipFuncSetAttribute((const void *)k_conv3x3_f32<0, 64, 9, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 128 + 2 * (512 + 2 * C32_HALO) * 128));
+                SPA_HIP(hipFuncSetAttribute((const void *)k_conv3x3_f32<1, 64, 9, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 128 + 2 * (512 + 2 * C32_HALO) * 128));
+                attr512 = true;
+            }
+            if (residual)
+                hipLaunchKernelGGL((k_conv3x3_f32<1, 64, 9, 512, true>), dim3((unsigned)grid), dim3(C32_THREADS), lds, s, x, wt, bias, residual, y,
+                                   (const char *)zero, B, H, W, Cin, Cout, dilation, relu, xtiles, ntiles, (int)total, zcount, xz, wz, yz, late,
+                                   (const unsigned *)amax_in, (unsigned *)amax_out, inv_t);
+            else
+                hipLaunchKernelGGL((k_conv3x3_f32<0, 64, 9, 512, true>), dim3((unsigned)grid), dim3(C32_THREADS), lds, s, x, wt, bias, residual, y,
+                                   (const char *)zero, B, H, W, Cin, Cout, dilation, relu, xtiles, ntiles, (int)total, zcount, xz, wz, yz, late,
+                                   (const unsigned *)amax_in, (unsigned *)amax_out, inv_t);
+            SPA_LAUNCH_CHECK();
+            return SPA_OK;
+        }
         if (bm == 64 && bn == 256) {
             static bool attr64 = false;
             if (!attr64) {
