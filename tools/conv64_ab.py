@@ -7,7 +7,7 @@ import torch
 eng_mod = importlib.import_module('superpixel-align_amd.engine')
 eng = eng_mod.default_engine()
 torch.manual_seed(0)
-for (B, C, H, W, res) in ((30, 64, 256, 512, True), (30, 64, 256, 512, False), (4, 64, 77, 500, True)):
+for (B, C, H, W, res) in ((30, 64, 256, 512, True), (30, 64, 256, 512, False), (4, 64, 77, 500, True), (30, 128, 128, 256, True), (30, 128, 128, 256, False)):
     x = torch.randn(B, C, H, W, device='cuda').contiguous(memory_format=torch.channels_last)
     r = torch.randn(B, C, H, W, device='cuda').contiguous(memory_format=torch.channels_last) if res else None
     w = torch.randn(C, C, 3, 3, device='cuda') * 0.05
@@ -26,5 +26,5 @@ for (B, C, H, W, res) in ((30, 64, 256, 512, True), (30, 64, 256, 512, False), (
     if res: ref = ref + r[:1].double()
     ref = ref.relu()
     err = float((y[:1].double() - ref).abs().max() / ref.abs().max())
-    print('BN512=%s B %d %dx%d res %s: %.3f ms, digest %s, max err vs float64 %.1e' % (os.environ.get('SPA_CONV32_BN512', 'default'), B, H, W, res, dt,
+    print('BN512=%s C %d B %d %dx%d res %s: %.3f ms, digest %s, max err vs float64 %.1e' % (os.environ.get('SPA_CONV32_BN512', 'default'), C, B, H, W, res, dt,
           hashlib.sha1(y.cpu().numpy().tobytes()).hexdigest()[:10], err))
