@@ -86,6 +86,10 @@ const char *spa_prof_name(int slot);
 int spa_prof_read(spa_ctx *ctx, int slot, double *total_ms_host, int *launches_host);
 /* Diagnostics only: copy `bytes` of internal workspace `which` (byte offset; -1 = the stamp buffer of diagnostic kernel builds) to the host. */
 int spa_debug_peek(spa_ctx *ctx, int which, size_t offset, size_t bytes, void *host);
+/* Diagnostics only: kernel selection switches for A/B runs inside one process (tests/test_gpu_conv.py).  key 1: the narrow
+   split-plane 3x3 layers (Cout 64 / 128) on the planes-in-LDS kernel (value 1, the default; environment SPA_CONVP at context
+   creation) or on the round-3 kernel they replaced (value 0) — bit-identical outputs either way.  No counterpart in the reference. */
+int spa_debug_set(spa_ctx *ctx, int32_t key, int32_t value);
 /* diagnostics (tools/lds_probe.py): an LDS table filled and read back per lane, n_wg workgroups of 256 threads, out[n_wg][256][4];
    mode 0: 16-byte reads, 1: 4-byte reads, 2: broadcast reads.  No counterpart in the reference. */
 int spa_debug_lds_probe(spa_ctx *ctx, float *out, int32_t n_wg, int32_t steps, int32_t mode, void *stream);

@@ -398,6 +398,10 @@ __global__ __launch_bounds__(C32_THREADS) void k_conv3x3_f32(const float *__rest
 
 // x (B,H,W,Cin) float32 channels-last, wt (Cout,taps,Cin) float32 (tap = ky*3 + kx), bias (Cout) float32,
 // residual (B,H,W,Cout) float32 or NULL, y (B,H,W,Cout) float32.  stride 1, padding = dilation.
+int conv3x3_p16_launch(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W, int32_t Cin, const void *wt2, float inv_t,
+                       int32_t Cout, const float *bias, const float *residual, int32_t relu, int32_t dilation,
+                       const void *amax_in, void *amax_out, float *y, const char *zero, hipStream_t s);          // spa_convp.hip
+
 template <int TAPS>
 static int conv_f32_launch(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W, int32_t Cin,
                            const float *wt, int32_t Cout, const float *bias, const float *residual,
@@ -474,6 +478,10 @@ static int conv_f32_launch(spa_ctx *ctx, const float *x, int32_t B, int32_t H, i
                        (const char *)zero, B, H, W, Cin, Cout, dilation, relu, xtiles, ntiles, (int)total, zcount, xz, wz, yz, late, \
                        (const unsigned *)amax_in, (unsigned *)amax_out, inv_t)
     if (split) {
+        // round 6: the 64- and 128-channel tiles of the 3x3 layers take the planes-in-LDS kernel of spa_convp.hip (bit-identical
+        // outputs; SPA_CONVP=0 / spa_debug_set(ctx, 1, 0): this file's kernel, kept for A/B runs)
+        if (ctx->convp_on && TAPS == 9 && (Cout == 64 || Cout == 128) && Cin >= 64 && zcount == 1)
+            return conv3x3_p16_launch(ctx, x, B, H, W, Cin, wt, inv_t, Cout, bias, residual, relu, dilation, amax_in, amax_out, y, zero, s);
         // (128 channels x 256 pixels, one workgroup per CU: 1.06 vs 1.04 ms — no gain, not kept)
         if (TAPS == 9 && bm == 64 && bn == 512) {
             static bool attr512 = false;

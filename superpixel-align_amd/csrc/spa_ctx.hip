@@ -40,6 +40,7 @@ extern "C" int spa_ctx_create(int device, spa_ctx **out)
     ctx->device = device;
     ctx->n_cu = prop.multiProcessorCount;
     if (const char *e = getenv("SPA_SLIC_GENERAL")) ctx->slic_force_general = atoi(e) != 0;
+    ctx->convp_on = getenv("SPA_CONVP") ? atoi(getenv("SPA_CONVP")) != 0 : 1;
     SPA_HIP(hipMalloc((void **)&ctx->d_status, 32 * sizeof(uint32_t)));        // [0] the bits, [16..31] ring of taken words
     SPA_HIP(hipMemset(ctx->d_status, 0, 32 * sizeof(uint32_t)));
     *out = ctx;
@@ -331,6 +332,13 @@ extern "C" int spa_debug_lds_probe(spa_ctx *ctx, float *out, int32_t n_wg, int32
 }
 
 // diagnostics: copy `bytes` of workspace `which` (offset in bytes) to the host; synchronises
+extern "C" int spa_debug_set(spa_ctx *ctx, int32_t key, int32_t value)
+{
+    SPA_ARG(ctx && key == 1 && (value == 0 || value == 1));
+    ctx->convp_on = value;
+    return SPA_OK;
+}
+
 extern "C" int spa_debug_peek(spa_ctx *ctx, int which, size_t offset, size_t bytes, void *host)
 {
     if (which == -1) which = WS_DEBUG;           // the stamp buffer of diagnostic kernel builds

@@ -96,6 +96,11 @@ class Engine(object):
             msgs = [m for bit, m in _lib.STATUS_BITS.items() if st & bit]
             raise SpalignError('device status 0x%x: %s' % (st, '; '.join(msgs)))
 
+    def debug_set(self, key, value):
+        """diagnostic kernel-selection switches (include/spalign.h: spa_debug_set); key 1 = planes-in-LDS kernel for the narrow
+        split-plane 3x3 layers (1, default) or the kernel it replaced (0)"""
+        check(self._lib.spa_debug_set(self._ctx, int(key), int(value)))
+
     # ------------------------------------------------------------------ per-kernel timing
     def prof_enable(self, on=True):
         check(self._lib.spa_prof_enable(self._ctx, 1 if on else 0))

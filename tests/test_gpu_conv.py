@@ -150,6 +150,33 @@ def test_conv3x3_split_planes_direct_matches_float64(eng, B, Cin, Cout, H, W, di
     assert float(am.view(torch.float32)) == float(y.abs().max())
 
 
+@pytest.mark.parametrize('B,C,H,W,dil,res,relu', [(3, 64, 33, 512, 1, True, True), (2, 64, 40, 300, 4, True, False), (1, 64, 9, 37, 2, False, True),
+                                                    (2, 64, 7, 1024, 1, False, True), (3, 128, 21, 256, 1, True, True), (2, 128, 50, 130, 2, False, True),
+                                                    (2, 128, 64, 257, 3, True, True), (2, 128, 33, 100, 1, True, False), (1, 128, 3, 5, 1, False, True),
+                                                    (30, 64, 64, 512, 1, True, True)])
+def test_planes_in_lds_kernel_is_bit_identical_with_the_kernel_it_replaces(eng, B, C, H, W, dil, res, relu):
+    """round 6: k_conv3x3_p16 (spa_convp.hip: planes built once per staged segment, in place in LDS, one barrier per group of three
+    taps) feeds every accumulator the same matrix instructions in the same order as k_conv3x3_f32<SPLIT>: same bits, same tracked
+    maximum, on partial tiles, image borders, every dilation — and the same bits again on every repetition (its waits are counted
+    by hand: a race would show as a run that differs)"""
+    x, w, bias, r = _operands(B, C, C, H, W, 3, res, 11)
+    wt2, inv_t = eng.split_planes(w.permute(0, 2, 3, 1).reshape(C, 9, C).contiguous())
+    am = eng.amax(x)
+    try:
+        eng.debug_set(1, 0)
+        y0, a0 = eng.conv3x3_f16s(x, wt2, inv_t, bias, r, relu, dil, amax_in=am)
+        eng.debug_set(1, 1)
+        for rep in range(6 if B < 30 else 3):
+            y1, a1 = eng.conv3x3_f16s(x, wt2, inv_t, bias, r, relu, dil, amax_in=am)
+            assert torch.equal(y0, y1), 'repetition %d' % rep
+            assert int(a0) == int(a1)
+    finally:
+        eng.debug_set(1, 1)
+    ref = _ref64(x[:1], w, bias, None if r is None else r[:1], relu, dil)
+    assert float((y1[:1].double() - ref).abs().max()) <= 4e-6 * float(ref.abs().max())
+    assert eng.status() == 0
+
+
 @pytest.mark.parametrize('B,Cin,Cout,Hi,Wi', [(2, 32, 64, 37, 301), (1, 64, 128, 20, 270), (1, 64, 64, 9, 130), (2, 32, 128, 16, 256),
                                               # maps narrower than one pixel tile (224 x 224 inputs: 112 -> 56 -> 28)
                                               (3, 32, 64, 112, 112), (3, 64, 128, 56, 56), (2, 64, 128, 29, 27)])
