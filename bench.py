@@ -374,6 +374,11 @@ def main():
     def gather(res):
         """the result.json reduction: one all_gather of per-image records (inside the timed region)"""
         res.stream.synchronize()                   # the scores were accumulated on the stream the results live on
+        # k > 2: retry runs a batch still owes are made by the pipeline before the next batch draws; the last batch settles here
+        # (the reference's messages go to stderr: stdout carries the one JSON line)
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):
+            res.check_retry()
         info = res.info.cpu().numpy()
         conf = conf_total.cpu().numpy()
         n_sp = res.n_labels.cpu().numpy()

@@ -356,6 +356,9 @@ int spa_nprandom_shuffle_host(spa_nprandom *rng, int64_t *a_host, int64_t n);
 /* numpy's rk_state of the generator as it stands: 624 state words + the position inside the current block (628 words written,
    the last three zero) — what spa_np_kmeans_init_dev keeps in device memory. */
 int spa_nprandom_state(spa_nprandom *rng, uint32_t *state628_host);
+/* the inverse: continue from a state taken with spa_nprandom_state or downloaded from the device copy spa_np_kmeans_init_dev
+   advances (a batch too large for the device initialisation draws on the host and hands the stream back). */
+int spa_nprandom_set_state(spa_nprandom *rng, const uint32_t *state628_host);
 /* The k > 2 initial assignment (:141-149) drawn ON THE DEVICE from numpy's stream (csrc/spa_nprng.hip): thr = sort(w)[N // 2],
    m = #(w <= thr), idx = arange(m) % (k - 1) + 1, np.random.shuffle(idx) -> init_other[0 .. m) for spa_kmeans_weighted.
    state_dev: 628 words of device memory holding the generator (advanced by the call); n_ptr: device word N; gate: device word

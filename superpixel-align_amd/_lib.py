@@ -107,6 +107,7 @@ PROTOTYPES = {
     'spa_nprandom_destroy': (None, [c_p]),
     'spa_nprandom_shuffle_host': (ctypes.c_int, [c_p, c_p, c_i64]),
     'spa_nprandom_state': (ctypes.c_int, [c_p, c_p]),
+    'spa_nprandom_set_state': (ctypes.c_int, [c_p, c_p]),
     'spa_np_kmeans_init_dev': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_i32, c_i32, c_p, c_p, c_p, c_p]),
     'spa_kmeans_retry_update': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_p, c_p, c_p, c_p, c_p]),
     'spa_pyrandom_dev_seed': (ctypes.c_int, [c_p, ctypes.c_uint64, c_p]),

@@ -48,6 +48,19 @@ struct MT {
     }
     uint32_t out[624];
     void export_state(uint32_t *state, int *pos) const { for (int i = 0; i < 624; ++i) state[i] = mt[i]; *pos = idx; }
+    void import_state(const uint32_t *state, int pos)
+    {
+        // (out[] holds the tempered words of the current block: rebuilt, so that a state taken in the middle of a block continues)
+        for (int i = 0; i < 624; ++i) {
+            uint32_t t = mt[i] = state[i];
+            t ^= (t >> 11);
+            t ^= (t << 7) & 0x9d2c5680u;
+            t ^= (t << 15) & 0xefc60000u;
+            t ^= (t >> 18);
+            out[i] = t;
+        }
+        idx = pos;
+    }
     void refill() { refill_to(out); idx = 0; }
     void refill_to(uint32_t *dst)
     {
@@ -435,6 +448,13 @@ extern "C" int spa_nprandom_state(spa_nprandom *r, uint32_t *state628)
     if (!r || !state628) return SPA_ERR_ARG;
     r->g.export_state(state628, (int *)&state628[624]);
     state628[625] = state628[626] = state628[627] = 0u;
+    return SPA_OK;
+}
+
+extern "C" int spa_nprandom_set_state(spa_nprandom *r, const uint32_t *state628)
+{
+    if (!r || !state628 || state628[624] > 624u) return SPA_ERR_ARG;
+    r->g.import_state(state628, (int)state628[624]);
     return SPA_OK;
 }
 

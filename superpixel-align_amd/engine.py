@@ -806,3 +806,9 @@ class NpRandom(object):
         out = np.zeros(628, np.uint32)
         check(self._lib.spa_nprandom_state(self._h, out.ctypes.data_as(ctypes.c_void_p)))
         return out
+
+    def set_state(self, state628):
+        """continue from a state taken with state() (or downloaded from the device copy np_kmeans_init advances)"""
+        a = np.ascontiguousarray(state628, dtype=np.uint32)
+        assert a.size == 628
+        check(self._lib.spa_nprandom_set_state(self._h, a.ctypes.data_as(ctypes.c_void_p)))

@@ -41,15 +41,20 @@ class BatchResult(object):
         the results are fetched: the flags are device-side and the batch loop stays asynchronous."""
         info = getattr(self, 'retry_info', None)
         if info is not None and flags is None:
-            # k > 2 with the generator on the device: [retry runs made, runs still pending] (LabelPipeline.cluster)
-            pending, made = (int(v) for v in info.cpu().tolist())
+            # k > 2 with the generator on the device: [runs still pending, retry runs made] (LabelPipeline.cluster).  Runs still
+            # pending after the speculative rounds are made up for by the pipeline — before the next batch draws (its cluster()
+            # settles the previous batch first) or, for the last batch of a run, right here.
             self.retry_info = None
-            for _ in range(made + pending):
+            settle = getattr(self, 'retry_settle', None)
+            if settle is not None:
+                pending, made = settle(info)
+            else:
+                pending, made = (int(v) for v in info.cpu().tolist())
+            for _ in range(made):
                 print('\nSomehow KMeans seems failed. Try again\n')
             if pending > 0:
-                raise _lib.SpalignError('weighted_kmeans retries (batch_spalign_kmeans.py:201-205): %d more run(s) were due than the '
-                                        '%d enqueued speculatively — numpy\'s stream is behind the reference\'s from the next batch on; '
-                                        'rerun with SPA_RETRY_ROUNDS=%d or --host_kmeans_init' % (pending, made, made + pending + 2))
+                raise _lib.SpalignError('weighted_kmeans retries (batch_spalign_kmeans.py:201-205): %d run(s) still due and a later batch '
+                                        'has already drawn from numpy\'s stream' % pending)
             return
         fail = getattr(self, 'retry_fail', None) if flags is None else flags
         if fail is None or not bool(fail.any().item()):
@@ -124,6 +129,8 @@ class LabelPipeline(object):
         self.pyrandom = PyRandom(seed)
         self.nprandom = NpRandom(seed)
         self._np_state = None                            # (the device copy is re-created from the fresh host state)
+        self._np_on_device = False
+        self._owed = None
 
     # ---------------------------------------------------------------- stages
     def features(self, imgs_dev):
@@ -251,22 +258,31 @@ class LabelPipeline(object):
         and runs are sequential (the recursion is depth first and a run draws before it recurses), so the stream only depends
         on HOW MANY runs there are: pending = failures of the first run; while pending: run again, pending += its failures - 1.
         SPA_RETRY_ROUNDS (default 2) such runs are enqueued speculatively behind a device-side gate — a gated run that is not
-        wanted draws nothing and does nothing — and the counters go to `retry_info` = [runs made, runs still pending], read
-        when the batch is fetched (BatchResult.check_retry prints the reference's message per run; runs still pending mean
-        the stream would differ from the reference's from the next batch on: raised as an error, never silently)."""
+        wanted draws nothing and does nothing — and the counters go to `retry_info` = [runs still pending, runs made].  Runs still
+        pending after those rounds (three or more failing images, or an image that keeps failing) are made up for by
+        _settle_retries() BEFORE the next batch draws — one host wait for the previous batch's counters per batch, the reference's
+        recursion limit as the bound — or when the last batch is fetched (BatchResult.check_retry, which prints the reference's
+        message per run).  A batch with more points than the device initialisation holds (felzenszwalb: data dependent) draws on
+        the host from the downloaded state and hands the stream back to the device."""
         a, eng = self.args, self.eng
         B = labels.shape[0]
         init_other = None
-        on_device = (a.n_clusters > 2 and not self.host_kmeans_init and X.shape[0] <= eng.NP_INIT_MAX)
+        if _depth == 0:
+            self._retry_info = None
+        on_device = (a.n_clusters > 2 and not self.host_kmeans_init and X.shape[0] <= getattr(self, 'np_init_max', eng.NP_INIT_MAX))
+        if a.n_clusters > 2 and not self.host_kmeans_init and _depth == 0:
+            # runs the previous batch still owes (more failures than the speculative rounds covered) come BEFORE this batch's draw
+            self._settle_retries()
         if on_device:
             if self._np_state is None:
                 self._np_state = torch.from_numpy(self.nprandom.state().view(np.int32)).to(labels.device)
-                self.nprandom = None                     # the stream lives on the device from here on
+            self._np_on_device = True                    # the stream lives on the device from here on
             init_other = eng.np_kmeans_init(self._np_state, prior, off[B:], a.n_clusters)
         elif a.n_clusters > 2:
-            if self.nprandom is None:
-                raise ValueError('the numpy stream already lives on the device: %d points exceed what the device initialisation '
-                                 'holds (%d); start with --host_kmeans_init' % (X.shape[0], eng.NP_INIT_MAX))
+            if getattr(self, '_np_on_device', False) and _depth == 0:
+                # more points than the device initialisation holds (felzenszwalb: data dependent): the stream comes back to the
+                # host for this batch — synchronously — and returns to the device afterwards
+                self.nprandom.set_state(self._np_state.cpu().numpy().view(np.uint32))
             # idx = arange(M) % (k-1) + 1 shuffled by numpy's global generator (:147-149)
             n = int(off[-1].item())
             w = prior[:n].cpu().numpy()
@@ -286,6 +302,10 @@ class LabelPipeline(object):
                 assign_r, _ = eng.kmeans(X, prior, off[B:], a.n_clusters, 1000, init_r, gate=gate)
                 eng.retry_update(assign_r, off, B, counters, gate=gate)
             self._retry_info = counters
+            # what a later settlement needs: the batch's operands and an event behind its last speculative round
+            ev = torch.cuda.Event()
+            ev.record()
+            self._owed = dict(counters=counters, X=X, prior=prior, off=off, B=B, k=a.n_clusters, event=ev, settled=None)
             return assign, info, cluster, road, None
         fail = images_without_cluster0(assign, off, B)
         if a.n_clusters > 2:
@@ -295,7 +315,47 @@ class LabelPipeline(object):
                     raise RecursionError(RETRY_MESSAGE)
                 self.cluster(labels, off, X, prior, _depth + 1)        # discarded, as in the reference
             fail = None
+            if _depth == 0 and getattr(self, '_np_on_device', False) and not self.host_kmeans_init:
+                # (an oversize batch drawn on the host: the stream goes back to the device for the batches that follow)
+                self._np_state.copy_(torch.from_numpy(self.nprandom.state().view(np.int32)))
         return assign, info, cluster, road, fail
+
+    def _settle_retries(self, info=None):
+        """k > 2, generator on the device: make the retry runs a batch still owes (batch_spalign_kmeans.py:201-205: the reference
+        recurses until no image fails, depth first — only the NUMBER of runs matters to the stream, see cluster()).  The speculative
+        rounds cover SPA_RETRY_ROUNDS of them without a host round trip; here the host reads the counters (one wait for the
+        batch's event — it precedes everything enqueued since) and enqueues run after run until none is pending, up to the
+        reference's recursion limit.  Called before the next batch draws, so numpy's stream stays the reference's; also by
+        BatchResult.check_retry (the last batch of a run).  -> (pending, made) of the settled batch, or None if nothing is owed."""
+        owed = getattr(self, '_owed', None)
+        if owed is None or (info is not None and info is not owed['counters']):
+            if info is not None:
+                # a batch that is no longer the latest: whatever it owed was settled when its successor drew
+                done = getattr(self, '_settled', {}).pop(id(info), None)
+                if done is not None:
+                    return done
+                return tuple(int(v) for v in info.cpu().tolist())
+            return None
+        self._owed = None
+        owed['event'].synchronize()
+        eng, c = self.eng, owed['counters']
+        pending, made = (int(v) for v in c.cpu().tolist())
+        one = torch.ones((1,), dtype=torch.int32, device=c.device)
+        while pending > 0:
+            if made >= RETRY_DEPTH_LIMIT:
+                raise RecursionError(RETRY_MESSAGE)
+            init_r = eng.np_kmeans_init(self._np_state, owed['prior'], owed['off'][owed['B']:], owed['k'], gate=one)
+            assign_r, _ = eng.kmeans(owed['X'], owed['prior'], owed['off'][owed['B']:], owed['k'], 1000, init_r, gate=one)
+            eng.retry_update(assign_r, owed['off'], owed['B'], c, gate=one)
+            pending, made = (int(v) for v in c.cpu().tolist())
+        if not hasattr(self, '_settled'):
+            self._settled = {}
+        if len(self._settled) > 64:
+            self._settled.clear()
+        self._settled[id(c)] = (pending, made)
+        if info is not None:
+            return self._settled.pop(id(c))
+        return (pending, made)
 
     # ---------------------------------------------------------------- whole batch
     def _tick(self, name):
@@ -369,7 +429,7 @@ class LabelPipeline(object):
                 done.record(aux)
             res = BatchResult(labels=labels, n_labels=n_labels, offsets=seg['off'], count=seg['count'],
                               X=X, prior=seg['prior'], assign=assign, info=info, cluster=cluster,
-                              road=road, fmap=fmap, retry_fail=fail, retry_info=self._retry_info,
+                              road=road, fmap=fmap, retry_fail=fail, retry_info=self._retry_info, retry_settle=self._settle_retries,
                               strict_retry=bool(getattr(self.args, 'strict_retry', False)), stream=aux, ready=done)
             if join:
                 main.wait_event(done)
@@ -416,7 +476,7 @@ class LabelPipeline(object):
         done.record(main)
         res = BatchResult(labels=labels, n_labels=n_labels, offsets=seg['off'], count=seg['count'],
                           X=X, prior=seg['prior'], assign=assign, info=info, cluster=cluster,
-                          road=road, fmap=fmap, retry_fail=fail, retry_info=self._retry_info,
+                          road=road, fmap=fmap, retry_fail=fail, retry_info=self._retry_info, retry_settle=self._settle_retries,
                           strict_retry=bool(getattr(self.args, 'strict_retry', False)), stream=main, ready=done)
         if check_status:
             self.eng.raise_on_status()

@@ -367,7 +367,7 @@ def test_kmeans_retry_branch_follows_the_reference(eng, capsys):
     # fused pipeline: same stages on device tensors.  Round 5: numpy's generator lives on the device, the initial assignment is
     # drawn there and the retry runs are enqueued speculatively behind a device-side gate (LabelPipeline.cluster); batch 0 of
     # the fixture needs three of them.  Round 4's synchronous host form (--host_kmeans_init) must give the same maps.
-    def run_pipe(rounds, host_init):
+    def run_pipe(rounds, host_init, seq=('0', '1'), defer=False, oversize=()):
         monkey = pytest.MonkeyPatch()
         monkey.setenv('SPA_RETRY_ROUNDS', str(rounds))
         try:
@@ -375,24 +375,41 @@ def test_kmeans_retry_branch_follows_the_reference(eng, capsys):
             pipe = pipeline.LabelPipeline(a, model=None, engine=eng, pool_mode='mean', overlap=False)
         finally:
             monkey.undo()
-        outs = []
-        for t in ('0', '1'):
+        outs, results = [], []
+        for i, t in enumerate(seq):
             n_per = g['n_per' + t].astype(np.int32)
             off = dev(np.concatenate([[0], np.cumsum(n_per)]).astype(np.int32))
+            pipe.np_init_max = 8 if i in oversize else eng.NP_INIT_MAX      # (8: this batch is "too large" for the device initialisation)
             assign, info, cluster, road, fail = pipe.cluster(dev(g['sps' + t].astype(np.int32)), off, dev(g['X' + t]), dev(g['w' + t]))
             assert fail is None
-            if not host_init:
-                pipeline.BatchResult(retry_info=pipe._retry_info).check_retry()      # prints the reference's message per retry run
+            res = pipeline.BatchResult(retry_info=pipe._retry_info, retry_settle=pipe._settle_retries)
+            if not host_init and not defer:
+                res.check_retry()                 # prints the reference's message per retry run
+            results.append(res)
             outs.append(cluster.cpu().numpy())
+        if defer:
+            for res in results:                   # fetched late, as an asynchronous batch loop does
+                res.check_retry()
         return outs
     for host_init in (False, True):
         capsys.readouterr()
         outs = run_pipe(4, host_init)
         assert capsys.readouterr().out.count('Somehow KMeans seems failed') == int(g['n_retry'])
         assert np.array_equal(outs[0], g['cl0']) and np.array_equal(outs[1], g['cl1'])
-    # fewer speculative rounds than the data needs: reported when the batch is fetched, never silent
-    with pytest.raises(RuntimeError, match='SPA_RETRY_ROUNDS'):
-        run_pipe(2, False)
+    # round 6: fewer speculative rounds than the data needs (batch 0 needs three) — the runs still owed are made before the next
+    # batch draws (or when the last batch is fetched): same maps, same messages, whenever the results are fetched
+    for rounds, defer in ((2, False), (0, False), (1, True), (0, True)):
+        capsys.readouterr()
+        outs = run_pipe(rounds, False, defer=defer)
+        assert capsys.readouterr().out.count('Somehow KMeans seems failed') == int(g['n_retry']), (rounds, defer)
+        assert np.array_equal(outs[0], g['cl0']) and np.array_equal(outs[1], g['cl1']), (rounds, defer)
+    # a batch too large for the device initialisation in the middle of a run (felzenszwalb: the row count is data dependent):
+    # it draws on the host from the downloaded state and hands the stream back — the sequence equals the all-host one
+    seq = ('0', '1', '0', '1')
+    want = run_pipe(4, True, seq=seq)
+    for oversize in ((1,), (0, 2), (3,)):
+        got = run_pipe(1, False, seq=seq, defer=True, oversize=oversize)
+        assert all(np.array_equal(x, y) for x, y in zip(got, want)), oversize
     capsys.readouterr()
     # k = 2
     args2 = types.SimpleNamespace(n_clusters=2, seed=1111, strict_retry=True)
