@@ -86,6 +86,10 @@ const char *spa_prof_name(int slot);
 int spa_prof_read(spa_ctx *ctx, int slot, double *total_ms_host, int *launches_host);
 /* Diagnostics only: copy `bytes` of internal workspace `which` (byte offset; -1 = the stamp buffer of diagnostic kernel builds) to the host. */
 int spa_debug_peek(spa_ctx *ctx, int which, size_t offset, size_t bytes, void *host);
+/* How many times a workspace of the context has been re-allocated (they grow with the largest shape seen).  A captured HIP graph holds
+   the addresses of the workspaces its launches used: a replay is valid only while this number is what it was at capture time
+   (drn.py keys its graph cache with it). */
+int spa_ws_generation(spa_ctx *ctx);
 /* Diagnostics only: kernel selection switches for A/B runs inside one process (tests/test_gpu_conv.py).  key 1: the narrow
    split-plane 3x3 layers (Cout 64 / 128) on the planes-in-LDS kernel (value 1, the default; environment SPA_CONVP at context
    creation) or on the round-3 kernel they replaced (value 0) — bit-identical outputs either way.  No counterpart in the reference. */

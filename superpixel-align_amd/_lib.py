@@ -84,6 +84,7 @@ PROTOTYPES = {
     'spa_resize_cvcubic_u8': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p]),
     'spa_debug_peek': (ctypes.c_int, [c_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, c_p]),
     'spa_debug_set': (ctypes.c_int, [c_p, ctypes.c_int32, ctypes.c_int32]),
+    'spa_ws_generation': (ctypes.c_int, [c_p]),
     'spa_debug_lds_probe': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_p]),
     'spa_slic_make_plan':(ctypes.c_int, [c_i32, c_i32, c_i32, ctypes.POINTER(SlicPlan)]),
     'spa_rgb2lab': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_f32, c_p, c_p]),

@@ -484,11 +484,10 @@ static int conv_f32_launch(spa_ctx *ctx, const float *x, int32_t B, int32_t H, i
             return conv3x3_p16_launch(ctx, x, B, H, W, Cin, wt, inv_t, Cout, bias, residual, relu, dilation, amax_in, amax_out, y, zero, s);
         // (128 channels x 256 pixels, one workgroup per CU: 1.06 vs 1.04 ms — no gain, not kept)
         if (TAPS == 9 && bm == 64 && bn == 512) {
-            static bool attr512 = false;
-            if (!attr512) {
+            if (!(ctx->conv32_attr_done & 16)) {
                 SPA_HIP(hipFuncSetAttribute((const void *)k_conv3x3_f32<0, 64, 9, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 128 + 2 * (512 + 2 * C32_HALO) * 128));
                 SPA_HIP(hipFuncSetAttribute((const void *)k_conv3x3_f32<1, 64, 9, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 128 + 2 * (512 + 2 * C32_HALO) * 128));
-                attr512 = true;
+                ctx->conv32_attr_done |= 16;
             }
             if (residual)
                 hipLaunchKernelGGL((k_conv3x3_f32<1, 64, 9, 512, true>), dim3((unsigned)grid), dim3(C32_THREADS), lds, s, x, wt, bias, residual, y,
@@ -502,11 +501,11 @@ static int conv_f32_launch(spa_ctx *ctx, const float *x, int32_t B, int32_t H, i
             return SPA_OK;
         }
         if (bm == 64 && bn == 256) {
-            static bool attr64 = false;
-            if (!attr64) {
+            const int bit64 = TAPS == 9 ? 32 : 64;
+            if (!(ctx->conv32_attr_done & bit64)) {
                 SPA_HIP(hipFuncSetAttribute((const void *)k_conv3x3_f32<0, 64, TAPS, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 128 + 2 * (256 + 2 * C32_HALO) * 128));
                 SPA_HIP(hipFuncSetAttribute((const void *)k_conv3x3_f32<1, 64, TAPS, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 128 + 2 * (256 + 2 * C32_HALO) * 128));
-                attr64 = true;
+                ctx->conv32_attr_done |= bit64;
             }
             if (residual) C32_LAUNCH_S(1, 64, 256); else C32_LAUNCH_S(0, 64, 256);
             SPA_LAUNCH_CHECK();

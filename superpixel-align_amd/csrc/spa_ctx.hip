@@ -79,6 +79,7 @@ int spa_ws_reserve(spa_ctx *ctx, int which, size_t bytes, void **out)
         size_t want = bytes + bytes / 8;
         SPA_HIP(hipMalloc(&ctx->ws[which], want));
         ctx->ws_bytes[which] = want;
+        ++ctx->ws_generation;
     }
     *out = ctx->ws[which];
     return SPA_OK;
@@ -332,6 +333,8 @@ extern "C" int spa_debug_lds_probe(spa_ctx *ctx, float *out, int32_t n_wg, int32
 }
 
 // diagnostics: copy `bytes` of workspace `which` (offset in bytes) to the host; synchronises
+extern "C" int spa_ws_generation(spa_ctx *ctx) { return ctx ? ctx->ws_generation : -1; }
+
 extern "C" int spa_debug_set(spa_ctx *ctx, int32_t key, int32_t value)
 {
     SPA_ARG(ctx && key == 1 && (value == 0 || value == 1));

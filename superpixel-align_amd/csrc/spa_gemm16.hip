@@ -508,8 +508,10 @@ int gemm_f16x3_raw(spa_ctx *ctx, const float *x, long long rows, int32_t Cin, co
     if (stagger && bm == 256) {
         if (!ctx->gemm16s_attr_done) {
 #define G16S_ATTR(RS, XP) SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, RS, XP>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128 + ((XP) & 16 ? 4096 : 0)))
-            G16S_ATTR(1, 0); G16S_ATTR(2, 0); G16S_ATTR(3, 0); G16S_ATTR(4, 0); G16S_ATTR(1, 2); G16S_ATTR(1, 4); G16S_ATTR(1, 6); G16S_ATTR(1, 16); G16S_ATTR(2, 16);
-            G16S_ATTR(1, 18); G16S_ATTR(1, 20);
+            G16S_ATTR(1, 0); G16S_ATTR(2, 0); G16S_ATTR(3, 0); G16S_ATTR(4, 0);
+#ifdef SPA_DIAG
+            G16S_ATTR(1, 2); G16S_ATTR(1, 4); G16S_ATTR(1, 6); G16S_ATTR(1, 16); G16S_ATTR(2, 16); G16S_ATTR(1, 18); G16S_ATTR(1, 20);
+#endif
 #undef G16S_ATTR
             ctx->gemm16s_attr_done = 1;
         }
@@ -522,12 +524,18 @@ int gemm_f16x3_raw(spa_ctx *ctx, const float *x, long long rows, int32_t Cin, co
                                (int)rows, Cin, Cout, ntiles, (int)total, zcount, rows * Cin, (long long)Cout * Cin, rows * Cout, (const unsigned *)amax, dbg)
         const int rs = stagger & 7, diag = stagger >> 3;          // diag: 1 no split, 2 no loads, 4 stamps
         if (diag == 0) { if (rs == 1) G16S_LAUNCH(1, 0); else if (rs == 2) G16S_LAUNCH(2, 0); else if (rs == 4) G16S_LAUNCH(4, 0); else G16S_LAUNCH(3, 0); }
+#ifdef SPA_DIAG
+        // timing-only forms (no split / no global loads: WRONG numbers) and the in-kernel stamps exist in diagnostic builds only
+        // (make EXTRA=-DSPA_DIAG): a stray SPA_GEMM16_STAGGER cannot select them in the production library
         else if (diag == 1) G16S_LAUNCH(1, 2);
         else if (diag == 2) G16S_LAUNCH(1, 4);
         else if (diag == 3) G16S_LAUNCH(1, 6);
         else if (diag == 4) { if (rs == 2) G16S_LAUNCH(2, 16); else G16S_LAUNCH(1, 16); }
         else if (diag == 5) G16S_LAUNCH(1, 18);
         else G16S_LAUNCH(1, 20);
+#else
+        else SPA_ARG(!"SPA_GEMM16_STAGGER >= 8 selects a diagnostic form of the GEMM: build libspalign with EXTRA=-DSPA_DIAG");
+#endif
 #undef G16S_LAUNCH
         SPA_LAUNCH_CHECK();
         return SPA_OK;

@@ -629,14 +629,30 @@ class DRN(nn.Module):
                E['own_conv32'], E['winograd'], id(eng), self.use_fused_stem,
                tuple(os.environ.get(k) for k in ('SPA_WINO_MIN_CIN', 'SPA_GEMM16_STAGGER', 'SPA_CONV16_STAGGER', 'SPA_C32_LATE_PREFETCH')))
         cache = self.__dict__.setdefault('_graphs', {})
+        # a captured launch holds the addresses of libspalign's workspaces (packed stem weights, the zero line, ...): when one of
+        # them has been re-allocated since (another model or a larger shape on the same context), every graph is stale
+        gen = eng.ws_generation()
+        if self.__dict__.get('_graphs_gen') != gen:
+            cache.clear()
+            self._graphs_gen = gen
         ent = cache.get(key)
         if ent is None:
-            if len(cache) >= 8:                     # (a graph keeps its activations: bound what a stream of odd shapes can pin)
+            # (a graph keeps its input and every activation of the forward: bound what a stream of odd shapes can pin — at most 8
+            # graphs and SPA_DRN_GRAPH_BYTES (default 8 GiB) of pinned activations, estimated at 40 x the input)
+            limit = int(os.environ.get('SPA_DRN_GRAPH_BYTES', str(8 << 30)))
+            need = 40 * x.numel() * 4
+            while cache and (len(cache) >= 8 or sum(e[4] for e in cache.values() if e) + need > limit):
                 cache.pop(next(iter(cache)))
-            ent = cache[key] = self._graph_capture(x, pick)
+            ent = self._graph_capture(x, pick)
+            if ent is not False:
+                ent = ent + (need,)
+            if eng.ws_generation() != gen:          # the capture's warm-up grew a workspace: graphs captured before it are stale
+                cache.clear()
+                self._graphs_gen = eng.ws_generation()
+            cache[key] = ent
         if ent is False:
             return pick(self._forward_chunk(x))
-        graph, g_in, g_out, delta = ent
+        graph, g_in, g_out, delta, _ = ent
         g_in.copy_(x)
         graph.replay()
         _epi_add(delta)

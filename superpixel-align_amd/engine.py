@@ -96,6 +96,10 @@ class Engine(object):
             msgs = [m for bit, m in _lib.STATUS_BITS.items() if st & bit]
             raise SpalignError('device status 0x%x: %s' % (st, '; '.join(msgs)))
 
+    def ws_generation(self):
+        """re-allocations of the context's workspaces so far (a captured graph is valid while this does not change)"""
+        return int(self._lib.spa_ws_generation(self._ctx))
+
     def debug_set(self, key, value):
         """diagnostic kernel-selection switches (include/spalign.h: spa_debug_set); key 1 = planes-in-LDS kernel for the narrow
         split-plane 3x3 layers (1, default) or the kernel it replaced (0)"""

@@ -148,3 +148,48 @@ def test_default_descriptors_against_a_float32_pytorch_cpu_forward(mods, orc, sy
     print('default path vs float32 PyTorch-CPU: %d descriptors, worst per-descriptor relative error %.2e (median %.2e)'
           % (n, float(err.max()), float(np.median(err))))
     assert float(err.max()) <= TOL, float(err.max())
+
+
+def _pool64(fmap64, labels, n):
+    """float64 mean pooling with nearest sampling (notebooks/Superpixel_Align.ipynb cell 4 on the map sampled at (y // 8, x // 8)):
+    X[s, c] = sum_cells count[s, cell] * F[c, cell] / pixels(s), everything in float64 (the yardstick, not the oracle's float32 sums)."""
+    import scipy.sparse as sp
+    C, fh, fw = fmap64.shape
+    Hh, Ww = labels.shape
+    yy, xx = np.meshgrid(np.arange(Hh) * fh // Hh, np.arange(Ww) * fw // Ww, indexing='ij')
+    cell = (yy * fw + xx).ravel()
+    M = sp.coo_matrix((np.ones(cell.size), (labels.ravel().astype(np.int64), cell)), shape=(n, fh * fw)).tocsr()
+    tot = np.asarray(M.sum(axis=1)).ravel()
+    return np.asarray(M @ fmap64.reshape(C, fh * fw).T) / tot[:, None]
+
+
+@pytest.mark.parametrize('arch', ['drn_d_22', 'drn_c_26'])
+def test_elementwise_descriptor_error_against_a_float64_network(mods, synth, tmp_path, arch):
+    """north_star says "pooled feature vectors within 1e-4 relative" without naming the norm.  Per descriptor
+    (max norm) the split planes are 1e-5 from float32 instructions (test above); ELEMENT by element (elements >= 1e-3 of their row) the
+    two differ by up to 2e-4 on hostile weights.  Whose error is that?  A float64 forward of the same hostile float32 weights
+    (unfolded BatchNorm, PyTorch CPU, no library convolution in float32 anywhere) pooled in float64 is the yardstick: the
+    element-wise error of (a) the split planes and (b) float32 matrix instructions against it, full size.  Asserted: (a) <= 2 x (b)
+    + 1e-6 — the element-wise deviation between the two arithmetics is float32's own rounding noise on small elements of a
+    descriptor, not something the planes add."""
+    path = _hostile_pth(mods.drn, arch, str(tmp_path / (arch + '-hostile.pth')))
+    imgs = synth.synth_batch([31], H, W)
+    s = _run(mods, arch, path, imgs, split=True)
+    r = _run(mods, arch, path, imgs, split=False)
+    assert np.array_equal(s.labels, r.labels) and s.N == r.N
+    ref_model = mods.drn.DRN(arch, bn_eps=mods.drn.CHAINER_BN_EPS, with_fc=True).double()
+    ref_model.load_state_dict({k: v.double() for k, v in torch.load(path).items()}, strict=False)
+    ref_model.eval()
+    with torch.no_grad():
+        f64 = ref_model.forward_maps(mods.drn.DRN.normalise(torch.from_numpy(imgs)).double())[7][0].numpy()
+    X64 = _pool64(f64, s.labels[0], s.N)
+    big = np.abs(X64) >= 1e-3 * np.abs(X64).max(axis=1, keepdims=True)
+    out = {}
+    for name, X in (('split planes', s.X), ('float32 instructions', r.X)):
+        d = np.abs(X[:, :512].astype(np.float64) - X64)
+        out[name] = (float((d[big] / np.abs(X64)[big]).max()), float((d.max(axis=1) / np.abs(X64).max(axis=1)).max()))
+    print('%s hostile weights, 1024 x 2048, %d descriptors, against the float64 network: worst ELEMENT (>= 1e-3 of its row) relative '
+          'error: split planes %.2e, float32 instructions %.2e; worst per-descriptor (max norm): %.2e / %.2e'
+          % (arch, s.N, out['split planes'][0], out['float32 instructions'][0], out['split planes'][1], out['float32 instructions'][1]))
+    assert out['split planes'][0] <= 2.0 * out['float32 instructions'][0] + 1e-6, out
+    assert out['split planes'][1] <= TOL

@@ -2,7 +2,7 @@
 """Development aid (round 5): in-kernel stamps of the staggered GEMM (k_gemm_f16x3_stag<..., XP & 16>): per period and wave (0 =
 early half, 4 = late half) the cycles between the stamps  0 top | 1 staged (early) | 2 R done | 3 late's wait done | 4 mid
 barrier passed | 5 M done | 6 end wait done | 7 end barrier passed.
-    SPA_GEMM16_STAGGER=33 python tools/gemm16_stamps.py        (32 + RS: stamps of the production form, RS = 1 or 2; 41: no split, 49: no loads)"""
+    (libspalign built with make EXTRA=-DSPA_DIAG)   SPA_GEMM16_STAGGER=33 python tools/gemm16_stamps.py        (32 + RS: stamps of the production form, RS = 1 or 2; 41: no split, 49: no loads)"""
 import ctypes, importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
