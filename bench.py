@@ -119,6 +119,13 @@ LIMITERS = {
                                    'with the split riding between them) + ~350 cycles of waits and barriers, the two waves\' matrix phases back to back: '
                                    '~68 % of the cycles multiply.  Timing-only ablations: no split 3.30 ms, no global loads 3.20, neither 2.49 '
                                    '(1.4 PFLOP/s) against 3.35-3.42 as shipped (512 -> 512, 30 images); round 3\'s lock-step kernel 3.70',
+    'k_conv3x3_p16': 'the staging, not the matrix pipe (round 6, csrc/spa_convp.hip; in-kernel stamps, tools/convp_stamps.py): planes built once per staged '
+                     'segment in place in LDS, one barrier per group of three taps, every LDS read between matrix instructions — a group of 72 matrix '
+                     'instructions per wave is ~5 000 cycles for 2 304 cycles of matrix work per SIMD: the tap that carries the 7-8 LDS-DMA instructions '
+                     'per wave takes 1 450-1 900 cycles (~100 cycles each, both waves of a SIMD staging at once), the tap beside the fragment reads of '
+                     'the next 840-1 650, the third runs at the matrix rate (760); matrix pipe 44-52 % busy (was 29-40 % in k_conv3x3_f32<split>, '
+                     'same bits: 64 -> 64 1.32 -> 1.11 ms, 128 -> 128 1.19 -> 0.99 ms per 30 images alone); fewer staged bytes per matrix '
+                     'instruction needs a 128 x 256 tile, which three segment buffers leave no LDS for',
     'k_conv3x3_f32<split>(all)': 'instruction issue, not the matrix pipe (SQ counters, profiles/r3_sq_counters_drn_split.txt): a K step of these '
                                  'narrow layers is 12-24 matrix instructions per wave next to 4-5 other vector and ~5 scalar instructions per '
                                  'matrix instruction (split of the pixels, staging addresses, scalar state spilled to vector lanes); matrix pipe busy '
@@ -561,7 +568,7 @@ def main():
                        frac=round(tf / FP32_MATRIX_PEAK_TF, 4), flops_per_step=fl / a.steps, flops_per_launch=fl / nl,
                        hbm_bytes_per_launch_by_construction=int(by / nl),
                        traffic=pmc_traffic('k_conv3x3_f32<taps 1>(GEMM form, all)', B, H, W, by / nl))
-        elif name.startswith('k_conv3x3_f32<split') or name.startswith('split-plane front'):
+        elif name.startswith('k_conv3x3_f32<split') or name.startswith('k_conv3x3_p16') or name.startswith('split-plane front'):
             # the direct split-plane kernels, one entry per instantiation (= one rocprofv3 row): the 64- / 128- / 256-channel tiles of
             # the stride-1 3x3 layers, the 1x1 projections, and the front (stride-2 openers with their projections, layer 2, DRN-C's
             # layers 1-2) — on the 16-bit matrix cores (three half-precision products per float32 product): executed FLOPs against
@@ -577,7 +584,7 @@ def main():
                        flops_per_step=3 * fl / a.steps, flops_per_launch=3 * fl / nl,
                        algorithmic_bytes_per_launch=int(by / nl),
                        achieved_hbm_GBs=round(gbs, 1), hbm_frac=round(gbs / HBM_PEAK_GBS, 4))
-            ent['limiter'] = LIMITERS.get('k_conv3x3_f32<split>(all)')
+            ent['limiter'] = LIMITERS.get('k_conv3x3_p16' if name.startswith('k_conv3x3_p16') else 'k_conv3x3_f32<split>(all)')
         elif name.startswith('k_gemm_f16x3'):
             # the Winograd GEMMs on the 16-bit matrix cores at float32 accuracy: every product of the float32 GEMM is three
             # half-precision matrix products (csrc/spa_gemm16.hip).  achieved = EXECUTED half-precision FLOPs (3 x the

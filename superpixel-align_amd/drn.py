@@ -516,6 +516,9 @@ class DRN(nn.Module):
             layer = getattr(self, 'layer%d' % i)
             x = plain(layer, x) if (self.arch == 'D' and i in (1, 2, 7, 8)) else layer(x)
             maps.append(x)
+            hook = self.__dict__.get('_layer_hook')
+            if hook is not None:
+                hook(i)                            # (LabelPipeline: work for another stream enqueued once layer i is in the queue)
         return maps
 
     def forward(self, x):

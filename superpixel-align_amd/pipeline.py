@@ -445,13 +445,35 @@ class LabelPipeline(object):
             # superpixel branch on the auxiliary stream; it also waits for the previous batch's
             # consumers of the shared workspaces, which ran on the main stream
             self.aux.wait_stream(main)
-            with torch.cuda.stream(self.aux):
-                self._tick('sp_start')
-                labels, n_labels = self.superpixels(imgs_dev)
-                self._tick('superpixel')
+            box = {}
+
+            def start_sp(after_layer=None):
+                if box:
+                    return
+                if after_layer is not None:
+                    ev = torch.cuda.Event()
+                    ev.record(main)                  # the forward up to and including that layer
+                    self.aux.wait_event(ev)
+                with torch.cuda.stream(self.aux):
+                    self._tick('sp_start')
+                    box['sp'] = self.superpixels(imgs_dev)
+                    self._tick('superpixel')
+            # SPA_SP_AFTER_LAYER = n: the superpixel branch starts when layer n of the forward has run (beside the Winograd layers
+            # instead of beside the network's front); unset: at once
+            after = int(os.environ.get('SPA_SP_AFTER_LAYER', '0'))
+            if after > 0 and self.model is not None:
+                self.model._layer_hook = lambda i: start_sp(i) if i == after else None
+            else:
+                start_sp()
             # enqueue the DRN forward BEFORE anything on the aux branch can block the host
             # (anchor mode synchronises the aux stream to draw the anchors on the host)
-            fmap = self.features(imgs_dev)
+            try:
+                fmap = self.features(imgs_dev)
+            finally:
+                if after > 0 and self.model is not None:
+                    self.model._layer_hook = None
+            start_sp()                               # (a forward that never passed the hook, e.g. a replayed graph)
+            labels, n_labels = box['sp']
             self._tick('features')
             with torch.cuda.stream(self.aux):
                 seg = self.segments(imgs_dev.shape, labels, n_labels)
