@@ -51,7 +51,7 @@ __device__ __forceinline__ void g16_lds_barrier()
 }
 
 template <int BM, int BN>
-__global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3(const char *__restrict__ X, const char *__restrict__ Wt,
+__global__ __launch_bounds__(G16_THREADS, (BM == 256 && BN == 128) ? 3 : 2) void k_gemm_f16x3(const char *__restrict__ X, const char *__restrict__ Wt,
                                                             float *__restrict__ Y, int rows_per_z, int Cin, int Cout,
                                                             int ntiles, int total_tiles, int zcount, long long xz,
                                                             long long wz, long long yz, const unsigned *__restrict__ amax)
@@ -485,7 +485,9 @@ int gemm_f16x3_raw(spa_ctx *ctx, const float *x, long long rows, int32_t Cin, co
     hipStream_t s = spa_stream(stream);
     static const int force_tile = getenv("SPA_GEMM16_TILE") ? atoi(getenv("SPA_GEMM16_TILE")) : 0;      // experiments: 128
     const int bm = (Cout % 256 == 0 && force_tile != 128) ? 256 : 128;
-    const int bn = bm == 256 ? 256 : 128;
+    // (SPA_GEMM16_TILE=2128, round 6 experiment: 256 channels x 128 rows, two LDS stages of 48 KB, <= 168 registers per wave —
+    // room for a third wave per SIMD from another kernel, tools/coresidency_probe.py)
+    const int bn = (bm == 256 && force_tile != 2128) ? 256 : 128;
     const int ntiles = Cout / bm;
     const long long total = rows / bn * ntiles;
     SPA_ARG(total < (1ll << 31));
@@ -493,6 +495,7 @@ int gemm_f16x3_raw(spa_ctx *ctx, const float *x, long long rows, int32_t Cin, co
     if (!ctx->gemm16_attr_done) {
         SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3<256, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
         SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 128));
+        SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3<256, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 384 * 128));
         ctx->gemm16_attr_done = 1;
     }
     SpaProfScope prof_(ctx, bm == 256 ? PROF_DRN_GEMM16 : PROF_DRN_GEMM16_N, s);
@@ -505,6 +508,12 @@ int gemm_f16x3_raw(spa_ctx *ctx, const float *x, long long rows, int32_t Cin, co
     // diagnostic builds of the RS = 1 form (timing only unless stamps alone): + 8 no split, + 16 no global loads, + 32 in-kernel
     // stamps (tools/gemm16_stamps.py; RS = 1 or 2)
     static const int stagger = getenv("SPA_GEMM16_STAGGER") ? atoi(getenv("SPA_GEMM16_STAGGER")) : 3;
+    if (bm == 256 && bn == 128) {
+        hipLaunchKernelGGL((k_gemm_f16x3<256, 128>), dim3((unsigned)grid), dim3(G16_THREADS), lds, s, (const char *)x, (const char *)wt, y,
+                           (int)rows, Cin, Cout, ntiles, (int)total, zcount, rows * Cin, (long long)Cout * Cin, rows * Cout, (const unsigned *)amax);
+        SPA_LAUNCH_CHECK();
+        return SPA_OK;
+    }
     if (stagger && bm == 256) {
         if (!ctx->gemm16s_attr_done) {
 #define G16S_ATTR(RS, XP) SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, RS, XP>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128 + ((XP) & 16 ? 4096 : 0)))

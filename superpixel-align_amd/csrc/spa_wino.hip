@@ -323,52 +323,52 @@ __global__ __launch_bounds__(256) void k_amax(const float4 *__restrict__ x, long
 }
 
 // k_wino4_out for the scaled GEMMs: M[i][j] * cs[i][j] * 2^(e - 14); optionally the maximum of what it stores
-template <int HAS_RES>
+template <int HAS_RES, typename V = float4>
 __global__ __launch_bounds__(256, 2) void k_wino4_out_s(const float *__restrict__ M, float *__restrict__ Y,
                                                      const float *__restrict__ bias, const float *__restrict__ R,
                                                      WinoGeom g, int K, long long Tpad, int relu, WinoScale cs,
                                                      const unsigned *__restrict__ amax_in, unsigned *__restrict__ amax_out)
 {
-    const int k2 = K >> 2;
+    constexpr int VN = sizeof(V) / 4;       // channels per thread: 4 (the default) or 2 (SPA_WINO_VEC2: half the registers, round 6's co-residency probe)
+    const int k2 = K / VN;
     const long long id = wino_block() * 256 + threadIdx.x;
     unsigned mx = 0;
     if (id < g.T * k2) {
         const long long t = id / k2;
-        const int k = (int)(id - t * k2) << 2;
+        const int k = (int)(id - t * k2) * VN;
         int b, sy, sx, ty, tx;
         wino_tile(g, t, b, sy, sx, ty, tx);
         const float inv = wino_pow2(wino_amax_exp(*amax_in) - 14);
-        float4 s[4][6];
+        V s[4][6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-            float4 col[6];
+            V col[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i)
                 // M is read exactly once: non-temporal (1.66 instead of 1.70 ms per 30 images of a 512-channel layer)
-                col[i] = (cs.c[i * 6 + j] * inv) * wino_nt_load((const float4 *)(M + ((long long)(i * 6 + j) * Tpad + t) * K + k));
-            float4 o[4];
+                col[i] = (cs.c[i * 6 + j] * inv) * wino_nt_load((const V *)(M + ((long long)(i * 6 + j) * Tpad + t) * K + k));
+            V o[4];
             wino4_at(col, o);
 #pragma unroll
             for (int i = 0; i < 4; ++i) s[i][j] = o[i];
         }
-        const float4 bv = *(const float4 *)(bias + k);
+        const V bv = *(const V *)(bias + k);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int y = sy + (4 * ty + i) * g.d;
-            float4 o[4];
+            V o[4];
             wino4_at(s[i], o);
             if (y >= g.H) continue;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int x = sx + (4 * tx + j) * g.d;
                 if (x >= g.W) continue;
-                float4 v = o[j] + bv;
+                V v = o[j] + bv;
                 const long long off = (((long long)b * g.H + y) * g.W + x) * K + k;
-                if (HAS_RES) v = v + *(const float4 *)(R + off);
+                if (HAS_RES) v = v + *(const V *)(R + off);
                 if (relu) v = wino_relu(v);
-                *(float4 *)(Y + off) = v;
-                mx = max(max(mx, __float_as_uint(v.x) & 0x7fffffffu), max(__float_as_uint(v.y) & 0x7fffffffu,
-                         max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu)));
+                *(V *)(Y + off) = v;
+                mx = max(mx, wino_absmax_bits(v));
             }
         }
     }
@@ -478,16 +478,31 @@ extern "C" int spa_conv3x3_wino4_f16s(spa_ctx *ctx, const float *x, int32_t B, i
     WinoScale sc;
     for (int i = 0; i < 36; ++i) sc.c[i] = cs[i];
     if (amax_out) spa_zero_word(amax_out, s);
+    static const int vec2 = getenv("SPA_WINO_VEC2") ? atoi(getenv("SPA_WINO_VEC2")) : 0;      // 1: out, 2: in, 3: both transforms 2 channels per thread
     {
         SpaProfScope prof_(ctx, PROF_WINO_IN, s);
-        const long long n = g.T * (Cin / 4);
-        hipLaunchKernelGGL(k_wino4_in<float4>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, (float *)v_scratch, g, Cin, Tpad);
+        if (vec2 & 2) {
+            const long long n = g.T * (Cin / 2);
+            hipLaunchKernelGGL(k_wino4_in<float2>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, (float *)v_scratch, g, Cin, Tpad);
+        } else {
+            const long long n = g.T * (Cin / 4);
+            hipLaunchKernelGGL(k_wino4_in<float4>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, (float *)v_scratch, g, Cin, Tpad);
+        }
     }
     {
         int rc = gemm_f16x3_raw(ctx, (const float *)v_scratch, Tpad, Cin, u2, Cout, m_scratch, stream, 36, amax_in);
         if (rc != SPA_OK) return rc;
     }
-    {
+    if (vec2 & 1) {
+        SpaProfScope prof_(ctx, PROF_WINO_OUT, s);
+        const long long n = g.T * (Cout / 2);
+        if (residual)
+            hipLaunchKernelGGL((k_wino4_out_s<1, float2>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float *)m_scratch, y,
+                               bias, residual, g, Cout, Tpad, relu, sc, (const unsigned *)amax_in, (unsigned *)amax_out);
+        else
+            hipLaunchKernelGGL((k_wino4_out_s<0, float2>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float *)m_scratch, y,
+                               bias, residual, g, Cout, Tpad, relu, sc, (const unsigned *)amax_in, (unsigned *)amax_out);
+    } else {
         SpaProfScope prof_(ctx, PROF_WINO_OUT, s);
         const long long n = g.T * (Cout / 4);
         if (residual)

@@ -16,6 +16,10 @@ __device__ __forceinline__ void wino_tile(const WinoGeom &g, long long t, int &b
     b = (int)(t / g.d);
 }
 
+typedef float wino_v2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 wino_nt_load(const float2 *p) { const wino_v2 v = __builtin_nontemporal_load((const wino_v2 *)p); return make_float2(v[0], v[1]); }
+__device__ __forceinline__ unsigned wino_absmax_bits(float2 v) { return max(__float_as_uint(v.x) & 0x7fffffffu, __float_as_uint(v.y) & 0x7fffffffu); }
+__device__ __forceinline__ unsigned wino_absmax_bits(float4 v) { return max(max(__float_as_uint(v.x) & 0x7fffffffu, __float_as_uint(v.y) & 0x7fffffffu), max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu)); }
 __device__ __forceinline__ float2 operator+(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 operator-(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 operator*(float s, float2 a) { return make_float2(s * a.x, s * a.y); }

@@ -4,7 +4,7 @@
 #   2. rocprofv3 --kernel-trace --stats of the default bench    -> gpurun_out/final_stats/
 #   3. HBM traffic PMC passes (FETCH_SIZE, WRITE_SIZE; separate passes) over tools/prof_stages.py
 #   4. the other operating points (one JSON line each)          -> gpurun_out/final_variant_*.json
-# then, in the build container:  python tools/write_profiles.py r4_final
+# then, in the build container:  python tools/write_profiles.py r6_final
 export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/final_stats gpurun_out/final_pmc_* gpurun_out/final_variant_*
