@@ -473,6 +473,206 @@ __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3_stag(const char *__r
     }
 }
 
+// Round 6: the PIPELINED form.  One barrier per K step and nothing in front of the matrix instructions: while step q multiplies out
+// of registers, the same wave reads step q's weight fragments one channel block ahead (i-outer order: a block's two fragments die
+// after its 12 matrix instructions), reads the raw float32 rows of step q + 1 and splits them into the planes of step q + 1 (a row
+// fragment at a time: 8 transient registers), and stages weights(q + 1) and rows(q + 2) by LDS-DMA — all between matrix instructions,
+// order pinned by scheduling barriers.  Buffers: two weight tiles (weights(q) are read during step q, weights(q + 1) land meanwhile)
+// and two row tiles (rows(q + 1) are read during step q, rows(q + 2) land meanwhile in the buffer rows(q) left during step q - 1):
+// the same 128 KB.  Registers: accumulators 128, planes of steps q and q + 1 32 + 32, weight fragments 8 + 8, raw rows 8.
+// Every accumulator still receives l.h, h.l, h.h of K step after K step in ascending order: the same bits as k_gemm_f16x3(_stag).
+template <int BM, int BN>
+__global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3_pipe(const char *__restrict__ X, const char *__restrict__ Wt,
+                                                                 float *__restrict__ Y, int rows_per_z, int Cin, int Cout,
+                                                                 int ntiles, int total_tiles, int zcount, long long xz,
+                                                                 long long wz, long long yz, const unsigned *__restrict__ amax)
+{
+    static_assert(BM == 256 && BN == 256, "one shape");
+    extern __shared__ __attribute__((aligned(1024))) char lds16[];   // [2] weight tiles | [2] row tiles, 128 bytes per row
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int all_i = zcount * total_tiles, gstep = (int)gridDim.x;
+    const int nwg = total_tiles;
+    float sb;
+    {
+        const unsigned bits = *amax;
+        int e = (int)(bits >> 23) - 127;
+        e = e < -100 ? -100 : (e > 100 ? 100 : e);
+        sb = __uint_as_float((unsigned)(127 + 14 - (bits == 0u ? 0 : e)) << 23);
+    }
+    struct Pos { int r0, n0, zz; float zscale; };
+    auto locate = [&](int vid) {
+        Pos p;
+        const int z = vid / total_tiles;
+        const int zi = z / 6, zj = z - zi * 6;
+        const int psum = ((0x433444 >> (4 * zi)) & 15) + ((0x433444 >> (4 * zj)) & 15);
+        int id = vid - z * total_tiles;
+        {
+            const int q = nwg / 8, rem = nwg % 8, xcd = id % 8, idx = id / 8;
+            id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+        }
+        const int nt = id % ntiles, pt = id / ntiles;
+        p.zz = __builtin_amdgcn_readfirstlane(z);
+        p.r0 = __builtin_amdgcn_readfirstlane(pt * BN);
+        p.n0 = __builtin_amdgcn_readfirstlane(nt * BM);
+        p.zscale = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(sb * __uint_as_float((unsigned)(127 - psum) << 23))));
+        return p;
+    };
+    constexpr int WN = 4, MI = 8, NJ = 4, WROWS = MI * 16;
+    char *const wbuf = lds16, *const xbuf = lds16 + 2 * (BM * 128);
+    const int sub = lane >> 3, cs = lane & 7;
+    const int chunk_byte = (cs ^ sub) << 4;
+    const int nk = Cin / 32;
+    const unsigned lane_off = (unsigned)((wave * 8 + sub) * Cin * 4 + chunk_byte);
+    if ((int)blockIdx.x >= all_i) return;
+    const int my_tiles = (all_i - (int)blockIdx.x + gstep - 1) / gstep;
+    const int S = my_tiles * nk;                                    // K steps of this workgroup
+
+    // cursors: the tile of the step being multiplied (cur), its successor (nxt); the weight stage cursor is one step ahead of the
+    // multiplying one, the row stage cursor two, the split cursor one: each only ever sits in cur or nxt (nk >= 2)
+    Pos cur = locate((int)blockIdx.x), nxt = cur;
+    int nxt_vid = (int)blockIdx.x + gstep;
+    if (nxt_vid < all_i) nxt = locate(nxt_vid);
+    int c_t = 0;
+    auto at = [&](int ahead, int &t_out) -> const Pos & {
+        const int t = c_t + ahead;
+        if (t < nk) { t_out = t; return cur; }
+        t_out = t - nk;
+        return nxt;
+    };
+    auto stage_w = [&](int ahead, int buf) {
+        int t;
+        const Pos &p = at(ahead, t);
+        const char *wk = Wt + ((long long)p.zz * wz + (long long)p.n0 * Cin) * 4 + (long long)t * 128;
+        char *dw = wbuf + buf * (BM * 128) + wave * 1024;
+#pragma unroll
+        for (int r = 0; r < BM / 64; ++r)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wk + (long long)r * 64 * Cin * 4 + lane_off),
+                                             (__attribute__((address_space(3))) void *)(dw + r * 8192), 16, 0, 0);
+    };
+    auto stage_x = [&](int ahead, int buf) {
+        int t;
+        const Pos &p = at(ahead, t);
+        const char *xk = X + ((long long)p.zz * xz + (long long)p.r0 * Cin) * 4 + (long long)t * 128;
+        char *dx = xbuf + buf * (BN * 128) + wave * 1024;
+#pragma unroll
+        for (int r = 0; r < BN / 64; ++r)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xk + (long long)r * 64 * Cin * 4 + lane_off),
+                                             (__attribute__((address_space(3))) void *)(dx + r * 8192), 16, 0, 0);
+    };
+    const int wm = wave / WN, wn = wave % WN;
+    const int frow = lane & 15, fk = lane >> 4;
+    const int w_h = (wm * WROWS + frow) * 128 + ((fk ^ (frow & 7)) << 4), w_l = (wm * WROWS + frow) * 128 + (((4 + fk) ^ (frow & 7)) << 4);
+    const int x_a = (wn * (NJ * 16) + frow) * 128 + (((2 * fk) ^ (frow & 7)) << 4), x_b = (wn * (NJ * 16) + frow) * 128 + (((2 * fk + 1) ^ (frow & 7)) << 4);
+
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    auto split_pair = [&](float x0, float x1, float sc, unsigned &l) {
+        unsigned h, lo;
+        asm("v_fma_mixlo_f16 %0, %2, %4, 0 op_sel_hi:[0,0,0]\n\t"
+            "v_fma_mixhi_f16 %0, %3, %4, 0 op_sel_hi:[0,0,0]\n\t"
+            "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+            : "=&v"(h), "=&v"(lo) : "v"(x0), "v"(x1), "s"(sc));
+        l = lo;
+        return h;
+    };
+
+    // ---- prologue: weights(0), rows(0), rows(1); the planes of step 0
+    stage_w(0, 0);
+    stage_x(0, 0);
+    if (S > 1) stage_x(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    g16_lds_barrier();
+    u32x4 hu[NJ], lu[NJ], hn[NJ], ln[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const f32x4 a = *(const f32x4 *)(xbuf + j * 2048 + x_a), b = *(const f32x4 *)(xbuf + j * 2048 + x_b);
+        unsigned l;
+        hu[j][0] = split_pair(a[0], a[1], cur.zscale, l); lu[j][0] = l;
+        hu[j][1] = split_pair(a[2], a[3], cur.zscale, l); lu[j][1] = l;
+        hu[j][2] = split_pair(b[0], b[1], cur.zscale, l); lu[j][2] = l;
+        hu[j][3] = split_pair(b[2], b[3], cur.zscale, l); lu[j][3] = l;
+    }
+    f32x4 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // (two steps per loop iteration with the two plane sets swapping roles: no register copies between steps)
+    auto kstep = [&](int q, u32x4 (&hu)[NJ], u32x4 (&lu)[NJ], u32x4 (&hn)[NJ], u32x4 (&ln)[NJ]) {
+        const bool s1 = q + 1 < S, s2 = q + 2 < S;
+        const char *lw = wbuf + (q & 1) * (BM * 128);
+        const char *lxn = xbuf + ((q + 1) & 1) * (BN * 128);              // rows of step q + 1
+        int tn;
+        const float scn = at(1, tn).zscale;                              // their scale
+        f16x8 wh0, wl0, wh1, wl1;                                          // weight fragments of channel blocks i (even: 0, odd: 1)
+        wh0 = *(const f16x8 *)(lw + w_h);
+        wl0 = *(const f16x8 *)(lw + w_l);
+        f32x4 ra, rb;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            // next block's weight fragments
+            if (i + 1 < MI) {
+                if (i & 1) { wh0 = *(const f16x8 *)(lw + (i + 1) * 2048 + w_h); wl0 = *(const f16x8 *)(lw + (i + 1) * 2048 + w_l); }
+                else { wh1 = *(const f16x8 *)(lw + (i + 1) * 2048 + w_h); wl1 = *(const f16x8 *)(lw + (i + 1) * 2048 + w_l); }
+            }
+            // rows of step q + 1: fragment j = i / 2 is read at even i and split behind the matrix instructions of blocks i, i + 1
+            if (s1 && (i & 1) == 0) { ra = *(const f32x4 *)(lxn + (i >> 1) * 2048 + x_a); rb = *(const f32x4 *)(lxn + (i >> 1) * 2048 + x_b); }
+            const f16x8 wh = (i & 1) ? wh1 : wh0, wl = (i & 1) ? wl1 : wl0;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const f16x8 phj = __builtin_bit_cast(f16x8, hu[j]), plj = __builtin_bit_cast(f16x8, lu[j]);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, phj, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, plj, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, phj, acc[i][j], 0, 0, 0);
+                if (s1 && j >= 2) {
+                    // element pair e of row fragment jn = i / 2: pairs 0, 1 behind block i even, 2, 3 behind block i odd
+                    const int jn = i >> 1, e = 2 * (i & 1) + (j - 2);
+                    const float x0 = e < 2 ? ra[2 * e] : rb[2 * e - 4], x1 = e < 2 ? ra[2 * e + 1] : rb[2 * e - 3];
+                    unsigned l;
+                    hn[jn][e] = split_pair(x0, x1, scn, l);
+                    ln[jn][e] = l;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // staging: weights of step q + 1 into the other weight tile, rows of step q + 2 into the tile rows(q) left a step ago
+            if (i == 0) { if (s1) stage_w(1, (q + 1) & 1); __builtin_amdgcn_sched_barrier(0); }
+            if (i == 1) { if (s2) stage_x(2, q & 1); __builtin_amdgcn_sched_barrier(0); }
+        }
+        bool stored = false;
+        if (c_t == nk - 1) {
+            // ---- a tile is complete: lane holds channels c..c+3 (c = tile channel base + (lane>>4)*4) of row (lane & 15)
+            float *e_y = Y + (long long)cur.zz * yz;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const long long row = (long long)cur.r0 + wn * (NJ * 16) + j * 16 + (lane & 15);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int c = cur.n0 + wm * WROWS + i * 16 + (lane >> 4) * 4;
+                    *(float4 *)(e_y + row * Cout + c) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                    acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            stored = true;
+            c_t = 0;
+            cur = nxt;
+            nxt_vid += gstep;
+            if (nxt_vid < all_i) nxt = locate(nxt_vid);
+        } else ++c_t;
+        if (s1) {
+            // what this step staged has landed (a tile's stores, issued behind it, stay in flight); every wave has read the buffers of step q
+            if (stored) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MI * NJ) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            g16_lds_barrier();
+        }
+    };
+    for (int q = 0; q < S; q += 2) {
+        kstep(q, hu, lu, hn, ln);
+        if (q + 1 < S) kstep(q + 1, hn, ln, hu, lu);
+    }
+}
+
 // zcount = 36 problems  y[z] (rows, Cout) float32 = (scale_z x[z]) (rows, Cin) . wt[z]^T, wt[z] (Cout, Cin): x float32, wt in
 // the two-plane layout of the header (4 bytes per element); rows a multiple of 256, Cin a multiple of 32, Cout of 128;
 // amax: device word, bit pattern of a bound on the largest magnitude of the layer input (the scale's exponent)
@@ -492,11 +692,11 @@ int gemm_f16x3_raw(spa_ctx *ctx, const float *x, long long rows, int32_t Cin, co
     const long long total = rows / bn * ntiles;
     SPA_ARG(total < (1ll << 31));
     const size_t lds = 2 * (size_t)(bm + bn) * 128;
-    if (!ctx->gemm16_attr_done) {
+    if (!(ctx->gemm16_attr_done & 1)) {
         SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3<256, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
         SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 128));
         SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3<256, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 384 * 128));
-        ctx->gemm16_attr_done = 1;
+        ctx->gemm16_attr_done |= 1;
     }
     SpaProfScope prof_(ctx, bm == 256 ? PROF_DRN_GEMM16 : PROF_DRN_GEMM16_N, s);
     static const int force_per_cu = getenv("SPA_GEMM16_PER_CU") ? atoi(getenv("SPA_GEMM16_PER_CU")) : 0;
@@ -508,6 +708,17 @@ int gemm_f16x3_raw(spa_ctx *ctx, const float *x, long long rows, int32_t Cin, co
     // diagnostic builds of the RS = 1 form (timing only unless stamps alone): + 8 no split, + 16 no global loads, + 32 in-kernel
     // stamps (tools/gemm16_stamps.py; RS = 1 or 2)
     static const int stagger = getenv("SPA_GEMM16_STAGGER") ? atoi(getenv("SPA_GEMM16_STAGGER")) : 3;
+    static const int pipe = getenv("SPA_GEMM16_PIPE") ? atoi(getenv("SPA_GEMM16_PIPE")) : 0;
+    if (pipe && bm == 256 && bn == 256 && Cin >= 64) {
+        if (!(ctx->gemm16_attr_done & 2)) {
+            SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_pipe<256, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128));
+            ctx->gemm16_attr_done |= 2;
+        }
+        hipLaunchKernelGGL((k_gemm_f16x3_pipe<256, 256>), dim3((unsigned)grid), dim3(G16_THREADS), lds, s, (const char *)x, (const char *)wt, y,
+                           (int)rows, Cin, Cout, ntiles, (int)total, zcount, rows * Cin, (long long)Cout * Cin, rows * Cout, (const unsigned *)amax);
+        SPA_LAUNCH_CHECK();
+        return SPA_OK;
+    }
     if (bm == 256 && bn == 128) {
         hipLaunchKernelGGL((k_gemm_f16x3<256, 128>), dim3((unsigned)grid), dim3(G16_THREADS), lds, s, (const char *)x, (const char *)wt, y,
                            (int)rows, Cin, Cout, ntiles, (int)total, zcount, rows * Cin, (long long)Cout * Cin, rows * Cout, (const unsigned *)amax);
