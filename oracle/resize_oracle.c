@@ -16,7 +16,7 @@
  *   - horizontal pass over every input row, then vertical pass, each  clip8((2^21 + sum pixel * k) >> 22).
  * chainercv's Pillow branch would pass mode "F", which raises for the uint8 image the reference hands it,
  * so the reference itself ran its OpenCV branch (cv2.INTER_CUBIC): that variant cannot be pinned here
- * (no cv2 in the image, no fixture in the reference) — DESIGN.md section 7.2.
+ * (no cv2 in the image, no fixture in the reference) — DESIGN.md section 7.
  * Pinned by tests/golden/resize_*.npz (outputs of Pillow 8.4.0 itself).
  */
 #include <math.h>

@@ -1,7 +1,7 @@
 // Connectivity enforcement of SLIC labels on gfx950, bit exact with skimage's
 // _enforce_label_connectivity_cython (a sequential scan-order breadth-first relabelling).
 //
-// The sequential algorithm, restated as order-free facts (DESIGN.md "Connectivity"):
+// The sequential algorithm, restated as order-free facts (HISTORY.md section 4 has the long form):
 //   * without a max_size cut, the components it discovers are exactly the 4-connected
 //     components of equal input label, visited in order of their first pixel in raster
 //     order (the "seed" = minimum raster index of the component);

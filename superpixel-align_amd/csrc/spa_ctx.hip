@@ -277,7 +277,7 @@ int spa_aux_streams(spa_ctx *ctx)
 
 
 // ---------------------------------------------------------------------------------------
-// diagnostics (tools/lds_probe.py): a kernel shaped like the k_slic_assign variant of DESIGN.md section 5 — every workgroup
+// diagnostics (tools/lds_probe.py): a kernel shaped like the k_slic_assign variant of HISTORY.md section 5 (open items) — every workgroup
 // fills an LDS table with values computed by its threads, then every thread reads four consecutive floats of a row per loop
 // step (address in a vector register advanced by a vector add) and folds them with packed adds — whose result is a pure
 // function of (workgroup, thread).  Run beside another kernel on a second stream and compared with a run alone.

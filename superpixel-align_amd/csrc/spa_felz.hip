@@ -1442,7 +1442,7 @@ static int fz_run(spa_ctx *ctx, const float *rgb, int32_t B, int32_t H, int32_t 
     {
         // the persistent passes need every workgroup resident: at most n_cu images per launch
         // (one workgroup per image: 256 full-size images in one launch keep every CU busy — 64 per launch measured
-        // 12.6 ms per image amortised; SPA_FZ_MAXB for experiments)
+        // 12.6 ms per image amortised, see HISTORY.md section 7; SPA_FZ_MAXB for experiments)
         int maxB = ctx->n_cu < FZ_MAXB ? ctx->n_cu : FZ_MAXB;
         if (const char *e = getenv("SPA_FZ_MAXB")) { const int v = atoi(e); if (v > 0 && v < maxB) maxB = v; }
         if (B > maxB) {

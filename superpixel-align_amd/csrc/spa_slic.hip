@@ -1,6 +1,6 @@
 // SLIC on gfx950: rgb -> Lab, the Lloyd sweeps of skimage's _slic_cython, bit exact.
 //
-// What "bit exact" forces on the design (see DESIGN.md section "SLIC"):
+// What "bit exact" forces on the design ("Exactness"):
 //  * skimage instantiates the Cython core in float32 for a float32 image, and rounds after
 //    every operation (no FMA in its x86-64 wheels).  This file is compiled with
 //    -ffp-contract=off and spells every float32 operation in skimage's order.

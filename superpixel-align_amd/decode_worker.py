@@ -3,7 +3,7 @@ ResizeImageDataset / ZippedCityscapesRoadDataset decode one PNG per image on the
 
 Threads scale the decode itself (zlib releases the GIL) but every thread still runs PIL's Python-level chunk loop,
 and with 32 of them the main thread — which issues ~400 kernel launches per batch from Python — waits 40-100 ms per
-batch for the interpreter lock (measured).  Worker processes have their own interpreters: they
+batch for the interpreter lock (measured, HISTORY.md section 5).  Worker processes have their own interpreters: they
 decode straight into shared-memory slabs the parent has registered as pinned host memory, so a batch goes from PNG
 to the GPU with one asynchronous DMA and no copy in the parent.
 

@@ -100,7 +100,7 @@ class LabelPipeline(object):
         self._retry_info = None
         if os.environ.get('SPA_PIPE_OVERLAP') in ('0', '1'):
             overlap = os.environ['SPA_PIPE_OVERLAP'] == '1'
-        # (the second stream's queue priority, SPA_AUX_PRIORITY: see DESIGN.md section 5 for the A/B)
+        # (the second stream's queue priority, SPA_AUX_PRIORITY: see HISTORY.md section 5 for the A/B)
         prio = int(os.environ.get('SPA_AUX_PRIORITY', '0'))
         self.aux = torch.cuda.Stream(device=self.eng.device, priority=prio) if overlap else None
         # SPA_PIPE_TAIL_AUX=1 (mean pooling on two streams): everything but the DRN forward — superpixels, segment statistics
@@ -114,7 +114,7 @@ class LabelPipeline(object):
         # module scope), its outputs produced a batch ahead on a side stream, and no superpixel size visits the
         # host (spa_anchor_ranks_dev).  Off by default: the rejection sampling is one sequential pass over
         # ~1.4 stream outputs per pixel whatever runs it — 296 ms per 30 full-size images as one workgroup
-        # against 117 ms on a host core hidden under the DRN forward
+        # against 117 ms on a host core hidden under the DRN forward (HISTORY.md section 5)
         self.device_rng = bool(getattr(args, 'device_rng', False))
         self._rng_ready = False
         self._gen_stream = None

@@ -102,7 +102,7 @@ def test_pipeline_at_the_reference_operating_point_same_bits_with_and_without_gr
 
 
 def test_forty_batches_beside_the_superpixel_branch_graph_vs_eager(mods):
-    """The failure the 4-byte memset nodes produced needed a busy second stream and showed from the second
+    """The failure the 4-byte memset nodes produced (HISTORY.md section 5) needed a busy second stream and showed from the second
     replay on: forty batches of 128 x 256 through the two-stream pipeline and through HostStream (uploads / downloads on copy
     streams, the next forward under the previous tail), graph replays against the launch-by-launch forward, every batch's
     feature map, descriptors and masks bit for bit."""

@@ -1,5 +1,5 @@
 """A kernel that fills an LDS table and reads it back per lane (spa_debug_lds_probe), alone and beside the split-plane stem on a
-second stream: is its output the same?  (development aid for DESIGN.md section 5's finding)"""
+second stream: is its output the same?  (development aid for HISTORY.md section 5's finding; DESIGN.md section 7, open items)"""
 import importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
