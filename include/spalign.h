@@ -207,6 +207,11 @@ int spa_conv1x1_f16s(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t
 int spa_conv3x3_s2_f16s(spa_ctx *ctx, const float *x, int32_t B, int32_t Hi, int32_t Wi, int32_t Cin,
                         const void *wt2, float inv_t, int32_t Cout, int32_t csplit, const float *bias,
                         int32_t relu, const void *amax_in, void *amax_out, float *y, float *y2, void *stream);
+/* the same opener (+ projection) with float32 matrix instructions, for the strict float32 network (`--fp32_mfma_gemm`): wt (Cout,9,Cin)
+   float32, the projection's rows holding its weights at tap 4; no scales, no tracked maximum.  models/drn.py:195-206. */
+int spa_conv3x3_s2_f32(spa_ctx *ctx, const float *x, int32_t B, int32_t Hi, int32_t Wi, int32_t Cin,
+                       const float *wt, int32_t Cout, int32_t csplit, const float *bias,
+                       int32_t relu, float *y, float *y2, void *stream);
 
 /* spa_drn_stem_d with out_dtype 2 that also records the largest value it stores (device word amax_out), and layer 2 of
  * DRN-D (models/drn.py:134-145: conv3x3 16 -> 32, stride 2, padding 1, BN folded, ReLU) on the 16-bit matrix cores at float32
@@ -236,6 +241,10 @@ int spa_conv_small_f16s(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int3
                         void *stream);
 int spa_drn_layer2_f16s(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W, const void *wp, float inv_t,
                         const float *bias, const void *amax_in, void *amax_out, float *y, void *stream);
+/* layer 2 of DRN-D (models/drn.py:134-145) in plain float32 (fmaf chains in (tap, channel) order) for the strict float32 network:
+   x (B,H,W,16) float32 channels-last, w9 (9,16,32) float32 = (ky*3+kx, input channel, output channel), y (B,(H+1)/2,(W+1)/2,32). */
+int spa_drn_layer2_f32(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W, const float *w9,
+                       const float *bias, float *y, void *stream);
 
 /* ---- input stage ---------------------------------------------------------------------------
  * replaces the host resize of ResizeImageDataset.get_example (datasets/resize_image_dataset.py:31-34:

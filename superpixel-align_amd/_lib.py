@@ -78,6 +78,8 @@ PROTOTYPES = {
     'spa_drn_stem_c_amax': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     'spa_conv_small_f16s': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p, c_f32, c_i32, c_i32, c_i32, c_p, c_p, c_i32, c_p, c_p, c_p, c_p, c_p]),
     'spa_drn_layer2_f16s': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_p, c_f32, c_p, c_p, c_p, c_p, c_p]),
+    'spa_drn_layer2_f32': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p]),
+    'spa_conv3x3_s2_f32': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p, c_i32, c_i32, c_p, c_i32, c_p, c_p, c_p]),
     'spa_amax_f32': (ctypes.c_int, [c_p, c_p, c_i64, c_p, c_p]),
     'spa_conv3x3_wino4_f16s': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_i32, c_p, c_p, c_i32, c_i32, c_p, c_p, c_p, c_p, c_p, c_p]),
     'spa_resize_bicubic_u8': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p]),

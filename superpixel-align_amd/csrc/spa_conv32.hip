@@ -615,6 +615,52 @@ extern "C" int spa_conv3x3_s2_f16s(spa_ctx *ctx, const float *x, int32_t B, int3
     return SPA_OK;
 }
 
+// The same stride-2 opener (+ projection) with float32 matrix instructions (round 6: the strict float32 network, `--fp32_mfma_gemm`,
+// no longer hands these layers to the library): the non-split form of the kernel, wt (Cout, 9, Cin) float32 with the projection's rows
+// holding its weights at tap 4; no scales, no tracked maximum.
+extern "C" int spa_conv3x3_s2_f32(spa_ctx *ctx, const float *x, int32_t B, int32_t Hi, int32_t Wi, int32_t Cin,
+                                  const float *wt, int32_t Cout, int32_t csplit, const float *bias,
+                                  int32_t relu, float *y, float *y2, void *stream)
+{
+    SPA_ARG(ctx && x && wt && bias && y && B > 0 && Hi > 0 && Wi > 0);
+    SPA_ARG(Cin % C32_BK == 0 && Cout % 128 == 0 && csplit % 64 == 0 && csplit > 0 && csplit <= Cout && (y2 || csplit == Cout));
+    SPA_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)wt % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)y2 % 16) == 0 && ((uintptr_t)bias % 16) == 0);
+    hipStream_t s = spa_stream(stream);
+    char *zero;
+    int rc = spa_ws_reserve(ctx, WS_ZERO_LINE, 4096, (void **)&zero);
+    if (rc != SPA_OK) return rc;
+    if (!ctx->zero_line_ready) {
+        SPA_HIP(hipMemsetAsync(zero, 0, 4096, s));
+        ctx->zero_line_ready = 1;
+    }
+    const int H = (Hi + 1) / 2, W = (Wi + 1) / 2;
+    const int bm = Cout % 256 == 0 ? 256 : 128, bn = 128;
+    const int xtiles = (W + bn - 1) / bn, ntiles = Cout / bm;
+    const long long total = (long long)B * H * xtiles * ntiles;
+    SPA_ARG(total < (1ll << 31));
+    SPA_ARG((long long)(2 * W + 1024) * Cin * 4 < (1ll << 31));
+    const size_t lds = 2 * (size_t)bm * 128 + 2 * (size_t)(2 * bn + 2 * C32_HALO) * 128;
+    if (!(ctx->conv32_attr_done & 128)) {
+        SPA_HIP(hipFuncSetAttribute((const void *)k_conv3x3_f32<0, 256, 9, 128, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 128 + 2 * (256 + 2 * C32_HALO) * 128));
+        SPA_HIP(hipFuncSetAttribute((const void *)k_conv3x3_f32<0, 128, 9, 128, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * 128 + 2 * (256 + 2 * C32_HALO) * 128));
+        ctx->conv32_attr_done |= 128;
+    }
+    SpaProfScope prof_(ctx, PROF_DRN_CONV32, s);
+    const int per_cu = lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3);
+    long long grid = (long long)ctx->n_cu * per_cu;
+    if (grid > total) grid = total;
+    if (bm == 256)
+        hipLaunchKernelGGL((k_conv3x3_f32<0, 256, 9, 128, false, 2>), dim3((unsigned)grid), dim3(C32_THREADS), lds, s, x, wt, bias,
+                           (const float *)nullptr, y, (const char *)zero, B, H, W, Cin, Cout, 1, relu, xtiles, ntiles, (int)total, 1, 0ll, 0ll, 0ll, 0,
+                           (const unsigned *)nullptr, (unsigned *)nullptr, 1.f, Hi, Wi, y2, csplit);
+    else
+        hipLaunchKernelGGL((k_conv3x3_f32<0, 128, 9, 128, false, 2>), dim3((unsigned)grid), dim3(C32_THREADS), lds, s, x, wt, bias,
+                           (const float *)nullptr, y, (const char *)zero, B, H, W, Cin, Cout, 1, relu, xtiles, ntiles, (int)total, 1, 0ll, 0ll, 0ll, 0,
+                           (const unsigned *)nullptr, (unsigned *)nullptr, 1.f, Hi, Wi, y2, csplit);
+    SPA_LAUNCH_CHECK();
+    return SPA_OK;
+}
+
 // plain GEMMs for the Winograd path (spa_wino.hip): y (rows, Cout) = x (rows, Cin) . wt^T, wt (Cout, Cin); rows is a
 // multiple of 256 — the 1x1 form of the kernel on x seen as an image of 256-pixel rows, zero bias, no activation
 int conv1x1_f32_raw(spa_ctx *ctx, const float *x, long long rows, int32_t Cin, const float *wt, int32_t Cout,

@@ -755,6 +755,65 @@ extern "C" int spa_drn_layer2_f16s(spa_ctx *ctx, const float *x, int32_t B, int3
     return SPA_OK;
 }
 
+// Layer 2 in plain float32 (round 6: the strict float32 network, `--fp32_mfma_gemm`, on own kernels throughout): one thread per output
+// pixel, 32 accumulators, the 9 x 16 x 32 weights in LDS read as wave-wide broadcasts, every output an fmaf chain in (tap, channel)
+// order.  4 608 fused multiply-adds per pixel on the vector pipe: ~3 ms per 30 full-size images — the strict mode's step is 120 ms.
+// w9: (9 taps, 16 input channels, 32 output channels) float32
+__global__ __launch_bounds__(256) void k_drn_layer2_f32(const float *__restrict__ x, int B, int H, int W, int Ho, int Wo,
+                                                       const float4 *__restrict__ w9, const float *__restrict__ bias, float *__restrict__ y)
+{
+    __shared__ float4 lw[9 * 16 * 8];
+    for (int i = threadIdx.x; i < 9 * 16 * 8; i += 256) lw[i] = w9[i];
+    __syncthreads();
+    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (long long)B * Ho * Wo) return;
+    const int xo = (int)(id % Wo);
+    const long long t = id / Wo;
+    const int yo = (int)(t % Ho), b = (int)(t / Ho);
+    typedef float l2f2 __attribute__((ext_vector_type(2)));
+    l2f2 acc[16];                                   // (packed fmas: two output channels per instruction, each an IEEE fma)
+#pragma unroll
+    for (int n = 0; n < 16; ++n) acc[n] = (l2f2){bias[2 * n], bias[2 * n + 1]};
+    for (int tap = 0; tap < 9; ++tap) {
+        const int yy = 2 * yo - 1 + tap / 3, xx = 2 * xo - 1 + tap % 3;
+        if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+        const float4 *px = (const float4 *)(x + (((long long)b * H + yy) * W + xx) * 16);
+        const float4 v4[4] = {px[0], px[1], px[2], px[3]};
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const float v = c & 2 ? (c & 1 ? v4[c >> 2].w : v4[c >> 2].z) : (c & 1 ? v4[c >> 2].y : v4[c >> 2].x);
+            const l2f2 vv = {v, v};
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                const float4 wv = lw[(tap * 16 + c) * 8 + n];
+                acc[2 * n] = __builtin_elementwise_fma(vv, (l2f2){wv.x, wv.y}, acc[2 * n]);
+                acc[2 * n + 1] = __builtin_elementwise_fma(vv, (l2f2){wv.z, wv.w}, acc[2 * n + 1]);
+            }
+        }
+    }
+    float4 *o = (float4 *)(y + id * 32);
+#pragma unroll
+    for (int n = 0; n < 8; ++n)
+        o[n] = make_float4(fmaxf(acc[2 * n][0], 0.f), fmaxf(acc[2 * n][1], 0.f), fmaxf(acc[2 * n + 1][0], 0.f), fmaxf(acc[2 * n + 1][1], 0.f));
+}
+
+// x (B,H,W,16) float32 channels-last -> y (B,(H+1)/2,(W+1)/2,32) = relu(conv3x3 stride 2 padding 1 + bias), float32 throughout;
+// w9 (9,16,32) float32 = the weights as (ky*3+kx, input channel, output channel)
+extern "C" int spa_drn_layer2_f32(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W, const float *w9,
+                                  const float *bias, float *y, void *stream)
+{
+    SPA_ARG(ctx && x && w9 && bias && y && B > 0 && H > 0 && W > 0);
+    SPA_ARG((((uintptr_t)x | (uintptr_t)w9 | (uintptr_t)bias | (uintptr_t)y) & 15) == 0);
+    hipStream_t s = spa_stream(stream);
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const long long n = (long long)B * Ho * Wo;
+    SPA_ARG((n + 255) / 256 < (1ll << 31));
+    SpaProfScope prof_(ctx, PROF_DRN_CONV32, s);
+    hipLaunchKernelGGL(k_drn_layer2_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, B, H, W, Ho, Wo, (const float4 *)w9, bias, y);
+    SPA_LAUNCH_CHECK();
+    return SPA_OK;
+}
+
 // weights -> scaled half-precision planes in MFMA A fragment order (one workgroup of 64 lanes per step, the k orders of
 // k_stem_pack_bf16), and the scale factors.  Every block recomputes the three maxima (2 352 + 2 304 weights: cheap).
 __global__ __launch_bounds__(64) void k_stem_pack_f16(const float *__restrict__ w0, const float *__restrict__ b0,

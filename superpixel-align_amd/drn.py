@@ -236,6 +236,12 @@ def conv_bias_act(conv, bn, x, residual=None, relu=True):
             _EPILOGUE['conv16_launches'] += 1
             _c16('front', fl2, by2)
             return eng.drn_layer2_f16s(x, l2[0], l2[1], l2[2], amax_in=getattr(x, '_spa_amax', None))
+        l232 = getattr(conv, '_spa_layer2_32', None)
+        if (l232 is not None and not _EPILOGUE['split_gemm'] and _EPILOGUE['own_conv32'] and x.dtype == torch.float32 and relu
+                and residual is None and x.is_contiguous(memory_format=torch.channels_last)):
+            # the strict float32 network (float32 instructions everywhere): layer 2 as fmaf chains on the vector pipe
+            _EPILOGUE['conv_flops'] += 2.0 * x.shape[0] * ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2) * 32 * 9 * 16
+            return eng.drn_layer2_f32(x, l232[0], l232[1])
         _EPILOGUE['library_convs'] += 1               # (MIOpen picks its algorithm per call context: such a forward is not captured)
         if os.environ.get('SPA_DRN_TRACE_LIBRARY'):
             import sys
@@ -291,6 +297,13 @@ class BasicBlock(nn.Module):
             _c16('front', fl2, by2)
             y, res, am = eng.conv3x3_s2_f16s(x, s2[0], s2[1], s2[2], s2[3], True, amax_in=getattr(x, '_spa_amax', None))
             y._spa_amax = am
+            return conv_bias_act(self.conv2, self.bn2, y, res, True)
+        s232 = getattr(self, '_spa_s2_32', None)
+        if (s232 is not None and eng is not None and not _EPILOGUE['split_gemm'] and _EPILOGUE['own_conv32'] and x.is_cuda
+                and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)):
+            # the strict float32 network: the same one-pass opener + projection with float32 matrix instructions
+            _EPILOGUE['conv_flops'] += 2.0 * x.shape[0] * ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2) * s232[2] * 10 * x.shape[1]
+            y, res = eng.conv3x3_s2_f32(x, s232[0], s232[1], s232[2], True)
             return conv_bias_act(self.conv2, self.bn2, y, res, True)
         y = conv_bias_act(self.conv1, self.bn1, x, None, True)
         res = None
@@ -406,10 +419,14 @@ class DRN(nn.Module):
                     m._spa_packed32 = None
                     m._spa_packed16 = None
                     m._spa_layer2 = None
+                    m._spa_layer2_32 = None
                     if (dtype == torch.float32 and self.folded and m.kernel_size == (3, 3) and m.stride == (2, 2)
                             and m.padding == (1, 1) and m.dilation == (1, 1) and m.groups == 1 and m.in_channels == 16
                             and m.out_channels == 32 and m.bias is not None):
                         m._spa_layer2 = Engine.layer2_planes(m.weight) + (m.bias.detach().float().contiguous(),)
+                        # (the strict float32 network's form: (tap, input channel, output channel) float32)
+                        m._spa_layer2_32 = (m.weight.detach().float().permute(2, 3, 1, 0).reshape(9, 16, 32).contiguous(),
+                                            m.bias.detach().float().contiguous())
                     m._spa_wino = {}
                     # Winograd where it wins (measured, 30 x 128 x 256 pixels, ms direct / F(2x2) / F(4x4)):
                     #   512 -> 512  33.2 / 19.8 / 11.9     256 -> 512  16.8 / 11.6 / 7.0     256 -> 256  8.5 / 6.6 / 4.2
@@ -450,6 +467,7 @@ class DRN(nn.Module):
             for blk in self.modules():
                 if isinstance(blk, BasicBlock):
                     blk._spa_s2 = None
+                    blk._spa_s2_32 = None
                     c1, ds = blk.conv1, blk.downsample
                     if (dtype == torch.float32 and self.folded and blk.residual and ds is not None and c1.stride == (2, 2)
                             and c1.kernel_size == (3, 3) and c1.padding == (1, 1) and c1.dilation == (1, 1) and c1.bias is not None
@@ -461,6 +479,7 @@ class DRN(nn.Module):
                         w[co:, 4] = ds[0].weight.detach().float().reshape(co, ci)
                         wt2, inv_t = Engine.split_planes(w)
                         blk._spa_s2 = (wt2, inv_t, torch.cat([c1.bias.detach().float(), ds[0].bias.detach().float()]).contiguous(), co)
+                        blk._spa_s2_32 = (w.contiguous(), blk._spa_s2[2], co)      # the strict float32 network's operands
             self._front_c = None
             if self.arch == 'C' and self.folded and dtype == torch.float32:
                 # DRN-C's full-resolution front on libspalign's own kernels (csrc/spa_stem.hip, spa_convs.hip): conv1 + layer1's first

@@ -210,6 +210,33 @@ class Engine(object):
         y._spa_amax = am
         return y
 
+    def drn_layer2_f32(self, x, w9, bias):
+        """relu(conv3x3(x; 16 -> 32 channels, stride 2, padding 1) + bias) in plain float32 (the strict float32 network);
+        w9 (9,16,32) float32 = (tap, input channel, output channel)"""
+        B, C, H, W = x.shape
+        assert C == 16 and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
+        assert w9.dtype == torch.float32 and tuple(w9.shape) == (9, 16, 32) and w9.is_contiguous()
+        assert bias.dtype == torch.float32 and bias.numel() == 32 and bias.is_contiguous()
+        y = torch.empty((B, 32, (H + 1) // 2, (W + 1) // 2), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        check(self._lib.spa_drn_layer2_f32(self._ctx, _ptr(x), B, H, W, _ptr(w9), _ptr(bias), _ptr(y), self._s()))
+        return y
+
+    def conv3x3_s2_f32(self, x, wt, bias, csplit, relu=True):
+        """conv3x3_s2_f16s with float32 matrix instructions: wt (Cout,9,Cin) float32 (the projection's rows hold its weights at
+        tap 4).  Returns (y, y2 or None)."""
+        B, Cin, Hi, Wi = x.shape
+        Cout = wt.shape[0]
+        assert x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
+        assert wt.dtype == torch.float32 and wt.is_contiguous() and tuple(wt.shape) == (Cout, 9, Cin)
+        assert bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == Cout
+        Ho, Wo = (Hi + 1) // 2, (Wi + 1) // 2
+        y = torch.empty((B, csplit, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        y2 = torch.empty((B, Cout - csplit, Ho, Wo), dtype=torch.float32, device=x.device,
+                         memory_format=torch.channels_last) if csplit < Cout else None
+        check(self._lib.spa_conv3x3_s2_f32(self._ctx, _ptr(x), B, Hi, Wi, Cin, _ptr(wt), Cout, int(csplit), _ptr(bias),
+                                           1 if relu else 0, _ptr(y), _ptr(y2), self._s()))
+        return y, y2
+
     @staticmethod
     def small_planes(weight, proj_weight=None):
         """(Cout,Cin,3,3) [+ the block's 1x1 projection (Cp,Cin,1,1)] -> (wp, inv_t) for conv_small_f16s: the MFMA A fragments of
