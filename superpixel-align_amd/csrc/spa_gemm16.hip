@@ -302,6 +302,7 @@ __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3_stag(const char *__r
     static_assert(BM / WROWS * WN == 8, "8 waves");
     static_assert(MI * NJ <= 63, "vmcnt range");
     static_assert(RS >= 1 && RS <= NJ && MI == 8, "split schedule: 4 element pairs over 8 groups of matrix instructions");
+    constexpr bool EARLY_STORE = (XP & 8) != 0;   // (XP & 8, SPA_GEMM16_EARLY_STORE=1: round 6's experiment below; measured 7 % slower, not the default)
 
     char *wbuf = lds16, *xbuf = lds16 + 2 * (BM * 128);
     const int sub = lane >> 3, cs = lane & 7;
@@ -417,7 +418,19 @@ __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3_stag(const char *__r
         g16_lds_barrier();
         STAMP(4);
         // ---- M: row fragment by row fragment, small terms first (they meet the accumulator while it is small); the split of
-        // fragment j + RS rides between the matrix instructions of fragment j
+        // fragment j + RS rides between the matrix instructions of fragment j.
+        // Round 6 experiment (EARLY_STORE): in-kernel stamps put the burst of 32 stores per wave behind a tile's last K step (every wave
+        // of the workgroup within half a period of each other) at ~16 % of the kernel — periods that end a tile take 15-25 k cycles
+        // against a median of 4.3 k (3 072 of them matrix work).  Storing (and clearing) every accumulator one accumulator behind its
+        // final matrix instruction instead, between the matrix instructions of the last step, was measured 7 % SLOWER (1.07 -> 1.00
+        // PFLOP/s executed, same bits): a store between matrix instructions waits for its accumulator and breaks the matrix stream
+        // the way an LDS-DMA instruction does.  The burst stays.
+        const bool last_step = c_t + 1 == nk;
+        float *const e_y = Y + (long long)c_z * yz + ((long long)c_r0 + wn * (NJ * 16) + (lane & 15)) * Cout + (c_n0 + wm * WROWS + (lane >> 4) * 4);
+        auto store_acc = [&](int i, int j) {
+            *(float4 *)(e_y + (long long)(j * 16) * Cout + i * 16) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        };
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const f16x8 phj = __builtin_bit_cast(f16x8, hu[j]), plj = __builtin_bit_cast(f16x8, lu[j]);
@@ -427,22 +440,19 @@ __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3_stag(const char *__r
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], plj, acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], phj, acc[i][j], 0, 0, 0);
                 if (j + RS < NJ) { if ((i & 1) == 0) split_h(j + RS, i >> 1); else split_l(j + RS, i >> 1); }
+                if (EARLY_STORE && last_step && (i > 0 || j > 0)) { if (i > 0) store_acc(i - 1, j); else store_acc(MI - 1, j - 1); }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         STAMP(5);
         if (++c_t == nk) {
             // ---- a tile is complete: lane holds channels c..c+3 (c = tile channel base + (lane>>4)*4) of row (lane & 15)
-            float *e_y = Y + (long long)c_z * yz;
+            if (EARLY_STORE) store_acc(MI - 1, NJ - 1);
+            else {
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const long long row = (long long)c_r0 + wn * (NJ * 16) + j * 16 + (lane & 15);
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    const int c = c_n0 + wm * WROWS + i * 16 + (lane >> 4) * 4;
-                    *(float4 *)(e_y + row * Cout + c) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-                    acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                }
+                    for (int i = 0; i < MI; ++i) store_acc(i, j);
             }
             stored = true;
             c_t = 0; c_vid += gstep;
@@ -728,7 +738,7 @@ int gemm_f16x3_raw(spa_ctx *ctx, const float *x, long long rows, int32_t Cin, co
     if (stagger && bm == 256) {
         if (!ctx->gemm16s_attr_done) {
 #define G16S_ATTR(RS, XP) SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, RS, XP>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128 + ((XP) & 16 ? 4096 : 0)))
-            G16S_ATTR(1, 0); G16S_ATTR(2, 0); G16S_ATTR(3, 0); G16S_ATTR(4, 0);
+            G16S_ATTR(1, 0); G16S_ATTR(2, 0); G16S_ATTR(3, 0); G16S_ATTR(4, 0); G16S_ATTR(3, 8);
 #ifdef SPA_DIAG
             G16S_ATTR(1, 2); G16S_ATTR(1, 4); G16S_ATTR(1, 6); G16S_ATTR(1, 16); G16S_ATTR(2, 16); G16S_ATTR(1, 18); G16S_ATTR(1, 20);
 #endif
@@ -743,7 +753,9 @@ int gemm_f16x3_raw(spa_ctx *ctx, const float *x, long long rows, int32_t Cin, co
 #define G16S_LAUNCH(RS, XP) hipLaunchKernelGGL((k_gemm_f16x3_stag<256, 256, RS, XP>), dim3((unsigned)grid), dim3(G16_THREADS), lds + ((XP) & 16 ? 4096 : 0), s, (const char *)x, (const char *)wt, y, \
                                (int)rows, Cin, Cout, ntiles, (int)total, zcount, rows * Cin, (long long)Cout * Cin, rows * Cout, (const unsigned *)amax, dbg)
         const int rs = stagger & 7, diag = stagger >> 3;          // diag: 1 no split, 2 no loads, 4 stamps
-        if (diag == 0) { if (rs == 1) G16S_LAUNCH(1, 0); else if (rs == 2) G16S_LAUNCH(2, 0); else if (rs == 4) G16S_LAUNCH(4, 0); else G16S_LAUNCH(3, 0); }
+        static const int early_store = getenv("SPA_GEMM16_EARLY_STORE") ? atoi(getenv("SPA_GEMM16_EARLY_STORE")) : 0;
+        if (diag == 0 && early_store) G16S_LAUNCH(3, 8);
+        else if (diag == 0) { if (rs == 1) G16S_LAUNCH(1, 0); else if (rs == 2) G16S_LAUNCH(2, 0); else if (rs == 4) G16S_LAUNCH(4, 0); else G16S_LAUNCH(3, 0); }
 #ifdef SPA_DIAG
         // timing-only forms (no split / no global loads: WRONG numbers) and the in-kernel stamps exist in diagnostic builds only
         // (make EXTRA=-DSPA_DIAG): a stray SPA_GEMM16_STAGGER cannot select them in the production library
