@@ -302,6 +302,7 @@ __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3_stag(const char *__r
     static_assert(BM / WROWS * WN == 8, "8 waves");
     static_assert(MI * NJ <= 63, "vmcnt range");
     static_assert(RS >= 1 && RS <= NJ && MI == 8, "split schedule: 4 element pairs over 8 groups of matrix instructions");
+    constexpr bool LATE_PRESTAGE = (XP & 32) != 0;   // (XP & 32, SPA_GEMM16_LATE_PRESTAGE=1: round 6's experiment, no gain measured; off)
     constexpr bool EARLY_STORE = (XP & 8) != 0;   // (XP & 8, SPA_GEMM16_EARLY_STORE=1: round 6's experiment below; measured 7 % slower, not the default)
 
     char *wbuf = lds16, *xbuf = lds16 + 2 * (BM * 128);
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3_stag(const char *__r
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     g16_lds_barrier();
     if (late) g16_lds_barrier();                   // the extra barrier = half a period of delay
-    bool stored = false;
+    bool stored = false, pre_staged = false, late_stored = false;
 
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     f32x4 acc[MI][NJ];
@@ -366,7 +367,8 @@ __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3_stag(const char *__r
         const int buf = q & 1;
         if (XP & 16) stamp_q = (q >= G16_Q0 && q < G16_Q0 + G16_NQ) ? q - G16_Q0 : -1;
         STAMP(0);
-        stage_next();                              // step q + 1
+        if (!pre_staged) stage_next();             // step q + 1 (the late half stages it in front of a tile's stores: below)
+        pre_staged = false;
         STAMP(1);
         // ---- R: the LDS reads (weight fragments, raw float32 rows) and the split of the first RS row fragments
         const char *lw = wbuf + buf * (BM * 128), *lx = xbuf + buf * (BN * 128);
@@ -411,9 +413,16 @@ __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3_stag(const char *__r
 #pragma unroll
             for (int e = 0; e < 4; ++e) { split_h(j, e); split_l(j, e); }
         STAMP(2);
-        // the late half's share of step q + 1 (staged at the top of this period) must have landed before the early half reads it
-        // behind this barrier (its own stores of the period before are older and have long drained)
-        if (late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the late half's share of step q + 1 must have landed before the early half reads it behind this barrier.  Round 6 experiment
+        // (LATE_PRESTAGE): a tile's 256 KB of stores per workgroup take ~10 k cycles to drain and this `vmcnt(0)` half a period behind
+        // them holds the workgroup (stamps: periods of 15-25 k cycles at a tile's end against 4.3 k); with the late half staging this
+        // share IN FRONT of its stores the wait can leave them in flight — measured: no gain (1.04 against 1.05 PFLOP/s): the stall only
+        // moves to the next wait, a CU's memory pipe (1 MB of loads + 256 KB of stores per tile, ~18 B / cycle) is what the tile waits for
+        if (late) {
+            if (late_stored) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MI * NJ) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        late_stored = false;
         STAMP(3);
         g16_lds_barrier();
         STAMP(4);
@@ -447,6 +456,12 @@ __global__ __launch_bounds__(G16_THREADS) void k_gemm_f16x3_stag(const char *__r
         STAMP(5);
         if (++c_t == nk) {
             // ---- a tile is complete: lane holds channels c..c+3 (c = tile channel base + (lane>>4)*4) of row (lane & 15)
+            if (late && LATE_PRESTAGE) {
+                // (the buffer of step q + 2 = the buffer of step q, which both halves finished reading before this period's mid barrier)
+                stage_next();
+                pre_staged = true;
+                late_stored = true;
+            }
             if (EARLY_STORE) store_acc(MI - 1, NJ - 1);
             else {
 #pragma unroll
@@ -738,7 +753,7 @@ int gemm_f16x3_raw(spa_ctx *ctx, const float *x, long long rows, int32_t Cin, co
     if (stagger && bm == 256) {
         if (!ctx->gemm16s_attr_done) {
 #define G16S_ATTR(RS, XP) SPA_HIP(hipFuncSetAttribute((const void *)k_gemm_f16x3_stag<256, 256, RS, XP>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128 + ((XP) & 16 ? 4096 : 0)))
-            G16S_ATTR(1, 0); G16S_ATTR(2, 0); G16S_ATTR(3, 0); G16S_ATTR(4, 0); G16S_ATTR(3, 8);
+            G16S_ATTR(1, 0); G16S_ATTR(2, 0); G16S_ATTR(3, 0); G16S_ATTR(4, 0); G16S_ATTR(3, 8); G16S_ATTR(3, 32);
 #ifdef SPA_DIAG
             G16S_ATTR(1, 2); G16S_ATTR(1, 4); G16S_ATTR(1, 6); G16S_ATTR(1, 16); G16S_ATTR(2, 16); G16S_ATTR(1, 18); G16S_ATTR(1, 20);
 #endif
@@ -754,7 +769,9 @@ int gemm_f16x3_raw(spa_ctx *ctx, const float *x, long long rows, int32_t Cin, co
                                (int)rows, Cin, Cout, ntiles, (int)total, zcount, rows * Cin, (long long)Cout * Cin, rows * Cout, (const unsigned *)amax, dbg)
         const int rs = stagger & 7, diag = stagger >> 3;          // diag: 1 no split, 2 no loads, 4 stamps
         static const int early_store = getenv("SPA_GEMM16_EARLY_STORE") ? atoi(getenv("SPA_GEMM16_EARLY_STORE")) : 0;
+        static const int late_prestage = getenv("SPA_GEMM16_LATE_PRESTAGE") ? atoi(getenv("SPA_GEMM16_LATE_PRESTAGE")) : 0;
         if (diag == 0 && early_store) G16S_LAUNCH(3, 8);
+        else if (diag == 0 && late_prestage) G16S_LAUNCH(3, 32);
         else if (diag == 0) { if (rs == 1) G16S_LAUNCH(1, 0); else if (rs == 2) G16S_LAUNCH(2, 0); else if (rs == 4) G16S_LAUNCH(4, 0); else G16S_LAUNCH(3, 0); }
 #ifdef SPA_DIAG
         // timing-only forms (no split / no global loads: WRONG numbers) and the in-kernel stamps exist in diagnostic builds only
