@@ -92,7 +92,9 @@ int spa_debug_peek(spa_ctx *ctx, int which, size_t offset, size_t bytes, void *h
 int spa_ws_generation(spa_ctx *ctx);
 /* Diagnostics only: kernel selection switches for A/B runs inside one process (tests/test_gpu_conv.py).  key 1: the narrow
    split-plane 3x3 layers (Cout 64 / 128) on the planes-in-LDS kernel (value 1, the default; environment SPA_CONVP at context
-   creation) or on the round-3 kernel they replaced (value 0) — bit-identical outputs either way.  No counterpart in the reference. */
+   creation) or on the round-3 kernel they replaced (value 0) — bit-identical outputs either way.  key 2 (libraries built with
+   EXTRA=-DSPA_DIAG only): k_slic_assign's shelved LDS-table variant, the reproducer of the co-residency miscompare (DESIGN.md section 7,
+   tools/race_probe8.py) — never use it for results.  No counterpart in the reference. */
 int spa_debug_set(spa_ctx *ctx, int32_t key, int32_t value);
 /* diagnostics (tools/lds_probe.py): an LDS table filled and read back per lane, n_wg workgroups of 256 threads, out[n_wg][256][4];
    mode 0: 16-byte reads, 1: 4-byte reads, 2: broadcast reads.  No counterpart in the reference. */

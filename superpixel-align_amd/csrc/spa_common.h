@@ -120,6 +120,7 @@ struct spa_ctx {
     int zero_line_ready, conv_attr_done, conv32_attr_done, fz_attr_done, gemm16_attr_done, gemm16s_attr_done, nprng_attr_done, conv_stag_attr_done;
     int rng_seeded;
     int ws_generation;             // counts workspace re-allocations (spa_ws_generation: captured graphs hold workspace addresses)
+    int dbg_slic_ldsx;             // spa_debug_set key 2 (diagnostic builds: the reproducer variant of k_slic_assign)
     int convp_on;                  // spa_debug_set key 1 (spa_convp.hip instead of spa_conv32.hip's narrow tiles)
     int rs_key[4], rs_ks[2];       // bicubic tables held in WS_RESIZE_TAB: (H, W, h, w) and tap counts
 };

@@ -337,8 +337,15 @@ extern "C" int spa_ws_generation(spa_ctx *ctx) { return ctx ? ctx->ws_generation
 
 extern "C" int spa_debug_set(spa_ctx *ctx, int32_t key, int32_t value)
 {
-    SPA_ARG(ctx && key == 1 && (value == 0 || value == 1));
-    ctx->convp_on = value;
+    SPA_ARG(ctx && (key == 1 || key == 2) && (value == 0 || value == 1));
+    if (key == 1) ctx->convp_on = value;
+    else {
+#ifdef SPA_DIAG
+        ctx->dbg_slic_ldsx = value;
+#else
+        SPA_ARG(!"spa_debug_set key 2 (the reproducer variant of k_slic_assign) exists in diagnostic builds only: make EXTRA=-DSPA_DIAG");
+#endif
+    }
     return SPA_OK;
 }
 

@@ -220,6 +220,10 @@ __global__ void k_slic_init(uint32_t *__restrict__ cen, int nC, int grid_nx, int
 #define TILE 32
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// LDSX (diagnostic builds only, make EXTRA=-DSPA_DIAG; spa_debug_set(ctx, 2, 1)): round 4's shelved variant of the candidate loop — the x
+// part of the spatial term shared through an LDS table — kept as the REPRODUCER of the co-residency miscompare (DESIGN.md section 7,
+// tools/race_probe8.py): bit-identical alone, 50-700 wrong centre words per batch when a wave of a matrix-instruction kernel shares the CU.
+template <bool LDSX>
 __global__ __launch_bounds__(256) void k_slic_assign(const float *__restrict__ lab,
                                                      uint32_t *__restrict__ cen, int nC,
                                                      int H, int W, float sw,
@@ -229,6 +233,7 @@ __global__ __launch_bounds__(256) void k_slic_assign(const float *__restrict__ l
                                                      uint32_t *__restrict__ status)
 {
     __shared__ uint4 cand[256 * 3];
+    __shared__ __attribute__((aligned(16))) float cdx[LDSX ? 32 * TILE : 4];
     __shared__ int wave_cnt[4];
     const int b = blockIdx.z;
     const int ty0 = blockIdx.y * TILE, tx0 = blockIdx.x * TILE;
@@ -295,47 +300,100 @@ __global__ __launch_bounds__(256) void k_slic_assign(const float *__restrict__ l
             cand[pos * 3 + 2] = make_uint4(w2.x, w2.y, 0u, 0u);
         }
         __syncthreads();
-        if (row_ok) {
-            // straight-line body: the three 16-byte LDS reads of an entry are issued together and
-            // the window test is folded into the final comparison (no divergent branches), so the
-            // compiler can overlap the next entry's reads with this entry's arithmetic.  The
-            // float arithmetic runs on pixel pairs (v_pk_add_f32 / v_pk_mul_f32: two IEEE float32
-            // operations per instruction, each rounded exactly like the scalar one — no FMA).
+        if constexpr (LDSX) {
+            // (cx - x)^2 per (candidate, column), +inf outside the candidate's columns or the image, once per tile in LDS; sub-chunks of 32
+            // candidates.  Every read of the table is fenced by workgroup barriers; the table's contents check out after the loop — and
+            // the values a lane READS from it in the loop are wrong now and then beside matrix-instruction waves (see above).
+            for (int j0 = 0; j0 < total; j0 += 32) {
+                const int jn = min(32, total - j0);
+                for (int e = tid; e < jn * TILE; e += 256) {
+                    const int j = j0 + (e >> 5), xi = e & 31;
+                    const uint4 e0 = cand[j * 3 + 0], e2 = cand[j * 3 + 2];
+                    const int xx = tx0 + xi;
+                    const float t = __uint_as_float(e0.y) - (float)xx;
+                    const bool in = ((unsigned)(xx - (int)e2.x) < (unsigned)((int)e2.y - (int)e2.x)) && xx < W;
+                    cdx[(e >> 5) * TILE + xi] = in ? t * t : INFINITY;
+                }
+                __syncthreads();
+                if (row_ok) {
 #pragma unroll 1
-            for (int j = 0; j < total; ++j) {
-                const uint4 e0 = cand[j * 3 + 0], e1 = cand[j * 3 + 1], e2 = cand[j * 3 + 2];
-                const int y0 = (int)e1.z, y1 = (int)e1.w, x0 = (int)e2.x, x1 = (int)e2.y;
-                const float cy = __uint_as_float(e0.x), cx = __uint_as_float(e0.y);
-                const float cl = __uint_as_float(e0.z), ca = __uint_as_float(e0.w);
-                const float cbb = __uint_as_float(e1.x);
-                const int kk = (int)e1.y;
-                const bool rowin = (y >= y0) && (y < y1);
-                const float ty = cy - fy;
-                const float dy = ty * ty;
-                const unsigned xw = (unsigned)(x1 - x0);
+                    for (int jj = 0; jj < jn; ++jj) {
+                        const int j = j0 + jj;
+                        const uint4 e0 = cand[j * 3 + 0], e1 = cand[j * 3 + 1];
+                        const float4 dx4 = *(const float4 *)(cdx + jj * TILE + (tid & 7) * 4);
+                        const int y0 = (int)e1.z, y1 = (int)e1.w;
+                        const float cy = __uint_as_float(e0.x);
+                        const float cl = __uint_as_float(e0.z), ca = __uint_as_float(e0.w);
+                        const float cbb = __uint_as_float(e1.x);
+                        const int kk = (int)e1.y;
+                        const bool rowin = (y >= y0) && (y < y1);
+                        const float ty = cy - fy;
+                        const float dy = rowin ? ty * ty : INFINITY;
+                        const f32x2 dxp[2] = {{dx4.x, dx4.y}, {dx4.z, dx4.w}};
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const f32x2 tx = f32x2{cx, cx} - fx2[h];
-                    const f32x2 dx = tx * tx;
-                    f32x2 dc = (f32x2{dy, dy} + dx) * f32x2{sw, sw};
-                    const f32x2 t0 = pL2[h] - f32x2{cl, cl}, t1 = pA2[h] - f32x2{ca, ca}, t2 = pB2[h] - f32x2{cbb, cbb};
-                    f32x2 col = t0 * t0;
-                    col = col + t1 * t1;
-                    col = col + t2 * t2;
-                    dc = dc + col;
+                        for (int h = 0; h < 2; ++h) {
+                            f32x2 dc = (f32x2{dy, dy} + dxp[h]) * f32x2{sw, sw};
+                            const f32x2 t0 = pL2[h] - f32x2{cl, cl}, t1 = pA2[h] - f32x2{ca, ca}, t2 = pB2[h] - f32x2{cbb, cbb};
+                            f32x2 col = t0 * t0;
+                            col = col + t1 * t1;
+                            col = col + t2 * t2;
+                            dc = dc + col;
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const int i = 2 * h + q;
-                        const float d = q ? dc.y : dc.x;
-                        const bool take = rowin && ok[i] && ((unsigned)(xb + i - x0) < xw) && (best[i] > d);
-                        best[i] = take ? d : best[i];
-                        bl[i] = take ? kk : bl[i];
+                            for (int q = 0; q < 2; ++q) {
+                                const int i = 2 * h + q;
+                                const float d = q ? dc.y : dc.x;
+                                const bool take = best[i] > d;
+                                best[i] = take ? d : best[i];
+                                bl[i] = take ? kk : bl[i];
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        } else {
+            if (row_ok) {
+                // straight-line body: the three 16-byte LDS reads of an entry are issued together and
+                // the window test is folded into the final comparison (no divergent branches), so the
+                // compiler can overlap the next entry's reads with this entry's arithmetic.  The
+                // float arithmetic runs on pixel pairs (v_pk_add_f32 / v_pk_mul_f32: two IEEE float32
+                // operations per instruction, each rounded exactly like the scalar one — no FMA).
+    #pragma unroll 1
+                for (int j = 0; j < total; ++j) {
+                    const uint4 e0 = cand[j * 3 + 0], e1 = cand[j * 3 + 1], e2 = cand[j * 3 + 2];
+                    const int y0 = (int)e1.z, y1 = (int)e1.w, x0 = (int)e2.x, x1 = (int)e2.y;
+                    const float cy = __uint_as_float(e0.x), cx = __uint_as_float(e0.y);
+                    const float cl = __uint_as_float(e0.z), ca = __uint_as_float(e0.w);
+                    const float cbb = __uint_as_float(e1.x);
+                    const int kk = (int)e1.y;
+                    const bool rowin = (y >= y0) && (y < y1);
+                    const float ty = cy - fy;
+                    const float dy = ty * ty;
+                    const unsigned xw = (unsigned)(x1 - x0);
+    #pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const f32x2 tx = f32x2{cx, cx} - fx2[h];
+                        const f32x2 dx = tx * tx;
+                        f32x2 dc = (f32x2{dy, dy} + dx) * f32x2{sw, sw};
+                        const f32x2 t0 = pL2[h] - f32x2{cl, cl}, t1 = pA2[h] - f32x2{ca, ca}, t2 = pB2[h] - f32x2{cbb, cbb};
+                        f32x2 col = t0 * t0;
+                        col = col + t1 * t1;
+                        col = col + t2 * t2;
+                        dc = dc + col;
+    #pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int i = 2 * h + q;
+                            const float d = q ? dc.y : dc.x;
+                            const bool take = rowin && ok[i] && ((unsigned)(xb + i - x0) < xw) && (best[i] > d);
+                            best[i] = take ? d : best[i];
+                            bl[i] = take ? kk : bl[i];
+                        }
                     }
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
-    }
+        }
     bool uncovered = false;
 #pragma unroll
     for (int i = 0; i < 4; ++i) uncovered = uncovered || (ok[i] && bl[i] < 0);
@@ -990,7 +1048,13 @@ extern "C" int spa_slic_core(spa_ctx *ctx, const float *lab, int32_t B, int32_t 
         { SpaProfScope prof_(ctx, PROF_SLIC_ASSIGN, s);
         // (the masks of the last sweep would never be read)
         const bool upd = it + 1 < max_iter || centres;
-        hipLaunchKernelGGL(k_slic_assign, ga, dim3(256), 0, s, lab, cen, nC, H, W, sw, labels,
+#ifdef SPA_DIAG
+        if (ctx->dbg_slic_ldsx)
+            hipLaunchKernelGGL(k_slic_assign<true>, ga, dim3(256), 0, s, lab, cen, nC, H, W, sw, labels,
+                               rowmask, HG, PW, upd ? (uint32_t *)fine : (uint32_t *)nullptr, RW, PWF, ctx->d_status);
+        else
+#endif
+        hipLaunchKernelGGL(k_slic_assign<false>, ga, dim3(256), 0, s, lab, cen, nC, H, W, sw, labels,
                            rowmask, HG, PW, upd ? (uint32_t *)fine : (uint32_t *)nullptr, RW, PWF,
                            ctx->d_status); }
         SPA_LAUNCH_CHECK();
