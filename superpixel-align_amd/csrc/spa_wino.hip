@@ -245,6 +245,102 @@ __global__ __launch_bounds__(256) void k_wino4_in(const float *__restrict__ X, f
     }
 }
 
+// The same transform with the input patch of a block of tiles staged in LDS — an experiment that is NOT the default
+// (SPA_WINO_IN_LDS=2|4 selects it).  k_wino4_in reads every input value 36 / 16 = 2.25 times (the 6 x 6 patches of
+// neighbouring tiles overlap by two); the repeats hit in L2 but cross the compute unit's vector memory path all the
+// same, and the question was whether that path bounds the kernel.  Here a workgroup of TBY waves owns TBY x 8 tiles x
+// 32 channels of one sub-grid: the (4 TBY + 2) x 34 pixel patch x 128 B goes to LDS once (1.2 - 1.33 reads per value),
+// every thread (one tile x 4 channels) reads its 36 float4 from there.  A wave holds 2 x 4 tiles x 8 channel quads;
+// the row pitch (34 x 128 + 32 B) moves a tile row by half a 256-byte bank row, which makes the 16-lane groups of
+// ds_read_b128 conflict-free.  V is the one k_wino4_in<float4> writes, bit for bit.
+// Measured (30 images, same box, profiles/r6_wino_in_lds.txt): 512 channels 1.34-1.59 ms against 1.39-1.55, 256 channels
+// 0.65-0.67 against 0.69-0.71: within the box's run-to-run spread.  Writing the 36 values of a tile side by side
+// instead of 36 planes 125 MB apart (timing only, the GEMM cannot read that) gave 1.24-1.48.  So neither the repeated
+// loads nor the scatter of the stores is the limit: 2 GB read + 4.5 GB written in 1.39 ms is 4.7 TB/s, and that is
+// what this part's HBM gives a write-heavy stream (6.8 TB/s for stores alone, 6.1 for one read per write).
+constexpr int WIL_PW = 34, WIL_PITCH = WIL_PW * 128 + 32;
+
+template <int TBY>
+__global__ __launch_bounds__(64 * TBY) void k_wino4_in_lds(const float *__restrict__ X, float *__restrict__ Vout, WinoGeom g, int C,
+                                                           long long Tpad, int nby, int nbx)
+{
+    constexpr int NT = 64 * TBY, PH = 4 * TBY + 2, ITEMS = PH * WIL_PW * 8, NIT = (ITEMS + NT - 1) / NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char wil_lds[];
+    const int ncb = C >> 5;
+    long long blk = wino_block();
+    const int cb = (int)(blk % ncb); blk /= ncb;
+    const int bx = (int)(blk % nbx); blk /= nbx;
+    const int by = (int)(blk % nby); blk /= nby;
+    const int sx = (int)(blk % g.d); blk /= g.d;
+    const int sy = (int)(blk % g.d);
+    const int b = (int)(blk / g.d);
+    const int tid = threadIdx.x;
+    {
+        const float *xb = X + (long long)b * g.H * g.W * C + cb * 32;
+        float4 v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int item = it * NT + tid, px = item >> 3, q = item & 7;
+            const int pu = px / WIL_PW, pv = px - pu * WIL_PW;
+            const int y = sy + (4 * TBY * by - 1 + pu) * g.d, x = sx + (32 * bx - 1 + pv) * g.d;
+            const bool ok = item < ITEMS && y >= 0 && y < g.H && x >= 0 && x < g.W;
+            v[it] = ok ? *(const float4 *)(xb + ((long long)y * g.W + x) * C + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int item = it * NT + tid, px = item >> 3, q = item & 7;
+            const int pu = px / WIL_PW, pv = px - pu * WIL_PW;
+            if (item < ITEMS) *(float4 *)(wil_lds + pu * WIL_PITCH + pv * 128 + q * 16) = v[it];
+        }
+    }
+    __syncthreads();
+    const int w = tid >> 6, tl = (tid >> 3) & 7, q = tid & 7;
+    const int ltx = 4 * (w & 1) + (tl & 1) + 2 * (tl >> 2), lty = 2 * (w >> 1) + ((tl >> 1) & 1);
+    const int ty = TBY * by + lty, tx = 8 * bx + ltx;
+    if (ty >= g.th || tx >= g.tw) return;
+    const long long t = ((((long long)b * g.d + sy) * g.d + sx) * g.th + ty) * g.tw + tx;
+    const int c = cb * 32 + q * 4;
+    const unsigned char *lp = wil_lds + (4 * lty) * WIL_PITCH + (4 * ltx) * 128 + q * 16;
+    float4 r[6][6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        float4 dv[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) dv[j] = *(const float4 *)(lp + a * WIL_PITCH + j * 128);
+        wino4_bt(dv, r[a]);
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const float4 col[6] = {r[0][j], r[1][j], r[2][j], r[3][j], r[4][j], r[5][j]};
+        float4 o[6];
+        wino4_bt(col, o);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) *(float4 *)(Vout + ((long long)(i * 6 + j) * Tpad + t) * C + c) = o[i];
+    }
+}
+
+// SPA_WINO_IN_LDS: 2 / 4 = k_wino4_in_lds<2 / 4>; anything else (the default) = k_wino4_in
+static int wino4_in_lds_choice(int C)
+{
+    static const int env = getenv("SPA_WINO_IN_LDS") ? atoi(getenv("SPA_WINO_IN_LDS")) : 0;
+    return C % 32 == 0 && (env == 2 || env == 4) ? env : 0;
+}
+
+// launches k_wino4_in_lds<TBY> (tby = 2 or 4)
+static void wino4_in_lds_launch(spa_ctx *ctx, int tby, const float *x, float *v, const WinoGeom &g, int C, long long Tpad, hipStream_t s)
+{
+    const int nby = (g.th + tby - 1) / tby, nbx = (g.tw + 7) / 8;
+    const long long nb = (long long)g.B * g.d * g.d * nby * nbx * (C / 32);
+    const size_t lds = (size_t)(4 * tby + 2) * WIL_PITCH;
+    if (!(ctx->conv32_attr_done & 256)) {        // per context = per device
+        (void)hipFuncSetAttribute((const void *)k_wino4_in_lds<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 18 * WIL_PITCH);
+        (void)hipFuncSetAttribute((const void *)k_wino4_in_lds<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * WIL_PITCH);
+        ctx->conv32_attr_done |= 256;
+    }
+    if (tby == 4) hipLaunchKernelGGL(k_wino4_in_lds<4>, dim3((unsigned)nb), dim3(256), lds, s, x, v, g, C, Tpad, nby, nbx);
+    else hipLaunchKernelGGL(k_wino4_in_lds<2>, dim3((unsigned)nb), dim3(128), lds, s, x, v, g, C, Tpad, nby, nbx);
+}
+
 template <int HAS_RES, typename V>
 __global__ __launch_bounds__(256) void k_wino4_out(const float *__restrict__ M, float *__restrict__ Y,
                                                    const float *__restrict__ bias, const float *__restrict__ R,
@@ -484,6 +580,8 @@ extern "C" int spa_conv3x3_wino4_f16s(spa_ctx *ctx, const float *x, int32_t B, i
         if (vec2 & 2) {
             const long long n = g.T * (Cin / 2);
             hipLaunchKernelGGL(k_wino4_in<float2>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, (float *)v_scratch, g, Cin, Tpad);
+        } else if (const int tby = wino4_in_lds_choice(Cin)) {
+            wino4_in_lds_launch(ctx, tby, x, (float *)v_scratch, g, Cin, Tpad, s);
         } else {
             const long long n = g.T * (Cin / 4);
             hipLaunchKernelGGL(k_wino4_in<float4>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, (float *)v_scratch, g, Cin, Tpad);
