@@ -139,6 +139,18 @@ int spa_conv3x3_bf16(spa_ctx *ctx, const void *x, int32_t B, int32_t H, int32_t 
                      const void *wt, int32_t Cout, const float *bias, const void *residual,
                      int32_t relu, int32_t dilation, void *y, void *stream);
 
+/* The LIGHT layers of the bfloat16 DRN (models/drn.py:134-151 layer 2 of arch D and the 16 / 32-channel blocks of arch C,
+ * :195-203 the stride-2 openers of layers 3 / 4 with their 1x1 stride-2 projections, the 1x1 projections of layers 5 / 6):
+ * every convolution spa_conv3x3_bf16 does not take, so that the bfloat16 network has no library convolution left.
+ * x (B,Hi,Wi,Cin) bfloat16 channels-last; wt (Cout,taps,Cin) bfloat16 (taps = 9: the 3x3 weight permuted to (n, ky, kx, c),
+ * padding = dilation; taps = 1: 1x1, no padding); stride 1 or 2, output ((Hi + stride - 1) / stride, (Wi + stride - 1) /
+ * stride); bias (Cout) float32; residual (B,Ho,Wo,Cout) bfloat16 or NULL; y (B,Ho,Wo,Cout) bfloat16.  Cin 16, 32 or 64
+ * (3x3 and 1x1) or 128, 256 (1x1); Cout % 64 == 0 (Cin >= 32), % 32 == 0 (Cin 16 / 32) or % 16 == 0 (Cin 16); every
+ * pointer 16-byte aligned; float32 accumulation, one rounding to bfloat16 at the end. */
+int spa_conv_bf16_light(spa_ctx *ctx, const void *x, int32_t B, int32_t Hi, int32_t Wi, int32_t Cin, const void *wt,
+                        int32_t taps, int32_t stride, int32_t Cout, const float *bias, const void *residual,
+                        int32_t relu, int32_t dilation, void *y, void *stream);
+
 /* The same layers of the float32 network on the float32 matrix cores (v_mfma_f32_16x16x4_f32), epilogue fused: every
  * stride-1 3x3 (dilated) convolution from 64 channels up (models/drn.py:230-285, the BasicBlocks' conv1 / conv2 and
  * the plain layers 7-8).  x (B,H,W,Cin) float32 channels-last; wt (Cout,9,Cin) float32 = the (Cout,Cin,3,3) weight

@@ -64,6 +64,7 @@ PROTOTYPES = {
     'spa_bias_act': (ctypes.c_int, [c_p, c_p, c_i32, c_i64, c_i32, c_p, c_p, c_i32, c_p]),
     'spa_drn_stem_d': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_p, c_p]),
     'spa_conv3x3_bf16': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p, c_i32, c_p, c_p, c_i32, c_i32, c_p, c_p]),
+    'spa_conv_bf16_light': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_i32, c_i32, c_p, c_p]),
     'spa_conv3x3_f32': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p, c_i32, c_p, c_p, c_i32, c_i32, c_p, c_p]),
     'spa_conv1x1_f32': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p, c_i32, c_p, c_p, c_i32, c_p, c_p]),
     'spa_wino_tiles': (ctypes.c_int64, [c_i32, c_i32, c_i32, c_i32]),

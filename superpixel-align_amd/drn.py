@@ -146,6 +146,14 @@ def conv_bias_act(conv, bn, x, residual=None, relu=True):
             # in its epilogue (no separate elementwise pass, one rounding to bf16)
             _EPILOGUE['conv_flops'] += 2.0 * x.shape[0] * x.shape[2] * x.shape[3] * conv.out_channels * 9 * conv.in_channels
             return eng.conv3x3_bf16(x, packed[0], packed[1], residual, relu, conv.dilation[0])
+        light = getattr(conv, '_spa_light', None)
+        if (light is not None and x.dtype == torch.bfloat16 and _EPILOGUE['own_conv'] and os.environ.get('SPA_BF16_LIGHT', '1') != '0'
+                and x.is_contiguous(memory_format=torch.channels_last)
+                and (residual is None or residual.is_contiguous(memory_format=torch.channels_last))):
+            # the light layers of the bf16 network (stride 2, 16 / 32 channels, 1x1 projections): libspalign's plain bf16 kernel
+            _EPILOGUE['conv_flops'] += 2.0 * x.shape[0] * -(-x.shape[2] // conv.stride[0]) * -(-x.shape[3] // conv.stride[1]) \
+                * conv.out_channels * light[0].shape[1] * conv.in_channels
+            return eng.conv_bf16_light(x, light[0], light[1], residual, relu, conv.stride[0], conv.dilation[0])
         tile = _EPILOGUE['winograd']                   # 4 (default), 2 or 0/False
         wino = getattr(conv, '_spa_wino', {}).get(4 if tile == 4 else 2) if tile else None
         # with the split-plane kernels the direct form wins below 256 input channels (30 x 128 x 256 pixels, ms Winograd /
@@ -464,6 +472,19 @@ class DRN(nn.Module):
                             and m.in_channels % 64 == 0 and m.out_channels % 64 == 0 and m.bias is not None):
                         wt = m.weight.detach().permute(0, 2, 3, 1).reshape(m.out_channels, 9, m.in_channels)
                         m._spa_packed = (wt.contiguous().to(torch.bfloat16), m.bias.detach().float().contiguous())
+                    # operands of spa_conv_bf16_light: every other convolution of the bf16 network (stride 2, 16 / 32 input
+                    # channels, 1x1 projections)
+                    m._spa_light = None
+                    if (dtype == torch.bfloat16 and self.folded and getattr(m, '_spa_packed', None) is None and m.groups == 1
+                            and m.bias is not None and m.stride in ((1, 1), (2, 2))
+                            and ((m.kernel_size == (3, 3) and m.padding == m.dilation and m.dilation[0] == m.dilation[1]
+                                  and m.in_channels in (16, 32, 64))
+                                 or (m.kernel_size == (1, 1) and m.padding == (0, 0) and m.in_channels in (16, 32, 64, 128, 256)))
+                            and (m.out_channels % 64 == 0 and m.in_channels >= 32 or m.out_channels % 32 == 0 and m.in_channels <= 32
+                                 or m.out_channels % 16 == 0 and m.in_channels == 16)):
+                        taps = m.kernel_size[0] * m.kernel_size[1]
+                        wt = m.weight.detach().permute(0, 2, 3, 1).reshape(m.out_channels, taps, m.in_channels)
+                        m._spa_light = (wt.contiguous().to(torch.bfloat16), m.bias.detach().float().contiguous())
             for blk in self.modules():
                 if isinstance(blk, BasicBlock):
                     blk._spa_s2 = None

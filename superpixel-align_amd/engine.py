@@ -495,6 +495,23 @@ class Engine(object):
                                          _ptr(residual), 1 if relu else 0, int(dilation), _ptr(y), self._s()))
         return y
 
+    def conv_bf16_light(self, x, wt, bias, residual=None, relu=True, stride=1, dilation=1):
+        """The light layers of the bf16 DRN (models/drn.py:134-151, 195-203) on libspalign's kernel: x (B,Cin,H,W) bf16
+        channels-last, wt (Cout,taps,Cin) bf16 with taps 9 (3x3, padding = dilation) or 1 (1x1), stride 1 or 2."""
+        B, Cin, H, W = x.shape
+        Cout, taps = wt.shape[0], wt.shape[1]
+        assert x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last)
+        assert wt.dtype == torch.bfloat16 and wt.is_contiguous() and tuple(wt.shape) == (Cout, taps, Cin) and taps in (1, 9)
+        assert bias.dtype == torch.float32 and bias.is_contiguous()
+        Ho, Wo = (H + stride - 1) // stride, (W + stride - 1) // stride
+        y = torch.empty((B, Cout, Ho, Wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+        if residual is not None:
+            assert residual.dtype == torch.bfloat16 and residual.shape == y.shape and \
+                residual.is_contiguous(memory_format=torch.channels_last)
+        check(self._lib.spa_conv_bf16_light(self._ctx, _ptr(x), B, H, W, Cin, _ptr(wt), int(taps), int(stride), Cout, _ptr(bias),
+                                            _ptr(residual), 1 if relu else 0, int(dilation), _ptr(y), self._s()))
+        return y
+
     def resize_bicubic_u8(self, src, shape):
         """Decoded 8-bit images (B,H,W,C) uint8 -> (B,C,h,w) float32, bicubic exactly as Pillow's 8-bit
         Image.resize(..., BICUBIC) per channel (datasets/resize_image_dataset.py:31-34)."""

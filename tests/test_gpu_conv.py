@@ -333,6 +333,72 @@ def test_conv3x3_bf16_matches_float32_of_the_same_values(eng, B, Cin, Cout, H, W
     assert float((y.float() - ref).abs().max()) <= 1e-2 * float(ref.abs().max())      # one rounding to bf16 at the end
 
 
+@pytest.mark.parametrize('Cin,Cout,taps,stride,dil,res,relu,B,H,W', [
+    (16, 32, 9, 2, 1, False, True, 2, 37, 61),         # layer 2 of arch D (odd sizes: the last input row / column is padding)
+    (32, 64, 9, 2, 1, False, True, 1, 64, 130),        # opener of layer 3 ...
+    (32, 64, 1, 2, 1, False, False, 1, 64, 130),       # ... and its 1x1 stride-2 projection (no ReLU)
+    (64, 128, 9, 2, 1, False, True, 2, 19, 67),        # opener of layer 4, ragged strips
+    (64, 128, 1, 2, 1, False, False, 2, 19, 67),
+    (128, 256, 1, 1, 1, False, False, 1, 9, 257),      # projections of layers 5 / 6
+    (256, 512, 1, 1, 1, False, False, 2, 5, 33),
+    (16, 16, 9, 1, 1, True, True, 2, 37, 61),          # arch C: layer 1's BasicBlock, layer 2's (stride 2, projection, 32 -> 32)
+    (16, 32, 1, 2, 1, False, False, 1, 8, 32),
+    (32, 32, 9, 1, 1, True, True, 2, 19, 67),
+    (64, 64, 9, 1, 2, True, True, 1, 11, 70),          # a dilated stride-1 layer the heavy kernel would take: same answer here
+])
+def test_light_bf16_convolutions_match_float32_of_the_same_values(eng, Cin, Cout, taps, stride, dil, res, relu, B, H, W):
+    """spa_conv_bf16_light (csrc/spa_convl.hip: the stride-2 / thin / 1x1 layers of the bf16 network, models/drn.py:134-151,
+    195-203) against torch's float32 convolution of the SAME bf16 operands: the only differences allowed are the float32
+    accumulation order and the final rounding to bf16 (one bf16 ulp of the largest output, 2^-8)."""
+    g = torch.Generator(device='cuda').manual_seed(Cin * 7 + Cout + H + taps)
+    k = 3 if taps == 9 else 1
+    x = torch.randn((B, Cin, H, W), device='cuda', generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn((Cout, Cin, k, k), device='cuda', generator=g) * (2.0 / (taps * Cin)) ** 0.5).to(torch.bfloat16)
+    bias = torch.randn((Cout,), device='cuda', generator=g)
+    Ho, Wo = (H + stride - 1) // stride, (W + stride - 1) // stride
+    r = torch.randn((B, Cout, Ho, Wo), device='cuda', generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) if res else None
+    y = eng.conv_bf16_light(x, w.permute(0, 2, 3, 1).reshape(Cout, taps, Cin).contiguous(), bias, r, relu, stride, dil)
+    ref = F.conv2d(x.float(), w.float(), bias, stride, dil if taps == 9 else 0, dil)
+    assert y.dtype == torch.bfloat16 and y.shape == ref.shape
+    if res:
+        ref = ref + r.float()
+    if relu:
+        ref = torch.relu(ref)
+    assert float((y.float() - ref).abs().max()) <= float(ref.abs().max()) * 2.0 ** -8
+    eng.raise_on_status()
+
+
+@pytest.mark.parametrize('arch', ['drn_d_22', 'drn_c_26'])
+def test_bf16_network_runs_on_own_kernels(eng, arch):
+    """BASELINE configs[4]: the bf16 network without a library convolution (the light layers on spa_conv_bf16_light, the
+    rest on spa_conv3x3_bf16 and the stem kernel), and as close to the float32 network as with the library's kernels."""
+    drn = importlib.import_module('superpixel-align_amd.drn')
+    synth = importlib.import_module('superpixel-align_amd.synth')
+    m32 = drn.create_drn(arch, device='cuda', dtype=torch.float32, seed=3)
+    m = drn.create_drn(arch, device='cuda', dtype=torch.bfloat16, seed=3)
+    x = synth.synth_batch([3, 4], 128, 320)
+    E = drn._EPILOGUE
+    _, ref = m32.batch_predict(x, need=[7])
+    E['library_convs'] = 0
+    _, own = m.batch_predict(x, need=[7])
+    assert own[7].dtype == torch.bfloat16
+    if arch == 'drn_d_22':
+        assert E['library_convs'] == 0
+    else:
+        assert E['library_convs'] <= 1                 # arch C: the 7x7 stem convolution (3 input channels) is the library's
+    saved = E['own_conv']
+    try:
+        E['own_conv'] = False
+        _, lib = m.batch_predict(x, need=[7])
+    finally:
+        E['own_conv'] = saved
+    scale = float(ref[7].abs().max())
+    e_own = float((own[7].float() - ref[7]).abs().max()) / scale
+    e_lib = float((lib[7].float() - ref[7]).abs().max()) / scale
+    print('%s bf16 map 7 vs the float32 network, of scale: own kernels %.3e, library %.3e' % (arch, e_own, e_lib))
+    assert e_own <= max(1.5 * e_lib, 2e-2)
+
+
 @pytest.mark.parametrize('Cin,Cout,stride,proj,res,relu,B,H,W', [(16, 16, 1, False, True, True, 2, 37, 61), (16, 16, 1, False, False, False, 1, 8, 32),
                                                                  (16, 32, 2, True, False, True, 2, 37, 61), (16, 32, 2, False, False, True, 1, 64, 130),
                                                                  (32, 32, 1, False, True, True, 2, 19, 67), (16, 32, 1, False, False, True, 1, 9, 33)])
