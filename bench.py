@@ -709,7 +709,7 @@ def main():
                                  if a.dtype == 'fp32' else
                                  'bf16: the stride-1 3x3 layers from 64 channels up are libspalign\'s bf16 implicit-GEMM convolution with '
                                  'the epilogue fused (k_conv3x3_bf16), the stem its bf16-MFMA kernel, the light layers (layer 2, the stride-2 openers and the 1x1 '
-                                 'projections) libspalign\'s plain bf16 kernel (k_conv_bf16_light): no MIOpen convolution is left in arch D')
+                                 'projections) libspalign\'s plain bf16 kernel (k_conv_bf16_light): no MIOpen convolution is left')
                          if (conv_flops > 0 or split16 or wino_direct > 0) else
                          'the big convolutions are PyTorch-ROCm (MIOpen); libspalign adds the fused float32-MFMA stem '
                          'of DRN-D (normalise + layer0 + layer1, k_drn_stem_d) and the bias/residual/ReLU epilogues')},

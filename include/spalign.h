@@ -241,6 +241,11 @@ int spa_drn_stem_c_amax(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int3
                         const float *w0, const float *b0, const float *w1, const float *b1,
                         const double *mean3_host, const double *std3_host, float *y, float *y0,
                         float *xn_scratch, void *amax_out, void *stream);
+/* the same for the bfloat16 network: y and y0 (B,H,W,16) bfloat16 (float32 arithmetic inside, bf16 matrix cores) */
+int spa_drn_stem_c_bf16(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W,
+                        const float *w0, const float *b0, const float *w1, const float *b1,
+                        const double *mean3_host, const double *std3_host, void *y, void *y0,
+                        float *xn_scratch, void *stream);
 /* the thin 3x3 convolutions at the top of DRN-C (layer1's second convolution 16 -> 16, layer2's BasicBlock 16 -> 32 stride 2
  * with its 1x1 stride-2 projection, 32 -> 32) on the 16-bit matrix cores at float32 accuracy (csrc/spa_convs.hip):
  * x (B,H,W,Cin) float32 channels-last, Cin 16 or 32 -> y (B,Ho,Wo,Cout) = relu?(conv3x3(x; stride, padding 1) + bias [+ residual]),

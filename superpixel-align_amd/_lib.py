@@ -77,6 +77,7 @@ PROTOTYPES = {
     'spa_bias_act_amax': (ctypes.c_int, [c_p, c_p, c_i64, c_i32, c_p, c_p, c_i32, c_p, c_p]),
     'spa_drn_stem_d_amax': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     'spa_drn_stem_c_amax': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    'spa_drn_stem_c_bf16': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     'spa_conv_small_f16s': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p, c_f32, c_i32, c_i32, c_i32, c_p, c_p, c_i32, c_p, c_p, c_p, c_p, c_p]),
     'spa_drn_layer2_f16s': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_p, c_f32, c_p, c_p, c_p, c_p, c_p]),
     'spa_drn_layer2_f32': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p]),

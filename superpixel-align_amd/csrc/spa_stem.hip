@@ -259,7 +259,8 @@ __global__ __launch_bounds__(256) void k_drn_stem_d_bf16(const unsigned short *_
                                                          const float *__restrict__ b0,
                                                          const unsigned short *__restrict__ w1p,   // [5][64] x 8 bf16
                                                          const float *__restrict__ b1,
-                                                         unsigned short *__restrict__ yh)
+                                                         unsigned short *__restrict__ yh,
+                                                         unsigned short *__restrict__ y0h)   // DRN-C: layer0's output too (or NULL)
 {
     // patch copy 0: pixel ix at [c][iy][ix]; copy 1: pixel ix at [c][iy][ix - 1] (so odd ix are 4-byte aligned)
     __shared__ __attribute__((aligned(16))) unsigned short in_s[2][SB_COPY];
@@ -373,6 +374,8 @@ __global__ __launch_bounds__(256) void k_drn_stem_d_bf16(const unsigned short *_
                 o.x = (unsigned)stem_bf16_rn(v0) | ((unsigned)stem_bf16_rn(v1) << 16);
                 o.y = (unsigned)stem_bf16_rn(v2) | ((unsigned)stem_bf16_rn(v3) << 16);
                 *(uint2 *)(l0_s + q0 * SB_L0_PITCH + 4 * g) = o;
+                if (y0h && in && py >= 1 && py <= ST_TH && px >= 1 && px <= ST_TW)       // the tile's own pixels (not its halo)
+                    *(uint2 *)(y0h + ((((long long)b * H + gy) * W + gx) * 16 + 4 * g)) = o;
             }
         }
         stem_lds_barrier();
@@ -916,13 +919,24 @@ extern "C" int spa_drn_stem_c_amax(spa_ctx *ctx, const float *x, int32_t B, int3
     return stem_impl(ctx, x, B, H, W, w0, b0, w1, b1, mean3_host, std3_host, y, 2, xn_scratch, amax_out, stream, y0);
 }
 
+// DRN-C in the bf16 network: y and y0 (B,H,W,16) bfloat16 — conv1's output and layer1's first convolution in one pass (round 6:
+// the last library convolution of the bf16 arch-C forward)
+extern "C" int spa_drn_stem_c_bf16(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W,
+                                   const float *w0, const float *b0, const float *w1, const float *b1,
+                                   const double *mean3_host, const double *std3_host, void *y, void *y0,
+                                   float *xn_scratch, void *stream)
+{
+    SPA_ARG(y0 && ((uintptr_t)y0 & 15) == 0);
+    return stem_impl(ctx, x, B, H, W, w0, b0, w1, b1, mean3_host, std3_host, y, 1, xn_scratch, nullptr, stream, (float *)y0);
+}
+
 static int stem_impl(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t W,
                      const float *w0, const float *b0, const float *w1, const float *b1,
                      const double *mean3_host, const double *std3_host, void *y, int32_t out_dtype,
                      float *xn_scratch, void *amax_out, void *stream, float *y0)
 {
     SPA_ARG(ctx && x && w0 && b0 && w1 && b1 && mean3_host && std3_host && y && B > 0 && H > 0 && W > 0);
-    SPA_ARG(!y0 || out_dtype == 2);
+    SPA_ARG(!y0 || out_dtype == 2 || out_dtype == 1);          // (out_dtype 1: y0 is bfloat16 as well)
     SPA_ARG(out_dtype == 0 || out_dtype == 1 || out_dtype == 2);      // 2: float32 output, 16-bit matrix cores (two planes)
     // exact input normalisation (models/drn.py:319-321) into a channels-last workspace, then the stem
     SpaProfScope prof_(ctx, PROF_DRN_STEM, spa_stream(stream));
@@ -943,7 +957,7 @@ static int stem_impl(spa_ctx *ctx, const float *x, int32_t B, int32_t H, int32_t
         if ((rc = spa_drn_normalise(ctx, x, B, H, W, xb, 1, mean3_host, std3_host, stream)) != SPA_OK) return rc;
         hipLaunchKernelGGL(k_drn_stem_d_bf16, dim3((unsigned)grid), dim3(256), 0, spa_stream(stream), (const unsigned short *)xb, B,
                            H, W, (const unsigned short *)wp, b0, (const unsigned short *)(wp + 6 * 64 * 8), b1,
-                           (unsigned short *)y);
+                           (unsigned short *)y, (unsigned short *)y0);
         SPA_LAUNCH_CHECK();
         return SPA_OK;
     }

@@ -519,6 +519,16 @@ class DRN(nn.Module):
                         l2c1=Engine.small_planes(b2.conv1.weight, b2.downsample[0].weight)
                         + (torch.cat([f32(b2.conv1.bias), f32(b2.downsample[0].bias)]).contiguous(),),
                         l2c2=Engine.small_planes(b2.conv2.weight) + (f32(b2.conv2.bias),))
+            self._stem_c16 = None
+            if self.arch == 'C' and self.folded and dtype == torch.bfloat16:
+                # bf16 DRN-C: conv1 + layer1's first convolution as the fused bf16 stem (which also stores conv1's output, the
+                # block's residual); the rest of layers 1 / 2 runs on spa_conv_bf16_light through the modules
+                c0, b1 = self.conv1, self.layer1[0]
+                if (len(self.layer1) == 1 and b1.residual and b1.downsample is None and c0.bias is not None
+                        and b1.conv1.bias is not None and b1.conv1.stride == (1, 1) and b1.conv1.dilation == (1, 1)):
+                    self._stem_c16 = (c0.weight.detach().float().reshape(16, 147).contiguous(), c0.bias.detach().float().contiguous(),
+                                      b1.conv1.weight.detach().float().permute(0, 2, 3, 1).reshape(16, 144).contiguous(),
+                                      b1.conv1.bias.detach().float().contiguous())
             if self.arch == 'D' and self.folded and dtype in (torch.float32, torch.bfloat16):
                 # operands of libspalign's fused stem kernel (normalise + layer0 + layer1)
                 c0, c1 = self.layer0[0], self.layer1[0]
@@ -596,6 +606,13 @@ class DRN(nn.Module):
             E['conv16_launches'] += 3
             _c16('front', fl2, by2, 3)
             return self.forward_maps(None, front_maps=[l1, l2])
+        sc16 = getattr(self, '_stem_c16', None)
+        if (eng is not None and xc.is_cuda and sc16 is not None and self.use_fused_stem and _EPILOGUE['own_conv']
+                and self.compute_dtype == torch.bfloat16):
+            a1, y0 = eng.drn_stem_d(xc.float().contiguous(), *sc16, dtype=torch.bfloat16, want_layer0=True)
+            b1 = self.layer1[0]
+            l1 = conv_bias_act(b1.conv2, b1.bn2, a1, y0, True)
+            return self.forward_maps(None, front_maps=[l1])
         if eng is not None and xc.is_cuda and getattr(self, '_stem', None) is not None and self.use_fused_stem:
             l1 = eng.drn_stem_d(xc.float().contiguous(), *self._stem, dtype=self.compute_dtype,
                                 split=_EPILOGUE['split_gemm'] and self.compute_dtype == torch.float32)

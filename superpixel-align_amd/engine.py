@@ -166,6 +166,13 @@ class Engine(object):
                                                 mean, std, _ptr(out), _ptr(scratch), _ptr(am), self._s()))
             out._spa_amax = am
             return out
+        if want_layer0:
+            # DRN-C in the bf16 network: conv1's output as well (the residual of layer1's BasicBlock)
+            assert dtype == torch.bfloat16, 'want_layer0: the split-plane float32 kernel or the bf16 kernel'
+            out0 = torch.empty((B, 16, H, W), dtype=dtype, device=x.device, memory_format=torch.channels_last)
+            check(self._lib.spa_drn_stem_c_bf16(self._ctx, _ptr(x), B, H, W, _ptr(w0), _ptr(b0), _ptr(w1p), _ptr(b1),
+                                                mean, std, _ptr(out), _ptr(out0), _ptr(scratch), self._s()))
+            return out, out0
         check(self._lib.spa_drn_stem_d(self._ctx, _ptr(x), B, H, W, _ptr(w0), _ptr(b0), _ptr(w1p), _ptr(b1),
                                        mean, std, _ptr(out), 0 if dtype == torch.float32 else 1, _ptr(scratch),
                                        self._s()))

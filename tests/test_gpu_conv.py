@@ -382,10 +382,7 @@ def test_bf16_network_runs_on_own_kernels(eng, arch):
     E['library_convs'] = 0
     _, own = m.batch_predict(x, need=[7])
     assert own[7].dtype == torch.bfloat16
-    if arch == 'drn_d_22':
-        assert E['library_convs'] == 0
-    else:
-        assert E['library_convs'] <= 1                 # arch C: the 7x7 stem convolution (3 input channels) is the library's
+    assert E['library_convs'] == 0                     # (arch C: conv1 + layer1's first convolution are the fused bf16 stem)
     saved = E['own_conv']
     try:
         E['own_conv'] = False

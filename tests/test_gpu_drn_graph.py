@@ -50,15 +50,11 @@ def test_graph_forward_is_the_eager_forward_bit_for_bit(mods, arch, dtype):
     again = _maps(model, xs[0], 'auto')
     ents = list(model._graphs.values())
     assert len(ents) == 1
-    own = dtype == 'fp32' or arch == 'drn_d_22'
-    if own:
-        # the float32 forward (and, since round 6, the bf16 forward of arch D: spa_conv_bf16_light) is libspalign's kernels at every
-        # shape: captured, and no convolution went to the library
-        assert ents[0] is not False, 'the forward was not captured'
-        assert mods.drn._EPILOGUE['library_convs'] == before
-    else:
-        # bf16 arch C: the 7x7 stem is still MIOpen's, whose algorithm choice differs inside a capture: such a forward stays eager
-        assert ents[0] is False
+    own = True
+    # the float32 forward (and, since round 6, the bf16 forward: spa_conv_bf16_light, the bf16 stem of both architectures) is libspalign's
+    # kernels at every shape: captured, and no convolution went to the library
+    assert ents[0] is not False, 'the forward was not captured'
+    assert mods.drn._EPILOGUE['library_convs'] == before
     for e, g in zip(eager + [eager[0]], graph + [again]):
         for i in (6, 7):
             assert g[i].dtype == e[i].dtype and g[i].shape == e[i].shape
