@@ -497,7 +497,7 @@ def main():
                 sys.stderr.write('[bench] rank placement unverified: ordinals %r\n' % (rank_devices,))
     assert allrec.shape[0] == ws * B, 'gathered %d records, expected N x B = %d' % (allrec.shape[0], ws * B)
     assert sorted(allrec[:, 0].tolist()) == list(range(ws * B)), 'record indices are not 0 .. N x B - 1'
-    backend = (torch.distributed.get_backend() if ws > 1 else None)
+    backend = (torch.distributed.get_backend() if torch.distributed.is_initialized() else None)
     stage = {'time_feature_maps': 0.0, 'time_superpixel': 0.0, 'time_roialign': 0.0, 'time_kmeans': 0.0}
     bias_bytes, bias_launches = drn._EPILOGUE['bytes'], drn._EPILOGUE['launches']
     conv_flops = drn._EPILOGUE['conv_flops']

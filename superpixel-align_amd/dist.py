@@ -45,7 +45,9 @@ def world():
 
 def init(backend=None):
     rank, ws, local = world()
-    if ws > 1 and not dist.is_initialized():
+    # SPA_DIST_FORCE=1: create the process group (and run every collective) with ONE rank too — the RCCL path of a single-GPU box
+    force = os.environ.get('SPA_DIST_FORCE') == '1'
+    if (ws > 1 or force) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
@@ -62,7 +64,12 @@ def init(backend=None):
             torch.cuda.set_device(dev)
             from .engine import default_engine
             default_engine()
-        dist.init_process_group(backend, rank=rank, world_size=ws)
+        kw = {}
+        if backend == 'nccl' and torch.cuda.is_available():
+            kw['device_id'] = torch.device('cuda', torch.cuda.current_device())     # RCCL binds to this rank's GPU, no guessing from the rank
+        dist.init_process_group(backend, rank=rank, world_size=ws, **kw)
+        import atexit
+        atexit.register(lambda: dist.is_initialized() and dist.destroy_process_group())
     return rank, ws, local
 
 
@@ -95,7 +102,7 @@ def gather_records(records, device=None):
     """records: (n, RECORD_WIDTH) int64 array of this rank -> concatenation over ranks, on every
     rank (rows of rank 0 first).  One all_gather of the counts + one of the padded payload."""
     rec = np.asarray(records, dtype=np.int64).reshape(-1, RECORD_WIDTH)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and os.environ.get('SPA_DIST_FORCE') != '1'):
         return rec
     ws = dist.get_world_size()
     if device is None:
@@ -120,7 +127,7 @@ def barrier():
 
 def all_values(value, device=None):
     """One float per rank -> the list over ranks, on every rank (bench.py: per-rank rates and gather times)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and os.environ.get('SPA_DIST_FORCE') != '1'):
         return [float(value)]
     if device is None:
         device = torch.device('cuda', torch.cuda.current_device()) \
@@ -132,7 +139,7 @@ def all_values(value, device=None):
 
 
 def max_over_ranks(value, device=None):
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and os.environ.get('SPA_DIST_FORCE') != '1'):
         return float(value)
     if device is None:
         device = torch.device('cuda', torch.cuda.current_device()) \
