@@ -374,7 +374,7 @@ def main():
     COUNTERS = ('bytes', 'launches', 'conv_flops', 'conv16_flops', 'conv16_launches', 'conv16_bytes', 'gemm16_flops', 'gemm16_launches',
                 'gemm16_bytes', 'gemm16n_flops', 'gemm16n_launches', 'gemm16n_bytes', 'gemm_flops', 'gemm_launches', 'gemm_bytes',
                 'gemmn_flops', 'gemmn_launches', 'gemmn_bytes', 'wino_direct_flops', 'wino_saved_flops', 'wino_in_bytes',
-                'wino_out_bytes', 'wino_launches', 'gemm16_layer_bytes')
+                'wino_out_bytes', 'wino_launches', 'gemm16_layer_bytes', 'light_flops', 'light_bytes', 'light_launches')
 
     gather_s, local_s = [0.0], [0.0]
 
@@ -612,6 +612,14 @@ def main():
             gbs = ab / (avg * 1e-3) / 1e9
             ent.update(bound='hbm', achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4),
                        algorithmic_bytes_per_launch=int(ab), traffic=pmc_traffic(name, B, H, W, ab))
+        elif name.startswith('k_conv_bf16_light'):
+            # the light layers of the bf16 network (stride 2, thin, 1x1): priced by their activations' bytes (in + out [+ residual], bf16)
+            ab = E['light_bytes'] / max(1, E['light_launches'])
+            gbs = ab / (avg * 1e-3) / 1e9
+            ent.update(bound='hbm', achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4),
+                       algorithmic_bytes_per_launch=int(ab), traffic=None, flops_per_step=E['light_flops'] / a.steps,
+                       limiter='the pixel operand is loaded per tap straight from the image (9 reads of a pixel through L1 / L2 per 3x3 '
+                               'layer, no LDS staging): bound by the CU\'s vector memory path, not by HBM or the matrix pipe')
         elif name.startswith('k_conv3x3_'):
             # libspalign's implicit-GEMM convolutions (the stride-1 3x3 layers, bf16 or float32 matrix cores):
             # family entry over all launches; FLOPs = 2 * MACs of exactly those layers (counted by drn.py)

@@ -93,7 +93,7 @@ enum {
 enum {
     PROF_RGB2LAB = 0, PROF_SLIC_ASSIGN, PROF_SLIC_UPDATE, PROF_CONNECT, PROF_STATS,
     PROF_CELL_WEIGHTS, PROF_POOL_MEAN, PROF_POOL_ANCHOR, PROF_KMEANS, PROF_PAINT,
-    PROF_DRN_STEM, PROF_DRN_BIAS_ACT, PROF_DRN_CONV, PROF_DRN_CONV32, PROF_DRN_GEMM32, PROF_DRN_GEMM32_N, PROF_WINO_IN, PROF_WINO_OUT, PROF_DRN_GEMM16, PROF_DRN_GEMM16_N, PROF_DRN_CONV16, PROF_DRN_CONV16_128, PROF_DRN_CONV16_256, PROF_DRN_CONV16_1X1, PROF_DRN_CONV16_FRONT, PROF_SLOTS
+    PROF_DRN_STEM, PROF_DRN_BIAS_ACT, PROF_DRN_CONV, PROF_DRN_CONV32, PROF_DRN_GEMM32, PROF_DRN_GEMM32_N, PROF_WINO_IN, PROF_WINO_OUT, PROF_DRN_GEMM16, PROF_DRN_GEMM16_N, PROF_DRN_CONV16, PROF_DRN_CONV16_128, PROF_DRN_CONV16_256, PROF_DRN_CONV16_1X1, PROF_DRN_CONV16_FRONT, PROF_DRN_CONV_LIGHT, PROF_SLOTS
 };
 
 struct spa_ctx {

@@ -158,7 +158,7 @@ static int conv_bf16_light_launch(spa_ctx *ctx, const void *x, int B, int Hi, in
         SPA_HIP(hipFuncSetAttribute(k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         SPA_HIP(hipFuncSetAttribute(k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    SpaProfScope prof_(ctx, PROF_DRN_CONV, s);
+    SpaProfScope prof_(ctx, PROF_DRN_CONV_LIGHT, s);
     if (residual)
         hipLaunchKernelGGL((k_conv_bf16_light<CIN, TAPS, S, MI, 1>), dim3((unsigned)gx, nblk), dim3(CL_THREADS), lds, s, (const __bf16 *)x,
                            (const __bf16 *)wt, bias, (const __bf16 *)residual, (__bf16 *)y, B, Hi, Wi, Ho, Wo, Cout, dil, relu, xstrips, nstrips);

@@ -238,7 +238,7 @@ extern "C" const char *spa_prof_name(int slot)
 {
     static const char *names[PROF_SLOTS] = {"k_rgb2lab", "k_slic_assign", "k_slic_update",
         "connectivity(all)", "segment_stats(all)", "k_cell_weights", "k_pool_mean", "k_pool_anchor",
-        "k_kmeans", "k_paint", "k_drn_stem_d(+normalise)", "k_bias_act(all)", "k_conv3x3_bf16(all)", "k_conv3x3_f32<taps 9>(all)", "k_conv3x3_f32<0, 256, 1, 256>", "k_conv3x3_f32<taps 1, narrow tiles>(all)", "k_wino_in", "k_wino_out", "k_gemm_f16x3_stag<256, 256>", "k_gemm_f16x3<128, 128>", "k_conv3x3_p16<64, 256> (split planes, 64-channel layers)", "k_conv3x3_p16<128, 128> (split planes, 128-channel layers)", "k_conv3x3_f32<split, 256-channel tile>", "k_conv3x3_f32<split, 1x1>", "split-plane front (stride-2 openers + projections, layer 2, DRN-C layers 1-2)"};
+        "k_kmeans", "k_paint", "k_drn_stem_d(+normalise)", "k_bias_act(all)", "k_conv3x3_bf16(all)", "k_conv3x3_f32<taps 9>(all)", "k_conv3x3_f32<0, 256, 1, 256>", "k_conv3x3_f32<taps 1, narrow tiles>(all)", "k_wino_in", "k_wino_out", "k_gemm_f16x3_stag<256, 256>", "k_gemm_f16x3<128, 128>", "k_conv3x3_p16<64, 256> (split planes, 64-channel layers)", "k_conv3x3_p16<128, 128> (split planes, 128-channel layers)", "k_conv3x3_f32<split, 256-channel tile>", "k_conv3x3_f32<split, 1x1>", "split-plane front (stride-2 openers + projections, layer 2, DRN-C layers 1-2)", "k_conv_bf16_light(all)"};
     return (slot >= 0 && slot < PROF_SLOTS) ? names[slot] : "";
 }
 

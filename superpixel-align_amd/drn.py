@@ -60,7 +60,7 @@ def _conv(cin, cout, k, stride=1, dilation=1):
 # set by DRN.prepare() on a GPU: libspalign's fused bias/residual/ReLU; 'bytes' accumulates the algorithmic
 # HBM bytes of its launches (read y + write y [+ read residual]) for bench.py's roofline entry
 _EPILOGUE = {'engine': None, 'bytes': 0, 'launches': 0, 'own_conv': True, 'own_conv32': True, 'winograd': 4, 'wino_saved_flops': 0.0,
-             'conv_flops': 0.0, 'gemm_flops': 0.0, 'gemm_launches': 0, 'gemm_bytes': 0.0,
+             'conv_flops': 0.0, 'light_flops': 0.0, 'light_bytes': 0.0, 'light_launches': 0, 'gemm_flops': 0.0, 'gemm_launches': 0, 'gemm_bytes': 0.0,
              'gemmn_flops': 0.0, 'gemmn_launches': 0, 'gemmn_bytes': 0.0, 'wino_direct_flops': 0.0, 'wino_in_bytes': 0.0,
              'wino_out_bytes': 0.0, 'wino_launches': 0,
              # F(4x4,3x3) GEMMs on the 16-bit matrix cores at float32 accuracy (two half-precision planes per operand, three
@@ -151,8 +151,11 @@ def conv_bias_act(conv, bn, x, residual=None, relu=True):
                 and x.is_contiguous(memory_format=torch.channels_last)
                 and (residual is None or residual.is_contiguous(memory_format=torch.channels_last))):
             # the light layers of the bf16 network (stride 2, 16 / 32 channels, 1x1 projections): libspalign's plain bf16 kernel
-            _EPILOGUE['conv_flops'] += 2.0 * x.shape[0] * -(-x.shape[2] // conv.stride[0]) * -(-x.shape[3] // conv.stride[1]) \
-                * conv.out_channels * light[0].shape[1] * conv.in_channels
+            opx = x.shape[0] * -(-x.shape[2] // conv.stride[0]) * -(-x.shape[3] // conv.stride[1])
+            _EPILOGUE['light_flops'] += 2.0 * opx * conv.out_channels * light[0].shape[1] * conv.in_channels
+            _EPILOGUE['light_bytes'] += 2.0 * (x.shape[0] * x.shape[2] * x.shape[3] * conv.in_channels
+                                               + opx * conv.out_channels * (2 if residual is not None else 1))
+            _EPILOGUE['light_launches'] += 1
             return eng.conv_bf16_light(x, light[0], light[1], residual, relu, conv.stride[0], conv.dilation[0])
         tile = _EPILOGUE['winograd']                   # 4 (default), 2 or 0/False
         wino = getattr(conv, '_spa_wino', {}).get(4 if tile == 4 else 2) if tile else None
