@@ -10,7 +10,7 @@ superpixel sizes additionally visit the host, because the anchors are drawn from
 
 Two HIP streams: the superpixel branch (SLIC, per-segment statistics, and in anchor mode the
 host-side random draws) does not depend on the DRN features, so it runs on an auxiliary stream
-while the DRN forward (MFMA-bound, MIOpen) occupies the main stream; they join before pooling.
+while the DRN forward (libspalign's MFMA kernels) occupies the main stream; they join before pooling.
 """
 import os
 
