@@ -368,6 +368,18 @@ def test_light_bf16_convolutions_match_float32_of_the_same_values(eng, Cin, Cout
     eng.raise_on_status()
 
 
+def test_light_bf16_convolution_refuses_shapes_it_does_not_take(eng):
+    """spa_conv_bf16_light fails loudly (no fallback): 48 input channels, a 3x3 layer with 128 input channels (spa_conv3x3_bf16's),
+    24 output channels"""
+    eng_mod = importlib.import_module('superpixel-align_amd.engine')
+    for Cin, Cout, taps in ((48, 64, 9), (128, 128, 9), (16, 24, 9)):
+        k = 3 if taps == 9 else 1
+        x = torch.zeros((1, Cin, 8, 16), device='cuda', dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        w = torch.zeros((Cout, taps, Cin), device='cuda', dtype=torch.bfloat16)
+        with pytest.raises(eng_mod.SpalignError):
+            eng.conv_bf16_light(x, w, torch.zeros((Cout,), device='cuda'), None, True, 1, 1)
+
+
 @pytest.mark.parametrize('arch', ['drn_d_22', 'drn_c_26'])
 def test_bf16_network_runs_on_own_kernels(eng, arch):
     """BASELINE configs[4]: the bf16 network without a library convolution (the light layers on spa_conv_bf16_light, the
